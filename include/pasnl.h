@@ -1,0 +1,155 @@
+/*
+ * pasnl.h -- C ABI of libpasnl_hip.so: the MI355X (gfx950) set-abstraction hot path of PointASNL.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one C++ "Launcher" (or CPU loop) that the
+ * reference's TensorFlow OpKernels call with raw pointers (citations are file:line in the reference
+ * tree).  Conventions, identical for every function:
+ *
+ *   - all tensors are contiguous row-major, float32 / int32 (int64 only where stated);
+ *   - pointers are DEVICE pointers owned by the caller (the Python host hands in torch storage);
+ *     inputs are borrowed const, outputs are fully overwritten;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = the null
+ *     stream); no implicit synchronisation, no allocation, no global state -> graph-capturable and
+ *     thread-safe;
+ *   - the return value is PASNL_OK (0) or a negative PASNL_E* code; nothing is enqueued on error.
+ *     `pasnl_strerror` gives the text.  Shape rules mirror the reference's OP_REQUIRES checks.
+ *   - b == 0 or an empty query/result dimension is a successful no-op.
+ *
+ * Arithmetic is the canonical fp32 of SURVEY.md Appendix A: IEEE round-to-nearest, no FMA
+ * contraction, operations in the written order.  Index outputs are bit-exact against oracle/.
+ */
+#ifndef PASNL_H_
+#define PASNL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PASNL_VERSION 100 /* 0.1.0 */
+
+enum {
+  PASNL_OK = 0,
+  PASNL_EINVAL = -1,       /* bad dimension / attribute (the reference's InvalidArgument)   */
+  PASNL_ENULL = -2,        /* a required pointer is NULL                                     */
+  PASNL_EWORKSPACE = -3,   /* workspace smaller than pasnl_*_workspace_bytes                 */
+  PASNL_ELAUNCH = -4,      /* hipGetLastError() != hipSuccess after the launch               */
+  PASNL_EUNSUPPORTED = -5  /* valid request outside what the kernels cover (documented)      */
+};
+
+typedef void* pasnl_stream_t; /* hipStream_t */
+
+int pasnl_version(void);
+const char* pasnl_strerror(int code);
+/* Number of HIP devices visible to the library (<0: HIP runtime error).  Used by the host to fail
+ * loudly instead of falling back to a CPU path. */
+int pasnl_device_count(void);
+
+/* ------------------------------------------------------------------ sampling (tf_ops/sampling) */
+
+/* Iterative farthest point sampling; idx[b,0] = 0.
+ * replaces farthestpointsamplingLauncher  tf_sampling_g.cu:203-205 (kernel :105-170)
+ * xyz (b,n,3) f32 -> idx (b,m) i32.  Tie rule: lowest (k mod 512, k) among maxima.
+ * The reference needs a 32*n float temp (tf_sampling.cpp:115); this kernel keeps the running
+ * distances in registers, so no workspace is required (m <= 0 -> PASNL_EINVAL as tf_sampling.cpp:99). */
+int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz, int* idx, pasnl_stream_t stream);
+
+/* out[b,j,:] = inp[b, idx[b,j], :] for 3-wide rows.
+ * replaces gatherpointLauncher  tf_sampling_g.cu:206-208 (kernel :172-181) */
+int pasnl_gather_point(int b, int n, int m, const float* inp, const int* idx, float* out, pasnl_stream_t stream);
+
+/* inp_g (b,n,3) = scatter-add of out_g (b,m,3) through idx (b,m); inp_g is zeroed first.
+ * replaces cudaMemset + scatteraddpointLauncher  tf_sampling.cpp:174-175, tf_sampling_g.cu:183-192 */
+int pasnl_gather_point_grad(int b, int n, int m, const float* out_g, const int* idx, float* inp_g, pasnl_stream_t stream);
+
+/* Inverse-CDF sampling: out[b,j] = first r with cdf[b,r] >= inpr[b,j]*cdf[b,n-1]; `temp` (b*n floats)
+ * receives the running sum.  replaces probsampleLauncher  tf_sampling_g.cu:198-201 (:7-104) */
+int pasnl_prob_sample(int b, int n, int m, const float* inp_p, const float* inp_r, float* temp, int* out, pasnl_stream_t stream);
+
+/* ------------------------------------------------------------------ grouping (tf_ops/grouping) */
+
+/* First `nsample` points (ascending index) with max(sqrtf(d2),1e-20f) < radius, padded with the first
+ * hit; pts_cnt = min(hits, nsample); zero-hit rows are all 0 (the reference leaves them undefined).
+ * replaces queryBallPointLauncher  tf_grouping_g.cu:125-126 (kernel :3-36)
+ * xyz1 (b,n,3) dataset, xyz2 (b,m,3) queries -> idx (b,m,nsample) i32, pts_cnt (b,m) i32 */
+int pasnl_query_ball_point(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
+                           int* idx, int* pts_cnt, pasnl_stream_t stream);
+
+/* out[b,j,k,:] = points[b, idx[b,j,k], :], row length c.
+ * replaces groupPointLauncher  tf_grouping_g.cu:133-134 (kernel :40-57).  With nsample == 1 this is the
+ * C-wide row gather the models do through tf.gather_nd (pointasnl_util.py:43-49,63-71). */
+int pasnl_group_point(int b, int n, int c, int m, int nsample, const float* points, const int* idx, float* out,
+                      pasnl_stream_t stream);
+
+/* grad_points (b,n,c) = scatter-add of grad_out (b,m,nsample,c); zeroed first.
+ * replaces cudaMemset + groupPointGradLauncher  tf_grouping.cpp:204-205, tf_grouping_g.cu:61-78 */
+int pasnl_group_point_grad(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx,
+                           float* grad_points, pasnl_stream_t stream);
+
+/* k rounds of in-place selection sort per row of a (b,m,n) distance tensor; FULL (b,m,n) outputs, first k
+ * columns meaningful, the tail is the swap residue.  replaces selectionSortLauncher
+ * tf_grouping_g.cu:129-130 (kernel :83-123) */
+int pasnl_select_top_k(int b, int n, int m, int k, const float* dist, int* outi, float* out, pasnl_stream_t stream);
+
+/* Exact K nearest neighbours, ascending by (squared distance, index); the grouping search of all three
+ * models.  replaces cpp_knn_batch / cpp_knn_batch_omp  utils/nearest_neighbors/knn_.cxx:72-135
+ * (binding knn.pyx:71-109).  support (b,n,3), queries (b,m,3) -> idx (b,m,k), int32 when
+ * idx_is_i64 == 0, int64 (the reference's `long`) otherwise.  dist2 (b,m,k) f32 is optional (NULL).
+ * Requires 1 <= k <= n; k <= PASNL_KNN_MAX_K. */
+#define PASNL_KNN_MAX_K 256
+int pasnl_knn_batch(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
+                    int idx_is_i64, float* dist2, pasnl_stream_t stream);
+
+/* ------------------------------------------------------- interpolation (tf_ops/3d_interpolation) */
+
+/* Three nearest known points, squared distances ascending, lowest index first on ties.
+ * replaces threenn_cpu  tf_interpolate.cpp:60-103
+ * xyz1 (b,n,3) unknown, xyz2 (b,m,3) known -> dist (b,n,3) f32, idx (b,n,3) i32 */
+int pasnl_three_nn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist, int* idx,
+                   pasnl_stream_t stream);
+
+/* out[b,j,l] = (p[i1,l]*w1 + p[i2,l]*w2) + p[i3,l]*w3.
+ * replaces threeinterpolate_cpu  tf_interpolate.cpp:107-127   (note the argument order b,m,c,n) */
+int pasnl_three_interpolate(int b, int m, int c, int n, const float* points, const int* idx, const float* weight,
+                            float* out, pasnl_stream_t stream);
+
+/* grad_points (b,m,c) = scatter-add; zeroed first.
+ * replaces memset + threeinterpolate_grad_cpu  tf_interpolate.cpp:258-259 (:131-153) */
+int pasnl_three_interpolate_grad(int b, int n, int c, int m, const float* grad_out, const int* idx,
+                                 const float* weight, float* grad_points, pasnl_stream_t stream);
+
+/* Inverse-distance weights for three_interpolate: d=max(d,1e-10); w=(1/d)/sum(1/d), in that order.
+ * replaces the four TF ops at pointasnl_util.py:308-311 / pointnet_util.py:212-215
+ * dist (rows,3) -> weight (rows,3) */
+int pasnl_three_weights(int rows, const float* dist, float* weight, pasnl_stream_t stream);
+
+/* ------------------------------------------------- PointASNL cells (utils/pointasnl_util.py) */
+
+/* Fused Point-NonLocal attention core, mode 'dot' (pointasnl_util.py:197-212):
+ *   out[b,i,:] = softmax_j( q[b,i,:] . k[b,j,:] / sqrt(cb) ) . v[b,j,:]
+ * q (b,p,cb); kv (b,n,2*cb) with K = kv[...,:cb], V = kv[...,cb:] exactly as conv_kv produces them
+ * (:193-194); out (b,p,cb).  The (b,p,n) attention map is never materialised.
+ * variant: 0 = auto, 1 = vector-FMA kernel, 2 = fp32 MFMA kernel.  cb must be a multiple of 32, <= 128. */
+int pasnl_nl_attention(int b, int p, int n, int cb, const float* q, const float* kv, float* out, int variant,
+                       pasnl_stream_t stream);
+
+/* Adaptive-Sampling micro self-attention over the first `as` neighbours of each query
+ * (SampleWeights, pointasnl_util.py:136-146):  g groups, each q,k,v (as,cb):
+ *   out[g,i,:] = softmax_j( q[g,i,:] . k[g,j,:] / sqrt(cb) ) . v[g,j,:]
+ * q (g,as,cb); kv (g,as,2*cb) (K first, V second, :133-134); out (g,as,cb).  as <= 16, cb <= 256. */
+int pasnl_as_attention(int g, int as, int cb, const float* q, const float* kv, float* out, pasnl_stream_t stream);
+
+/* AdaptiveSampling tail (pointasnl_util.py:154-155,167-171): softmax over the neighbour axis of
+ * logits (g,as,1+ch), then new_xyz[g,:] = sum_k w[g,k,0]*xyz[g,k,:] and
+ * new_feature[g,c] = sum_k w[g,k,1+c]*feat[g,k,c].
+ * xyz rows are taken from grouped_xyz (g,nsample,3) and feat from grouped_feature (g,nsample,ch):
+ * only the first `as` of `nsample` neighbours are read (the :165-166 slices). */
+int pasnl_as_reweight(int g, int as, int nsample, int ch, const float* logits, const float* grouped_xyz,
+                      const float* grouped_feature, float* new_xyz, float* new_feature, pasnl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PASNL_H_ */

@@ -1,0 +1,195 @@
+"""oracle -- CPU restatement of the reference's set-abstraction hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import this
+package; nothing under ``pointasnl_amd/`` does (tests/test_boundary.py greps for it).
+
+``oracle.ops``   numpy front-ends of oracle/pasnl_oracle.c (index/byte-exact ops)
+``oracle.cells`` numpy fp32/fp64 restatement of the AS / NL cells (utils/pointasnl_util.py:112-219)
+``oracle.ref``   the reference's own sources compiled into oracle/_ref (when built)
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "pasnl_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "_build/liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/tf_ops"):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = ctypes.CDLL(_LIB)
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class ops:
+    """numpy in, numpy out; argument order follows the reference's Python wrappers."""
+
+    @staticmethod
+    def set_threads(t):
+        lib().oracle_set_threads(ctypes.c_int(int(t)))
+
+    @staticmethod
+    def farthest_point_sample(npoint, inp):
+        inp = _f32(inp)
+        b, n, _ = inp.shape
+        out = np.zeros((b, npoint), np.int32)
+        lib().oracle_fps(b, n, int(npoint), _p(inp), _p(out))
+        return out
+
+    @staticmethod
+    def gather_point(inp, idx):
+        inp, idx = _f32(inp), _i32(idx)
+        b, n, _ = inp.shape
+        m = idx.shape[1]
+        out = np.zeros((b, m, 3), np.float32)
+        lib().oracle_gather_point(b, n, m, _p(inp), _p(idx), _p(out))
+        return out
+
+    @staticmethod
+    def gather_point_grad(inp, idx, out_g):
+        inp, idx, out_g = _f32(inp), _i32(idx), _f32(out_g)
+        b, n, _ = inp.shape
+        m = idx.shape[1]
+        g = np.zeros((b, n, 3), np.float32)
+        lib().oracle_gather_point_grad(b, n, m, _p(out_g), _p(idx), _p(g))
+        return g
+
+    @staticmethod
+    def cumsum(inp):
+        inp = _f32(inp)
+        b, n = inp.shape
+        out = np.zeros((b, n), np.float32)
+        lib().oracle_cumsum(b, n, _p(inp), _p(out))
+        return out
+
+    @staticmethod
+    def prob_sample(inp, inpr):
+        inp, inpr = _f32(inp), _f32(inpr)
+        b, n = inp.shape
+        m = inpr.shape[1]
+        temp = np.zeros((b, n), np.float32)
+        out = np.zeros((b, m), np.int32)
+        lib().oracle_prob_sample(b, n, m, _p(inp), _p(inpr), _p(temp), _p(out))
+        return out
+
+    @staticmethod
+    def query_ball_point(radius, nsample, xyz1, xyz2):
+        xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        idx = np.zeros((b, m, nsample), np.int32)
+        cnt = np.zeros((b, m), np.int32)
+        lib().oracle_query_ball_point(b, n, m, ctypes.c_float(radius), int(nsample), _p(xyz1), _p(xyz2), _p(idx), _p(cnt))
+        return idx, cnt
+
+    @staticmethod
+    def group_point(points, idx):
+        points, idx = _f32(points), _i32(idx)
+        b, n, c = points.shape
+        _, m, ns = idx.shape
+        out = np.zeros((b, m, ns, c), np.float32)
+        lib().oracle_group_point(b, n, c, m, ns, _p(points), _p(idx), _p(out))
+        return out
+
+    @staticmethod
+    def group_point_grad(points, idx, grad_out):
+        points, idx, grad_out = _f32(points), _i32(idx), _f32(grad_out)
+        b, n, c = points.shape
+        _, m, ns = idx.shape
+        g = np.zeros((b, n, c), np.float32)
+        lib().oracle_group_point_grad(b, n, c, m, ns, _p(grad_out), _p(idx), _p(g))
+        return g
+
+    @staticmethod
+    def select_top_k(k, dist):
+        dist = _f32(dist)
+        b, m, n = dist.shape
+        outi = np.zeros((b, m, n), np.int32)
+        out = np.zeros((b, m, n), np.float32)
+        lib().oracle_select_top_k(b, n, m, int(k), _p(dist), _p(outi), _p(out))
+        return outi, out
+
+    @staticmethod
+    def knn_point(k, xyz1, xyz2):
+        """tf_grouping.py:48-73: (b,m,n) squared distances by broadcasting, then selection sort."""
+        xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+        diff = xyz1[:, None, :, :] - xyz2[:, :, None, :]
+        sq = diff * diff
+        dist = sq[..., 0]
+        for c in range(1, sq.shape[-1]):  # tf.reduce_sum over the last axis, left to right
+            dist = dist + sq[..., c]
+        outi, out = ops.select_top_k(k, dist)
+        return out[:, :, :k].copy(), outi[:, :, :k].copy()
+
+    @staticmethod
+    def knn_batch(pts, queries, K, omp=False, return_dist=False):
+        pts, queries = _f32(pts), _f32(queries)
+        b, n, _ = pts.shape
+        m = queries.shape[1]
+        idx = np.zeros((b, m, K), np.int64)
+        d = np.zeros((b, m, K), np.float32)
+        lib().oracle_knn(b, n, m, int(K), _p(pts), _p(queries), _p(idx), _p(d))
+        return (idx, d) if return_dist else idx
+
+    @staticmethod
+    def three_nn(xyz1, xyz2):
+        xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        dist = np.zeros((b, n, 3), np.float32)
+        idx = np.zeros((b, n, 3), np.int32)
+        lib().oracle_three_nn(b, n, m, _p(xyz1), _p(xyz2), _p(dist), _p(idx))
+        return dist, idx
+
+    @staticmethod
+    def three_interpolate(points, idx, weight):
+        points, idx, weight = _f32(points), _i32(idx), _f32(weight)
+        b, m, c = points.shape
+        n = idx.shape[1]
+        out = np.zeros((b, n, c), np.float32)
+        lib().oracle_three_interpolate(b, m, c, n, _p(points), _p(idx), _p(weight), _p(out))
+        return out
+
+    @staticmethod
+    def three_interpolate_grad(points, idx, weight, grad_out):
+        points, idx, weight, grad_out = _f32(points), _i32(idx), _f32(weight), _f32(grad_out)
+        b, m, c = points.shape
+        n = idx.shape[1]
+        g = np.zeros((b, m, c), np.float32)
+        lib().oracle_three_interpolate_grad(b, n, c, m, _p(grad_out), _p(idx), _p(weight), _p(g))
+        return g
+
+    @staticmethod
+    def three_weights(dist):
+        dist = _f32(dist)
+        w = np.zeros_like(dist)
+        lib().oracle_three_weights(ctypes.c_long(dist.size // 3), _p(dist), _p(w))
+        return w

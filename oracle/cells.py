@@ -1,0 +1,157 @@
+"""oracle.cells -- numpy restatement of the PointASNL cells and of the classification graph around them.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED: the arithmetic of these cells lives in
+TensorFlow 1.13 core ops (tf.nn.conv2d, tf.matmul, tf.nn.softmax, tf.contrib.layers.batch_norm), an
+un-vendored dependency that is not installable here, and the reference holds no test or golden vector for
+them.  The restatement follows the reference call sites line by line (cited below), is
+evaluated in fp32 like the reference, and every test also evaluates it in fp64 as a cross-check; the
+tolerance against the HIP path is 1e-5.
+
+Weights are passed in as ``params``: a mapping  scope -> {"w": (cin,cout), "b": (cout,), and when the layer
+has batch norm "gamma","beta","mean","var"}  (utils/tf_util.py:120-185 conv2d = conv, bias, BN, activation;
+BN inference = gamma*(x-mean)/sqrt(var+1e-3)+beta, tf_util.py:527-531 with the contrib default epsilon).
+"""
+import numpy as np
+
+from . import ops
+
+BN_EPS = 1e-3
+
+
+def _layer(x, p, act):
+    """tf_util.conv2d / conv1d / fully_connected with a 1x1 kernel: matmul, bias, [BN], [activation]."""
+    dt = x.dtype
+    y = x @ p["w"].astype(dt) + p["b"].astype(dt)
+    if "gamma" in p:
+        y = (y - p["mean"].astype(dt)) / np.sqrt(p["var"].astype(dt) + dt.type(BN_EPS)) * p["gamma"].astype(dt) + p["beta"].astype(dt)
+    if act == "relu":
+        y = np.maximum(y, 0)
+    elif act == "sigmoid":
+        y = 1 / (1 + np.exp(-y))
+    return y
+
+
+def _softmax(x, axis):
+    m = x.max(axis=axis, keepdims=True)
+    e = np.exp(x - m)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def batched_gather(points, idx):
+    """tf.gather_nd with a leading batch index (pointasnl_util.py:43-49, 63-71): points (B,N,C), idx (B,...)"""
+    b = points.shape[0]
+    bi = np.arange(b).reshape((b,) + (1,) * (idx.ndim - 1))
+    return points[bi, idx]
+
+
+def sample_weights(new_point, grouped_xyz, mlps, params, scope):
+    """SampleWeights, pointasnl_util.py:112-156.  new_point (B,P,as,ch), grouped_xyz (B,P,as,3)."""
+    ch = new_point.shape[-1]
+    cb = max(32, ch // 2)  # :121
+    normalized_xyz = grouped_xyz - grouped_xyz[:, :, :1, :]  # :122
+    x = np.concatenate([normalized_xyz, new_point], axis=-1)  # :123
+    kv = _layer(x, params[scope + "/conv_kv_ds"], None)  # :125-129
+    q = _layer(x, params[scope + "/conv_query_ds"], None)  # :130-134
+    k, v = kv[..., :cb], kv[..., cb:]  # :136-137
+    w = q @ np.swapaxes(k, -1, -2)  # :139
+    w = w / np.sqrt(x.dtype.type(cb))  # :141
+    w = _softmax(w, -1)  # :142
+    g = w @ v  # :145
+    for i, _c in enumerate(mlps):  # :147-153
+        g = _layer(g, params[scope + "/mlp2_%d" % i], "relu" if i < len(mlps) - 1 else None)
+    return _softmax(g, 2)  # :154
+
+
+def adaptive_sampling(group_xyz, group_feature, num_neighbor, params, scope):
+    """AdaptiveSampling, pointasnl_util.py:158-173."""
+    if num_neighbor == 0:
+        return group_xyz[:, :, 0, :], group_feature[:, :, 0, :]
+    num_channel = group_feature.shape[-1]
+    sxyz = group_xyz[:, :, :num_neighbor, :]
+    sfeat = group_feature[:, :, :num_neighbor, :]
+    w = sample_weights(sfeat, sxyz, [32, 1 + num_channel], params, scope)
+    new_xyz = (sxyz * w[..., :1]).sum(axis=2)
+    new_feature = (sfeat * w[..., 1:]).sum(axis=2)
+    return new_xyz, new_feature
+
+
+def point_nonlocal_cell(feature, new_point, mlp, params, scope):
+    """PointNonLocalCell mode='dot', pointasnl_util.py:175-219.  feature (B,N,C), new_point (B,P,C')."""
+    cb = mlp[0]
+    kv = _layer(feature, params[scope + "/conv_kv"], None)  # :187-190
+    q = _layer(new_point, params[scope + "/conv_query"], None)  # :191-194
+    k, v = kv[..., :cb], kv[..., cb:]  # :196-197
+    att = q @ np.swapaxes(k, -1, -2)  # :199
+    att = att / np.sqrt(feature.dtype.type(cb))  # :201
+    att = _softmax(att, -1)  # :211
+    y = att @ v  # :212
+    return _layer(y, params[scope + "/conv_back_project"], "relu")  # :213-216 (conv2d default activation)
+
+
+def nl_attention_core(q, kv, cb):
+    """Just the part the fused HIP kernel computes: softmax(q k^T / sqrt(cb)) v."""
+    k, v = kv[..., :cb], kv[..., cb:]
+    att = q @ np.swapaxes(k, -1, -2) / np.sqrt(q.dtype.type(cb))
+    return _softmax(att, -1) @ v
+
+
+def knn_query(k, support, query):
+    """pointasnl_util.py:22-30"""
+    return ops.knn_batch(support, query, k, omp=True).astype(np.int32)
+
+
+def set_abstraction(xyz, feature, npoint, nsample, mlp, params, scope, as_neighbor=8, NL=True):
+    """PointASNLSetAbstraction, pointasnl_util.py:221-292 (use_knn=True, bn=True)."""
+    dt = feature.dtype
+    num_points, num_channel = feature.shape[1:]
+    if num_points == npoint:  # :236-240
+        new_xyz, new_feature = xyz, feature
+    else:
+        fps_idx = ops.farthest_point_sample(npoint, xyz.astype(np.float32))
+        new_xyz, new_feature = batched_gather(xyz, fps_idx), batched_gather(feature, fps_idx)
+    idx = knn_query(nsample, xyz.astype(np.float32), new_xyz.astype(np.float32))  # :242 -> :62
+    grouped_xyz = batched_gather(xyz, idx)
+    new_point = np.concatenate([grouped_xyz, batched_gather(feature, idx)], axis=-1)  # :71-74
+    if num_points != npoint:  # :246-247
+        new_xyz, new_feature = adaptive_sampling(grouped_xyz, new_point, as_neighbor, params, scope)
+    grouped_xyz = grouped_xyz - new_xyz[:, :, None, :]  # :248
+    new_point = np.concatenate([grouped_xyz, new_point], axis=-1)  # :249
+    if NL:  # :252-255
+        nonlocal_pt = point_nonlocal_cell(feature, new_feature, [max(32, num_channel // 2), mlp[-1]], params, scope)
+    skip = _layer(new_point.max(axis=2), params[scope + "/skip"], "relu")  # :258-261
+    for i in range(len(mlp) - 1):  # :264-269
+        new_point = _layer(new_point, params[scope + "/conv%d" % i], "relu")
+    weight = _layer(grouped_xyz, params[scope + "/weight_net/wconv0"], "relu")  # :272
+    new_point = np.swapaxes(new_point, 2, 3) @ weight  # :273-274  (B,P,C',32)
+    b, p = new_point.shape[:2]
+    # :275-278 conv2d with kernel [1, C'] over a (B,P,C',32) map == one matmul over the flattened (C',32) window
+    new_point = _layer(new_point.reshape(b, p, -1), params[scope + "/after_conv"], "relu")
+    new_point = new_point + skip  # :282
+    if NL:
+        new_point = new_point + nonlocal_pt  # :285
+    new_point = _layer(new_point, params[scope + "/aggregation"], "relu")  # :288-290
+    return new_xyz.astype(dt), new_point
+
+
+def sa_group_all(xyz, points, mlp, params, scope):
+    """pointnet_sa_module(group_all=True), utils/pointnet_util.py:59-84,109-125: concat xyz, MLP, max."""
+    x = np.concatenate([xyz, points], axis=2)
+    for i in range(len(mlp)):
+        x = _layer(x, params[scope + "/conv%d" % i], "relu")
+    return x.max(axis=1)
+
+
+def cls_forward(point_cloud, params, adaptive_sample=False, dtype=np.float32):
+    """models/pointasnl_cls.py:17-52, use_normal=False, inference (dropout = identity, tf_util.py:612-614)."""
+    pc = point_cloud.astype(dtype)
+    l0_xyz, l0_points = pc, pc
+    as_neighbor = [12, 12] if adaptive_sample else [0, 0]
+    l1_xyz, l1_points = set_abstraction(l0_xyz, l0_points, 512, 32, [64, 64, 128], params, "layer1", as_neighbor[0])
+    l2_xyz, l2_points = set_abstraction(l1_xyz, l1_points, 128, 64, [128, 128, 256], params, "layer2", as_neighbor[1])
+    res = sa_group_all(l1_xyz, l1_points, [128, 256, 512], params, "layer3_1")
+    top = sa_group_all(l2_xyz, l2_points, [256, 512, 1024], params, "layer3_2")
+    net = np.concatenate([top, res], axis=-1)
+    net = _layer(net, params["fc1"], "relu")
+    net = _layer(net, params["fc2"], "relu")
+    net = _layer(net, params["fc3"], None)
+    return net, {"l1_xyz": l1_xyz, "l2_xyz": l2_xyz, "l1_points": l1_points, "l2_points": l2_points}

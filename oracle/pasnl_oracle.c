@@ -1,0 +1,322 @@
+/*
+ * pasnl_oracle.c -- CPU restatement of the PointASNL set-abstraction native ops.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pointasnl_amd/ may import, link or call this file; it is the
+ * checker for tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py.
+ *
+ * Each function follows the reference algorithm it cites (paths relative to the reference tree) with the
+ * canonical arithmetic of SURVEY.md Appendix A: IEEE fp32, round-to-nearest, NO fused multiply-add,
+ * operations in the written order.  Build with -O2 -ffp-contract=off (oracle/Makefile).
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   knn, three_nn, three_interpolate(+grad)  -- checked against the reference's own C++ compiled from
+ *       /root/reference into oracle/_ref (tests/golden/make_golden.py, tests/test_oracle_ref.py);
+ *   fps, gather, ball query, group, selection sort, prob_sample -- the reference has GPU kernels only;
+ *       checked on the GPU box against the reference .cu files compiled unchanged by hipcc
+ *       (oracle/_ref/libref_tfops_hip.so, tests/test_gpu_ref_kernels.py).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define API __attribute__((visibility("default")))
+
+/* cpu_baseline only: OpenMP over the batch dimension (the reference's kNN does the same, knn_.cxx:108).
+ * 1 thread unless oracle_set_threads() is called; results do not depend on the thread count. */
+static int g_threads = 1;
+API void oracle_set_threads(int t) { g_threads = t > 0 ? t : 1; }
+#define OMP_BATCH _Pragma("omp parallel for schedule(dynamic) num_threads(g_threads) if (g_threads > 1)")
+
+static inline float sqdist(const float* a, const float* b) {
+  float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+/* ---- tf_ops/sampling/tf_sampling_g.cu:105-170 ------------------------------------------------------
+ * idx[0]=0, running distance starts at 1e38 (:119), each round takes min(d,temp) (:143) and picks the
+ * maximum.  The reference scans point k in CUDA thread (k mod 512), each thread keeping its FIRST
+ * strict maximum (:146), and the pairwise tree keeps the LOWER thread on equality (:158): the winner is
+ * the maximum with the smallest (k mod 512, k). */
+API void oracle_fps(int b, int n, int m, const float* xyz, int* idx) {
+  if (m <= 0) return; /* :106 */
+  OMP_BATCH
+  for (int i = 0; i < b; ++i) {
+    float* temp = (float*)malloc(sizeof(float) * (size_t)n);
+    const float* cloud = xyz + (size_t)i * n * 3;
+    int* out = idx + (size_t)i * m;
+    for (int k = 0; k < n; ++k) temp[k] = 1e38f;
+    int old = 0;
+    out[0] = 0;
+    for (int j = 1; j < m; ++j) {
+      float best = -1.0f;
+      int besti = 0, best_lane = 0x7fffffff;
+      for (int k = 0; k < n; ++k) {
+        float d = sqdist(cloud + 3 * k, cloud + 3 * old);
+        float d2 = fminf(d, temp[k]);
+        temp[k] = d2;
+        int lane = k & 511;
+        /* ascending k: a later k replaces only with a larger value or an equal value from a lower lane */
+        if (d2 > best || (d2 == best && lane < best_lane)) {
+          best = d2;
+          besti = k;
+          best_lane = lane;
+        }
+      }
+      old = besti;
+      out[j] = old;
+    }
+    free(temp);
+  }
+}
+
+/* ---- tf_sampling_g.cu:172-181 */
+API void oracle_gather_point(int b, int n, int m, const float* inp, const int* idx, float* out) {
+  for (int i = 0; i < b; ++i)
+    for (int j = 0; j < m; ++j) {
+      int a = idx[(size_t)i * m + j];
+      memcpy(out + ((size_t)i * m + j) * 3, inp + ((size_t)i * n + a) * 3, 3 * sizeof(float));
+    }
+}
+
+/* ---- tf_sampling_g.cu:183-192 (atomicAdd order is unspecified there; sequential here) */
+API void oracle_gather_point_grad(int b, int n, int m, const float* out_g, const int* idx, float* inp_g) {
+  memset(inp_g, 0, sizeof(float) * (size_t)b * n * 3); /* tf_sampling.cpp:174 */
+  for (int i = 0; i < b; ++i)
+    for (int j = 0; j < m; ++j) {
+      int a = idx[(size_t)i * m + j];
+      for (int c = 0; c < 3; ++c) inp_g[((size_t)i * n + a) * 3 + c] += out_g[((size_t)i * m + j) * 3 + c];
+    }
+}
+
+/* ---- tf_sampling_g.cu:7-88: blocked running sum.  Tiles of 8192; groups of four are summed as
+ * v2+=v1; v4+=v3; v3+=v2; v4+=v2 (:22-28); group totals go through an up-sweep/down-sweep tree (:46-67);
+ * element = in-group prefix + previous group's tree prefix (:69-76) + carry (:79); the carry is
+ * compensated (:81-84).  The padding offsets of the reference only dodge bank conflicts. */
+API void oracle_cumsum(int b, int n, const float* inp, float* out) {
+  enum { TILE = 8192, GROUPS = 2048 };
+  float* g4 = (float*)malloc(sizeof(float) * TILE);
+  float* tree = (float*)malloc(sizeof(float) * GROUPS);
+  for (int i = 0; i < b; ++i) {
+    const float* row = inp + (size_t)i * n;
+    float* orow = out + (size_t)i * n;
+    float runningsum = 0.f, runningsum2 = 0.f;
+    for (int j = 0; j < n; j += TILE) {
+      int len = n - j < TILE ? n - j : TILE;
+      int len4 = (len + 3) & ~3, n2 = len4 >> 2;
+      for (int g = 0; g < n2; ++g) {
+        int k = g * 4;
+        if (k + 3 < len) {
+          float v1 = row[j + k], v2 = row[j + k + 1], v3 = row[j + k + 2], v4 = row[j + k + 3];
+          v2 += v1; v4 += v3; v3 += v2; v4 += v2;
+          g4[k] = v1; g4[k + 1] = v2; g4[k + 2] = v3; g4[k + 3] = v4;
+          tree[g] = v4;
+        } else {
+          float v = 0.f;
+          for (int k2 = k; k2 < len; ++k2) { v += row[j + k2]; g4[k2] = v; }
+          for (int k2 = len; k2 < len4; ++k2) g4[k2] = v;
+          tree[g] = v;
+        }
+      }
+      int u = 0;
+      for (; (2 << u) <= n2; ++u)
+        for (int k = 0; k < (n2 >> (u + 1)); ++k) {
+          int i1 = (((k << 1) + 2) << u) - 1, i2 = (((k << 1) + 1) << u) - 1;
+          tree[i1] += tree[i2];
+        }
+      for (--u; u >= 0; --u)
+        for (int k = 0; k < ((n2 - (1 << u)) >> (u + 1)); ++k) {
+          int i1 = (((k << 1) + 3) << u) - 1, i2 = (((k << 1) + 2) << u) - 1;
+          tree[i1] += tree[i2];
+        }
+      for (int k = 0; k < len; ++k) {
+        float v = g4[k];
+        if (k >= 4) v += tree[(k >> 2) - 1];
+        orow[j + k] = v + runningsum;
+      }
+      float t = tree[n2 - 1] + runningsum2;
+      float r2 = runningsum + t;
+      runningsum2 = t - (r2 - runningsum);
+      runningsum = r2;
+    }
+  }
+  free(g4);
+  free(tree);
+}
+
+/* ---- tf_sampling_g.cu:90-104 + :198-201 */
+API void oracle_prob_sample(int b, int n, int m, const float* inp_p, const float* inp_r, float* temp, int* out) {
+  oracle_cumsum(b, n, inp_p, temp);
+  int base = 1;
+  while (base < n) base <<= 1;
+  for (int i = 0; i < b; ++i)
+    for (int j = 0; j < m; ++j) {
+      const float* c = temp + (size_t)i * n;
+      float q = inp_r[(size_t)i * m + j] * c[n - 1];
+      int r = n - 1;
+      for (int k = base; k >= 1; k >>= 1)
+        if (r >= k && c[r - k] >= q) r -= k;
+      out[(size_t)i * m + j] = r;
+    }
+}
+
+/* ---- tf_ops/grouping/tf_grouping_g.cu:3-36.  Zero-hit rows are left uninitialised by the reference
+ * (tf_grouping.cpp:88 allocate_output); defined as zeros here. */
+API void oracle_query_ball_point(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
+                                 int* idx, int* pts_cnt) {
+  OMP_BATCH
+  for (int i = 0; i < b; ++i)
+    for (int j = 0; j < m; ++j) {
+      const float* q = xyz2 + ((size_t)i * m + j) * 3;
+      int* o = idx + ((size_t)i * m + j) * nsample;
+      int cnt = 0;
+      for (int l = 0; l < nsample; ++l) o[l] = 0;
+      for (int k = 0; k < n && cnt < nsample; ++k) {
+        float d = fmaxf(sqrtf(sqdist(q, xyz1 + ((size_t)i * n + k) * 3)), 1e-20f);
+        if (d < radius) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) o[l] = k;
+          o[cnt++] = k;
+        }
+      }
+      pts_cnt[(size_t)i * m + j] = cnt;
+    }
+}
+
+/* ---- tf_grouping_g.cu:40-57 */
+API void oracle_group_point(int b, int n, int c, int m, int nsample, const float* points, const int* idx, float* out) {
+  OMP_BATCH
+  for (int i = 0; i < b; ++i)
+    for (long r = 0; r < (long)m * nsample; ++r) {
+      int a = idx[(size_t)i * m * nsample + r];
+      memcpy(out + ((size_t)i * m * nsample + r) * c, points + ((size_t)i * n + a) * c, sizeof(float) * c);
+    }
+}
+
+/* ---- tf_grouping_g.cu:61-78 (sequential accumulation) */
+API void oracle_group_point_grad(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx,
+                                 float* grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)b * n * c); /* tf_grouping.cpp:204 */
+  for (int i = 0; i < b; ++i)
+    for (long r = 0; r < (long)m * nsample; ++r) {
+      int a = idx[(size_t)i * m * nsample + r];
+      for (int l = 0; l < c; ++l)
+        grad_points[((size_t)i * n + a) * c + l] += grad_out[((size_t)i * m * nsample + r) * c + l];
+    }
+}
+
+/* ---- tf_grouping_g.cu:83-123: copy, then k rounds of "first strict minimum in [s,n), swap". */
+API void oracle_select_top_k(int b, int n, int m, int k, const float* dist, int* outi, float* out) {
+  for (long row = 0; row < (long)b * m; ++row) {
+    float* pd = out + row * n;
+    int* pi = outi + row * n;
+    for (int s = 0; s < n; ++s) { pd[s] = dist[row * n + s]; pi[s] = s; }
+    for (int s = 0; s < k && s < n; ++s) {
+      int mn = s;
+      for (int t = s + 1; t < n; ++t)
+        if (pd[t] < pd[mn]) mn = t;
+      if (mn != s) {
+        float tv = pd[mn]; pd[mn] = pd[s]; pd[s] = tv;
+        int ti = pi[mn]; pi[mn] = pi[s]; pi[s] = ti;
+      }
+    }
+  }
+}
+
+/* ---- utils/nearest_neighbors/knn_.cxx:72-135 through nanoflann (L2_Adaptor, nanoflann.hpp:343-346 for
+ * dim 3; KNNResultSet :79-145).  The KD-tree is an exact search, so the result is the K smallest
+ * squared distances in ascending order; nanoflann's order among EQUAL distances depends on the tree
+ * traversal, the canonical order here is ascending index.  Brute force + insertion into a
+ * sorted list, points visited in ascending index so equal distances stay in index order. */
+API void oracle_knn(int b, int n, int m, int k, const float* support, const float* queries, int64_t* idx, float* dist2) {
+  OMP_BATCH
+  for (int i = 0; i < b; ++i) {
+    float* bd = (float*)malloc(sizeof(float) * (size_t)k);
+    int64_t* bi = (int64_t*)malloc(sizeof(int64_t) * (size_t)k);
+    for (int j = 0; j < m; ++j) {
+      const float* q = queries + ((size_t)i * m + j) * 3;
+      int cnt = 0;
+      for (int p = 0; p < n; ++p) {
+        float d = sqdist(q, support + ((size_t)i * n + p) * 3);
+        if (cnt == k && !(d < bd[k - 1])) continue;
+        int pos = cnt < k ? cnt : k - 1;
+        while (pos > 0 && bd[pos - 1] > d) {
+          bd[pos] = bd[pos - 1];
+          bi[pos] = bi[pos - 1];
+          --pos;
+        }
+        bd[pos] = d;
+        bi[pos] = p;
+        if (cnt < k) ++cnt;
+      }
+      for (int s = 0; s < k; ++s) {
+        idx[((size_t)i * m + j) * k + s] = s < cnt ? bi[s] : 0;
+        if (dist2) dist2[((size_t)i * m + j) * k + s] = s < cnt ? bd[s] : INFINITY;
+      }
+    }
+    free(bd);
+    free(bi);
+  }
+}
+
+/* ---- tf_ops/3d_interpolation/tf_interpolate.cpp:60-103.  The reference evaluates the distance in float
+ * and compares it as double against best = 1e40 (:68,:73): identical to float compares against +inf. */
+API void oracle_three_nn(int b, int n, int m, const float* xyz1, const float* xyz2, float* dist, int* idx) {
+  OMP_BATCH
+  for (int i = 0; i < b; ++i)
+    for (int j = 0; j < n; ++j) {
+      const float* u = xyz1 + ((size_t)i * n + j) * 3;
+      float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+      int i1 = 0, i2 = 0, i3 = 0;
+      for (int k = 0; k < m; ++k) {
+        float d = sqdist(xyz2 + ((size_t)i * m + k) * 3, u);
+        if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+        else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+        else if (d < b3) { b3 = d; i3 = k; }
+      }
+      size_t o = ((size_t)i * n + j) * 3;
+      dist[o] = b1; dist[o + 1] = b2; dist[o + 2] = b3;
+      idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+    }
+}
+
+/* ---- tf_interpolate.cpp:107-127 */
+API void oracle_three_interpolate(int b, int m, int c, int n, const float* points, const int* idx, const float* weight,
+                                  float* out) {
+  OMP_BATCH
+  for (int i = 0; i < b; ++i)
+    for (int j = 0; j < n; ++j) {
+      size_t r = ((size_t)i * n + j) * 3;
+      const float* p1 = points + ((size_t)i * m + idx[r]) * c;
+      const float* p2 = points + ((size_t)i * m + idx[r + 1]) * c;
+      const float* p3 = points + ((size_t)i * m + idx[r + 2]) * c;
+      float w1 = weight[r], w2 = weight[r + 1], w3 = weight[r + 2];
+      float* o = out + ((size_t)i * n + j) * c;
+      for (int l = 0; l < c; ++l) o[l] = (p1[l] * w1 + p2[l] * w2) + p3[l] * w3;
+    }
+}
+
+/* ---- tf_interpolate.cpp:131-153 */
+API void oracle_three_interpolate_grad(int b, int n, int c, int m, const float* grad_out, const int* idx,
+                                       const float* weight, float* grad_points) {
+  memset(grad_points, 0, sizeof(float) * (size_t)b * m * c); /* :258 */
+  for (int i = 0; i < b; ++i)
+    for (int j = 0; j < n; ++j) {
+      size_t r = ((size_t)i * n + j) * 3;
+      const float* g = grad_out + ((size_t)i * n + j) * c;
+      for (int l = 0; l < c; ++l)
+        for (int t = 0; t < 3; ++t) grad_points[((size_t)i * m + idx[r + t]) * c + l] += g[l] * weight[r + t];
+    }
+}
+
+/* ---- utils/pointasnl_util.py:308-311 / utils/pointnet_util.py:212-215 */
+API void oracle_three_weights(long rows, const float* dist, float* weight) {
+  for (long r = 0; r < rows; ++r) {
+    float d0 = fmaxf(dist[r * 3], 1e-10f), d1 = fmaxf(dist[r * 3 + 1], 1e-10f), d2 = fmaxf(dist[r * 3 + 2], 1e-10f);
+    float r0 = 1.0f / d0, r1 = 1.0f / d1, r2 = 1.0f / d2;
+    float norm = (r0 + r1) + r2;
+    weight[r * 3] = r0 / norm;
+    weight[r * 3 + 1] = r1 / norm;
+    weight[r * 3 + 2] = r2 / norm;
+  }
+}

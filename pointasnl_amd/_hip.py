@@ -1,0 +1,80 @@
+"""ctypes binding of libpasnl_hip.so (include/pasnl.h) -- the only native code the product path runs.
+
+There is NO fallback: if the library is missing, or no HIP device is visible, every op raises.  Tensors are
+torch CUDA(ROCm) tensors used as plain device buffers; launches go to torch's current stream, so the ops
+compose with torch work and can be captured into a HIP graph (no allocation or sync happens inside the
+library).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpasnl_hip.so")
+
+# every symbol include/pasnl.h declares; tests/test_boundary.py checks the header and this list agree
+SYMBOLS = [
+    "pasnl_version", "pasnl_strerror", "pasnl_device_count",
+    "pasnl_farthest_point_sample", "pasnl_gather_point", "pasnl_gather_point_grad", "pasnl_prob_sample",
+    "pasnl_query_ball_point", "pasnl_group_point", "pasnl_group_point_grad", "pasnl_select_top_k", "pasnl_knn_batch",
+    "pasnl_three_nn", "pasnl_three_interpolate", "pasnl_three_interpolate_grad", "pasnl_three_weights",
+    "pasnl_nl_attention", "pasnl_as_attention", "pasnl_as_reweight",
+]
+
+
+class PasnlError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PasnlError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C pointasnl_amd/csrc`).  pointasnl_amd has no CPU or eager fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.pasnl_strerror.restype = ctypes.c_char_p
+        for s in SYMBOLS:
+            getattr(_lib, s)  # AttributeError here == header / library mismatch
+    return _lib
+
+
+def require_device():
+    if not torch.cuda.is_available():
+        raise PasnlError("no HIP device visible: pointasnl_amd runs on MI355X (gfx950) only and has no CPU fallback")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().pasnl_strerror(code).decode()
+        if code == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise PasnlError(f"{what}: {msg} (code {code})")
+
+
+def as_dev(x, dtype):
+    """Accept a torch tensor (must already live on the GPU) or a numpy array (host buffer: copied over PCIe)."""
+    require_device()
+    if isinstance(x, torch.Tensor):
+        if not x.is_cuda:
+            raise PasnlError("CPU torch tensor passed to a pointasnl_amd op: move it to the GPU (no CPU fallback)")
+        if x.dtype != dtype:
+            raise ValueError(f"expected dtype {dtype}, got {x.dtype}")
+        return x.contiguous()
+    import numpy as np
+
+    return torch.from_numpy(np.ascontiguousarray(x)).to(device="cuda", dtype=dtype)

@@ -1,0 +1,407 @@
+// PointASNL cells for gfx950: the attention cores of PointNonLocalCell and SampleWeights, and the
+// AdaptiveSampling re-weighting tail.  Behaviour contract: reference utils/pointasnl_util.py:112-219
+// (chains of separate TF ops that materialise the (B,P,N) attention map); restated in oracle/cells.py.
+// The 1x1 convolutions around these cores are plain GEMMs and stay with the vendor BLAS on the host side.
+//
+// fp32 in, fp32 out, tolerance 1e-5 against the fp32 oracle.  The matrix products run on the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact fp32 fmaf chains at the vector-FMA rate, which
+// leaves the VALU free for the softmax); a vector-FMA variant of the non-local kernel is kept so the
+// choice is measured, not assumed (bench.py --ops, profiles/).
+#include <math.h>
+#include "common.hpp"
+
+namespace pasnl {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// =============================================================================================
+// Non-local attention, MFMA variant ("swapped" flash form).
+//   A wave owns 32 queries.  For a sub-tile of 32 keys it forms S^T = K_tile . Q^T with cb/2
+//   32x32x2 MFMAs, so lane l holds, for ITS query (l & 31), the 16 keys kappa(r,h) =
+//   (r&3) + 8*(r>>2) + 4*h, h = l>>5: the softmax statistics of a query are 16 in-lane values plus
+//   one exchange with lane l^32 -- no transposes.  P^T is then already in B-operand position for
+//   O^T += V^T . P^T when MFMA step t is defined to contract key kappa(t,h): the A operand
+//   V[kappa(t,h)][c0 + (l&31)] is a conflict-free LDS row read.
+//   K rows are stored with stride CB+1 so that the A-operand read K[l&31][2t+h] is conflict-free.
+// =============================================================================================
+constexpr int NL_STAGE_KEYS = 64;  // keys staged in LDS per barrier pair
+
+template <int CB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void nl_attention_mfma_kernel(int p, int n, float qscale,
+                                                                     const float* __restrict__ q,
+                                                                     const float* __restrict__ kv,
+                                                                     float* __restrict__ out) {
+  constexpr int KS = CB + 1;  // padded K row stride
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Ks = reinterpret_cast<float*>(smem);  // [NL_STAGE_KEYS][KS]
+  // [NL_STAGE_KEYS][CB], rounded up to a 16-byte boundary for the float4 stores
+  float* Vs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(Ks + NL_STAGE_KEYS * KS) + 15) & ~uintptr_t(15));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, ql = lane & 31;
+  const int bi = blockIdx.y;
+  const int q0 = (blockIdx.x * WAVES + wave) * 32;
+  const int qi = min(q0 + ql, p - 1);
+  const float* kvb = kv + (size_t)bi * n * 2 * CB;
+
+  // Q as MFMA B operand: B[k = h][j = ql] = Q[q][2t+h] * (log2e / sqrt(cb))
+  float qreg[CB / 2];
+  {
+    const float* qp = q + ((size_t)bi * p + qi) * CB;
+#pragma unroll
+    for (int t = 0; t < CB / 2; ++t) qreg[t] = qp[2 * t + h] * qscale;
+  }
+  f32x16 O[CB / 32];
+#pragma unroll
+  for (int c = 0; c < CB / 32; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+
+  for (int base = 0; base < n; base += NL_STAGE_KEYS) {
+    const int cnt = min(NL_STAGE_KEYS, n - base);
+    __syncthreads();
+    // stage [K | V] rows; global reads are coalesced float4.  Rows past cnt (only in the last stage) are
+    // zero-filled up to the 32-key sub-tile boundary: their probabilities are 0, and 0 * stale-LDS-NaN must
+    // not reach the accumulator.
+    const int fill = min(NL_STAGE_KEYS, (cnt + 31) & ~31);
+    for (int f = tid; f < fill * (2 * CB / 4); f += WAVES * 64) {
+      int row = f / (2 * CB / 4), c4 = (f - row * (2 * CB / 4)) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < cnt) v = *reinterpret_cast<const float4*>(kvb + (size_t)(base + row) * 2 * CB + c4);
+      if (c4 < CB) {
+        float* d = Ks + row * KS + c4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      } else {
+        *reinterpret_cast<float4*>(Vs + row * CB + (c4 - CB)) = v;
+      }
+    }
+    __syncthreads();
+    for (int sub = 0; sub < cnt; sub += 32) {
+      // ---- S^T = K_sub . Q^T
+      f32x16 S;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = 0.f;
+      const float* krow = Ks + (sub + ql) * KS + h;  // rows beyond cnt hold stale data; masked below
+#pragma unroll
+      for (int t = 0; t < CB / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * t], qreg[t], S, 0, 0, 0);
+      // ---- online softmax over this lane's 16 keys (+ the other half-wave's 16)
+      const int valid = cnt - sub;  // keys kappa >= valid are padding
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int kap = (r & 3) + 8 * (r >> 2) + 4 * h;
+        S[r] = kap < valid ? S[r] : -INFINITY;
+        tmax = fmaxf(tmax, S[r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float mnew = fmaxf(mrun, tmax);  // finite: every sub-tile has >= 1 valid key
+      const float alpha = fast_exp2(mrun - mnew);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        S[r] = fast_exp2(S[r] - mnew);
+        psum += S[r];
+      }
+      psum += __shfl_xor(psum, 32);
+      lrun = lrun * alpha + psum;
+      mrun = mnew;
+      // ---- O^T = alpha * O^T + V^T . P^T
+#pragma unroll
+      for (int c = 0; c < CB / 32; ++c) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
+        const float* vcol = Vs + (size_t)sub * CB + c * 32 + ql;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          int kap = (t & 3) + 8 * (t >> 2) + 4 * h;
+          O[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[kap * CB], S[t], O[c], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // O^T[channel = c*32 + (r&3) + 8*(r>>2) + 4*h][query = ql] / l
+  if (q0 + ql < p) {
+    const float inv = 1.0f / lrun;
+    float* op = out + ((size_t)bi * p + q0 + ql) * CB;
+#pragma unroll
+    for (int c = 0; c < CB / 32; ++c)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(O[c][4 * g] * inv, O[c][4 * g + 1] * inv, O[c][4 * g + 2] * inv, O[c][4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + c * 32 + 8 * g + 4 * h) = v;
+      }
+  }
+}
+
+// =============================================================================================
+// Non-local attention, vector-FMA variant: one query per lane, K/V rows broadcast from LDS.
+// Kept for the MFMA-vs-FMA comparison (cb <= 64: q and the accumulator live in VGPRs).
+// =============================================================================================
+template <int CB, int TB>
+__global__ __launch_bounds__(TB) void nl_attention_valu_kernel(int p, int n, float qscale, const float* __restrict__ q,
+                                                               const float* __restrict__ kv, float* __restrict__ out) {
+  constexpr int TK = 64;
+  __shared__ float4 Ks[TK * CB / 4];
+  __shared__ float4 Vs[TK * CB / 4];
+  const int tid = threadIdx.x;
+  const int bi = blockIdx.y;
+  const int qi = blockIdx.x * TB + tid;
+  const bool ok = qi < p;
+  const float* qp = q + ((size_t)bi * p + (ok ? qi : p - 1)) * CB;
+  const float* kvb = kv + (size_t)bi * n * 2 * CB;
+  float qr[CB], acc[CB];
+#pragma unroll
+  for (int c = 0; c < CB; ++c) { qr[c] = qp[c] * qscale; acc[c] = 0.f; }
+  float mrun = -INFINITY, lrun = 0.f;
+  for (int base = 0; base < n; base += TK) {
+    const int cnt = min(TK, n - base);
+    __syncthreads();
+    for (int f = tid; f < cnt * (2 * CB / 4); f += TB) {
+      int row = f / (2 * CB / 4), c4 = f - row * (2 * CB / 4);
+      float4 v = *reinterpret_cast<const float4*>(kvb + (size_t)(base + row) * 2 * CB + c4 * 4);
+      if (c4 < CB / 4) Ks[row * (CB / 4) + c4] = v; else Vs[row * (CB / 4) + c4 - CB / 4] = v;
+    }
+    __syncthreads();
+    for (int j0 = 0; j0 < cnt; j0 += 4) {
+      float s[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        float a = 0.f;
+        int j = min(j0 + jj, cnt - 1);
+#pragma unroll
+        for (int c4 = 0; c4 < CB / 4; ++c4) {
+          float4 k4 = Ks[j * (CB / 4) + c4];
+          a = __builtin_fmaf(qr[4 * c4], k4.x, a);
+          a = __builtin_fmaf(qr[4 * c4 + 1], k4.y, a);
+          a = __builtin_fmaf(qr[4 * c4 + 2], k4.z, a);
+          a = __builtin_fmaf(qr[4 * c4 + 3], k4.w, a);
+        }
+        s[jj] = (j0 + jj < cnt) ? a : -INFINITY;
+      }
+      float mnew = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), mrun);
+      float alpha = fast_exp2(mrun - mnew);
+      mrun = mnew;
+      float pw[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) pw[jj] = fast_exp2(s[jj] - mnew);
+      lrun = lrun * alpha + ((pw[0] + pw[1]) + (pw[2] + pw[3]));
+#pragma unroll
+      for (int c = 0; c < CB; ++c) acc[c] *= alpha;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        int j = min(j0 + jj, cnt - 1);
+#pragma unroll
+        for (int c4 = 0; c4 < CB / 4; ++c4) {
+          float4 v4 = Vs[j * (CB / 4) + c4];
+          acc[4 * c4] = __builtin_fmaf(pw[jj], v4.x, acc[4 * c4]);
+          acc[4 * c4 + 1] = __builtin_fmaf(pw[jj], v4.y, acc[4 * c4 + 1]);
+          acc[4 * c4 + 2] = __builtin_fmaf(pw[jj], v4.z, acc[4 * c4 + 2]);
+          acc[4 * c4 + 3] = __builtin_fmaf(pw[jj], v4.w, acc[4 * c4 + 3]);
+        }
+      }
+    }
+  }
+  if (ok) {
+    float inv = 1.0f / lrun;
+    float* op = out + ((size_t)bi * p + qi) * CB;
+#pragma unroll
+    for (int c4 = 0; c4 < CB / 4; ++c4)
+      *reinterpret_cast<float4*>(op + 4 * c4) =
+          make_float4(acc[4 * c4] * inv, acc[4 * c4 + 1] * inv, acc[4 * c4 + 2] * inv, acc[4 * c4 + 3] * inv);
+  }
+}
+
+// =============================================================================================
+// Adaptive-Sampling micro attention: one wave per group, as <= 16 neighbours padded to a 16x16 tile,
+// v_mfma_f32_16x16x4_f32, operands straight from global memory (a group is a few KB, L2/L1 resident).
+//   S^T[key][query]:  D[row = 4*(l>>4)+r][col = l&15],   A = K[key = l&15][4t + (l>>4)],
+//                                                        B = Q[query = l&15][4t + (l>>4)]
+//   softmax over keys = 4 in-lane values + exchanges with lanes l^16, l^32
+//   O^T[ch][query] += V^T . P^T with step t contracting key 4*(l>>4)+t
+// =============================================================================================
+__global__ __launch_bounds__(256) void as_attention_kernel(long groups, int as, int cb, float qscale,
+                                                          const float* __restrict__ q, const float* __restrict__ kv,
+                                                          float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= groups) return;
+  const int col = lane & 15, grp = lane >> 4;
+  const float* qg = q + (size_t)g * as * cb;
+  const float* kg = kv + (size_t)g * as * 2 * cb;
+  const bool rowok = col < as;  // this lane's key row (as A operand) / query (as B operand) exists
+  f32x4 S = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < cb; c0 += 4) {
+    int c = c0 + grp;
+    bool okc = rowok && c < cb;
+    float a = okc ? kg[(size_t)col * 2 * cb + c] : 0.f;
+    float b = okc ? qg[(size_t)col * cb + c] * qscale : 0.f;
+    S = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, S, 0, 0, 0);
+  }
+  float tmax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    S[r] = (4 * grp + r) < as ? S[r] : -INFINITY;
+    tmax = fmaxf(tmax, S[r]);
+  }
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+  tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+  float psum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    S[r] = fast_exp2(S[r] - tmax);
+    psum += S[r];
+  }
+  psum += __shfl_xor(psum, 16);
+  psum += __shfl_xor(psum, 32);
+  const float inv = 1.0f / psum;
+  const float* vg = kg + cb;  // V = second half of each kv row
+  for (int c0 = 0; c0 < cb; c0 += 16) {
+    f32x4 O = {0.f, 0.f, 0.f, 0.f};
+    int ch = c0 + col;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int key = 4 * grp + t;
+      float a = (key < as && ch < cb) ? vg[(size_t)key * 2 * cb + ch] : 0.f;
+      O = __builtin_amdgcn_mfma_f32_16x16x4f32(a, S[t], O, 0, 0, 0);
+    }
+    // O^T[ch = c0 + 4*grp + r][query = col]
+    if (rowok) {
+      float* op = out + ((size_t)g * as + col) * cb + c0 + 4 * grp;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (c0 + 4 * grp + r < cb) op[r] = O[r] * inv;
+    }
+  }
+}
+
+// =============================================================================================
+// AdaptiveSampling tail: softmax over the neighbour axis, then the weighted sums.
+// One thread per (group, column) of the (1+ch)-wide logits; column 0 re-weights xyz.
+// =============================================================================================
+constexpr int AS_MAX = 16;
+__global__ __launch_bounds__(256) void as_reweight_kernel(long groups, int as, int nsample, int ch,
+                                                         const float* __restrict__ logits,
+                                                         const float* __restrict__ gxyz, const float* __restrict__ gfeat,
+                                                         float* __restrict__ new_xyz, float* __restrict__ new_feature) {
+  const int w = 1 + ch;
+  const long total = groups * w;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    long g = e / w;
+    int c = (int)(e - g * w);
+    float v[AS_MAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < AS_MAX; ++k) {
+      v[k] = k < as ? logits[((size_t)g * as + k) * w + c] : -INFINITY;
+      mx = fmaxf(mx, v[k]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < AS_MAX; ++k) {
+      v[k] = k < as ? expf(v[k] - mx) : 0.f;
+      sum += v[k];
+    }
+    if (c == 0) {
+      float ax = 0.f, ay = 0.f, az = 0.f;
+      const float* xp = gxyz + (size_t)g * nsample * 3;
+#pragma unroll
+      for (int k = 0; k < AS_MAX; ++k)
+        if (k < as) {
+          float wk = v[k] / sum;
+          ax += xp[k * 3] * wk; ay += xp[k * 3 + 1] * wk; az += xp[k * 3 + 2] * wk;
+        }
+      new_xyz[g * 3] = ax; new_xyz[g * 3 + 1] = ay; new_xyz[g * 3 + 2] = az;
+    } else {
+      float a = 0.f;
+      const float* fp = gfeat + (size_t)g * nsample * ch + (c - 1);
+#pragma unroll
+      for (int k = 0; k < AS_MAX; ++k)
+        if (k < as) a += fp[(size_t)k * ch] * (v[k] / sum);
+      new_feature[(size_t)g * ch + (c - 1)] = a;
+    }
+  }
+}
+
+}  // namespace pasnl
+
+using namespace pasnl;
+
+template <int CB, int WAVES>
+static int nl_mfma_launch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, hipStream_t st) {
+  size_t lds = (size_t)NL_STAGE_KEYS * (CB + 1) * 4 + 16 + (size_t)NL_STAGE_KEYS * CB * 4;
+  auto kern = nl_attention_mfma_kernel<CB, WAVES>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  int qpb = WAVES * 32;
+  hipLaunchKernelGGL(kern, dim3((p + qpb - 1) / qpb, b), dim3(WAVES * 64), lds, st, p, n, qscale, q, kv, out);
+  return pasnl_launch_status();
+}
+
+template <int CB>
+static int nl_mfma_dispatch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, hipStream_t st) {
+  // fill the 256 CUs: fewer waves per workgroup when there are few query tiles
+  long tiles = (long)b * ((p + 31) / 32);
+  if (tiles >= 4 * 512) return nl_mfma_launch<CB, 4>(b, p, n, qscale, q, kv, out, st);
+  if (tiles >= 2 * 512) return nl_mfma_launch<CB, 2>(b, p, n, qscale, q, kv, out, st);
+  return nl_mfma_launch<CB, 1>(b, p, n, qscale, q, kv, out, st);
+}
+
+template <int CB>
+static int nl_valu_launch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, hipStream_t st) {
+  hipLaunchKernelGGL((nl_attention_valu_kernel<CB, 64>), dim3((p + 63) / 64, b), dim3(64), 0, st, p, n, qscale, q, kv, out);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_nl_attention(int b, int p, int n, int cb, const float* q, const float* kv, float* out, int variant,
+                                  pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && p >= 0 && n > 0 && cb > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(variant >= 0 && variant <= 2, PASNL_EINVAL);
+  PASNL_REQUIRE(cb == 32 || cb == 64 || cb == 128, PASNL_EUNSUPPORTED);
+  if (b == 0 || p == 0) return PASNL_OK;
+  PASNL_REQUIRE(q && kv && out, PASNL_ENULL);
+  PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE(((reinterpret_cast<uintptr_t>(kv) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, PASNL_EINVAL);
+  hipStream_t st = pasnl_hip_stream(stream);
+  // scores are kept in the log2 domain: exp(x/sqrt(cb) - m) == exp2((x*log2e/sqrt(cb)) - m')
+  const float qscale = LOG2E / sqrtf((float)cb);
+  if (variant == 1) {
+    if (cb == 32) return nl_valu_launch<32>(b, p, n, qscale, q, kv, out, st);
+    if (cb == 64) return nl_valu_launch<64>(b, p, n, qscale, q, kv, out, st);
+    return PASNL_EUNSUPPORTED;  // cb=128 does not fit the one-query-per-lane register budget
+  }
+  if (cb == 32) return nl_mfma_dispatch<32>(b, p, n, qscale, q, kv, out, st);
+  if (cb == 64) return nl_mfma_dispatch<64>(b, p, n, qscale, q, kv, out, st);
+  return nl_mfma_dispatch<128>(b, p, n, qscale, q, kv, out, st);
+}
+
+extern "C" int pasnl_as_attention(int g, int as, int cb, const float* q, const float* kv, float* out,
+                                  pasnl_stream_t stream) {
+  PASNL_REQUIRE(g >= 0 && as > 0 && cb > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(as <= 16 && cb <= 256, PASNL_EUNSUPPORTED);
+  if (g == 0) return PASNL_OK;
+  PASNL_REQUIRE(q && kv && out, PASNL_ENULL);
+  const float qscale = LOG2E / sqrtf((float)cb);
+  hipLaunchKernelGGL(as_attention_kernel, dim3((unsigned)(((long)g + 3) / 4)), dim3(256), 0, pasnl_hip_stream(stream), (long)g,
+                     as, cb, qscale, q, kv, out);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_as_reweight(int g, int as, int nsample, int ch, const float* logits, const float* grouped_xyz,
+                                 const float* grouped_feature, float* new_xyz, float* new_feature, pasnl_stream_t stream) {
+  PASNL_REQUIRE(g >= 0 && as > 0 && nsample >= as && ch > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(as <= AS_MAX, PASNL_EUNSUPPORTED);
+  if (g == 0) return PASNL_OK;
+  PASNL_REQUIRE(logits && grouped_xyz && grouped_feature && new_xyz && new_feature, PASNL_ENULL);
+  long total = (long)g * (1 + ch);
+  long grid = (total + 255) / 256;
+  hipLaunchKernelGGL(as_reweight_kernel, dim3((unsigned)(grid > 16384 ? 16384 : grid)), dim3(256), 0, pasnl_hip_stream(stream),
+                     (long)g, as, nsample, ch, logits, grouped_xyz, grouped_feature, new_xyz, new_feature);
+  return pasnl_launch_status();
+}

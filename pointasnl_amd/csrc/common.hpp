@@ -1,0 +1,76 @@
+// Shared device/host helpers for libpasnl_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pasnl.h"
+
+#define PASNL_WAVE 64
+
+#define PASNL_REQUIRE(cond, code) \
+  do {                            \
+    if (!(cond)) return (code);   \
+  } while (0)
+
+// Launch epilogue: the reference launchers never check errors; this ABI does.
+static inline int pasnl_launch_status() { return hipGetLastError() == hipSuccess ? PASNL_OK : PASNL_ELAUNCH; }
+
+static inline hipStream_t pasnl_hip_stream(pasnl_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+namespace pasnl {
+
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// DPP controls (GFX9 encoding).
+constexpr int DPP_ROW_SHR1 = 0x111;
+constexpr int DPP_ROW_SHR2 = 0x112;
+constexpr int DPP_ROW_SHR4 = 0x114;
+constexpr int DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142;
+constexpr int DPP_ROW_BCAST31 = 0x143;
+constexpr int DPP_WAVE_SHR1 = 0x138;
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t keep, uint32_t src) {
+  // lanes whose DPP source is invalid or masked keep `keep`
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)keep, (int)src, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// Wave-wide maximum of an unsigned 64-bit key; result is wave-uniform (taken from lane 63).
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#define PASNL_STEP(CTRL, RM)                                            \
+  {                                                                     \
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);                \
+    uint32_t olo = dpp_u32<CTRL, RM>(lo, lo);                           \
+    uint32_t ohi = dpp_u32<CTRL, RM>(hi, hi);                           \
+    uint64_t o = ((uint64_t)ohi << 32) | olo;                           \
+    v = o > v ? o : v;                                                  \
+  }
+  PASNL_STEP(DPP_ROW_SHR1, 0xf)
+  PASNL_STEP(DPP_ROW_SHR2, 0xf)
+  PASNL_STEP(DPP_ROW_SHR4, 0xf)
+  PASNL_STEP(DPP_ROW_SHR8, 0xf)
+  PASNL_STEP(DPP_ROW_BCAST15, 0xa)
+  PASNL_STEP(DPP_ROW_BCAST31, 0xc)
+#undef PASNL_STEP
+  uint32_t lo = __builtin_amdgcn_readlane((int)(uint32_t)v, 63);
+  uint32_t hi = __builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// value of lane-1 (lane 0 keeps its own); the in-wave "shift the sorted list up by one" primitive.
+__device__ __forceinline__ float wave_shr1_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), DPP_WAVE_SHR1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int wave_shr1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
+
+// Canonical squared distance: ((dx*dx)+(dy*dy))+(dz*dz), no contraction.
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
+  float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return (dx * dx + dy * dy) + dz * dz;
+}
+
+}  // namespace pasnl

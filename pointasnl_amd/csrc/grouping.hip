@@ -1,0 +1,410 @@
+// Grouping ops for gfx950: ball query, group (+grad), selection-sort top-k, exact batched kNN.
+// Behaviour contract: reference tf_ops/grouping/tf_grouping_g.cu (:3-123) and
+// utils/nearest_neighbors/knn_.cxx:72-135; restated in oracle/.
+//
+// Shared shape of the two search kernels (ball query, kNN): a workgroup of 4 waves works on QPB
+// queries of ONE cloud; the cloud streams through LDS in tiles (coalesced flat loads of the AoS
+// (n,3) array, stored as x|y|z planes so that lane l reads point base+l conflict-free); ONE WAVE
+// OWNS ONE QUERY at a time and looks at 64 points per step, so "first nsample in index order" and
+// "sorted by (distance, index)" both fall out of lane order + ballot/popcount, never from atomics.
+#include <math.h>
+#include "common.hpp"
+
+namespace pasnl {
+
+constexpr int SEARCH_TILE = 2048;  // points per LDS tile (24 KiB)
+constexpr int SEARCH_WAVES = 4;
+
+__device__ __forceinline__ void stage_tile(const float* __restrict__ cloud, int n, int base, int cnt, float* sx, float* sy,
+                                           float* sz) {
+  // flat coalesced copy of `cnt` points starting at point `base`
+  const float* src = cloud + (size_t)base * 3;
+  for (int f = threadIdx.x; f < cnt * 3; f += SEARCH_WAVES * 64) {
+    float v = src[f];
+    int p = f / 3, c = f - p * 3;
+    (c == 0 ? sx : (c == 1 ? sy : sz))[p] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ball query.  `thr2` is the smallest float t with sqrtf(t) >= radius (computed on the host), so
+// "max(sqrtf(d2),1e-20f) < radius" == "d2 < thr2" bit-for-bit without a per-pair square root.
+// QW queries per wave, processed one after another inside each tile; per-query state that must
+// survive a tile boundary (count, first hit) lives in registers, the hit list in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int QW>
+__global__ __launch_bounds__(SEARCH_WAVES * 64) void ball_query_kernel(int n, int m, float thr2, int nsample,
+                                                                      const float* __restrict__ xyz1,
+                                                                      const float* __restrict__ xyz2,
+                                                                      int* __restrict__ idx, int* __restrict__ pts_cnt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sx = reinterpret_cast<float*>(smem);
+  float* sy = sx + SEARCH_TILE;
+  float* sz = sy + SEARCH_TILE;
+  int* hits = reinterpret_cast<int*>(sz + SEARCH_TILE);  // [SEARCH_WAVES*QW][nsample]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bi = blockIdx.y;
+  const float* cloud = xyz1 + (size_t)bi * n * 3;
+  const int q0 = (blockIdx.x * SEARCH_WAVES + wave) * QW;
+
+  float qx[QW], qy[QW], qz[QW];
+  int cnt[QW], first[QW];
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    int j = q0 + q;
+    bool ok = j < m;
+    const float* p = xyz2 + ((size_t)bi * m + (ok ? j : 0)) * 3;
+    qx[q] = p[0]; qy[q] = p[1]; qz[q] = p[2];
+    cnt[q] = ok ? 0 : nsample;  // out-of-range queries are born finished
+    first[q] = 0;
+  }
+
+  for (int base = 0; base < n; base += SEARCH_TILE) {
+    int tcnt = min(SEARCH_TILE, n - base);
+    __syncthreads();
+    stage_tile(cloud, n, base, tcnt, sx, sy, sz);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+      int c = cnt[q];
+      if (c >= nsample) continue;  // wave-uniform
+      int* hq = hits + (size_t)(wave * QW + q) * nsample;
+      for (int it = 0; it < tcnt; it += 64) {
+        int p = it + lane;
+        bool in = p < tcnt;
+        float d2 = dist2(qx[q], qy[q], qz[q], in ? sx[p] : 0.f, in ? sy[p] : 0.f, in ? sz[p] : 0.f);
+        bool hit = in && (d2 < thr2);
+        unsigned long long mask = __ballot(hit);
+        if (mask) {
+          if (c == 0) first[q] = base + it + (int)__builtin_ctzll(mask);
+          int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+          int slot = c + rank;
+          if (hit && slot < nsample) hq[slot] = base + it + lane;
+          c += (int)__builtin_popcountll(mask);
+          if (c >= nsample) { c = nsample; break; }
+        }
+      }
+      cnt[q] = c;
+    }
+  }
+  // emit: hits in index order, then the first hit as padding; zero-hit rows -> 0
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    int j = q0 + q;
+    if (j >= m) continue;
+    const int* hq = hits + (size_t)(wave * QW + q) * nsample;
+    int* o = idx + ((size_t)bi * m + j) * nsample;
+    int c = cnt[q], pad = c > 0 ? first[q] : 0;
+    for (int s = lane; s < nsample; s += 64) o[s] = s < c ? hq[s] : pad;
+    if (lane == 0) pts_cnt[(size_t)bi * m + j] = c;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact kNN, K <= 64*SLOTS.  The running result of a query is a list sorted ascending by
+// (d, index) spread over the wave: lane l, slot s holds rank s*64 + l.  Points are visited in
+// ascending index, so a candidate enters iff d < tau (tau = current K-th distance): an equal
+// distance with a larger index never displaces.  Insertion = ballot-count of list entries <= d
+// (its rank), DPP shift of the tail by one lane, write.  Output order is therefore exactly
+// (distance, index) ascending.
+// ---------------------------------------------------------------------------------------------
+template <int SLOTS>
+struct KnnList {
+  float d[SLOTS];
+  int i[SLOTS];
+};
+
+template <int SLOTS>
+__device__ __forceinline__ void knn_insert(KnnList<SLOTS>& L, float cd, int ck, int lane) {
+  // rank of the candidate = number of entries with d <= cd (all of those have smaller indices)
+  int pos = 0;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) pos += (int)__builtin_popcountll(__ballot(L.d[s] <= cd));
+  // shift entries at rank >= pos up by one; entry 63 of slot s carries into entry 0 of slot s+1
+  float carry_d = 0.f;
+  int carry_i = 0;
+#pragma unroll
+  for (int s = 0; s < SLOTS; ++s) {
+    float top_d = readlane_f(L.d[s], 63);
+    int top_i = __builtin_amdgcn_readlane(L.i[s], 63);
+    float sd = wave_shr1_f(L.d[s]);
+    int si = wave_shr1_i(L.i[s]);
+    if (lane == 0) { sd = carry_d; si = carry_i; }
+    int r = s * 64 + lane;
+    if (r > pos) { L.d[s] = sd; L.i[s] = si; }
+    if (r == pos) { L.d[s] = cd; L.i[s] = ck; }
+    carry_d = top_d;
+    carry_i = top_i;
+  }
+}
+
+template <int SLOTS, int QW, typename IdxT>
+__global__ __launch_bounds__(SEARCH_WAVES * 64) void knn_kernel(int n, int m, int k, const float* __restrict__ support,
+                                                               const float* __restrict__ queries, IdxT* __restrict__ idx,
+                                                               float* __restrict__ dist_out) {
+  __shared__ float sx[SEARCH_TILE], sy[SEARCH_TILE], sz[SEARCH_TILE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bi = blockIdx.y;
+  const float* cloud = support + (size_t)bi * n * 3;
+  const int q0 = (blockIdx.x * SEARCH_WAVES + wave) * QW;
+
+  float qx[QW], qy[QW], qz[QW], tau[QW];
+  KnnList<SLOTS> L[QW];
+  const int ks = (k - 1) >> 6, kl = (k - 1) & 63;  // slot / lane of the K-th entry
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    int j = min(q0 + q, m - 1);
+    const float* p = queries + ((size_t)bi * m + j) * 3;
+    qx[q] = p[0]; qy[q] = p[1]; qz[q] = p[2];
+    tau[q] = INFINITY;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) { L[q].d[s] = INFINITY; L[q].i[s] = 0; }
+  }
+
+  for (int base = 0; base < n; base += SEARCH_TILE) {
+    int tcnt = min(SEARCH_TILE, n - base);
+    __syncthreads();
+    stage_tile(cloud, n, base, tcnt, sx, sy, sz);
+    __syncthreads();
+    for (int it = 0; it < tcnt; it += 64) {
+      int p = it + lane;
+      bool in = p < tcnt;
+      float x = in ? sx[p] : 0.f, y = in ? sy[p] : 0.f, z = in ? sz[p] : 0.f;
+#pragma unroll
+      for (int q = 0; q < QW; ++q) {
+        float d = dist2(qx[q], qy[q], qz[q], x, y, z);
+        unsigned long long mask = __ballot(in && d < tau[q]);
+        while (mask) {
+          int src = (int)__builtin_ctzll(mask);
+          mask &= mask - 1;
+          float cd = readlane_f(d, src);
+          if (cd < tau[q]) {  // tau may have dropped since the ballot
+            knn_insert<SLOTS>(L[q], cd, base + it + src, lane);
+            float t = INFINITY;
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+              if (s == ks) t = readlane_f(L[q].d[s], kl);
+            tau[q] = t;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    int j = q0 + q;
+    if (j >= m) continue;
+    size_t o = ((size_t)bi * m + j) * k;
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+      int r = s * 64 + lane;
+      if (r < k) {
+        idx[o + r] = (IdxT)L[q].i[s];
+        if (dist_out) dist_out[o + r] = L[q].d[s];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// group_point: out row r=(b,j,k) <- points[b, idx[r], :].  VEC floats per thread.
+// ---------------------------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void group_point_kernel(int n, int c, long rows_per_batch, long total_chunks,
+                                                         const float* __restrict__ points, const int* __restrict__ idx,
+                                                         float* __restrict__ out) {
+  const int cpr = c / VEC;  // chunks per row
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total_chunks; g += (long)gridDim.x * 256) {
+    long row = g / cpr;
+    int ch = (int)(g - row * cpr);
+    long bi = row / rows_per_batch;
+    int a = idx[row];
+    const float* src = points + ((size_t)bi * n + a) * c + (size_t)ch * VEC;
+    float* dst = out + (size_t)row * c + (size_t)ch * VEC;
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+    } else {
+      *dst = *src;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void group_point_grad_kernel(int n, int c, long rows_per_batch, long total,
+                                                              const float* __restrict__ grad_out,
+                                                              const int* __restrict__ idx, float* __restrict__ grad_points) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    long row = e / c;
+    int l = (int)(e - row * c);
+    long bi = row / rows_per_batch;
+    int a = idx[row];
+    atomicAdd(&grad_points[((size_t)bi * n + a) * c + l], grad_out[e]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// select_top_k: one wave per (b,m) row; k rounds of "first strict minimum of the current row in
+// [s,n), swap with position s" (tf_grouping_g.cu:100-121), on the output arrays in global memory.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void select_top_k_kernel(int n, int k, long rows, const float* __restrict__ dist,
+                                                          int* __restrict__ outi, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* src = dist + (size_t)row * n;
+  float* pd = out + (size_t)row * n;
+  int* pi = outi + (size_t)row * n;
+  for (int s = lane; s < n; s += 64) { pd[s] = src[s]; pi[s] = s; }
+  // Lane 0 rewrites two elements per round and other lanes must see them in the next round: stores are
+  // drained (write-through to this XCD's L2) and the row is re-read with agent-scope loads that bypass the
+  // CU's L1.  Only this wave ever touches the row.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int s = 0; s < k && s < n; ++s) {
+    // (value, position) lexicographic minimum over [s, n): strict '<' scanning upward == lowest position on ties
+    float bv = INFINITY;
+    int bp = 0x7fffffff;
+    for (int t = s + lane; t < n; t += 64) {
+      float v = __hip_atomic_load(&pd[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v < bv) { bv = v; bp = t; }  // t ascending inside a lane
+    }
+    // NaN-free total order on (bv, bp): smaller value, then smaller position
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      float ov = __shfl_xor(bv, off);
+      int op = __shfl_xor(bp, off);
+      if (ov < bv || (ov == bv && op < bp)) { bv = ov; bp = op; }
+    }
+    // the reference starts with min = s and only moves on a strict '<': if nothing in (s,n) is smaller
+    // than pd[s], position s stays.  The lexicographic minimum above returns s in that case as well
+    // unless every value is +inf/NaN (bp stays 0x7fffffff) -> no swap.
+    int mn = (bp == 0x7fffffff) ? s : bp;
+    if (mn != s && lane == 0) {
+      float vs = __hip_atomic_load(&pd[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int is = __hip_atomic_load(&pi[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int im = __hip_atomic_load(&pi[mn], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&pd[mn], vs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&pd[s], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&pi[mn], is, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&pi[s], im, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+}  // namespace pasnl
+
+using namespace pasnl;
+
+static int grid_for(long total) {
+  long g = (total + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// smallest float t such that sqrtf(t) >= r  (r > 0): then sqrtf(d) < r  <=>  d < t for every float d >= 0
+static float ball_threshold(float r) {
+  float t = r * r;
+  if (!(t < INFINITY)) return INFINITY;
+  while (sqrtf(t) >= r && t > 0.f) t = nextafterf(t, -INFINITY);  // now sqrtf(t) < r (or t == 0)
+  while (sqrtf(t) < r) t = nextafterf(t, INFINITY);
+  return t;
+}
+
+extern "C" int pasnl_query_ball_point(int b, int n, int m, float radius, int nsample, const float* xyz1, const float* xyz2,
+                                      int* idx, int* pts_cnt, pasnl_stream_t stream) {
+  PASNL_REQUIRE(radius > 0.f, PASNL_EINVAL);  // "QueryBallPoint expects positive radius"
+  PASNL_REQUIRE(nsample > 0, PASNL_EINVAL);   // "QueryBallPoint expects positive nsample"
+  PASNL_REQUIRE(b >= 0 && n > 0 && m >= 0, PASNL_EINVAL);
+  if (b == 0 || m == 0) return PASNL_OK;
+  PASNL_REQUIRE(xyz1 && xyz2 && idx && pts_cnt, PASNL_ENULL);
+  PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
+  constexpr int QW = 4;
+  size_t lds = (size_t)SEARCH_TILE * 12 + (size_t)SEARCH_WAVES * QW * nsample * sizeof(int);
+  PASNL_REQUIRE(lds <= 160 * 1024, PASNL_EUNSUPPORTED);
+  // max(sqrtf(d2),1e-20f) < radius: for radius <= 1e-20f nothing can hit -> threshold 0 (d2 < 0 never true)
+  float thr2 = (radius > 1e-20f) ? ball_threshold(radius) : 0.f;
+  auto kern = ball_query_kernel<QW>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  int qpb = SEARCH_WAVES * QW;
+  hipLaunchKernelGGL(kern, dim3((m + qpb - 1) / qpb, b), dim3(SEARCH_WAVES * 64), lds, pasnl_hip_stream(stream), n, m, thr2,
+                     nsample, xyz1, xyz2, idx, pts_cnt);
+  return pasnl_launch_status();
+}
+
+template <int SLOTS, int QW>
+static int knn_launch(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
+                      float* dist2, hipStream_t st) {
+  int qpb = SEARCH_WAVES * QW;
+  dim3 grid((m + qpb - 1) / qpb, b), block(SEARCH_WAVES * 64);
+  if (idx_is_i64)
+    hipLaunchKernelGGL((knn_kernel<SLOTS, QW, long long>), grid, block, 0, st, n, m, k, support, queries,
+                       static_cast<long long*>(idx), dist2);
+  else
+    hipLaunchKernelGGL((knn_kernel<SLOTS, QW, int>), grid, block, 0, st, n, m, k, support, queries, static_cast<int*>(idx),
+                       dist2);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_knn_batch(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
+                               int idx_is_i64, float* dist2, pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && m >= 0 && k > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(k <= n, PASNL_EINVAL);  // nanoflann leaves slots uninitialised when K > npts; refuse instead
+  PASNL_REQUIRE(k <= PASNL_KNN_MAX_K, PASNL_EUNSUPPORTED);
+  if (b == 0 || m == 0) return PASNL_OK;
+  PASNL_REQUIRE(support && queries && idx, PASNL_ENULL);
+  PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
+  hipStream_t st = pasnl_hip_stream(stream);
+  if (k <= 64) return knn_launch<1, 4>(b, n, m, k, support, queries, idx, idx_is_i64, dist2, st);
+  if (k <= 128) return knn_launch<2, 2>(b, n, m, k, support, queries, idx, idx_is_i64, dist2, st);
+  return knn_launch<4, 1>(b, n, m, k, support, queries, idx, idx_is_i64, dist2, st);
+}
+
+extern "C" int pasnl_group_point(int b, int n, int c, int m, int nsample, const float* points, const int* idx, float* out,
+                                 pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && m >= 0 && nsample >= 0, PASNL_EINVAL);
+  long rows_per_batch = (long)m * nsample;
+  long rows = (long)b * rows_per_batch;
+  if (rows == 0) return PASNL_OK;
+  PASNL_REQUIRE(points && idx && out, PASNL_ENULL);
+  hipStream_t st = pasnl_hip_stream(stream);
+  bool vec4 = (c % 4 == 0) && ((reinterpret_cast<uintptr_t>(points) | reinterpret_cast<uintptr_t>(out)) % 16 == 0);
+  if (vec4) {
+    long chunks = rows * (c / 4);
+    hipLaunchKernelGGL(group_point_kernel<4>, dim3(grid_for(chunks)), dim3(256), 0, st, n, c, rows_per_batch, chunks, points,
+                       idx, out);
+  } else {
+    long chunks = rows * c;
+    hipLaunchKernelGGL(group_point_kernel<1>, dim3(grid_for(chunks)), dim3(256), 0, st, n, c, rows_per_batch, chunks, points,
+                       idx, out);
+  }
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_group_point_grad(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx,
+                                      float* grad_points, pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && m >= 0 && nsample >= 0, PASNL_EINVAL);
+  if (b == 0) return PASNL_OK;
+  PASNL_REQUIRE(grad_points, PASNL_ENULL);
+  hipStream_t st = pasnl_hip_stream(stream);
+  if (hipMemsetAsync(grad_points, 0, (size_t)b * n * c * sizeof(float), st) != hipSuccess) return PASNL_ELAUNCH;
+  long rows_per_batch = (long)m * nsample;
+  long total = (long)b * rows_per_batch * c;
+  if (total == 0) return PASNL_OK;
+  PASNL_REQUIRE(grad_out && idx, PASNL_ENULL);
+  hipLaunchKernelGGL(group_point_grad_kernel, dim3(grid_for(total)), dim3(256), 0, st, n, c, rows_per_batch, total, grad_out,
+                     idx, grad_points);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_select_top_k(int b, int n, int m, int k, const float* dist, int* outi, float* out,
+                                  pasnl_stream_t stream) {
+  PASNL_REQUIRE(k > 0, PASNL_EINVAL);  // "SelectionSort expects positive k"
+  PASNL_REQUIRE(b >= 0 && n > 0 && m >= 0, PASNL_EINVAL);
+  long rows = (long)b * m;
+  if (rows == 0) return PASNL_OK;
+  PASNL_REQUIRE(dist && outi && out, PASNL_ENULL);
+  hipLaunchKernelGGL(select_top_k_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, pasnl_hip_stream(stream), n, k, rows,
+                     dist, outi, out);
+  return pasnl_launch_status();
+}

@@ -1,0 +1,54 @@
+"""pointasnl_cls -- inference graph of the reference's ModelNet40 classifier (models/pointasnl_cls.py:17-52)
+on the MI355X hot path.  ``get_model`` keeps the reference signature; tensors are torch CUDA tensors and the
+weights live in the active tf_util.VariableStore (seeded; there are no checkpoints offline).
+"""
+import torch
+
+from pointasnl_amd.utils import tf_util
+from pointasnl_amd.utils.pointnet_util import pointnet_sa_module
+from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction
+
+
+def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, weight_decay=None, num_class=40,
+              adaptive_sample=False):
+    """ Classification PointNet, input is BxNx3 (BxNx6 with normals), output Bx40 """
+    batch_size = point_cloud.shape[0]
+    end_points = {}
+    if use_normal:
+        l0_xyz = point_cloud[:, :, 0:3].contiguous()
+        l0_points = point_cloud[:, :, 3:6].contiguous()
+    else:
+        l0_xyz = point_cloud
+        l0_points = point_cloud
+    end_points['l0_xyz'] = l0_xyz
+    as_neighbor = [12, 12] if adaptive_sample else [0, 0]
+
+    # Set abstraction layers
+    l1_xyz, l1_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=512, nsample=32, mlp=[64, 64, 128],
+                                                is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
+                                                scope='layer1', as_neighbor=as_neighbor[0])
+    end_points['l1_xyz'] = l1_xyz
+    l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=128, nsample=64, mlp=[128, 128, 256],
+                                                is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
+                                                scope='layer2', as_neighbor=as_neighbor[1])
+    end_points['l2_xyz'] = l1_xyz  # sic: the reference stores l1_xyz here (pointasnl_cls.py:38)
+    _, l3_points_res, _ = pointnet_sa_module(l1_xyz, l1_points, npoint=None, radius=None, nsample=None,
+                                             mlp=[128, 256, 512], mlp2=None, group_all=True, is_training=is_training,
+                                             bn_decay=bn_decay, scope='layer3_1')
+    _, l3_points, _ = pointnet_sa_module(l2_xyz, l2_points, npoint=None, radius=None, nsample=None,
+                                         mlp=[256, 512, 1024], mlp2=None, group_all=True, is_training=is_training,
+                                         bn_decay=bn_decay, scope='layer3_2')
+
+    # Fully connected layers
+    l3_points = l3_points.reshape(batch_size, -1)
+    l3_points_res = l3_points_res.reshape(batch_size, -1)
+    net = torch.cat([l3_points, l3_points_res], dim=-1)
+    net = tf_util.fully_connected(net, 512, bn=True, is_training=is_training, scope='fc1', bn_decay=bn_decay)
+    net = tf_util.dropout(net, keep_prob=0.4, is_training=is_training, scope='dp1')
+    net = tf_util.fully_connected(net, 256, bn=True, is_training=is_training, scope='fc2', bn_decay=bn_decay)
+    net = tf_util.dropout(net, keep_prob=0.4, is_training=is_training, scope='dp2')
+    net = tf_util.fully_connected(net, num_class, activation_fn=None, scope='fc3')
+    end_points['l1_points'] = l1_points
+    end_points['l2_points'] = l2_points
+    end_points['l2_xyz_true'] = l2_xyz
+    return net, end_points

@@ -1,0 +1,87 @@
+"""tf_interpolate -- drop-in for the reference module (tf_ops/3d_interpolation/tf_interpolate.py:8-35).
+
+The reference runs these two ops as single-threaded CPU kernels (tf_interpolate.cpp:187,222); here they are
+gfx950 kernels on the caller's stream, so the decoder never leaves the GPU.
+"""
+import torch
+
+from pointasnl_amd import _hip
+
+
+def three_nn(xyz1, xyz2):
+    '''
+    Input:
+        xyz1: (b,n,3) float32 array, unknown points
+        xyz2: (b,m,3) float32 array, known points
+    Output:
+        dist: (b,n,3) float32 array, distances to known points
+        idx: (b,n,3) int32 array, indices to known points
+    '''
+    xyz1, xyz2 = _hip.as_dev(xyz1, torch.float32), _hip.as_dev(xyz2, torch.float32)
+    if xyz1.dim() != 3 or xyz1.shape[2] != 3:
+        raise ValueError("ThreeNN expects (b,n,3) xyz1 shape.")
+    if xyz2.dim() != 3 or xyz2.shape[2] != 3:
+        raise ValueError("ThreeNN expects (b,m,3) xyz2 shape.")
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
+    _hip.check(_hip.lib().pasnl_three_nn(b, n, m, _hip.ptr(xyz1), _hip.ptr(xyz2), _hip.ptr(dist), _hip.ptr(idx),
+                                         _hip.stream_ptr()), "ThreeNN")
+    return dist, idx
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx, weight):
+        b, m, c = points.shape
+        n = idx.shape[1]
+        out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
+        _hip.check(_hip.lib().pasnl_three_interpolate(b, m, c, n, _hip.ptr(points), _hip.ptr(idx), _hip.ptr(weight),
+                                                      _hip.ptr(out), _hip.stream_ptr()), "ThreeInterpolate")
+        ctx.save_for_backward(idx, weight)
+        ctx.m = m
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):  # tf_interpolate.py:29-34 -> ThreeInterpolateGrad
+        idx, weight = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        b, n, c = grad_out.shape
+        g = torch.empty((b, ctx.m, c), dtype=torch.float32, device=grad_out.device)
+        _hip.check(_hip.lib().pasnl_three_interpolate_grad(b, n, c, ctx.m, _hip.ptr(grad_out), _hip.ptr(idx),
+                                                           _hip.ptr(weight), _hip.ptr(g), _hip.stream_ptr()),
+                   "ThreeInterpolateGrad")
+        return g, None, None
+
+
+def three_interpolate(points, idx, weight):
+    '''
+    Input:
+        points: (b,m,c) float32 array, known points
+        idx: (b,n,3) int32 array, indices to known points
+        weight: (b,n,3) float32 array, weights on known points
+    Output:
+        out: (b,n,c) float32 array, interpolated point values
+    '''
+    points = _hip.as_dev(points, torch.float32)
+    idx = _hip.as_dev(idx, torch.int32)
+    weight = _hip.as_dev(weight, torch.float32)
+    if points.dim() != 3:
+        raise ValueError("ThreeInterpolate expects (b,m,c) points shape")
+    b = points.shape[0]
+    if idx.dim() != 3 or idx.shape[0] != b or idx.shape[2] != 3:
+        raise ValueError("ThreeInterpolate expects (b,n,3) idx shape")
+    if weight.dim() != 3 or tuple(weight.shape) != (b, idx.shape[1], 3):
+        raise ValueError("ThreeInterpolate expects (b,n,3) weight shape")
+    return _ThreeInterpolate.apply(points, idx, weight)
+
+
+def three_weights(dist):
+    """The four TF ops at pointasnl_util.py:308-311 / pointnet_util.py:212-215 as one kernel:
+    d=max(d,1e-10); w=(1/d)/sum(1/d).  dist (b,n,3) -> weight (b,n,3)."""
+    dist = _hip.as_dev(dist, torch.float32)
+    w = torch.empty_like(dist)
+    _hip.check(_hip.lib().pasnl_three_weights(dist.numel() // 3, _hip.ptr(dist), _hip.ptr(w), _hip.stream_ptr()),
+               "ThreeWeights")
+    return w

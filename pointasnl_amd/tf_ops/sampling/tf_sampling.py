@@ -1,0 +1,90 @@
+"""tf_sampling -- drop-in for the reference module of the same name (tf_ops/sampling/tf_sampling.py:13-57).
+
+Same function names, argument order, shapes, dtypes and results; tensors are torch CUDA(ROCm) tensors and the
+work is done by hand-written gfx950 kernels behind the C ABI (include/pasnl.h).  Shape errors raise ValueError
+with the reference's OP_REQUIRES message text (tf_sampling.cpp).
+"""
+import torch
+
+from pointasnl_amd import _hip
+
+
+def prob_sample(inp, inpr):
+    '''
+input:
+    batch_size * ncategory float32
+    batch_size * npoints   float32
+returns:
+    batch_size * npoints   int32
+    '''
+    inp, inpr = _hip.as_dev(inp, torch.float32), _hip.as_dev(inpr, torch.float32)
+    if inp.dim() != 2:
+        raise ValueError("ProbSample expects (batch_size,num_choices) inp shape")
+    b, n = inp.shape
+    if inpr.dim() != 2 or inpr.shape[0] != b:
+        raise ValueError("ProbSample expects (batch_size,num_points) inpr shape")
+    m = inpr.shape[1]
+    out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
+    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)  # tf_sampling.cpp:85 allocate_temp
+    _hip.check(_hip.lib().pasnl_prob_sample(b, n, m, _hip.ptr(inp), _hip.ptr(inpr), _hip.ptr(temp), _hip.ptr(out),
+                                            _hip.stream_ptr()), "ProbSample")
+    return out
+
+
+class _GatherPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, idx):
+        b, n, _ = inp.shape
+        m = idx.shape[1]
+        out = torch.empty((b, m, 3), dtype=torch.float32, device=inp.device)
+        _hip.check(_hip.lib().pasnl_gather_point(b, n, m, _hip.ptr(inp), _hip.ptr(idx), _hip.ptr(out), _hip.stream_ptr()),
+                   "GatherPoint")
+        ctx.save_for_backward(idx)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, out_g):  # tf_sampling.py:43-47 -> GatherPointGrad
+        (idx,) = ctx.saved_tensors
+        out_g = out_g.contiguous()
+        b, m, _ = out_g.shape
+        inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=out_g.device)
+        _hip.check(_hip.lib().pasnl_gather_point_grad(b, ctx.n, m, _hip.ptr(out_g), _hip.ptr(idx), _hip.ptr(inp_g),
+                                                      _hip.stream_ptr()), "GatherPointGrad")
+        return inp_g, None
+
+
+def gather_point(inp, idx):
+    '''
+input:
+    batch_size * ndataset * 3   float32
+    batch_size * npoints        int32
+returns:
+    batch_size * npoints * 3    float32
+    '''
+    inp, idx = _hip.as_dev(inp, torch.float32), _hip.as_dev(idx, torch.int32)
+    if inp.dim() != 3 or inp.shape[2] != 3:
+        raise ValueError("GatherPoint expects (batch_size,num_points,3) inp shape")
+    if idx.dim() != 2 or idx.shape[0] != inp.shape[0]:
+        raise ValueError("GatherPoint expects (batch_size,num_result) idx shape")
+    return _GatherPoint.apply(inp, idx)
+
+
+def farthest_point_sample(npoint, inp):
+    '''
+input:
+    int32
+    batch_size * ndataset * 3   float32
+returns:
+    batch_size * npoint         int32
+    '''
+    if int(npoint) <= 0:
+        raise ValueError("FarthestPointSample expects positive npoint")
+    inp = _hip.as_dev(inp, torch.float32)
+    if inp.dim() != 3 or inp.shape[2] != 3:
+        raise ValueError("FarthestPointSample expects (batch_size,num_points,3) inp shape")
+    b, n, _ = inp.shape
+    out = torch.empty((b, int(npoint)), dtype=torch.int32, device=inp.device)
+    _hip.check(_hip.lib().pasnl_farthest_point_sample(b, n, int(npoint), _hip.ptr(inp), _hip.ptr(out), _hip.stream_ptr()),
+               "FarthestPointSample")
+    return out

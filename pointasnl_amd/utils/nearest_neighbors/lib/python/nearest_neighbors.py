@@ -1,0 +1,48 @@
+"""nearest_neighbors -- drop-in for the reference's Cython module (utils/nearest_neighbors/knn.pyx:33-148),
+imported by the models as ``nearest_neighbors.lib.python.nearest_neighbors`` (pointasnl_util.py:19).
+
+The reference builds a nanoflann KD-tree per cloud on the host (OpenMP over the batch) and is reached through
+tf.py_func, i.e. a device->host->device round trip per layer.  Here the search is an exact brute-force gfx950
+kernel; results are the K nearest in ascending (squared distance, index) order -- identical to nanoflann
+whenever distances are distinct (nanoflann's order among exactly equal distances is traversal dependent).
+
+numpy in -> numpy int64 out like the reference (host buffers cross PCIe); torch CUDA tensors in -> torch CUDA
+tensors out (no copies), which is what utils/pointasnl_util.py uses.
+"""
+import numpy as np
+import torch
+
+from pointasnl_amd import _hip
+
+
+def _knn_dev(pts, queries, K, i64):
+    if pts.dim() != 3 or pts.shape[2] != 3 or queries.dim() != 3 or queries.shape[2] != 3:
+        raise ValueError("knn_batch expects (B,N,3) pts and (B,M,3) queries")
+    if queries.shape[0] != pts.shape[0]:
+        raise ValueError("knn_batch expects the same batch size for pts and queries")
+    b, n, _ = pts.shape
+    m = queries.shape[1]
+    out = torch.empty((b, m, int(K)), dtype=torch.int64 if i64 else torch.int32, device=pts.device)
+    _hip.check(_hip.lib().pasnl_knn_batch(b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
+                                          _hip.ptr(None), _hip.stream_ptr()), "knn_batch")
+    return out
+
+
+def knn_batch(pts, queries, K, omp=False, dtype=None):
+    """(B,N,3), (B,M,3) -> (B,M,K) neighbour indices (int64 like the reference; ``dtype=torch.int32`` skips
+    the cast the models do at pointasnl_util.py:30).  ``omp`` is accepted and ignored."""
+    host = not isinstance(pts, torch.Tensor)
+    p = _hip.as_dev(pts, torch.float32)
+    q = _hip.as_dev(queries, torch.float32)
+    i64 = dtype in (None, torch.int64, np.int64)
+    out = _knn_dev(p, q, K, i64)
+    return out.cpu().numpy() if host else out
+
+
+def knn(pts, queries, K, omp=False):
+    """single cloud: (N,3), (M,3) -> (M,K)   (knn.pyx:33-69)"""
+    host = not isinstance(pts, torch.Tensor)
+    p = _hip.as_dev(pts, torch.float32)[None]
+    q = _hip.as_dev(queries, torch.float32)[None]
+    out = _knn_dev(p, q, K, True)[0]
+    return out.cpu().numpy() if host else out

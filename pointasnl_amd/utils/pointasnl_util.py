@@ -1,0 +1,319 @@
+"""pointasnl_util -- host-side mirror of the reference's utils/pointasnl_util.py (same function names,
+argument order and results), inference only, on torch device tensors.
+
+What changes underneath (and nothing else):
+  * farthest_point_sample / kNN / gathers / three_nn / three_interpolate are the gfx950 kernels behind the
+    C ABI -- no tf.py_func, no host KD-tree, no CPU ops, so a layer never leaves the GPU
+    (reference: GPU -> CPU -> GPU per layer);
+  * the attention cores of SampleWeights and PointNonLocalCell are fused kernels: the (B,P,N) attention map
+    of pointasnl_util.py:199-212 is never written to HBM;
+  * 1x1 convolutions + inference BN are folded GEMMs on the vendor BLAS (tf_util.py here).
+"""
+import ctypes
+
+import torch
+
+from pointasnl_amd import _hip
+from pointasnl_amd import tf_sampling, tf_grouping, nearest_neighbors
+from pointasnl_amd.tf_interpolate import three_nn, three_interpolate, three_weights
+from pointasnl_amd.utils import tf_util
+
+NL_VARIANT = 0  # 0 auto / 1 vector-FMA / 2 MFMA  (pasnl_nl_attention); bench.py --ops sweeps it
+
+
+def knn_query(k, support_pts, query_pts):
+    """
+    :param support_pts: points you have, B*N1*3
+    :param query_pts: points you want to know the neighbour index, B*N2*3
+    :param k: Number of neighbours in knn search
+    :return: neighbor_idx: neighboring points indexes, B*N2*k   (int32, pointasnl_util.py:22-30)
+    """
+    return nearest_neighbors.knn_batch(support_pts, query_pts, k, omp=True, dtype=torch.int32)
+
+
+def _gather_rows(points, idx):
+    """tf.gather_nd(points, [batch, idx]) for idx (B,M): one C-wide row per index (pointasnl_util.py:43-49)."""
+    return tf_grouping.group_point(points, idx.unsqueeze(-1)).squeeze(2)
+
+
+def sampling(npoint, pts, feature=None):
+    '''
+    inputs:
+    npoint: scalar, number of points to sample
+    pointcloud: B * N * D, input point cloud
+    output:
+    sub_pts: B * npoint * D, sub-sampled point cloud
+    '''
+    fps_idx = tf_sampling.farthest_point_sample(npoint, pts)
+    if feature is None:
+        return _gather_rows(pts, fps_idx)
+    return _gather_rows(pts, fps_idx), _gather_rows(feature, fps_idx)
+
+
+def grouping(feature, K, src_xyz, q_xyz, use_xyz=True, use_knn=True, radius=0.2):
+    '''
+    K: neighbor size
+    src_xyz: original point xyz (batch_size, ndataset, 3)
+    q_xyz: query point xyz (batch_size, npoint, 3)
+    '''
+    if use_knn:
+        point_indices = knn_query(K, src_xyz, q_xyz)
+    else:
+        # the reference branch never defines `idx` and raises NameError at pointasnl_util.py:71; this is the
+        # evident intent (ball query indices used for both gathers)
+        point_indices, _ = tf_grouping.query_ball_point(radius, K, src_xyz, q_xyz)
+    grouped_xyz = tf_grouping.group_point(src_xyz, point_indices)
+    grouped_feature = tf_grouping.group_point(feature, point_indices)
+    if use_xyz:
+        grouped_feature = torch.cat([grouped_xyz, grouped_feature], dim=-1)
+    return grouped_xyz, grouped_feature, point_indices
+
+
+def weight_net_hidden(xyz, hidden_units, scope, is_training, bn_decay=None, weight_decay=None, activation_fn="relu"):
+    with tf_util.variable_scope(scope):
+        net = xyz
+        for i, num_hidden_units in enumerate(hidden_units):
+            net = tf_util.conv2d(net, num_hidden_units, [1, 1], padding='VALID', stride=[1, 1], bn=True,
+                                 is_training=is_training, activation_fn=activation_fn, scope='wconv%d' % (i),
+                                 bn_decay=bn_decay, weight_decay=weight_decay)
+    return net
+
+
+def as_attention(q, kv):
+    """softmax(q k^T / sqrt(cb)) v per group of `as` neighbours (pointasnl_util.py:136-146), fused.
+    q (..., as, cb), kv (..., as, 2cb) -> (..., as, cb)"""
+    as_, cb = q.shape[-2], q.shape[-1]
+    g = q.numel() // (as_ * cb)
+    q, kv = q.contiguous(), kv.contiguous()
+    out = torch.empty_like(q)
+    _hip.check(_hip.lib().pasnl_as_attention(g, as_, cb, _hip.ptr(q), _hip.ptr(kv), _hip.ptr(out), _hip.stream_ptr()),
+               "as_attention")
+    return out
+
+
+def SampleWeights(new_point, grouped_xyz, mlps, is_training, bn_decay, weight_decay, scope, bn=True, scaled=True,
+                  return_logits=False):
+    """Input
+        grouped_feature: (batch_size, npoint, nsample, channel) tensor
+        grouped_xyz: (batch_size, npoint, nsample, 3)
+        new_point: (batch_size, npoint, nsample, channel)
+        Output
+        (batch_size, npoint, nsample, 1)
+    """
+    if not scaled:
+        raise NotImplementedError("scaled=False is never used by the reference models")
+    with tf_util.variable_scope(scope):
+        channel = new_point.shape[-1]
+        bottleneck_channel = max(32, channel // 2)
+        normalized_xyz = grouped_xyz - grouped_xyz[:, :, :1, :]
+        new_point = torch.cat([normalized_xyz, new_point], dim=-1)  # (batch_size, npoint, nsample, channel+3)
+
+        transformed_feature = tf_util.conv2d(new_point, bottleneck_channel * 2, [1, 1], padding='VALID', stride=[1, 1],
+                                             bn=bn, is_training=is_training, scope='conv_kv_ds', bn_decay=bn_decay,
+                                             weight_decay=weight_decay, activation_fn=None)
+        transformed_new_point = tf_util.conv2d(new_point, bottleneck_channel, [1, 1], padding='VALID', stride=[1, 1],
+                                               bn=bn, is_training=is_training, scope='conv_query_ds',
+                                               bn_decay=bn_decay, weight_decay=weight_decay, activation_fn=None)
+        # QK^T / sqrt(cb) -> softmax -> . V  : one fused kernel, K and V read in place from the conv_kv_ds output
+        new_group_features = as_attention(transformed_new_point, transformed_feature)
+        for i, c in enumerate(mlps):
+            activation = "relu" if i < len(mlps) - 1 else None
+            new_group_features = tf_util.conv2d(new_group_features, c, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                                                is_training=is_training, scope='mlp2_%d' % (i), bn_decay=bn_decay,
+                                                weight_decay=weight_decay, activation_fn=activation)
+        if return_logits:
+            return new_group_features
+        return torch.softmax(new_group_features, dim=2)  # (batch_size, npoint, nsample, mlp[-1])
+
+
+def AdaptiveSampling(group_xyz, group_feature, num_neighbor, is_training, bn_decay, weight_decay, scope, bn):
+    with tf_util.variable_scope(scope):
+        nsample, num_channel = group_feature.shape[-2:]
+        if num_neighbor == 0:
+            new_xyz = group_xyz[:, :, 0, :].contiguous()
+            new_feature = group_feature[:, :, 0, :].contiguous()
+            return new_xyz, new_feature
+        shift_group_xyz = group_xyz[:, :, :num_neighbor, :]
+        shift_group_points = group_feature[:, :, :num_neighbor, :]
+        logits = SampleWeights(shift_group_points, shift_group_xyz, [32, 1 + num_channel], is_training, bn_decay,
+                               weight_decay, scope, bn, return_logits=True)
+        # softmax over the neighbour axis + the two weighted sums (pointasnl_util.py:154,167-171) in one kernel
+        # that reads the first `num_neighbor` rows of the full grouped tensors in place
+        b, p = group_xyz.shape[:2]
+        group_xyz, group_feature, logits = group_xyz.contiguous(), group_feature.contiguous(), logits.contiguous()
+        new_xyz = torch.empty((b, p, 3), dtype=torch.float32, device=group_xyz.device)
+        new_feature = torch.empty((b, p, num_channel), dtype=torch.float32, device=group_xyz.device)
+        _hip.check(_hip.lib().pasnl_as_reweight(b * p, int(num_neighbor), int(nsample), int(num_channel),
+                                                _hip.ptr(logits), _hip.ptr(group_xyz), _hip.ptr(group_feature),
+                                                _hip.ptr(new_xyz), _hip.ptr(new_feature), _hip.stream_ptr()),
+                   "as_reweight")
+        return new_xyz, new_feature
+
+
+def nl_attention(q, kv, variant=None):
+    """softmax(q k^T / sqrt(cb)) v with K,V = halves of kv; q (B,P,cb), kv (B,N,2cb) -> (B,P,cb).  Fused."""
+    b, p, cb = q.shape
+    n = kv.shape[1]
+    q, kv = q.contiguous(), kv.contiguous()
+    out = torch.empty_like(q)
+    _hip.check(_hip.lib().pasnl_nl_attention(b, p, n, cb, _hip.ptr(q), _hip.ptr(kv), _hip.ptr(out),
+                                             int(NL_VARIANT if variant is None else variant), _hip.stream_ptr()),
+               "nl_attention")
+    return out
+
+
+def PointNonLocalCell(feature, new_point, mlp, is_training, bn_decay, weight_decay, scope, bn=True, scaled=True,
+                      mode='dot'):
+    """Input
+        feature: (batch_size, ndataset, channel) tensor
+        new_point: (batch_size, npoint, nsample, channel)
+        Output
+        (batch_size, npoint, nsample, channel)
+    """
+    if mode != 'dot' or not scaled:
+        raise NotImplementedError("only mode='dot', scaled=True is reachable in the reference models (SURVEY a11)")
+    with tf_util.variable_scope(scope):
+        bottleneck_channel = mlp[0]
+        batch_size, npoint, nsample, channel = new_point.shape
+        feature = feature.unsqueeze(2)  # (batch_size, ndataset, 1, channel)
+        transformed_feature = tf_util.conv2d(feature, bottleneck_channel * 2, [1, 1], padding='VALID', stride=[1, 1],
+                                             bn=bn, is_training=is_training, scope='conv_kv', bn_decay=bn_decay,
+                                             weight_decay=weight_decay, activation_fn=None)
+        transformed_new_point = tf_util.conv2d(new_point, bottleneck_channel, [1, 1], padding='VALID', stride=[1, 1],
+                                               bn=bn, is_training=is_training, scope='conv_query', bn_decay=bn_decay,
+                                               weight_decay=weight_decay, activation_fn=None)
+        transformed_new_point = transformed_new_point.reshape(batch_size, npoint * nsample, bottleneck_channel)
+        new_nonlocal_point = nl_attention(transformed_new_point, transformed_feature.squeeze(2))
+        new_nonlocal_point = tf_util.conv2d(
+            new_nonlocal_point.reshape(batch_size, npoint, nsample, bottleneck_channel), mlp[-1], [1, 1],
+            padding='VALID', stride=[1, 1], bn=bn, is_training=is_training, scope='conv_back_project',
+            bn_decay=bn_decay, weight_decay=weight_decay)
+        new_nonlocal_point = new_nonlocal_point.squeeze(1)  # (batch_size, npoints, mlp2[-1])
+        return new_nonlocal_point
+
+
+def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_decay, weight_decay, scope, bn=True,
+                            use_knn=True, radius=None, as_neighbor=8, NL=True):
+    ''' Input:
+            xyz: (batch_size, ndataset, 3) tensor
+            feature: (batch_size, ndataset, channel) tensor
+            point: int32 -- #points sampled in Euclidean space by farthest point sampling
+            nsample: int32 -- how many points in each local region
+            mlp: list of int32 -- output size for MLP on each point
+        Return:
+            new_xyz: (batch_size, npoint, 3) tensor
+            new_points: (batch_size, npoint, mlp[-1] or mlp2[-1]) tensor
+    '''
+    with tf_util.variable_scope(scope):
+        batch_size, num_points, num_channel = feature.shape
+        '''Farthest Point Sampling'''
+        if num_points == npoint:
+            new_xyz = xyz
+            new_feature = feature
+        else:
+            new_xyz, new_feature = sampling(npoint, xyz, feature)
+
+        grouped_xyz, new_point, idx = grouping(feature, nsample, xyz, new_xyz, use_knn=use_knn, radius=radius)
+        nl_channel = mlp[-1]
+
+        '''Adaptive Sampling'''
+        if num_points != npoint:
+            new_xyz, new_feature = AdaptiveSampling(grouped_xyz, new_point, as_neighbor, is_training, bn_decay,
+                                                    weight_decay, scope, bn)
+        grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)  # translation normalization
+        new_point = torch.cat([grouped_xyz, new_point], dim=-1)
+
+        '''Point NonLocal Cell'''
+        if NL:
+            new_nonlocal_point = PointNonLocalCell(feature, new_feature.unsqueeze(1),
+                                                   [max(32, num_channel // 2), nl_channel], is_training, bn_decay,
+                                                   weight_decay, scope, bn)
+
+        '''Skip Connection'''
+        skip_spatial = new_point.max(dim=2).values
+        skip_spatial = tf_util.conv1d(skip_spatial, mlp[-1], 1, padding='VALID', stride=1, bn=bn,
+                                      is_training=is_training, scope='skip', bn_decay=bn_decay,
+                                      weight_decay=weight_decay)
+
+        '''Point Local Cell'''
+        for i, num_out_channel in enumerate(mlp):
+            if i != len(mlp) - 1:
+                new_point = tf_util.conv2d(new_point, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                                           is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay,
+                                           weight_decay=weight_decay)
+
+        weight = weight_net_hidden(grouped_xyz, [32], scope='weight_net', is_training=is_training, bn_decay=bn_decay,
+                                   weight_decay=weight_decay)
+        new_point = new_point.transpose(2, 3)
+        new_point = torch.matmul(new_point, weight)
+        new_point = tf_util.conv2d(new_point, mlp[-1], [1, new_point.shape[2]], padding='VALID', stride=[1, 1], bn=bn,
+                                   is_training=is_training, scope='after_conv', bn_decay=bn_decay,
+                                   weight_decay=weight_decay)
+        new_point = new_point.squeeze(2)  # (batch_size, npoints, mlp2[-1])
+        new_point = new_point + skip_spatial
+        if NL:
+            new_point = new_point + new_nonlocal_point
+
+        '''Feature Fushion'''
+        new_point = tf_util.conv1d(new_point, mlp[-1], 1, padding='VALID', stride=1, bn=bn, is_training=is_training,
+                                   scope='aggregation', bn_decay=bn_decay, weight_decay=weight_decay)
+        return new_xyz, new_point
+
+
+def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_training, bn_decay, weight_decay, scope,
+                           bn=True, use_xyz=True, use_knn=True, radius=None, dilate_rate=1, mode='concat', NL=False):
+    ''' Input:
+            xyz1: (batch_size, ndataset1, 3) tensor
+            xyz2: (batch_size, ndataset2, 3) tensor, sparser than xyz1
+            points1: (batch_size, ndataset1, nchannel1) tensor
+            points2: (batch_size, ndataset2, nchannel2) tensor
+            K: int32 -- how many points in each local region
+            mlp: list of int32 -- output size for MLP on each point
+        Return:
+            new_points: (batch_size, ndataset1, mlp[-1]) tensor
+    '''
+    if NL:
+        raise NotImplementedError("NL=True in the decoder selects mode='concat', never used by the models (SURVEY a11)")
+    with tf_util.variable_scope(scope):
+        dist, idx = three_nn(xyz1, xyz2)
+        weight = three_weights(dist)  # pointasnl_util.py:308-311 as one kernel
+        interpolated_points = three_interpolate(points2, idx, weight)
+
+        '''Point Local Cell'''
+        grouped_xyz, grouped_feature, idx = grouping(interpolated_points, nsample, xyz1, xyz1, use_xyz=use_xyz,
+                                                     use_knn=use_knn, radius=radius)
+        grouped_xyz = grouped_xyz - xyz1.unsqueeze(2)  # translation normalization
+        weight = weight_net_hidden(grouped_xyz, [32], scope='decode_weight_net', is_training=is_training,
+                                   bn_decay=bn_decay, weight_decay=weight_decay)
+        new_points = grouped_feature.transpose(2, 3)
+        new_points = torch.matmul(new_points, weight)
+        new_points = tf_util.conv2d(new_points, mlp[0], [1, new_points.shape[2]], padding='VALID', stride=[1, 1], bn=bn,
+                                    is_training=is_training, scope='decode_after_conv', bn_decay=bn_decay,
+                                    weight_decay=weight_decay)
+        if points1 is not None:
+            new_points1 = torch.cat([new_points, points1.unsqueeze(2)], dim=-1)
+        else:
+            new_points1 = new_points
+        for i, num_out_channel in enumerate(mlp):
+            if i != 0:
+                new_points1 = tf_util.conv2d(new_points1, num_out_channel, [1, 1], padding='VALID', stride=[1, 1],
+                                             bn=bn, is_training=is_training, scope='conv_%d' % (i), bn_decay=bn_decay,
+                                             weight_decay=weight_decay)
+        new_points = new_points1.squeeze(2)  # B,ndataset1,mlp[-1]
+        return new_points
+
+
+def get_repulsion_loss(pred, nsample=20, radius=0.07):
+    """pointasnl_util.py:361-378; the only in-model consumer of query_ball_point / group_point."""
+    idx, pts_cnt = tf_grouping.query_ball_point(radius, nsample, pred, pred)
+    grouped_pred = tf_grouping.group_point(pred, idx)  # (batch_size, npoint, nsample, 3)
+    grouped_pred = grouped_pred - pred.unsqueeze(2)
+    h = 0.03
+    dist_square = (grouped_pred ** 2).sum(dim=-1)
+    dist_square, _ = torch.topk(-dist_square, 5)
+    dist_square = -dist_square[:, :, 1:]  # remove the first one
+    dist_square = torch.clamp(dist_square, min=1e-12)
+    dist = torch.sqrt(dist_square)
+    weight = torch.exp(-dist_square / h ** 2)
+    uniform_loss = torch.mean(radius - dist * weight)
+    return uniform_loss

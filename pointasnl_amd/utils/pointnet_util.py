@@ -1,0 +1,106 @@
+"""pointnet_util -- the PointNet++ helpers the PointASNL models call (reference utils/pointnet_util.py:22-229):
+sample_and_group, sample_and_group_all, pointnet_sa_module (max pooling) and pointnet_fp_module.
+Inference only, torch device tensors; the native ops are the gfx950 kernels.  The MSG / pooling variants the
+three models never reach are out of scope.
+"""
+import torch
+
+from pointasnl_amd.tf_sampling import farthest_point_sample, gather_point
+from pointasnl_amd.tf_grouping import query_ball_point, group_point, knn_point
+from pointasnl_amd.tf_interpolate import three_nn, three_interpolate, three_weights
+from pointasnl_amd.utils import tf_util
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
+    '''
+    Input:
+        npoint: int32
+        radius: float32
+        nsample: int32
+        xyz: (batch_size, ndataset, 3) tensor
+        points: (batch_size, ndataset, channel) tensor, if None will just use xyz as points
+        knn: bool, if True use kNN instead of radius search
+        use_xyz: bool, if True concat XYZ with local point features, otherwise just use point features
+    Output:
+        new_xyz: (batch_size, npoint, 3), new_points: (batch_size, npoint, nsample, 3+channel),
+        idx: (batch_size, npoint, nsample), grouped_xyz: (batch_size, npoint, nsample, 3) centred on new_xyz
+    '''
+    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    if knn:
+        _, idx = knn_point(nsample, xyz, new_xyz)
+    else:
+        idx, pts_cnt = query_ball_point(radius, nsample, xyz, new_xyz)
+    grouped_xyz = group_point(xyz, idx)
+    grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)
+    if points is not None:
+        grouped_points = group_point(points, idx)
+        new_points = torch.cat([grouped_xyz, grouped_points], dim=-1) if use_xyz else grouped_points
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sample_and_group_all(xyz, points, use_xyz=True):
+    '''
+    Equivalent to sample_and_group with npoint=1, radius=inf, (0,0,0) as the centroid (pointnet_util.py:59-84).
+    '''
+    batch_size, nsample = xyz.shape[0], xyz.shape[1]
+    new_xyz = torch.zeros((batch_size, 1, 3), dtype=torch.float32, device=xyz.device)
+    idx = torch.arange(nsample, dtype=torch.int32, device=xyz.device).reshape(1, 1, nsample).repeat(batch_size, 1, 1)
+    grouped_xyz = xyz.reshape(batch_size, 1, nsample, 3)
+    if points is not None:
+        new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
+        new_points = new_points.unsqueeze(1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
+                       bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False):
+    ''' PointNet Set Abstraction (SA) Module (pointnet_util.py:87-153), max pooling
+        Return:
+            new_xyz: (batch_size, npoint, 3), new_points: (batch_size, npoint, mlp[-1] or mlp2[-1]),
+            idx: (batch_size, npoint, nsample)
+    '''
+    if pooling != 'max' or use_nchw:
+        raise NotImplementedError("only pooling='max', NHWC is used by the PointASNL models")
+    with tf_util.variable_scope(scope):
+        if group_all:
+            nsample = xyz.shape[1]
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
+        else:
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, knn, use_xyz)
+        for i, num_out_channel in enumerate(mlp):
+            new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                                        is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay)
+        new_points = new_points.max(dim=2, keepdim=True).values
+        if mlp2 is not None:
+            for i, num_out_channel in enumerate(mlp2):
+                new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                                            is_training=is_training, scope='conv_post_%d' % (i), bn_decay=bn_decay)
+        new_points = new_points.squeeze(2)
+        return new_xyz, new_points, idx
+
+
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True):
+    ''' PointNet Feature Propogation (FP) Module (pointnet_util.py:199-229)
+        Input:
+            xyz1: (batch_size, ndataset1, 3), xyz2: (batch_size, ndataset2, 3) sparser than xyz1
+            points1: (batch_size, ndataset1, nchannel1), points2: (batch_size, ndataset2, nchannel2)
+        Return:
+            new_points: (batch_size, ndataset1, mlp[-1])
+    '''
+    with tf_util.variable_scope(scope):
+        dist, idx = three_nn(xyz1, xyz2)
+        weight = three_weights(dist)  # pointnet_util.py:212-215 as one kernel
+        interpolated_points = three_interpolate(points2, idx, weight)
+        if points1 is not None:
+            new_points1 = torch.cat([interpolated_points, points1], dim=2)
+        else:
+            new_points1 = interpolated_points
+        new_points1 = new_points1.unsqueeze(2)
+        for i, num_out_channel in enumerate(mlp):
+            new_points1 = tf_util.conv2d(new_points1, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                                         is_training=is_training, scope='conv_%d' % (i), bn_decay=bn_decay)
+        return new_points1.squeeze(2)

@@ -1,0 +1,186 @@
+"""tf_util -- host-side mirror of the reference's layer wrappers (utils/tf_util.py:52,120,327,512,594),
+inference only, on torch.
+
+The reference builds TF variables under ``tf.variable_scope``; here a ``VariableStore`` plays that role: a
+layer looks its variables up by scope path (``layer1/conv_kv/weights`` ...) and creates them on first use from
+a seed, so a model is defined by calling the same functions in the same order as the reference.  Variable
+names and shapes follow the reference (weights [kh,kw,cin,cout] flattened to [kh*kw*cin, cout], biases,
+bn/gamma, bn/beta, bn/moving_mean, bn/moving_variance).
+
+These are plain GEMMs and go to the vendor BLAS through torch (they are NOT custom ops in the reference
+either).  Inference batch norm (tf.contrib.layers.batch_norm, epsilon 1e-3) is folded into the GEMM:
+    W' = W * s,  b' = (b - mean) * s + beta,  s = gamma / sqrt(var + 1e-3)
+"""
+import contextlib
+import hashlib
+import math
+
+import numpy as np
+import torch
+
+BN_EPS = 1e-3
+
+
+class VariableStore:
+    """Seeded variable container + scope stack (the stand-in for TF's graph collections)."""
+
+    def __init__(self, seed=0, device="cuda", randomize_bn=False):
+        self.seed = int(seed)
+        self.device = device
+        self.randomize_bn = randomize_bn  # non-trivial gamma/beta/mean/var so that BN folding is actually tested
+        self.vars = {}
+        self._folded = {}
+        self._scope = []
+
+    # ---- scopes
+    @contextlib.contextmanager
+    def scope(self, name):
+        self._scope.append(name)
+        try:
+            yield
+        finally:
+            self._scope.pop()
+
+    def path(self, name):
+        return "/".join(self._scope + [name])
+
+    # ---- variables
+    def _rng(self, full):
+        h = hashlib.sha256(f"{self.seed}:{full}".encode()).digest()
+        return np.random.Generator(np.random.PCG64(int.from_bytes(h[:8], "little")))
+
+    def get(self, name, shape, kind):
+        full = self.path(name)
+        if full not in self.vars:
+            rng = self._rng(full)
+            if kind == "xavier":  # tf.contrib.layers.xavier_initializer (uniform): limit = sqrt(6/(fan_in+fan_out))
+                fan_in, fan_out = shape[0], shape[1]
+                lim = math.sqrt(6.0 / (fan_in + fan_out))
+                v = rng.uniform(-lim, lim, size=shape)
+            elif kind == "zeros":
+                v = np.zeros(shape)
+            elif kind == "ones":
+                v = np.ones(shape)
+            elif kind == "small":  # randomised BN statistics / biases for tests
+                v = rng.uniform(-0.2, 0.2, size=shape)
+            elif kind == "positive":
+                v = rng.uniform(0.5, 1.5, size=shape)
+            else:
+                raise ValueError(kind)
+            self.vars[full] = torch.tensor(v, dtype=torch.float32, device=self.device)
+        return self.vars[full]
+
+    def layer(self, cin, cout, bn):
+        """(W', b') of the layer at the current scope, BN folded, cached."""
+        key = self.path("")
+        if key not in self._folded:
+            w = self.get("weights", (cin, cout), "xavier")
+            b = self.get("biases", (cout,), "small" if self.randomize_bn else "zeros")
+            if bn:
+                with self.scope("bn"):
+                    gamma = self.get("gamma", (cout,), "positive" if self.randomize_bn else "ones")
+                    beta = self.get("beta", (cout,), "small" if self.randomize_bn else "zeros")
+                    mean = self.get("moving_mean", (cout,), "small" if self.randomize_bn else "zeros")
+                    var = self.get("moving_variance", (cout,), "positive" if self.randomize_bn else "ones")
+                s = gamma / torch.sqrt(var + BN_EPS)
+                w, b = w * s, (b - mean) * s + beta
+            self._folded[key] = (w.contiguous(), b.contiguous())
+        return self._folded[key]
+
+    def export_numpy(self):
+        """scope -> {"w","b"[, "gamma","beta","mean","var"]} as the oracle expects (oracle/cells.py)."""
+        out = {}
+        for full, t in self.vars.items():
+            parts = full.split("/")
+            a = t.detach().cpu().numpy()
+            if parts[-2:-1] == ["bn"]:
+                sc = "/".join(parts[:-2])
+                key = {"gamma": "gamma", "beta": "beta", "moving_mean": "mean", "moving_variance": "var"}[parts[-1]]
+            else:
+                sc = "/".join(parts[:-1])
+                key = {"weights": "w", "biases": "b"}[parts[-1]]
+            out.setdefault(sc, {})[key] = a
+        return out
+
+
+_STORE = None
+
+
+def set_store(store):
+    global _STORE
+    _STORE = store
+    return store
+
+
+def store():
+    if _STORE is None:
+        raise RuntimeError("no VariableStore active: call tf_util.set_store(VariableStore(seed)) first")
+    return _STORE
+
+
+def variable_scope(name):
+    return store().scope(name)
+
+
+def _require_inference(is_training):
+    if is_training not in (False, None):
+        raise NotImplementedError("pointasnl_amd mirrors the inference graph only (is_training must be False)")
+
+
+def _act(x, activation_fn):
+    if activation_fn is None:
+        return x
+    if activation_fn in ("relu", torch.relu, torch.nn.functional.relu):
+        return torch.relu_(x)
+    if activation_fn in ("sigmoid", torch.sigmoid):
+        return torch.sigmoid_(x)
+    return activation_fn(x)
+
+
+def _dense(inputs, num_output_channels, scope, bn, activation_fn):
+    cin = inputs.shape[-1]
+    with variable_scope(scope):
+        w, b = store().layer(cin, num_output_channels, bn)
+    out = torch.addmm(b, inputs.reshape(-1, cin), w).reshape(*inputs.shape[:-1], num_output_channels)
+    return _act(out, activation_fn)
+
+
+def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='SAME', data_format='NHWC',
+           use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn="relu", bn=False, bn_decay=None,
+           is_training=None):
+    """tf_util.py:52-117, kernel_size 1 only (all the models use)."""
+    _require_inference(is_training)
+    if kernel_size != 1 or data_format != 'NHWC':
+        raise NotImplementedError("conv1d mirror supports kernel_size=1, NHWC")
+    return _dense(inputs, num_output_channels, scope, bn, activation_fn)
+
+
+def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], padding='SAME', data_format='NHWC',
+           use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn="relu", bn=False, bn_decay=None,
+           is_training=None):
+    """tf_util.py:120-185.  [1,1] kernels, and the [1,W] VALID kernel that collapses the whole W axis
+    (pointasnl_util.py:275, 337): inputs (B,H,W,C) -> (B,H,1,cout) == one GEMM over the flattened (W,C) window."""
+    _require_inference(is_training)
+    kh, kw = kernel_size
+    if data_format != 'NHWC' or kh != 1:
+        raise NotImplementedError("conv2d mirror supports NHWC, kernel height 1")
+    if kw == 1:
+        return _dense(inputs, num_output_channels, scope, bn, activation_fn)
+    if padding != 'VALID' or kw != inputs.shape[2]:
+        raise NotImplementedError("conv2d mirror supports [1,1] or the full-width VALID kernel")
+    b, h, w, c = inputs.shape
+    out = _dense(inputs.reshape(b, h, w * c), num_output_channels, scope, bn, activation_fn)
+    return out.reshape(b, h, 1, num_output_channels)
+
+
+def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, weight_decay=None,
+                    activation_fn="relu", bn=False, bn_decay=None, is_training=None):
+    """tf_util.py:327-365"""
+    _require_inference(is_training)
+    return _dense(inputs, num_outputs, scope, bn, activation_fn)
+
+
+def dropout(inputs, is_training, scope, keep_prob=0.5, noise_shape=None):
+    """tf_util.py:594-615: identity at inference."""
+    _require_inference(is_training)
+    return inputs

@@ -1,0 +1,209 @@
+"""Parity of the HIP path (through the C ABI, via the reference-named Python modules) against the oracle.
+Bit-exact for indices; exact for gathers; 1e-5 (in fact exact) for interpolation."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import clouds
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pointasnl_amd
+
+    return pointasnl_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("b,n,m,kind", [
+    (3, 1024, 512, "ball"), (2, 512, 128, "ball"), (2, 1024, 512, "lattice"), (2, 600, 77, "cube"),
+    (1, 64, 64, "ball"), (1, 37, 5, "lattice"), (2, 2048, 300, "lattice"), (1, 8192, 1024, "cube"),
+    (1, 10240, 1280, "ball"), (2, 1, 1, "ball"), (1, 300, 1, "ball"),
+])
+def test_fps(P, b, n, m, kind):
+    xyz = clouds(11 + n, b, n, kind)
+    want = O.farthest_point_sample(m, xyz)
+    got = P.tf_sampling.farthest_point_sample(m, dev(xyz)).cpu().numpy()
+    assert got.dtype == np.int32 and got.shape == (b, m)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_fps_exhausted_cloud(P):
+    # more samples than distinct points: once every distance is 0 the reference keeps returning index 0
+    xyz = np.repeat(clouds(5, 1, 4, "cube"), 8, axis=1)
+    want = O.farthest_point_sample(20, xyz)
+    got = P.tf_sampling.farthest_point_sample(20, dev(xyz)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
+def test_gather_point_and_grad(P):
+    xyz = clouds(3, 4, 777)
+    idx = np.random.default_rng(0).integers(0, 777, (4, 333)).astype(np.int32)
+    got = P.tf_sampling.gather_point(dev(xyz), dev(idx)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.gather_point(xyz, idx))
+    x = dev(xyz).requires_grad_(True)
+    out = P.tf_sampling.gather_point(x, dev(idx))
+    g = np.random.default_rng(1).random((4, 333, 3), dtype=np.float32)
+    out.backward(dev(g))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), O.gather_point_grad(xyz, idx, g), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("b,n,m,ns,r,kind", [
+    (32, 512, 128, 64, 0.1, "cube"),      # the reference's own micro-bench shape (tf_grouping.py:78-88)
+    (4, 1024, 512, 32, 0.2, "ball"),
+    (2, 1024, 1024, 20, 0.07, "ball"),    # repulsion-loss shape (pointasnl_util.py:361)
+    (2, 700, 90, 16, 0.25, "lattice"),    # distances exactly on / next to the radius
+    (2, 5000, 64, 8, 0.5, "cube"),        # early exit, multi-tile cloud
+    (1, 3000, 50, 200, 0.4, "cube"),      # nsample > 64
+    (2, 100, 10, 4, 1e-3, "cube"),        # zero-hit rows
+])
+def test_query_ball_point(P, b, n, m, ns, r, kind):
+    xyz1 = clouds(21, b, n, kind)
+    xyz2 = clouds(22, b, m, kind) if kind != "lattice" else xyz1[:, :m].copy()
+    want_idx, want_cnt = O.query_ball_point(r, ns, xyz1, xyz2)
+    idx, cnt = P.tf_grouping.query_ball_point(r, ns, dev(xyz1), dev(xyz2))
+    np.testing.assert_array_equal(cnt.cpu().numpy(), want_cnt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+
+
+def test_ball_radius_boundary(P):
+    # points at distances straddling sqrt: radius 0.25 exactly representable, lattice of 1/8
+    xyz1 = clouds(9, 1, 2000, "lattice")
+    for r in (0.125, 0.25, 0.375, np.float32(0.21650635), np.float32(0.2165064)):
+        want_idx, want_cnt = O.query_ball_point(float(r), 32, xyz1, xyz1[:, :200])
+        idx, cnt = P.tf_grouping.query_ball_point(float(r), 32, dev(xyz1), dev(xyz1[:, :200]))
+        np.testing.assert_array_equal(cnt.cpu().numpy(), want_cnt)
+        np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+
+
+@pytest.mark.parametrize("b,n,c,m,ns", [(4, 512, 64, 128, 64), (2, 1024, 3, 512, 32), (2, 512, 131, 128, 64),
+                                        (3, 100, 6, 7, 1), (2, 300, 8, 11, 5)])
+def test_group_point_and_grad(P, b, n, c, m, ns):
+    rng = np.random.default_rng(c)
+    pts = rng.random((b, n, c), dtype=np.float32)
+    idx = rng.integers(0, n, (b, m, ns)).astype(np.int32)
+    got = P.tf_grouping.group_point(dev(pts), dev(idx)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.group_point(pts, idx))
+    x = dev(pts).requires_grad_(True)
+    g = rng.random((b, m, ns, c), dtype=np.float32)
+    P.tf_grouping.group_point(x, dev(idx)).backward(dev(g))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), O.group_point_grad(pts, idx, g), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,m,k,kind", [
+    (4, 1024, 512, 32, "ball"), (4, 512, 128, 64, "ball"), (2, 1024, 512, 32, "lattice"),
+    (1, 8192, 1024, 32, "cube"), (1, 10240, 700, 32, "ball"), (2, 40, 40, 32, "ball"), (2, 64, 32, 64, "cube"),
+    (2, 300, 33, 1, "cube"), (1, 500, 20, 100, "cube"), (1, 700, 9, 200, "lattice"), (2, 1024, 1024, 16, "ball"),
+])
+def test_knn_batch(P, b, n, m, k, kind):
+    sup = clouds(31, b, n, kind)
+    qry = sup[:, :m].copy() if m <= n else clouds(32, b, m, kind)
+    want, wd = O.knn_batch(sup, qry, k, return_dist=True)
+    got = P.nearest_neighbors.knn_batch(dev(sup), dev(qry), k, omp=True)
+    assert got.dtype == torch.int64
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    got32 = P.nearest_neighbors.knn_batch(dev(sup), dev(qry), k, dtype=torch.int32)
+    assert got32.dtype == torch.int32
+    np.testing.assert_array_equal(got32.cpu().numpy(), want.astype(np.int32))
+    # numpy in -> numpy int64 out, like the reference binding
+    got_np = P.nearest_neighbors.knn_batch(sup, qry, k)
+    assert isinstance(got_np, np.ndarray) and got_np.dtype == np.int64
+    np.testing.assert_array_equal(got_np, want)
+
+
+def test_knn_self_first(P):
+    # AdaptiveSampling relies on neighbour 0 being the query itself (pointasnl_util.py:162-163)
+    sup = clouds(41, 2, 1024)
+    got = P.nearest_neighbors.knn_batch(dev(sup), dev(sup[:, :512]), 32).cpu().numpy()
+    np.testing.assert_array_equal(got[:, :, 0], np.broadcast_to(np.arange(512), (2, 512)))
+
+
+@pytest.mark.parametrize("b,m,n,k", [(32, 128, 512, 64), (2, 10, 100, 100), (2, 7, 33, 5), (1, 4, 700, 16)])
+def test_select_top_k(P, b, m, n, k):
+    rng = np.random.default_rng(n)
+    dist = rng.random((b, m, n), dtype=np.float32)
+    dist[:, :, ::7] = np.round(dist[:, :, ::7] * 4) / 4  # ties
+    wi, wo = O.select_top_k(k, dist)
+    gi, go = P.tf_grouping.select_top_k(k, dev(dist))
+    np.testing.assert_array_equal(go.cpu().numpy(), wo)
+    np.testing.assert_array_equal(gi.cpu().numpy(), wi)
+
+
+def test_knn_point(P):
+    xyz1, xyz2 = clouds(51, 4, 512, "cube"), clouds(52, 4, 128, "cube")
+    wv, wi = O.knn_point(16, xyz1, xyz2)
+    val, idx = P.tf_grouping.knn_point(16, dev(xyz1), dev(xyz2))
+    np.testing.assert_array_equal(idx.cpu().numpy(), wi)
+    np.testing.assert_array_equal(val.cpu().numpy(), wv)
+
+
+@pytest.mark.parametrize("b,n,m,kind", [(32, 512, 128, "cube"), (2, 8192, 1024, "ball"), (2, 1280, 320, "lattice"),
+                                        (2, 64, 32, "ball"), (2, 10, 2, "cube"), (1, 5000, 3000, "cube")])
+def test_three_nn(P, b, n, m, kind):
+    x1, x2 = clouds(61, b, n, kind), clouds(62, b, m, kind)
+    wd, wi = O.three_nn(x1, x2)
+    d, i = P.tf_interpolate.three_nn(dev(x1), dev(x2))
+    np.testing.assert_array_equal(i.cpu().numpy(), wi)
+    np.testing.assert_array_equal(d.cpu().numpy(), wd)
+
+
+@pytest.mark.parametrize("b,m,c,n", [(32, 128, 64, 512), (2, 1024, 128, 8192), (2, 64, 512, 256), (2, 50, 7, 33)])
+def test_three_interpolate_and_grad(P, b, m, c, n):
+    rng = np.random.default_rng(m)
+    pts = rng.random((b, m, c), dtype=np.float32)
+    x1, x2 = clouds(71, b, n, "cube"), clouds(72, b, m, "cube")
+    d, i = O.three_nn(x1, x2)
+    w = O.three_weights(d)
+    gw = P.tf_interpolate.three_weights(dev(d)).cpu().numpy()
+    np.testing.assert_array_equal(gw, w)
+    got = P.tf_interpolate.three_interpolate(dev(pts), dev(i), dev(w)).cpu().numpy()
+    np.testing.assert_allclose(got, O.three_interpolate(pts, i, w), rtol=1e-5, atol=1e-6)
+    np.testing.assert_array_equal(got, O.three_interpolate(pts, i, w))  # same op order, no contraction -> identical
+    x = dev(pts).requires_grad_(True)
+    g = rng.random((b, n, c), dtype=np.float32)
+    P.tf_interpolate.three_interpolate(x, dev(i), dev(w)).backward(dev(g))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), O.three_interpolate_grad(pts, i, w, g), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 100, 10), (3, 8192 + 1000, 2048), (2, 5, 100), (1, 20000, 64)])
+def test_prob_sample(P, b, n, m):
+    rng = np.random.default_rng(n)
+    p = rng.random((b, n), dtype=np.float32)
+    r = rng.random((b, m), dtype=np.float32)
+    got = P.tf_sampling.prob_sample(dev(p), dev(r)).cpu().numpy()
+    np.testing.assert_array_equal(got, O.prob_sample(p, r))
+
+
+def test_errors(P):
+    x = dev(clouds(1, 2, 16))
+    with pytest.raises(ValueError, match="positive npoint"):
+        P.tf_sampling.farthest_point_sample(0, x)
+    with pytest.raises(ValueError, match="FarthestPointSample expects"):
+        P.tf_sampling.farthest_point_sample(4, x[:, :, :2])
+    with pytest.raises(ValueError, match="positive radius"):
+        P.tf_grouping.query_ball_point(0.0, 4, x, x)
+    with pytest.raises(ValueError, match="positive nsample"):
+        P.tf_grouping.query_ball_point(0.1, 0, x, x)
+    with pytest.raises(ValueError, match="positive k"):
+        P.tf_grouping.select_top_k(0, torch.zeros(1, 2, 3).cuda())
+    with pytest.raises(ValueError):
+        P.nearest_neighbors.knn_batch(x, x, 17)  # k > n
+    with pytest.raises(Exception, match="no CPU fallback|CPU torch tensor"):
+        P.tf_sampling.farthest_point_sample(4, x.cpu())
+
+
+def test_empty(P):
+    x = dev(clouds(1, 2, 16))
+    e = torch.zeros((2, 0, 3), device="cuda")
+    idx, cnt = P.tf_grouping.query_ball_point(0.1, 4, x, e)
+    assert idx.shape == (2, 0, 4) and cnt.shape == (2, 0)
+    assert P.nearest_neighbors.knn_batch(x, e, 3).shape == (2, 0, 3)
+    d, i = P.tf_interpolate.three_nn(e, x)
+    assert d.shape == (2, 0, 3)
+    assert P.tf_grouping.group_point(x, torch.zeros((2, 0, 5), dtype=torch.int32, device="cuda")).shape == (2, 0, 5, 3)
