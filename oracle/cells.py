@@ -44,8 +44,15 @@ def batched_gather(points, idx):
     return points[bi, idx]
 
 
-def sample_weights(new_point, grouped_xyz, mlps, params, scope):
+def _join(outer, scope):
+    """TF variable scopes nest: every cell re-opens tf.variable_scope(scope) with the SAME scope string it was
+    handed (pointasnl_util.py:119,159,182,233), so variables live under layer1/layer1/layer1/conv_kv_ds etc."""
+    return scope if not outer else outer + "/" + scope
+
+
+def sample_weights(new_point, grouped_xyz, mlps, params, scope, outer=""):
     """SampleWeights, pointasnl_util.py:112-156.  new_point (B,P,as,ch), grouped_xyz (B,P,as,3)."""
+    scope = _join(outer, scope)
     ch = new_point.shape[-1]
     cb = max(32, ch // 2)  # :121
     normalized_xyz = grouped_xyz - grouped_xyz[:, :, :1, :]  # :122
@@ -62,21 +69,23 @@ def sample_weights(new_point, grouped_xyz, mlps, params, scope):
     return _softmax(g, 2)  # :154
 
 
-def adaptive_sampling(group_xyz, group_feature, num_neighbor, params, scope):
+def adaptive_sampling(group_xyz, group_feature, num_neighbor, params, scope, outer=""):
     """AdaptiveSampling, pointasnl_util.py:158-173."""
+    path = _join(outer, scope)
     if num_neighbor == 0:
         return group_xyz[:, :, 0, :], group_feature[:, :, 0, :]
     num_channel = group_feature.shape[-1]
     sxyz = group_xyz[:, :, :num_neighbor, :]
     sfeat = group_feature[:, :, :num_neighbor, :]
-    w = sample_weights(sfeat, sxyz, [32, 1 + num_channel], params, scope)
+    w = sample_weights(sfeat, sxyz, [32, 1 + num_channel], params, scope, outer=path)
     new_xyz = (sxyz * w[..., :1]).sum(axis=2)
     new_feature = (sfeat * w[..., 1:]).sum(axis=2)
     return new_xyz, new_feature
 
 
-def point_nonlocal_cell(feature, new_point, mlp, params, scope):
+def point_nonlocal_cell(feature, new_point, mlp, params, scope, outer=""):
     """PointNonLocalCell mode='dot', pointasnl_util.py:175-219.  feature (B,N,C), new_point (B,P,C')."""
+    scope = _join(outer, scope)
     cb = mlp[0]
     kv = _layer(feature, params[scope + "/conv_kv"], None)  # :187-190
     q = _layer(new_point, params[scope + "/conv_query"], None)  # :191-194
@@ -113,11 +122,12 @@ def set_abstraction(xyz, feature, npoint, nsample, mlp, params, scope, as_neighb
     grouped_xyz = batched_gather(xyz, idx)
     new_point = np.concatenate([grouped_xyz, batched_gather(feature, idx)], axis=-1)  # :71-74
     if num_points != npoint:  # :246-247
-        new_xyz, new_feature = adaptive_sampling(grouped_xyz, new_point, as_neighbor, params, scope)
+        new_xyz, new_feature = adaptive_sampling(grouped_xyz, new_point, as_neighbor, params, scope, outer=scope)
     grouped_xyz = grouped_xyz - new_xyz[:, :, None, :]  # :248
     new_point = np.concatenate([grouped_xyz, new_point], axis=-1)  # :249
     if NL:  # :252-255
-        nonlocal_pt = point_nonlocal_cell(feature, new_feature, [max(32, num_channel // 2), mlp[-1]], params, scope)
+        nonlocal_pt = point_nonlocal_cell(feature, new_feature, [max(32, num_channel // 2), mlp[-1]], params, scope,
+                                          outer=scope)
     skip = _layer(new_point.max(axis=2), params[scope + "/skip"], "relu")  # :258-261
     for i in range(len(mlp) - 1):  # :264-269
         new_point = _layer(new_point, params[scope + "/conv%d" % i], "relu")

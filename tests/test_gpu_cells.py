@@ -1,0 +1,128 @@
+"""AS / NL cells and the classification graph on the HIP path vs the numpy oracle (fp32, cross-checked in fp64).
+Tolerance 1e-5 (BASELINE.json north_star) on the attention cores; the end-to-end logits accumulate ~10 layers
+of fp32 GEMMs in a different summation order (vendor BLAS vs numpy) and are held to 1e-4 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import clouds
+from oracle import cells
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("b,p,n,cb", [
+    (4, 512, 1024, 32),   # cls layer1
+    (4, 128, 512, 64),    # cls layer2
+    (1, 1024, 8192, 32),  # ScanNet layer1 (512 MiB map if materialised at B=16)
+    (2, 32, 64, 128),     # ScanNet layer4
+    (2, 45, 77, 32),      # ragged: P, N not multiples of the tiles
+    (1, 1, 1, 64),
+    (2, 40, 80, 128),     # KITTI layer4_1
+])
+def test_nl_attention(b, p, n, cb, variant):
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    if variant == 1 and cb == 128:
+        pytest.skip("vector-FMA variant covers cb<=64")
+    rng = np.random.default_rng(p * 7 + n)
+    q = rng.standard_normal((b, p, cb)).astype(np.float32)
+    kv = rng.standard_normal((b, n, 2 * cb)).astype(np.float32)
+    want64 = cells.nl_attention_core(q.astype(np.float64), kv.astype(np.float64), cb)
+    want32 = cells.nl_attention_core(q, kv, cb)
+    got = U.nl_attention(dev(q), dev(kv), variant=variant).cpu().numpy()
+    assert np.abs(want32 - want64).max() < 1e-5  # the fp32 oracle itself is within tolerance of fp64
+    np.testing.assert_allclose(got, want64, rtol=1e-5, atol=1e-5)
+
+
+def test_nl_attention_spike():
+    # one key dominates from a late tile: forces the online-softmax rescale branch with a large max jump
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    rng = np.random.default_rng(5)
+    b, p, n, cb = 1, 64, 300, 32
+    q = rng.standard_normal((b, p, cb)).astype(np.float32)
+    kv = rng.standard_normal((b, n, 2 * cb)).astype(np.float32) * 0.1
+    kv[0, 250, :cb] = q[0, 3] * 6.0
+    want = cells.nl_attention_core(q.astype(np.float64), kv.astype(np.float64), cb)
+    for variant in (1, 2):
+        got = U.nl_attention(dev(q), dev(kv), variant=variant).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("g,as_,cb", [(2048, 12, 32), (512, 12, 65), (300, 8, 32), (100, 4, 32), (7, 16, 40), (3, 1, 33)])
+def test_as_attention(g, as_, cb):
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    rng = np.random.default_rng(g)
+    q = rng.standard_normal((g, as_, cb)).astype(np.float32)
+    kv = rng.standard_normal((g, as_, 2 * cb)).astype(np.float32)
+    want = cells.nl_attention_core(q.astype(np.float64), kv.astype(np.float64), cb)
+    got = U.as_attention(dev(q), dev(kv)).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def _store(seed):
+    from pointasnl_amd.utils import tf_util
+
+    return tf_util.set_store(tf_util.VariableStore(seed=seed, randomize_bn=True))
+
+
+@pytest.mark.parametrize("as_,c", [(12, 3), (12, 128), (8, 32), (4, 64)])
+def test_adaptive_sampling_cell(as_, c):
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    st = _store(as_ * 100 + c)
+    rng = np.random.default_rng(c)
+    b, p, k = 2, 96, 32
+    gxyz = rng.standard_normal((b, p, k, 3)).astype(np.float32) * 0.2
+    gfeat = np.concatenate([gxyz, rng.standard_normal((b, p, k, c)).astype(np.float32)], -1)
+    nx, nf = U.AdaptiveSampling(dev(gxyz), dev(gfeat), as_, False, None, None, "layer1", True)
+    params = st.export_numpy()
+    wx, wf = cells.adaptive_sampling(gxyz.astype(np.float64), gfeat.astype(np.float64), as_, params, "layer1")
+    np.testing.assert_allclose(nx.cpu().numpy(), wx, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(nf.cpu().numpy(), wf, rtol=1e-5, atol=1e-5)
+    wx32, wf32 = cells.adaptive_sampling(gxyz, gfeat, as_, params, "layer1")
+    np.testing.assert_allclose(wx32, wx, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n,c,p,cq", [(1024, 3, 512, 6), (512, 128, 128, 131), (256, 256, 64, 259)])
+def test_point_nonlocal_cell(n, c, p, cq):
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    st = _store(n + c)
+    rng = np.random.default_rng(n)
+    b = 2
+    feat = rng.standard_normal((b, n, c)).astype(np.float32)
+    newf = rng.standard_normal((b, p, cq)).astype(np.float32)
+    mlp = [max(32, c // 2), 2 * max(32, c // 2)]
+    got = U.PointNonLocalCell(dev(feat), dev(newf).unsqueeze(1), mlp, False, None, None, "layerX", True)
+    want = cells.point_nonlocal_cell(feat.astype(np.float64), newf.astype(np.float64), mlp, st.export_numpy(), "layerX")
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_cls_forward_matches_oracle(adaptive):
+    from pointasnl_amd.models import pointasnl_cls
+
+    st = _store(17)
+    pc = clouds(99, 2, 1024)
+    with torch.no_grad():
+        logits, ep = pointasnl_cls.get_model(dev(pc), is_training=False, adaptive_sample=adaptive)
+    params = st.export_numpy()
+    want, wep = cells.cls_forward(pc, params, adaptive_sample=adaptive)
+    want64, _ = cells.cls_forward(pc, params, adaptive_sample=adaptive, dtype=np.float64)
+    # sampled coordinates: without AS they are gathered input points -> exact
+    if not adaptive:
+        np.testing.assert_array_equal(ep["l1_xyz"].cpu().numpy(), wep["l1_xyz"])
+    else:
+        np.testing.assert_allclose(ep["l1_xyz"].cpu().numpy(), wep["l1_xyz"], rtol=1e-5, atol=1e-5)
+    scale = max(1.0, np.abs(want64).max())
+    assert np.abs(logits.cpu().numpy() - want64).max() / scale < 1e-4
+    assert np.abs(want - want64).max() / scale < 1e-4
+    assert (logits.argmax(1).cpu().numpy() == want64.argmax(1)).all()
