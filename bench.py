@@ -1,0 +1,297 @@
+#!/usr/bin/env python
+"""bench.py -- ModelNet40 pointasnl_cls forward throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" is one inference forward of models/pointasnl_cls.py over one batch of synthetic clouds
+(B=64 x 1024 x 3 per GPU, BASELINE.json configs[1]; --AS selects configs[2]); inputs are resident in HBM before
+the timed region.  The forward is captured once into a HIP graph and replayed; with N>1 every rank owns its own
+64 clouds (weak scaling, no data-path collective) and the per-shard logits are all-gathered over RCCL each step.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the hand-written kernel that takes the largest share of the
+step: algorithmic bytes/flops / its average launch duration, measured with HIP events on the
+launch stream in an event-instrumented pass of the same forward.  `cpu_baseline` times the CPU restatement of
+the same forward (oracle/, "port") on the host cores over a bounded sample.  `kernels` lists every hand-written
+kernel the same way (extra, for the record).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: fp32 matrix (= vector) peak
+
+
+def synth_clouds(seed, b, n):
+    """uniform in the unit ball, then pc_normalize (zero mean, max norm 1)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    v = rng.standard_normal((b, n, 3))
+    v /= np.linalg.norm(v, axis=-1, keepdims=True)
+    pc = v * rng.random((b, n, 1)) ** (1 / 3)
+    pc -= pc.mean(axis=1, keepdims=True)
+    pc /= np.linalg.norm(pc, axis=-1).max(axis=1)[:, None, None]
+    return pc.astype(np.float32)
+
+
+def add_noise(pc, noise, seed):
+    """configs[2]: overwrite the first `noise` points per cloud with uniform outliers (test.py:128-132)."""
+    if noise <= 0:
+        return pc
+    rng = np.random.Generator(np.random.PCG64(seed + 1000))
+    pc = pc.copy()
+    pc[:, :noise, :] = rng.random((pc.shape[0], noise, 3), dtype=np.float32) * 2 - 1
+    return pc
+
+
+# ---- algorithmic work per launch, SURVEY.md 8(d).  ints = the integer arguments of the C-ABI call.
+def algorithmic(symbol, ints):
+    """-> (bytes, flops, bound) for one launch"""
+    if symbol == "pasnl_farthest_point_sample":
+        b, n, m = ints
+        return 12 * b * n + 4 * b * m, 10 * b * n * m, "hbm"
+    if symbol == "pasnl_gather_point":
+        b, n, m = ints
+        return 28 * b * m, 0, "hbm"
+    if symbol == "pasnl_group_point":
+        b, n, c, m, ns = ints
+        return 4 * b * (n * c + m * ns + m * ns * c), 0, "hbm"
+    if symbol == "pasnl_knn_batch":
+        b, n, m, k = ints[:4]
+        return 12 * b * (n + m) + 4 * b * m * k, 8 * b * n * m, "hbm"
+    if symbol == "pasnl_query_ball_point":
+        b, n, m, ns = ints
+        return 12 * b * (n + m) + 4 * b * m * (ns + 1), 10 * b * n * m, "hbm"
+    if symbol == "pasnl_three_nn":
+        b, n, m = ints
+        return 12 * b * (n + m) + 24 * b * n, 8 * b * n * m, "hbm"
+    if symbol == "pasnl_three_interpolate":
+        b, m, c, n = ints
+        return 24 * b * n + 4 * b * c * (m + n), 5 * b * n * c, "hbm"
+    if symbol == "pasnl_three_weights":
+        (rows,) = ints
+        return 24 * rows, 8 * rows, "hbm"
+    if symbol == "pasnl_nl_attention":
+        b, p, n, cb = ints[:4]
+        return 4 * b * cb * (2 * p + 2 * n), 4 * b * p * n * cb + 5 * b * p * n, "mfma"
+    if symbol == "pasnl_as_attention":
+        g, as_, cb = ints
+        return 4 * g * as_ * cb * 4, 4 * g * as_ * as_ * cb + 5 * g * as_ * as_, "mfma"
+    if symbol == "pasnl_as_reweight":
+        g, as_, ns, ch = ints
+        return 4 * g * (as_ * (1 + ch) + as_ * (3 + ch) + 3 + ch), 4 * g * as_ * (1 + ch), "hbm"
+    return 0, 0, "hbm"
+
+
+def kernel_table(records):
+    """records: list of (symbol, ints, e0, e1) over several steps -> per (symbol, ints) averages"""
+    agg = {}
+    for sym, ints, e0, e1 in records:
+        key = (sym, ints)
+        a = agg.setdefault(key, [0.0, 0])
+        a[0] += e0.elapsed_time(e1)
+        a[1] += 1
+    rows = []
+    for (sym, ints), (ms, cnt) in agg.items():
+        by, fl, bound = algorithmic(sym, ints)
+        avg_s = ms / cnt * 1e-3
+        row = {"kernel": sym, "dims": list(ints), "launches": cnt, "avg_us": round(avg_s * 1e6, 2), "bound": bound,
+               "alg_bytes": by, "alg_flops": fl, "GB/s": round(by / avg_s / 1e9, 2),
+               "TFLOP/s": round(fl / avg_s / 1e12, 3)}
+        rows.append(row)
+    rows.sort(key=lambda r: -r["avg_us"] * 1.0)
+    return rows
+
+
+def cpu_baseline(pc_all, params, adaptive, seconds_budget=25.0):
+    """The same forward on the host: C oracle ops (OpenMP over the batch) + numpy/BLAS dense layers, fp32."""
+    from oracle import cells, ops
+
+    cores = os.cpu_count() or 1
+    ops.set_threads(cores)
+    bsz = 16  # BASELINE.json configs[0]: the reference's CPU-runnable case
+    sample = pc_all[:bsz]
+    t0 = time.perf_counter()
+    cells.cls_forward(sample, params, adaptive_sample=adaptive)  # warm-up (also pages in BLAS)
+    one = time.perf_counter() - t0
+    reps = max(1, min(5, int(seconds_budget / max(one, 1e-3)) - 1))
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        cells.cls_forward(sample, params, adaptive_sample=adaptive)
+        ts.append(time.perf_counter() - t0)
+    med = float(np.median(ts))
+    return {"value": round(bsz / med, 2), "unit": "point-clouds/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} forwards of B={bsz}x1024 (configs[0]) after 1 warm-up; C oracle ops with OpenMP over batch + "
+                      f"numpy fp32 dense layers; median {med:.3f} s/forward"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="clouds per GPU (weak scaling)")
+    ap.add_argument("--AS", action="store_true", help="configs[2]: adaptive sampling on, noisy clouds")
+    ap.add_argument("--noise", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        args.gpus = world
+
+    from pointasnl_amd import _hip
+    from pointasnl_amd.models import pointasnl_cls
+    from pointasnl_amd.utils import tf_util
+    from pointasnl_amd import sharding
+
+    _hip.lib()
+    _hip.require_device()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B, N = args.batch, 1024
+    cfg_index = 2 if args.AS else 1
+    pc = synth_clouds(1234 + cfg_index + 100 * rank, B, N)
+    if args.AS:
+        pc = add_noise(pc, args.noise, 1234 + cfg_index + 100 * rank)
+    x = torch.from_numpy(pc).cuda()
+    store = tf_util.set_store(tf_util.VariableStore(seed=1234))  # identical weights on every rank
+
+    def forward():
+        logits, _ = pointasnl_cls.get_model(x, is_training=False, adaptive_sample=args.AS)
+        return logits
+
+    gathered = sharding.LogitsGather(world, B, 40, x.device) if world > 1 else None
+
+    with torch.no_grad():
+        # ---- warm-up (eager: creates weights, BLAS workspaces), then capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(2, min(3, args.warmup))):
+                logits = forward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = None
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                logits = forward()
+
+        def step():
+            if graph is not None:
+                graph.replay()
+                out = logits
+            else:
+                out = forward()
+            if gathered is not None:
+                gathered.all_gather(out)
+            return out
+
+        for _ in range(args.warmup):
+            step()
+
+        # ---- timed region: barrier + sync on both sides, max over ranks
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=x.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- per-kernel pass: the same forward, eager, every C-ABI launch bracketed by HIP events
+        rows = []
+        if rank == 0:
+            _hip.PROFILE = []
+            for _ in range(min(args.steps, 20)):
+                forward()
+            torch.cuda.synchronize()
+            rows = kernel_table(_hip.PROFILE)
+            _hip.PROFILE = None
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    # dominant hand-written kernel = largest total time per step
+    roofline = None
+    if rows:
+        dom = max(rows, key=lambda r: r["avg_us"])
+        if dom["bound"] == "mfma":
+            ach, peak, unit = dom["TFLOP/s"], F32_MFMA_PEAK_TF, "TFLOP/s"
+        else:
+            ach, peak, unit = dom["GB/s"], HBM_PEAK_GBS, "GB/s"
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(dom["kernel"] + ":" + ",".join(map(str, dom["dims"])))
+        roofline = {"kernel": dom["kernel"], "dims": dom["dims"], "bound": dom["bound"], "achieved": ach, "peak": peak,
+                    "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic, "avg_us": dom["avg_us"],
+                    "alg_bytes": dom["alg_bytes"], "alg_flops": dom["alg_flops"]}
+
+    cpu = None
+    if not args.no_cpu_baseline:
+        cpu = cpu_baseline(pc, store.export_numpy(), args.AS)
+
+    handwritten_us = sum(r["avg_us"] for r in rows)
+    out = {
+        "metric": "point-clouds/sec fwd (Bx1024 pts, ModelNet40 cls)",
+        "value": round(value, 2),
+        "unit": "point-clouds/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": ("configs[2]: ModelNet40 pointasnl_cls --AS, 1024 pts + noise" if args.AS else
+                                "configs[1]: ModelNet40 pointasnl_cls, 1024 pts") + f", batch={B}/GPU, seeded random weights",
+                   "global_batch": world * B, "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
+                   "hip_graph": graph is not None},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "handwritten_kernel_us_per_step": round(handwritten_us, 1),
+        "kernels": rows,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,26 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+# Optional per-launch timing for bench.py: when PROFILE is a list, every C-ABI launch is bracketed by two
+# HIP events recorded on the stream the kernel is enqueued on (torch's current stream) and
+# (symbol, integer-arguments, start_event, end_event) is appended.  Off (None) in normal operation.
+PROFILE = None
+
+
+def launch(symbol, what, *args):
+    """Call one pasnl_* entry point with the current stream appended; raise on a non-zero status."""
+    fn = getattr(lib(), symbol)
+    if PROFILE is None:
+        check(fn(*args, stream_ptr()), what)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    code = fn(*args, stream_ptr())
+    e1.record()
+    check(code, what)
+    PROFILE.append((symbol, tuple(a for a in args if isinstance(a, int)), e0, e1))
+
+
 def check(code, what):
     if code != 0:
         msg = lib().pasnl_strerror(code).decode()

@@ -1,0 +1,53 @@
+"""Batch sharding of the forward path over the GPUs of one node.
+
+Every op and cell of the path is independent per cloud (inference batch norm uses running statistics), so the
+path shards over the batch with NO data-path collective: rank r of W owns clouds [r*B/W, (r+1)*B/W).  The only
+exchange is one all-gather of the per-shard logits per forward (cls: (B/W,40) fp32 = 10 KB per rank) -- on the
+fully connected xGMI fabric a direct all-gather, latency- not bandwidth-bound.  One process per GPU; backend
+"nccl" is RCCL on ROCm, "gloo" is used by the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(rank, world, total):
+    """Clouds owned by `rank`: contiguous, sizes differ by at most one when world does not divide total."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class LogitsGather:
+    """Pre-allocated all-gather of equally sized per-rank logits (weak scaling: same batch on every rank)."""
+
+    def __init__(self, world, rows_per_rank, width, device, dtype=torch.float32):
+        self.world = world
+        self.out = torch.empty((world * rows_per_rank, width), dtype=dtype, device=device)
+
+    def all_gather(self, local):
+        if self.world == 1:
+            self.out.copy_(local)
+        else:
+            dist.all_gather_into_tensor(self.out, local.contiguous())
+        return self.out
+
+
+def gather_ragged(local, total, width):
+    """All-gather for shards of unequal size (strong-scaling split of a fixed batch): pad to the largest shard,
+    gather, drop the padding.  Returns the (total, width) logits in cloud order on every rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(r, world, total)[1] - shard_range(r, world, total)[0] for r in range(world)]
+    mx = max(sizes)
+    buf = torch.zeros((mx, width), dtype=local.dtype, device=local.device)
+    buf[: local.shape[0]] = local
+    out = torch.empty((world * mx, width), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, buf)
+    return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
+
+
+def sharded_forward(forward, clouds, width):
+    """Run `forward` on this rank's shard of `clouds` (B_total,...) and return the full (B_total,width) result."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(rank, world, clouds.shape[0])
+    local = forward(clouds[lo:hi])
+    return gather_ragged(local, clouds.shape[0], width)

@@ -26,8 +26,7 @@ def three_nn(xyz1, xyz2):
     m = xyz2.shape[1]
     dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
-    _hip.check(_hip.lib().pasnl_three_nn(b, n, m, _hip.ptr(xyz1), _hip.ptr(xyz2), _hip.ptr(dist), _hip.ptr(idx),
-                                         _hip.stream_ptr()), "ThreeNN")
+    _hip.launch("pasnl_three_nn", "ThreeNN", b, n, m, _hip.ptr(xyz1), _hip.ptr(xyz2), _hip.ptr(dist), _hip.ptr(idx))
     return dist, idx
 
 
@@ -37,8 +36,8 @@ class _ThreeInterpolate(torch.autograd.Function):
         b, m, c = points.shape
         n = idx.shape[1]
         out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
-        _hip.check(_hip.lib().pasnl_three_interpolate(b, m, c, n, _hip.ptr(points), _hip.ptr(idx), _hip.ptr(weight),
-                                                      _hip.ptr(out), _hip.stream_ptr()), "ThreeInterpolate")
+        _hip.launch("pasnl_three_interpolate", "ThreeInterpolate", b, m, c, n, _hip.ptr(points), _hip.ptr(idx), _hip.ptr(weight),
+                                                      _hip.ptr(out))
         ctx.save_for_backward(idx, weight)
         ctx.m = m
         return out
@@ -49,9 +48,8 @@ class _ThreeInterpolate(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         b, n, c = grad_out.shape
         g = torch.empty((b, ctx.m, c), dtype=torch.float32, device=grad_out.device)
-        _hip.check(_hip.lib().pasnl_three_interpolate_grad(b, n, c, ctx.m, _hip.ptr(grad_out), _hip.ptr(idx),
-                                                           _hip.ptr(weight), _hip.ptr(g), _hip.stream_ptr()),
-                   "ThreeInterpolateGrad")
+        _hip.launch("pasnl_three_interpolate_grad", "ThreeInterpolateGrad", b, n, c, ctx.m, _hip.ptr(grad_out), _hip.ptr(idx),
+                                                           _hip.ptr(weight), _hip.ptr(g))
         return g, None, None
 
 
@@ -82,6 +80,5 @@ def three_weights(dist):
     d=max(d,1e-10); w=(1/d)/sum(1/d).  dist (b,n,3) -> weight (b,n,3)."""
     dist = _hip.as_dev(dist, torch.float32)
     w = torch.empty_like(dist)
-    _hip.check(_hip.lib().pasnl_three_weights(dist.numel() // 3, _hip.ptr(dist), _hip.ptr(w), _hip.stream_ptr()),
-               "ThreeWeights")
+    _hip.launch("pasnl_three_weights", "ThreeWeights", dist.numel() // 3, _hip.ptr(dist), _hip.ptr(w))
     return w

@@ -30,9 +30,8 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     m = xyz2.shape[1]
     idx = torch.empty((b, m, int(nsample)), dtype=torch.int32, device=xyz1.device)
     pts_cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
-    _hip.check(_hip.lib().pasnl_query_ball_point(b, n, m, ctypes.c_float(float(radius)), int(nsample), _hip.ptr(xyz1),
-                                                 _hip.ptr(xyz2), _hip.ptr(idx), _hip.ptr(pts_cnt), _hip.stream_ptr()),
-               "QueryBallPoint")
+    _hip.launch("pasnl_query_ball_point", "QueryBallPoint", b, n, m, ctypes.c_float(float(radius)), int(nsample), _hip.ptr(xyz1),
+                                                 _hip.ptr(xyz2), _hip.ptr(idx), _hip.ptr(pts_cnt))
     return idx, pts_cnt
 
 
@@ -53,8 +52,7 @@ def select_top_k(k, dist):
     b, m, n = dist.shape
     outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
     out = torch.empty((b, m, n), dtype=torch.float32, device=dist.device)
-    _hip.check(_hip.lib().pasnl_select_top_k(b, n, m, int(k), _hip.ptr(dist), _hip.ptr(outi), _hip.ptr(out),
-                                             _hip.stream_ptr()), "SelectionSort")
+    _hip.launch("pasnl_select_top_k", "SelectionSort", b, n, m, int(k), _hip.ptr(dist), _hip.ptr(outi), _hip.ptr(out))
     return outi, out
 
 
@@ -64,8 +62,7 @@ class _GroupPoint(torch.autograd.Function):
         b, n, c = points.shape
         _, m, ns = idx.shape
         out = torch.empty((b, m, ns, c), dtype=torch.float32, device=points.device)
-        _hip.check(_hip.lib().pasnl_group_point(b, n, c, m, ns, _hip.ptr(points), _hip.ptr(idx), _hip.ptr(out),
-                                                _hip.stream_ptr()), "GroupPoint")
+        _hip.launch("pasnl_group_point", "GroupPoint", b, n, c, m, ns, _hip.ptr(points), _hip.ptr(idx), _hip.ptr(out))
         ctx.save_for_backward(idx)
         ctx.n = n
         return out
@@ -76,8 +73,7 @@ class _GroupPoint(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         b, m, ns, c = grad_out.shape
         g = torch.empty((b, ctx.n, c), dtype=torch.float32, device=grad_out.device)
-        _hip.check(_hip.lib().pasnl_group_point_grad(b, ctx.n, c, m, ns, _hip.ptr(grad_out), _hip.ptr(idx), _hip.ptr(g),
-                                                     _hip.stream_ptr()), "GroupPointGrad")
+        _hip.launch("pasnl_group_point_grad", "GroupPointGrad", b, ctx.n, c, m, ns, _hip.ptr(grad_out), _hip.ptr(idx), _hip.ptr(g))
         return g, None
 
 

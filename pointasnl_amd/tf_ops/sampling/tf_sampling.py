@@ -26,8 +26,7 @@ returns:
     m = inpr.shape[1]
     out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
     temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)  # tf_sampling.cpp:85 allocate_temp
-    _hip.check(_hip.lib().pasnl_prob_sample(b, n, m, _hip.ptr(inp), _hip.ptr(inpr), _hip.ptr(temp), _hip.ptr(out),
-                                            _hip.stream_ptr()), "ProbSample")
+    _hip.launch("pasnl_prob_sample", "ProbSample", b, n, m, _hip.ptr(inp), _hip.ptr(inpr), _hip.ptr(temp), _hip.ptr(out))
     return out
 
 
@@ -37,8 +36,7 @@ class _GatherPoint(torch.autograd.Function):
         b, n, _ = inp.shape
         m = idx.shape[1]
         out = torch.empty((b, m, 3), dtype=torch.float32, device=inp.device)
-        _hip.check(_hip.lib().pasnl_gather_point(b, n, m, _hip.ptr(inp), _hip.ptr(idx), _hip.ptr(out), _hip.stream_ptr()),
-                   "GatherPoint")
+        _hip.launch("pasnl_gather_point", "GatherPoint", b, n, m, _hip.ptr(inp), _hip.ptr(idx), _hip.ptr(out))
         ctx.save_for_backward(idx)
         ctx.n = n
         return out
@@ -49,8 +47,7 @@ class _GatherPoint(torch.autograd.Function):
         out_g = out_g.contiguous()
         b, m, _ = out_g.shape
         inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=out_g.device)
-        _hip.check(_hip.lib().pasnl_gather_point_grad(b, ctx.n, m, _hip.ptr(out_g), _hip.ptr(idx), _hip.ptr(inp_g),
-                                                      _hip.stream_ptr()), "GatherPointGrad")
+        _hip.launch("pasnl_gather_point_grad", "GatherPointGrad", b, ctx.n, m, _hip.ptr(out_g), _hip.ptr(idx), _hip.ptr(inp_g))
         return inp_g, None
 
 
@@ -85,6 +82,5 @@ returns:
         raise ValueError("FarthestPointSample expects (batch_size,num_points,3) inp shape")
     b, n, _ = inp.shape
     out = torch.empty((b, int(npoint)), dtype=torch.int32, device=inp.device)
-    _hip.check(_hip.lib().pasnl_farthest_point_sample(b, n, int(npoint), _hip.ptr(inp), _hip.ptr(out), _hip.stream_ptr()),
-               "FarthestPointSample")
+    _hip.launch("pasnl_farthest_point_sample", "FarthestPointSample", b, n, int(npoint), _hip.ptr(inp), _hip.ptr(out))
     return out

@@ -23,8 +23,8 @@ def _knn_dev(pts, queries, K, i64):
     b, n, _ = pts.shape
     m = queries.shape[1]
     out = torch.empty((b, m, int(K)), dtype=torch.int64 if i64 else torch.int32, device=pts.device)
-    _hip.check(_hip.lib().pasnl_knn_batch(b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
-                                          _hip.ptr(None), _hip.stream_ptr()), "knn_batch")
+    _hip.launch("pasnl_knn_batch", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
+                                          _hip.ptr(None))
     return out
 
 

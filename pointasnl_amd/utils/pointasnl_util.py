@@ -86,8 +86,7 @@ def as_attention(q, kv):
     g = q.numel() // (as_ * cb)
     q, kv = q.contiguous(), kv.contiguous()
     out = torch.empty_like(q)
-    _hip.check(_hip.lib().pasnl_as_attention(g, as_, cb, _hip.ptr(q), _hip.ptr(kv), _hip.ptr(out), _hip.stream_ptr()),
-               "as_attention")
+    _hip.launch("pasnl_as_attention", "as_attention", g, as_, cb, _hip.ptr(q), _hip.ptr(kv), _hip.ptr(out))
     return out
 
 
@@ -143,10 +142,9 @@ def AdaptiveSampling(group_xyz, group_feature, num_neighbor, is_training, bn_dec
         group_xyz, group_feature, logits = group_xyz.contiguous(), group_feature.contiguous(), logits.contiguous()
         new_xyz = torch.empty((b, p, 3), dtype=torch.float32, device=group_xyz.device)
         new_feature = torch.empty((b, p, num_channel), dtype=torch.float32, device=group_xyz.device)
-        _hip.check(_hip.lib().pasnl_as_reweight(b * p, int(num_neighbor), int(nsample), int(num_channel),
+        _hip.launch("pasnl_as_reweight", "as_reweight", b * p, int(num_neighbor), int(nsample), int(num_channel),
                                                 _hip.ptr(logits), _hip.ptr(group_xyz), _hip.ptr(group_feature),
-                                                _hip.ptr(new_xyz), _hip.ptr(new_feature), _hip.stream_ptr()),
-                   "as_reweight")
+                                                _hip.ptr(new_xyz), _hip.ptr(new_feature))
         return new_xyz, new_feature
 
 
@@ -156,9 +154,8 @@ def nl_attention(q, kv, variant=None):
     n = kv.shape[1]
     q, kv = q.contiguous(), kv.contiguous()
     out = torch.empty_like(q)
-    _hip.check(_hip.lib().pasnl_nl_attention(b, p, n, cb, _hip.ptr(q), _hip.ptr(kv), _hip.ptr(out),
-                                             int(NL_VARIANT if variant is None else variant), _hip.stream_ptr()),
-               "nl_attention")
+    _hip.launch("pasnl_nl_attention", "nl_attention", b, p, n, cb, _hip.ptr(q), _hip.ptr(kv), _hip.ptr(out),
+                                             int(NL_VARIANT if variant is None else variant))
     return out
 
 
