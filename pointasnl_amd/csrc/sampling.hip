@@ -1,96 +1,200 @@
 // Sampling ops for gfx950: farthest point sampling, 3-wide gather (+grad), probability sampling.
 // Behaviour contract: reference tf_ops/sampling/tf_sampling_g.cu (kernels :7-192), restated in oracle/.
 // The design is NOT the reference's: FPS keeps every point and its running min-distance in VGPRs,
-// reduces with DPP inside a wave and one LDS hop across waves, one workgroup per cloud.
+// reduces with DPP inside a wave and one LDS hop across waves, one workgroup per cloud (details below).
+#include <stdio.h>
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace pasnl {
 
 // ---------------------------------------------------------------------------------------------
 // Farthest point sampling.
-//   One workgroup (WAVES x 64 lanes) owns one cloud; lane t holds points k = i*T + t, i < PPL.
-//   Round j:  read the last pick's coordinates from the LDS copy of the cloud (broadcast read),
-//             update PPL running distances in registers, form the 64-bit key
-//                 (bits(d2) << 32) | ~tiekey(k),  tiekey(k) = ((k & 511) << 22) | k
-//             whose maximum is exactly the reference's winner: largest d2, then lowest k mod 512,
-//             then lowest k (tf_sampling_g.cu:142-164),
-//             DPP-reduce inside the wave, exchange WAVES partial keys through a double-buffered LDS
-//             slot (one barrier per round).
+//   One workgroup (WAVES x 64 lanes) owns one cloud; lane t keeps points k = i*T + t (i < PPL, T = WAVES*64)
+//   and their running min-distances in VGPRs for the whole kernel.  The loop is a chain of npoint DEPENDENT
+//   rounds (a dependent VALU op costs ~6.5 cycles with one wave per SIMD), so the design minimises the depth
+//   of one round:
+//     * distances for two points per instruction (v_pk_* fp32), all PPL points independent;
+//     * in-lane argmax as a tournament tree (depth log2 PPL) with strict '>' and left preference; the leaves
+//       are ordered by (i*T mod 512, i), which makes "leftmost maximum" exactly the reference tie rule
+//       "largest d2, then lowest k mod 512, then lowest k" (tf_sampling_g.cu:142-164) -- T divides
+//       512 or 512 divides T, so the order is a compile-time permutation;
+//     * wave argmax = six single-instruction v_max_i32_dpp steps on the distance bits (real distances are
+//       >= +0 and order like signed ints; padding carries distinct negative sentinels) + one ballot; several
+//       lanes holding the maximum is the rare uniform slow path that compares tie keys;
+//     * cross-wave (WAVES > 1): one {d2,k} slot per wave, double-buffered, ONE barrier per round; afterwards
+//       lane w of every wave reads slot w and a 4-step row DPP max finishes -- cost independent of WAVES;
+//     * no global memory traffic inside the loop: picks are buffered in LDS (a store in the loop would make
+//       every barrier wait for its acknowledgement) and the cloud sits in LDS as 16-byte records for the one
+//       b128 broadcast read "coordinates of the pick".
+//   Single-wave clouds (n <= 1024) need no barrier at all.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t fps_tiekey(int k) { return (((uint32_t)k & 511u) << 22) | (uint32_t)k; }
-__device__ __forceinline__ int fps_key_to_index(uint64_t key) { return (int)((~(uint32_t)key) & ((1u << 22) - 1u)); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int WAVES, int PPL>
+__device__ __forceinline__ uint32_t fps_tiekey(int k) { return (((uint32_t)k & 511u) << 22) | (uint32_t)k; }
+
+// max over the wave of an int; result in lane 63 (rows of 16: shr 1,2,4,8 then row broadcasts)
+__device__ __forceinline__ int wave_max_i32_to_lane63(int x) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+      : "+v"(x));
+  return x;
+}
+// max over each row of 16 lanes; result in lane 15 of the row
+__device__ __forceinline__ int row_max_i32_to_lane15(int x) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+      : "+v"(x));
+  return x;
+}
+
+template <int T, int PPL>
+struct FpsOrder {
+  // tournament leaf order of a lane's points: ascending ((i*T) mod 512, i)
+  int idx[PPL];
+  constexpr FpsOrder() : idx{} {
+    for (int i = 0; i < PPL; ++i) idx[i] = i;
+    for (int a = 0; a < PPL; ++a)
+      for (int b = a + 1; b < PPL; ++b) {
+        int ka = ((idx[a] * T) % 512) * 1024 + idx[a], kb = ((idx[b] * T) % 512) * 1024 + idx[b];
+        if (kb < ka) { int t = idx[a]; idx[a] = idx[b]; idx[b] = t; }
+      }
+  }
+};
+
+// uniform helper: among the lanes in `tie`, the one whose candidate index has the smallest tie key
+__device__ __forceinline__ int fps_break_tie(unsigned long long tie, int cand_k) {
+  uint32_t bestkey = 0xffffffffu;
+  int win = 0;
+  while (tie) {
+    int l = (int)__builtin_ctzll(tie);
+    tie &= tie - 1;
+    uint32_t key = fps_tiekey(__builtin_amdgcn_readlane(cand_k, l));
+    if (key < bestkey) { bestkey = key; win = l; }
+  }
+  return win;
+}
+
+// Tournament over leaves [LO, LO+N) of the tie order; every index is a compile-time constant (plain recursion
+// instead of loops over arrays: selects between array elements inside unrolled loops get rewritten by the
+// compiler into "element [select(index)]" gathers, i.e. 16-deep select chains).
+template <int T, int PPL, int LO, int N>
+__device__ __forceinline__ void fps_tournament(const int (&td)[PPL], int tid, int& d, int& k) {
+  if constexpr (N == 1) {
+    constexpr FpsOrder<T, PPL> ORDER{};
+    d = td[ORDER.idx[LO]];
+    k = ORDER.idx[LO] * T + tid;
+  } else {
+    int dl, kl, dr, kr;
+    fps_tournament<T, PPL, LO, N / 2>(td, tid, dl, kl);
+    fps_tournament<T, PPL, LO + N / 2, N - N / 2>(td, tid, dr, kr);
+    const bool right = dr > dl;
+    d = right ? dr : dl;
+    k = right ? kr : kl;
+  }
+}
+
+template <int WAVES, int PPL, int STRIDE>  // STRIDE = floats per LDS point record (4: one b128 read; 3: 10240-point clouds)
 __global__ __launch_bounds__(WAVES * 64) void fps_kernel(int n, int m, const float* __restrict__ xyz,
                                                         int* __restrict__ idx) {
+  static_assert(PPL % 2 == 0, "points are processed in packed pairs");
   constexpr int T = WAVES * 64;
+  constexpr int NP = PPL / 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // layout: [2][WAVES] u64 exchange slots (16-byte aligned block), then the cloud as x|y|z planes
-  uint64_t* slots = reinterpret_cast<uint64_t*>(smem);
-  constexpr int SLOT_BYTES = ((2 * WAVES * 8 + 15) / 16) * 16;
-  float* sx = reinterpret_cast<float*>(smem + SLOT_BYTES);
-  float* sy = sx + n;
-  float* sz = sy + n;
+  float2* slots = reinterpret_cast<float2*>(smem);                 // [2][16] {d2 bits, k}
+  float* spt = reinterpret_cast<float*>(smem + 2 * 16 * 8);        // [n][STRIDE] {x,y,z[,-]}: broadcast read per pick
+  int* picks = reinterpret_cast<int*>(spt + (size_t)n * STRIDE);   // [m]
 
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* cloud = xyz + (size_t)blockIdx.x * n * 3;
-  int* out = idx + (size_t)blockIdx.x * m;
 
-  // coalesced flat copy of the AoS cloud into SoA planes
-  for (int f = tid; f < n * 3; f += T) {
+  for (int f = tid; f < n * 3; f += T) {  // coalesced flat copy of the (n,3) array into 16-byte LDS records
     float v = cloud[f];
     int p = f / 3, c = f - p * 3;
-    (c == 0 ? sx : (c == 1 ? sy : sz))[p] = v;
+    spt[p * STRIDE + c] = v;
   }
+  if (tid == 0) picks[0] = 0;
   __syncthreads();
 
-  float px[PPL], py[PPL], pz[PPL], td[PPL];
+  f32x2 px[NP], py[NP], pz[NP];
+  int td[PPL];    // running min-distance as float BITS: non-negative floats order like signed ints, so min/max are
+                  // single integer ops (a float min would first canonicalise both operands)
 #pragma unroll
-  for (int i = 0; i < PPL; ++i) {
-    int k = i * T + tid;
-    bool ok = k < n;
-    px[i] = ok ? sx[k] : 0.f;
-    py[i] = ok ? sy[k] : 0.f;
-    pz[i] = ok ? sz[k] : 0.f;
-    td[i] = 1e38f;
-  }
+  for (int q = 0; q < NP; ++q)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      int k = (2 * q + e) * T + tid;
+      bool ok = k < n;
+      px[q][e] = ok ? spt[k * STRIDE] : 0.f;
+      py[q][e] = ok ? spt[k * STRIDE + 1] : 0.f;
+      pz[q][e] = ok ? spt[k * STRIDE + 2] : 0.f;
+      // padding: negative and distinct per lane -> never wins, never ties
+      td[2 * q + e] = ok ? __float_as_int(1e38f) : __float_as_int(-(float)(tid + 1));
+    }
+  float x1 = spt[0], y1 = spt[1], z1 = spt[2];
 
-  int old = 0;
-  if (tid == 0) out[0] = 0;
   for (int j = 1; j < m; ++j) {
-    const float x1 = sx[old], y1 = sy[old], z1 = sz[old];
-    uint64_t best = 0;  // every real point has a key > 0 (tiekey < 2^31 => ~tiekey != 0)
+    // ---- running distances (no FMA contraction; ((dx*dx)+(dy*dy))+(dz*dz))
 #pragma unroll
-    for (int i = 0; i < PPL; ++i) {
-      int k = i * T + tid;
-      float d = dist2(px[i], py[i], pz[i], x1, y1, z1);
-      float d2 = fminf(d, td[i]);
-      td[i] = d2;
-      uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)(~fps_tiekey(k));
-      key = k < n ? key : 0;
-      best = key > best ? key : best;
+    for (int q = 0; q < NP; ++q) {
+      f32x2 dx = px[q] - x1, dy = py[q] - y1, dz = pz[q] - z1;
+      f32x2 d = (dx * dx + dy * dy) + dz * dz;
+      td[2 * q] = min(td[2 * q], __float_as_int(d[0]));
+      td[2 * q + 1] = min(td[2 * q + 1], __float_as_int(d[1]));
     }
-    best = wave_max_u64(best);
+    // ---- in-lane tournament over the leaves in tie order; left wins ties
+    int bd, bk;
+    fps_tournament<T, PPL, 0, PPL>(td, tid, bd, bk);
+    // ---- wave argmax
+    const int wmaxi = __builtin_amdgcn_readlane(wave_max_i32_to_lane63(bd), 63);
+    unsigned long long tie = __ballot(bd == wmaxi);
+    int win = (int)__builtin_ctzll(tie);
+    if (__builtin_popcountll(tie) > 1) win = fps_break_tie(tie, bk);
+    int old = __builtin_amdgcn_readlane(bk, win);
     if constexpr (WAVES > 1) {
-      uint64_t* slot = slots + (j & 1) * WAVES;
-      if ((tid & 63) == 0) slot[wave] = best;
+      float2* slot = slots + (j & 1) * 16;
+      if (lane == 0) slot[wave] = make_float2(__int_as_float(wmaxi), __int_as_float(old));
       __syncthreads();
-#pragma unroll
-      for (int w = 0; w < WAVES; ++w) {
-        uint64_t o = slot[w];
-        best = o > best ? o : best;
-      }
+      float2 sv = lane < WAVES ? slot[lane] : make_float2(__int_as_float((int)0x80000000), 0.f);
+      const int di = __float_as_int(sv.x), ki = __float_as_int(sv.y);
+      const int gmax = __builtin_amdgcn_readlane(row_max_i32_to_lane15(di), 15);
+      unsigned long long wt = __ballot(di == gmax) & 0xffffull;
+      int ww = (int)__builtin_ctzll(wt);
+      if (__builtin_popcountll(wt) > 1) ww = fps_break_tie(wt, ki);
+      old = __builtin_amdgcn_readlane(ki, ww);
     }
-    old = fps_key_to_index(best);
-    if (tid == 0) out[j] = old;
+    if (tid == 0) picks[j] = old;
+    if constexpr (STRIDE == 4) {
+      float4 pick = *reinterpret_cast<const float4*>(spt + old * 4);
+      x1 = pick.x; y1 = pick.y; z1 = pick.z;
+    } else {
+      x1 = spt[old * 3]; y1 = spt[old * 3 + 1]; z1 = spt[old * 3 + 2];
+    }
   }
+  __syncthreads();
+  int* out = idx + (size_t)blockIdx.x * m;
+  for (int j = tid; j < m; j += T) out[j] = picks[j];
 }
 
 template <int WAVES, int PPL>
 static int fps_launch(int b, int n, int m, const float* xyz, int* idx, hipStream_t st) {
-  size_t lds = ((2 * WAVES * 8 + 15) / 16) * 16 + (size_t)n * 12;
-  auto kern = fps_kernel<WAVES, PPL>;
+  size_t lds = (size_t)2 * 16 * 8 + (size_t)n * 16 + (size_t)m * 4;
+  auto kern = fps_kernel<WAVES, PPL, 4>;
+  if (lds > 160 * 1024) {  // fall back to 12-byte records
+    lds = (size_t)2 * 16 * 8 + (size_t)n * 12 + (size_t)m * 4;
+    kern = fps_kernel<WAVES, PPL, 3>;
+  }
+  if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
   if (lds > 48 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
         hipSuccess)
@@ -220,16 +324,29 @@ extern "C" int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz
   if (b == 0) return PASNL_OK;
   PASNL_REQUIRE(xyz && idx, PASNL_ENULL);
   hipStream_t st = pasnl_hip_stream(stream);
-  // lanes x points-per-lane must cover n; LDS holds the whole cloud (12 B/point, <= 160 KiB)
-  if (n <= 64) return fps_launch<1, 1>(b, n, m, xyz, idx, st);
+  // lanes x points-per-lane must cover n.  PASNL_FPS_CFG="waves,ppl" overrides the table (tuning only).
+  const char* cfg = getenv("PASNL_FPS_CFG");
+  if (cfg) {
+    int w = 0, p = 0;
+    if (sscanf(cfg, "%d,%d", &w, &p) == 2 && (long)w * 64 * p >= n) {
+#define PASNL_FPS_TRY(W, P) if (w == W && p == P) return fps_launch<W, P>(b, n, m, xyz, idx, st);
+      PASNL_FPS_TRY(1, 2) PASNL_FPS_TRY(1, 4) PASNL_FPS_TRY(1, 8) PASNL_FPS_TRY(1, 16) PASNL_FPS_TRY(2, 4) PASNL_FPS_TRY(2, 8)
+      PASNL_FPS_TRY(2, 16) PASNL_FPS_TRY(4, 2) PASNL_FPS_TRY(4, 4) PASNL_FPS_TRY(4, 8) PASNL_FPS_TRY(4, 16) PASNL_FPS_TRY(8, 2)
+      PASNL_FPS_TRY(8, 4) PASNL_FPS_TRY(8, 8) PASNL_FPS_TRY(8, 16) PASNL_FPS_TRY(16, 2) PASNL_FPS_TRY(16, 4) PASNL_FPS_TRY(16, 8)
+      PASNL_FPS_TRY(16, 10)
+#undef PASNL_FPS_TRY
+    }
+  }
+  if (n <= 128) return fps_launch<1, 2>(b, n, m, xyz, idx, st);
   if (n <= 256) return fps_launch<1, 4>(b, n, m, xyz, idx, st);
-  if (n <= 512) return fps_launch<2, 4>(b, n, m, xyz, idx, st);
-  if (n <= 1024) return fps_launch<4, 4>(b, n, m, xyz, idx, st);
-  if (n <= 2048) return fps_launch<8, 4>(b, n, m, xyz, idx, st);
-  if (n <= 4096) return fps_launch<16, 4>(b, n, m, xyz, idx, st);
+  if (n <= 512) return fps_launch<1, 8>(b, n, m, xyz, idx, st);
+  if (n <= 1024) return fps_launch<4, 4>(b, n, m, xyz, idx, st);   // measured: (4,4) 192 us vs (1,16) 241 us at B=64, m=512
+  if (n <= 2048) return fps_launch<2, 16>(b, n, m, xyz, idx, st);
+  if (n <= 4096) return fps_launch<4, 16>(b, n, m, xyz, idx, st);
   if (n <= 8192) return fps_launch<16, 8>(b, n, m, xyz, idx, st);
-  if (n <= 12288) return fps_launch<16, 12>(b, n, m, xyz, idx, st);
-  return PASNL_EUNSUPPORTED;  // > 12288 points/cloud: LDS-resident design limit (reference configs <= 10240)
+  if (n <= 10240) return fps_launch<16, 10>(b, n, m, xyz, idx, st);
+  return PASNL_EUNSUPPORTED;  // > 10240 points/cloud (or cloud + picks > 160 KiB LDS): LDS-resident design limit = the
+                              // largest reference config (SemanticKITTI, 10240 points)
 }
 
 static int grid_for(long total) {
