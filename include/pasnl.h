@@ -88,6 +88,16 @@ int pasnl_group_point(int b, int n, int c, int m, int nsample, const float* poin
 int pasnl_group_point_grad(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx,
                            float* grad_points, pasnl_stream_t stream);
 
+/* Set-abstraction grouping, fused (pointasnl_util.py:63-74 + :248-249 + :258): for every query j and neighbour s
+ *   new_point[b,j,s,:] = [ xyz[b,i,:] - new_xyz[b,j,:] | xyz[b,i,:] | feature[b,i,:] ],  i = idx[b,j,s]
+ *   skip_max[b,j,:]    = max over s of new_point[b,j,s,:]
+ * i.e. the two tf.gather_nd, the concat with xyz, the translation normalisation, the second concat and the
+ * reduce_max of the skip connection in one pass; new_point is written once, nothing else touches HBM.
+ * xyz (b,n,3), feature (b,n,c), idx (b,m,k) i32, new_xyz (b,m,3) -> new_point (b,m,k,6+c), skip_max (b,m,6+c).
+ * 6+c <= 512. */
+int pasnl_sa_group(int b, int n, int c, int m, int k, const float* xyz, const float* feature, const int* idx,
+                   const float* new_xyz, float* new_point, float* skip_max, pasnl_stream_t stream);
+
 /* k rounds of in-place selection sort per row of a (b,m,n) distance tensor; FULL (b,m,n) outputs, first k
  * columns meaningful, the tail is the swap residue.  replaces selectionSortLauncher
  * tf_grouping_g.cu:129-130 (kernel :83-123) */

@@ -243,6 +243,54 @@ __global__ __launch_bounds__(256) void group_point_grad_kernel(int n, int c, lon
 }
 
 // ---------------------------------------------------------------------------------------------
+// sa_group: one workgroup per (cloud, query).  Thread t owns output column c = t % W of rows s = t / W,
+// t / W + R, ... (R = T / W rows per pass), so a pass writes R*W consecutive floats (coalesced) and the
+// running column maximum stays in a register; R partial maxima per column meet in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void sa_group_kernel(int n, int c, int m, int k, const float* __restrict__ xyz,
+                                                    const float* __restrict__ feature, const int* __restrict__ idx,
+                                                    const float* __restrict__ new_xyz, float* __restrict__ new_point,
+                                                    float* __restrict__ skip_max) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* sidx = reinterpret_cast<int*>(smem);        // [k]
+  float* part = reinterpret_cast<float*>(sidx + k);  // [R][W]
+  const int W = 6 + c;
+  const int R = T / W;
+  const long g = blockIdx.x;  // (b, j) flattened
+  const long bi = g / m;
+  const int t = threadIdx.x;
+  for (int s = t; s < k; s += T) sidx[s] = idx[g * k + s];
+  __syncthreads();
+  const int col = t % W, r0 = t / W;
+  const bool active = r0 < R;
+  const float* cx = xyz + (size_t)bi * n * 3;
+  const float* cf = feature + (size_t)bi * n * c;
+  float centre = 0.f;
+  if (active && col < 3) centre = new_xyz[g * 3 + col];
+  float mx = -INFINITY;
+  if (active) {
+    float* out = new_point + (size_t)g * k * W;
+    for (int s = r0; s < k; s += R) {
+      const int i = sidx[s];
+      float v;
+      if (col < 3) v = cx[(size_t)i * 3 + col] - centre;
+      else if (col < 6) v = cx[(size_t)i * 3 + (col - 3)];
+      else v = cf[(size_t)i * c + (col - 6)];
+      out[(size_t)s * W + col] = v;
+      mx = fmaxf(mx, v);
+    }
+    part[r0 * W + col] = mx;
+  }
+  __syncthreads();
+  if (t < W) {
+    float v = part[t];
+    for (int r = 1; r < R; ++r) v = fmaxf(v, part[r * W + t]);
+    skip_max[g * W + t] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // select_top_k: one wave per (b,m) row; k rounds of "first strict minimum of the current row in
 // [s,n), swap with position s" (tf_grouping_g.cu:100-121), on the output arrays in global memory.
 // ---------------------------------------------------------------------------------------------
@@ -377,6 +425,28 @@ extern "C" int pasnl_group_point(int b, int n, int c, int m, int nsample, const 
     long chunks = rows * c;
     hipLaunchKernelGGL(group_point_kernel<1>, dim3(grid_for(chunks)), dim3(256), 0, st, n, c, rows_per_batch, chunks, points,
                        idx, out);
+  }
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_sa_group(int b, int n, int c, int m, int k, const float* xyz, const float* feature, const int* idx,
+                              const float* new_xyz, float* new_point, float* skip_max, pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && m >= 0 && k > 0, PASNL_EINVAL);
+  const int W = 6 + c;
+  PASNL_REQUIRE(W <= 512, PASNL_EUNSUPPORTED);
+  long groups = (long)b * m;
+  if (groups == 0) return PASNL_OK;
+  PASNL_REQUIRE(groups < (1L << 31), PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE(xyz && feature && idx && new_xyz && new_point && skip_max, PASNL_ENULL);
+  hipStream_t st = pasnl_hip_stream(stream);
+  if (W <= 256) {
+    size_t lds = (size_t)k * 4 + (size_t)(256 / W) * W * 4;
+    hipLaunchKernelGGL(sa_group_kernel<256>, dim3((unsigned)groups), dim3(256), lds, st, n, c, m, k, xyz, feature, idx, new_xyz,
+                       new_point, skip_max);
+  } else {
+    size_t lds = (size_t)k * 4 + (size_t)(512 / W) * W * 4;
+    hipLaunchKernelGGL(sa_group_kernel<512>, dim3((unsigned)groups), dim3(512), lds, st, n, c, m, k, xyz, feature, idx, new_xyz,
+                       new_point, skip_max);
   }
   return pasnl_launch_status();
 }

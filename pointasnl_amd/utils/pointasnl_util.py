@@ -69,6 +69,21 @@ def grouping(feature, K, src_xyz, q_xyz, use_xyz=True, use_knn=True, radius=0.2)
     return grouped_xyz, grouped_feature, point_indices
 
 
+def sa_group(xyz, feature, idx, new_xyz):
+    """Fused grouping of one set-abstraction layer (pointasnl_util.py:63-74, 248-249, 258):
+        new_point[b,j,s,:] = [xyz[i]-new_xyz[j] | xyz[i] | feature[i]],  i = idx[b,j,s];   skip = max_s new_point
+    One kernel instead of two gathers, two concats, a subtraction and a reduce_max.
+    -> new_point (B,P,K,6+C), skip (B,P,6+C)"""
+    b, n, c = feature.shape
+    _, p, k = idx.shape
+    xyz, feature, idx, new_xyz = xyz.contiguous(), feature.contiguous(), idx.contiguous(), new_xyz.contiguous()
+    new_point = torch.empty((b, p, k, 6 + c), dtype=torch.float32, device=xyz.device)
+    skip = torch.empty((b, p, 6 + c), dtype=torch.float32, device=xyz.device)
+    _hip.launch("pasnl_sa_group", "sa_group", b, n, c, p, k, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx),
+                _hip.ptr(new_xyz), _hip.ptr(new_point), _hip.ptr(skip))
+    return new_point, skip
+
+
 def weight_net_hidden(xyz, hidden_units, scope, is_training, bn_decay=None, weight_decay=None, activation_fn="relu"):
     with tf_util.variable_scope(scope):
         net = xyz
@@ -210,15 +225,26 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
         else:
             new_xyz, new_feature = sampling(npoint, xyz, feature)
 
-        grouped_xyz, new_point, idx = grouping(feature, nsample, xyz, new_xyz, use_knn=use_knn, radius=radius)
+        # neighbour search (the reference's grouping(): pointasnl_util.py:242 -> :51-76)
+        if use_knn:
+            idx = knn_query(nsample, xyz, new_xyz)
+        else:
+            idx, _ = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
         nl_channel = mlp[-1]
 
         '''Adaptive Sampling'''
         if num_points != npoint:
-            new_xyz, new_feature = AdaptiveSampling(grouped_xyz, new_point, as_neighbor, is_training, bn_decay,
-                                                    weight_decay, scope, bn)
-        grouped_xyz = grouped_xyz - new_xyz.unsqueeze(2)  # translation normalization
-        new_point = torch.cat([grouped_xyz, new_point], dim=-1)
+            # AdaptiveSampling only ever reads the first `as_neighbor` neighbours (:165-166; neighbour 0 when
+            # as_neighbor == 0, :161-164): gather just those instead of slicing the full grouped tensors
+            k_as = max(1, as_neighbor)
+            idx_as = idx[:, :, :k_as].contiguous()
+            g_xyz = tf_grouping.group_point(xyz, idx_as)
+            g_pts = torch.cat([g_xyz, tf_grouping.group_point(feature, idx_as)], dim=-1)
+            new_xyz, new_feature = AdaptiveSampling(g_xyz, g_pts, as_neighbor, is_training, bn_decay, weight_decay,
+                                                    scope, bn)
+        # gather + translation normalisation + both concats + the skip connection's reduce_max: one kernel
+        new_point, skip_spatial = sa_group(xyz, feature, idx, new_xyz)
+        grouped_xyz = new_point[..., 0:3]
 
         '''Point NonLocal Cell'''
         if NL:
@@ -227,7 +253,6 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                                                    weight_decay, scope, bn)
 
         '''Skip Connection'''
-        skip_spatial = new_point.max(dim=2).values
         skip_spatial = tf_util.conv1d(skip_spatial, mlp[-1], 1, padding='VALID', stride=1, bn=bn,
                                       is_training=is_training, scope='skip', bn_decay=bn_decay,
                                       weight_decay=weight_decay)

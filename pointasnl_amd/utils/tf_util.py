@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 BN_EPS = 1e-3
+FUSE_RELU_EPILOGUE = True
 
 
 class VariableStore:
@@ -141,7 +142,12 @@ def _dense(inputs, num_output_channels, scope, bn, activation_fn):
     cin = inputs.shape[-1]
     with variable_scope(scope):
         w, b = store().layer(cin, num_output_channels, bn)
-    out = torch.addmm(b, inputs.reshape(-1, cin), w).reshape(*inputs.shape[:-1], num_output_channels)
+    x2d = inputs.reshape(-1, cin)
+    if activation_fn in ("relu", torch.relu, torch.nn.functional.relu) and FUSE_RELU_EPILOGUE:
+        # bias + ReLU in the GEMM epilogue (hipBLASLt) instead of a second pass over the output
+        out = torch._addmm_activation(b, x2d, w)
+        return out.reshape(*inputs.shape[:-1], num_output_channels)
+    out = torch.addmm(b, x2d, w).reshape(*inputs.shape[:-1], num_output_channels)
     return _act(out, activation_fn)
 
 

@@ -207,3 +207,22 @@ def test_empty(P):
     d, i = P.tf_interpolate.three_nn(e, x)
     assert d.shape == (2, 0, 3)
     assert P.tf_grouping.group_point(x, torch.zeros((2, 0, 5), dtype=torch.int32, device="cuda")).shape == (2, 0, 5, 3)
+
+
+@pytest.mark.parametrize("b,n,c,m,k", [(4, 1024, 3, 512, 32), (2, 512, 128, 128, 64), (2, 64, 256, 32, 32), (1, 50, 7, 50, 5),
+                                       (2, 300, 300, 9, 3)])
+def test_sa_group(P, b, n, c, m, k):
+    # fused gather + centre + concat + max-over-K == the reference's op-by-op composition
+    # (pointasnl_util.py:63-74, 248-249, 258), bit for bit (gathers, one subtraction, max)
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    rng = np.random.default_rng(c)
+    xyz = clouds(5, b, n)
+    feat = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, k)).astype(np.int32)
+    new_xyz = clouds(6, b, m)
+    gx = O.group_point(xyz, idx)
+    want = np.concatenate([gx - new_xyz[:, :, None, :], gx, O.group_point(feat, idx)], axis=-1)
+    new_point, skip = U.sa_group(dev(xyz), dev(feat), dev(idx), dev(new_xyz))
+    np.testing.assert_array_equal(new_point.cpu().numpy(), want)
+    np.testing.assert_array_equal(skip.cpu().numpy(), want.max(axis=2))
