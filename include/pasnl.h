@@ -159,6 +159,17 @@ int pasnl_as_attention(int g, int as, int cb, const float* q, const float* kv, f
 int pasnl_as_reweight(int g, int as, int nsample, int ch, const float* logits, const float* grouped_xyz,
                       const float* grouped_feature, float* new_xyz, float* new_feature, pasnl_stream_t stream);
 
+/* Set-abstraction "local cell", fused (pointasnl_util.py:264-274): per query group of k
+ * neighbours, with x = new_point (groups,k,w) as produced by pasnl_sa_group (w = 6+C, columns 0..2 = centred xyz):
+ *   H1 = relu(x W0 + b0) (k,c1);  H2 = relu(H1 W1 + b1) (k,c2);  G = relu(x[:,0:3] Ww + bw) (k,32);
+ *   out[g] = H2^T G  flattened as (c2*32)   -- the input of the [1,c2] `after_conv` GEMM (:275-278).
+ * W0 (w,c1), W1 (c1,c2), Ww (3,32) row-major with inference BN already folded in (tf_util.py).  Replaces two
+ * conv2d, the weight-net conv2d, a transpose and a batched matmul of the reference graph; H1, H2 and G never
+ * reach HBM.  k % 32 == 0; (c1,c2) in {(32,32),(64,64),(128,128)}; weights must fit 160 KiB of LDS. */
+int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, const float* x, const float* w0, const float* b0,
+                        const float* w1, const float* b1, const float* ww, const float* bw, float* out,
+                        pasnl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

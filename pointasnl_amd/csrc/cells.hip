@@ -328,6 +328,129 @@ __global__ __launch_bounds__(256) void as_reweight_kernel(long groups, int as, i
   }
 }
 
+
+// =============================================================================================
+// Set-abstraction "local cell" (pointasnl_util.py:264-274), fused:
+//     H1 = relu(X W0 + b0)   (K x C1)       X = new_point of one query: K neighbours x (6+C) channels
+//     H2 = relu(H1 W1 + b1)  (K x C2)
+//     G  = relu(X[:, 0:3] Ww + bw)  (K x 32)   weight net on the centred coordinates
+//     M  = H2^T G            (C2 x 32)      -> out[group] (the input of the [1,C2] `after_conv` GEMM)
+// One wave owns one query group and walks its neighbours 32 at a time; everything between X and M lives in
+// registers.  The four products are chained on v_mfma_f32_32x32x2_f32 WITHOUT any transpose or LDS round trip
+// by alternating transposed / untransposed forms, using that a D tile holds, in lane l, column (l & 31) and the
+// 16 rows kappa(r, l>>5) = (r&3) + 8*(r>>2) + 4*(l>>5) -- exactly an A (or B) operand whose k index at MFMA
+// step t is kappa(t, l>>5):
+//     H1^T[c1][p] : A = W0[c][c1]        (LDS)   B = X[p][c]   (regs)      D rows c1, cols p
+//     H2 [p][c2]  : A = H1^T tile regs           B = W1[c1][c2](LDS)       D rows p,  cols c2
+//     G  [p][j]   : A = X[p][c] regs             B = Ww[c][j]  (LDS)       D rows p,  cols j
+//     M  [c2][j]  : A = H2 tile regs             B = G tile regs           D rows c2, cols j
+// LDS holds only the (BN-folded) weights, staged once per persistent workgroup.  fp32 in, fp32 accumulate
+// (the MFMA is an exact fp32 fmaf chain); tolerance vs the fp32 oracle 1e-5 relative.
+// =============================================================================================
+__device__ __forceinline__ int kappa(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
+
+template <int C1, int C2>
+__global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, int w, const float* __restrict__ x,
+                                                           const float* __restrict__ w0, const float* __restrict__ b0,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ ww, const float* __restrict__ bw,
+                                                           float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wp = (w + 31) & ~31;                    // input channels padded to whole 32-chunks (zero rows)
+  float* W0s = reinterpret_cast<float*>(smem);      // [wp][C1]
+  float* W1s = W0s + (size_t)wp * C1;               // [C1][C2]
+  float* Wws = W1s + C1 * C2;                       // [4][32]  (row 3 = 0: channel 3 is not a centred coordinate)
+  float* B0s = Wws + 4 * 32;                        // [C1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, ql = lane & 31;
+
+  for (int i = tid; i < wp * C1; i += 256) W0s[i] = (i / C1) < w ? w0[i] : 0.f;
+  for (int i = tid; i < C1 * C2; i += 256) W1s[i] = w1[i];
+  for (int i = tid; i < 4 * 32; i += 256) Wws[i] = i < 3 * 32 ? ww[i] : 0.f;
+  for (int i = tid; i < C1; i += 256) B0s[i] = b0[i];
+  __syncthreads();
+
+  float b1r[C2 / 32];
+#pragma unroll
+  for (int cb = 0; cb < C2 / 32; ++cb) b1r[cb] = b1[cb * 32 + ql];
+  const float bwr = bw[ql];
+  const int nchunk = wp / 32;
+
+  for (long g = (long)blockIdx.x * 4 + wave; g < groups; g += (long)gridDim.x * 4) {
+    f32x16 M[C2 / 32];
+#pragma unroll
+    for (int cb = 0; cb < C2 / 32; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) M[cb][r] = 0.f;
+
+    for (int tile = 0; tile < k; tile += 32) {
+      const float* xrow = x + ((size_t)g * k + tile + ql) * w;  // this lane's neighbour row
+      f32x16 H1T[C1 / 32];
+#pragma unroll
+      for (int ob = 0; ob < C1 / 32; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1T[ob][r] = 0.f;
+      f32x16 G;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) G[r] = 0.f;
+
+      for (int ch = 0; ch < nchunk; ++ch) {
+        float xr[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          int c = ch * 32 + 2 * t + h;
+          xr[t] = c < w ? xrow[c] : 0.f;
+        }
+        const int live = min(16, (w - ch * 32 + 1) >> 1);  // MFMA steps with a non-zero k pair (uniform)
+        if (ch == 0) {
+          // weight net: channels 0..2 are the centred coordinates
+          G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0], Wws[h * 32 + ql], G, 0, 0, 0);
+          G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[1], Wws[(2 + h) * 32 + ql], G, 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+          if (t < live) {
+            const float* wrow = W0s + (size_t)(ch * 32 + 2 * t + h) * C1 + ql;
+#pragma unroll
+            for (int ob = 0; ob < C1 / 32; ++ob)
+              H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[ob * 32], xr[t], H1T[ob], 0, 0, 0);
+          }
+        }
+      }
+      // bias + ReLU: H1^T rows are output channels c1 = ob*32 + kappa(r,h); G columns are j = ql
+#pragma unroll
+      for (int ob = 0; ob < C1 / 32; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1T[ob][r] = fmaxf(H1T[ob][r] + B0s[ob * 32 + kappa(r, h)], 0.f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) G[r] = fmaxf(G[r] + bwr, 0.f);
+
+#pragma unroll
+      for (int cb = 0; cb < C2 / 32; ++cb) {
+        f32x16 H2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H2[r] = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < C1 / 32; ++blk)
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            H2 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1T[blk][t], W1s[(size_t)(blk * 32 + kappa(t, h)) * C2 + cb * 32 + ql],
+                                                      H2, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H2[r] = fmaxf(H2[r] + b1r[cb], 0.f);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) M[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(H2[t], G[t], M[cb], 0, 0, 0);
+      }
+    }
+    // M[c2 = cb*32 + kappa(r,h)][j = ql] -> out[g][c2*32 + j]
+    float* o = out + (size_t)g * C2 * 32;
+#pragma unroll
+    for (int cb = 0; cb < C2 / 32; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(size_t)(cb * 32 + kappa(r, h)) * 32 + ql] = M[cb][r];
+  }
+}
+
 }  // namespace pasnl
 
 using namespace pasnl;
@@ -404,4 +527,37 @@ extern "C" int pasnl_as_reweight(int g, int as, int nsample, int ch, const float
   hipLaunchKernelGGL(as_reweight_kernel, dim3((unsigned)(grid > 16384 ? 16384 : grid)), dim3(256), 0, pasnl_hip_stream(stream),
                      (long)g, as, nsample, ch, logits, grouped_xyz, grouped_feature, new_xyz, new_feature);
   return pasnl_launch_status();
+}
+
+template <int C1, int C2>
+static int local_cell_launch(long groups, int k, int w, const float* x, const float* w0, const float* b0, const float* w1,
+                             const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
+  const int wp = (w + 31) & ~31;
+  size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 4 * 32 + C1) * sizeof(float);
+  if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
+  auto kern = sa_local_cell_kernel<C1, C2>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  // persistent workgroups: the weights are staged into LDS once per workgroup
+  long wgs = (groups + 3) / 4;
+  int per_cu = lds > 80 * 1024 ? 1 : (lds > 40 * 1024 ? 2 : 3);
+  long cap = 256L * per_cu;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), lds, st, groups, k, w, x, w0, b0, w1, b1, ww, bw,
+                     out);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, const float* x, const float* w0, const float* b0,
+                                   const float* w1, const float* b1, const float* ww, const float* bw, float* out,
+                                   pasnl_stream_t stream) {
+  PASNL_REQUIRE(groups >= 0 && k > 0 && w >= 3 && c1 > 0 && c2 > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(k % 32 == 0, PASNL_EUNSUPPORTED);
+  if (groups == 0) return PASNL_OK;
+  PASNL_REQUIRE(x && w0 && b0 && w1 && b1 && ww && bw && out, PASNL_ENULL);
+  hipStream_t st = pasnl_hip_stream(stream);
+  if (c1 == 32 && c2 == 32) return local_cell_launch<32, 32>(groups, k, w, x, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 64 && c2 == 64) return local_cell_launch<64, 64>(groups, k, w, x, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 128 && c2 == 128) return local_cell_launch<128, 128>(groups, k, w, x, w0, b0, w1, b1, ww, bw, out, st);
+  return PASNL_EUNSUPPORTED;
 }

@@ -84,6 +84,36 @@ def sa_group(xyz, feature, idx, new_xyz):
     return new_point, skip
 
 
+LOCAL_CELL_FUSED = True  # False = the reference's op-by-op chain on the vendor BLAS (kept for A/B and as fallback)
+
+
+def _local_cell_supported(w, mlp, nsample):
+    if not LOCAL_CELL_FUSED or len(mlp) != 3 or mlp[0] != mlp[1] or mlp[0] not in (32, 64, 128) or nsample % 32:
+        return False
+    wp = (w + 31) // 32 * 32
+    return (wp * mlp[0] + mlp[0] * mlp[1] + 128 + mlp[0]) * 4 <= 160 * 1024  # weights must fit the LDS
+
+
+def sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn):
+    """Fused local cell (pointasnl_util.py:264-274): conv0 -> conv1 on the grouped points, the weight net on the
+    centred coordinates, and H2^T . G, in one MFMA kernel.  (B,P,K,6+C) -> (B,P,mlp[1],32) = the input of after_conv.
+    The variables are the same ones the op-by-op chain would create (scopes conv0, conv1, weight_net/wconv0)."""
+    b, p, k, w = new_point.shape
+    c1, c2 = mlp[0], mlp[1]
+    st = tf_util.store()
+    with tf_util.variable_scope('conv0'):
+        w0, b0 = st.layer(w, c1, bn)
+    with tf_util.variable_scope('conv1'):
+        w1, b1 = st.layer(c1, c2, bn)
+    with tf_util.variable_scope('weight_net'), tf_util.variable_scope('wconv0'):
+        ww, bw = st.layer(3, 32, True)
+    new_point = new_point.contiguous()
+    out = torch.empty((b, p, c2, 32), dtype=torch.float32, device=new_point.device)
+    _hip.launch("pasnl_sa_local_cell", "sa_local_cell", b * p, k, w, c1, c2, _hip.ptr(new_point), _hip.ptr(w0), _hip.ptr(b0),
+                _hip.ptr(w1), _hip.ptr(b1), _hip.ptr(ww), _hip.ptr(bw), _hip.ptr(out))
+    return out
+
+
 def weight_net_hidden(xyz, hidden_units, scope, is_training, bn_decay=None, weight_decay=None, activation_fn="relu"):
     with tf_util.variable_scope(scope):
         net = xyz
@@ -258,16 +288,19 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                                       weight_decay=weight_decay)
 
         '''Point Local Cell'''
-        for i, num_out_channel in enumerate(mlp):
-            if i != len(mlp) - 1:
-                new_point = tf_util.conv2d(new_point, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
-                                           is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay,
-                                           weight_decay=weight_decay)
-
-        weight = weight_net_hidden(grouped_xyz, [32], scope='weight_net', is_training=is_training, bn_decay=bn_decay,
-                                   weight_decay=weight_decay)
-        new_point = new_point.transpose(2, 3)
-        new_point = torch.matmul(new_point, weight)
+        if _local_cell_supported(new_point.shape[-1], mlp, nsample):
+            tf_util._require_inference(is_training)
+            new_point = sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn)
+        else:
+            for i, num_out_channel in enumerate(mlp):
+                if i != len(mlp) - 1:
+                    new_point = tf_util.conv2d(new_point, num_out_channel, [1, 1], padding='VALID', stride=[1, 1],
+                                               bn=bn, is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay,
+                                               weight_decay=weight_decay)
+            weight = weight_net_hidden(grouped_xyz, [32], scope='weight_net', is_training=is_training,
+                                       bn_decay=bn_decay, weight_decay=weight_decay)
+            new_point = new_point.transpose(2, 3)
+            new_point = torch.matmul(new_point, weight)
         new_point = tf_util.conv2d(new_point, mlp[-1], [1, new_point.shape[2]], padding='VALID', stride=[1, 1], bn=bn,
                                    is_training=is_training, scope='after_conv', bn_decay=bn_decay,
                                    weight_decay=weight_decay)

@@ -126,3 +126,25 @@ def test_cls_forward_matches_oracle(adaptive):
     assert np.abs(logits.cpu().numpy() - want64).max() / scale < 1e-4
     assert np.abs(want - want64).max() / scale < 1e-4
     assert (logits.argmax(1).cpu().numpy() == want64.argmax(1)).all()
+
+
+@pytest.mark.parametrize("g,k,c,c1", [(64, 32, 3, 64), (16, 64, 128, 128), (8, 32, 64, 32), (5, 96, 30, 64), (3, 32, 3, 128)])
+def test_sa_local_cell(g, k, c, c1):
+    """Fused conv0 -> conv1, weight net, H2^T.G (pointasnl_util.py:264-274) vs the numpy restatement in fp64."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    st = _store(g * 7 + c)
+    rng = np.random.default_rng(k + c)
+    w = 6 + c
+    x = rng.standard_normal((1, g, k, w)).astype(np.float32)
+    x[..., :3] *= 0.2
+    with st.scope("L"):
+        got = U.sa_local_cell(dev(x), [c1, c1, 2 * c1], False, None, None, True).cpu().numpy()
+    p = st.export_numpy()
+    x64 = x.astype(np.float64)
+    h = cells._layer(cells._layer(x64, p["L/conv0"], "relu"), p["L/conv1"], "relu")
+    wn = cells._layer(x64[..., :3], p["L/weight_net/wconv0"], "relu")
+    want = np.swapaxes(h, 2, 3) @ wn  # (1,g,c1,32)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() / scale < 1e-5
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * scale)
