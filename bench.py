@@ -85,6 +85,13 @@ def algorithmic(symbol, ints):
     if symbol == "pasnl_as_attention":
         g, as_, cb = ints
         return 4 * g * as_ * cb * 4, 4 * g * as_ * as_ * cb + 5 * g * as_ * as_, "mfma"
+    if symbol == "pasnl_sa_group":
+        b, n, c, m, k = ints
+        return 4 * b * (3 * n + n * c + m * k + 3 * m + m * k * (6 + c) + m * (6 + c)), 0, "hbm"
+    if symbol == "pasnl_sa_local_cell":
+        g, k, w, c1, c2 = ints
+        # reads the grouped points once, writes (c2 x 32) per group; weights are LDS-resident
+        return 4 * (g * k * w + g * c2 * 32 + w * c1 + c1 * c2), g * (2 * k * (w * c1 + c1 * c2 + 3 * 32) + 2 * c2 * k * 32), "mfma"
     if symbol == "pasnl_as_reweight":
         g, as_, ns, ch = ints
         return 4 * g * (as_ * (1 + ch) + as_ * (3 + ch) + 3 + ch), 4 * g * as_ * (1 + ch), "hbm"

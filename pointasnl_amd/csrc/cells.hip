@@ -430,12 +430,23 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
         f32x16 H2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) H2[r] = 0.f;
+        // The W1 operands are read in batches of 16 (one 32-channel block), one batch ahead of the MFMAs that use
+        // them; sched_barriers keep the compiler from hoisting all C1*C2/32 LDS reads to the top (which spills).
+        float wv[2][16];
+        const float* w1p = W1s + (size_t)kappa(0, h) * C2 + cb * 32 + ql;
 #pragma unroll
-        for (int blk = 0; blk < C1 / 32; ++blk)
+        for (int t = 0; t < 16; ++t) wv[0][t] = w1p[(size_t)(kappa(t, 0)) * C2];
 #pragma unroll
-          for (int t = 0; t < 16; ++t)
-            H2 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1T[blk][t], W1s[(size_t)(blk * 32 + kappa(t, h)) * C2 + cb * 32 + ql],
-                                                      H2, 0, 0, 0);
+        for (int blk = 0; blk < C1 / 32; ++blk) {
+          if (blk + 1 < C1 / 32) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) wv[(blk + 1) & 1][t] = w1p[(size_t)((blk + 1) * 32 + kappa(t, 0)) * C2];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 16; ++t) H2 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1T[blk][t], wv[blk & 1][t], H2, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) H2[r] = fmaxf(H2[r] + b1r[cb], 0.f);
 #pragma unroll
