@@ -149,6 +149,10 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clouds per GPU (weak scaling)")
     ap.add_argument("--AS", action="store_true", help="configs[2]: adaptive sampling on, noisy clouds")
     ap.add_argument("--noise", type=int, default=10)
+    ap.add_argument("--model", default="cls", choices=["cls", "sem_seg", "sem_seg_res"],
+                    help="cls = the BASELINE metric (default).  sem_seg / sem_seg_res = configs[3] / configs[4] "
+                         "(ScanNet 8192 pts / SemanticKITTI 10240 pts); own measurements, not the driver's metric")
+    ap.add_argument("--points", type=int, default=0, help="points per cloud (default: 1024 cls, 8192 sem_seg, 10240 sem_seg_res)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -176,8 +180,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    B, N = args.batch, 1024
-    cfg_index = 2 if args.AS else 1
+    import importlib
+
+    default_pts = {"cls": 1024, "sem_seg": 8192, "sem_seg_res": 10240}[args.model]
+    B, N = args.batch, (args.points or default_pts)
+    if args.model != "cls" and args.batch == 64:
+        B = 16 if args.model == "sem_seg" else 8  # BASELINE configs[3] / per-GPU share of configs[4]
+    seg_model = importlib.import_module(f"pointasnl_amd.models.pointasnl_{args.model}") if args.model != "cls" else None
+    cfg_index = {"cls": 2 if args.AS else 1, "sem_seg": 3, "sem_seg_res": 4}[args.model]
     pc = synth_clouds(1234 + cfg_index + 100 * rank, B, N)
     if args.AS:
         pc = add_noise(pc, args.noise, 1234 + cfg_index + 100 * rank)
@@ -185,10 +195,14 @@ def main():
     store = tf_util.set_store(tf_util.VariableStore(seed=1234))  # identical weights on every rank
 
     def forward():
+        if seg_model is not None:
+            logits, _ = seg_model.get_model(x, False, 20)
+            return logits.reshape(B, -1)
         logits, _ = pointasnl_cls.get_model(x, is_training=False, adaptive_sample=args.AS)
         return logits
 
-    gathered = sharding.LogitsGather(world, B, 40, x.device) if world > 1 else None
+    width = 40 if seg_model is None else N * 20
+    gathered = sharding.LogitsGather(world, B, width, x.device) if world > 1 else None
 
     with torch.no_grad():
         # ---- warm-up (eager: creates weights, BLAS workspaces), then capture
@@ -269,12 +283,13 @@ def main():
                     "alg_bytes": dom["alg_bytes"], "alg_flops": dom["alg_flops"]}
 
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.model == "cls":
         cpu = cpu_baseline(pc, store.export_numpy(), args.AS)
 
     handwritten_us = sum(r["avg_us"] for r in rows)
     out = {
-        "metric": "point-clouds/sec fwd (Bx1024 pts, ModelNet40 cls)",
+        "metric": "point-clouds/sec fwd (Bx1024 pts, ModelNet40 cls)" if args.model == "cls" else
+                  f"point-clouds/sec fwd (Bx{N} pts, pointasnl_{args.model})",
         "value": round(value, 2),
         "unit": "point-clouds/s",
         "n_gpus": world,
@@ -286,8 +301,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": ("configs[2]: ModelNet40 pointasnl_cls --AS, 1024 pts + noise" if args.AS else
-                                "configs[1]: ModelNet40 pointasnl_cls, 1024 pts") + f", batch={B}/GPU, seeded random weights",
+        "config": {"workload": (("configs[2]: ModelNet40 pointasnl_cls --AS, 1024 pts + noise" if args.AS else
+                                 "configs[1]: ModelNet40 pointasnl_cls, 1024 pts") if args.model == "cls" else
+                                f"configs[{cfg_index}]: pointasnl_{args.model}, {N} pts") + f", batch={B}/GPU, seeded random weights",
                    "global_batch": world * B, "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
                    "hip_graph": graph is not None},
         "roofline": roofline,

@@ -93,8 +93,7 @@ int pasnl_group_point_grad(int b, int n, int c, int m, int nsample, const float*
  *   skip_max[b,j,:]    = max over s of new_point[b,j,s,:]
  * i.e. the two tf.gather_nd, the concat with xyz, the translation normalisation, the second concat and the
  * reduce_max of the skip connection in one pass; new_point is written once, nothing else touches HBM.
- * xyz (b,n,3), feature (b,n,c), idx (b,m,k) i32, new_xyz (b,m,3) -> new_point (b,m,k,6+c), skip_max (b,m,6+c).
- * 6+c <= 512. */
+ * xyz (b,n,3), feature (b,n,c), idx (b,m,k) i32, new_xyz (b,m,3) -> new_point (b,m,k,6+c), skip_max (b,m,6+c). */
 int pasnl_sa_group(int b, int n, int c, int m, int k, const float* xyz, const float* feature, const int* idx,
                    const float* new_xyz, float* new_point, float* skip_max, pasnl_stream_t stream);
 

@@ -28,6 +28,8 @@ def _layer(x, p, act):
         y = np.maximum(y, 0)
     elif act == "sigmoid":
         y = 1 / (1 + np.exp(-y))
+    elif act == "leaky_relu":  # tf.nn.leaky_relu, alpha 0.2
+        y = np.where(y > 0, y, y * dt.type(0.2))
     return y
 
 
@@ -141,6 +143,86 @@ def set_abstraction(xyz, feature, npoint, nsample, mlp, params, scope, as_neighb
         new_point = new_point + nonlocal_pt  # :285
     new_point = _layer(new_point, params[scope + "/aggregation"], "relu")  # :288-290
     return new_xyz.astype(dt), new_point
+
+
+def decoding_layer(xyz1, xyz2, points1, points2, nsample, mlp, params, scope):
+    """PointASNLDecodingLayer, pointasnl_util.py:294-351 (NL=False, use_xyz=True, use_knn=True)."""
+    dist, idx = ops.three_nn(xyz1.astype(np.float32), xyz2.astype(np.float32))  # :307
+    w = ops.three_weights(dist).astype(points2.dtype)  # :308-311
+    bi = np.arange(xyz1.shape[0])[:, None, None]
+    interpolated = (points2[bi, idx] * w[..., None]).sum(axis=2) if points2.dtype != np.float32 else \
+        ops.three_interpolate(points2, idx, w)  # :320
+    kidx = knn_query(nsample, xyz1.astype(np.float32), xyz1.astype(np.float32))  # :323
+    grouped_xyz = batched_gather(xyz1, kidx)
+    grouped_feature = np.concatenate([grouped_xyz, batched_gather(interpolated, kidx)], axis=-1)
+    grouped_xyz = grouped_xyz - xyz1[:, :, None, :]  # :324
+    weight = _layer(grouped_xyz, params[scope + "/decode_weight_net/wconv0"], "relu")  # :326
+    new_points = np.swapaxes(grouped_feature, 2, 3) @ weight  # :328-331
+    b, p = new_points.shape[:2]
+    new_points = _layer(new_points.reshape(b, p, -1), params[scope + "/decode_after_conv"], "relu")  # :333-336
+    if points1 is not None:
+        new_points = np.concatenate([new_points, points1], axis=-1)  # :338-341
+    for i in range(1, len(mlp)):  # :343-348
+        new_points = _layer(new_points, params[scope + "/conv_%d" % i], "relu")
+    return new_points
+
+
+def fp_module(xyz1, xyz2, points1, points2, mlp, params, scope):
+    """pointnet_fp_module, utils/pointnet_util.py:199-229."""
+    dist, idx = ops.three_nn(xyz1.astype(np.float32), xyz2.astype(np.float32))
+    w = ops.three_weights(dist).astype(points2.dtype)
+    bi = np.arange(xyz1.shape[0])[:, None, None]
+    interpolated = (points2[bi, idx] * w[..., None]).sum(axis=2) if points2.dtype != np.float32 else \
+        ops.three_interpolate(points2, idx, w)
+    x = np.concatenate([interpolated, points1], axis=2) if points1 is not None else interpolated
+    for i in range(len(mlp)):
+        x = _layer(x, params[scope + "/conv_%d" % i], "relu")
+    return x
+
+
+def sem_seg_forward(point_cloud, params, num_class, dtype=np.float32):
+    """models/pointasnl_sem_seg.py:18-50, feature_channel=0."""
+    pc = point_cloud.astype(dtype)
+    n = pc.shape[1]
+    nps = [n // 8, n // 32, n // 128, n // 256]
+    l0_xyz, l0_points = pc, pc
+    l1_xyz, l1_points = set_abstraction(l0_xyz, l0_points, nps[0], 32, [32, 32, 64], params, "layer1", 8)
+    l2_xyz, l2_points = set_abstraction(l1_xyz, l1_points, nps[1], 32, [64, 64, 128], params, "layer2", 4)
+    l3_xyz, l3_points = set_abstraction(l2_xyz, l2_points, nps[2], 32, [128, 128, 256], params, "layer3", 0)
+    l4_xyz, l4_points = set_abstraction(l3_xyz, l3_points, nps[3], 32, [256, 256, 512], params, "layer4", 0)
+    l3_points = decoding_layer(l3_xyz, l4_xyz, l3_points, l4_points, 16, [512, 512], params, "fa_layer1")
+    l2_points = decoding_layer(l2_xyz, l3_xyz, l2_points, l3_points, 16, [256, 256], params, "fa_layer2")
+    l1_points = decoding_layer(l1_xyz, l2_xyz, l1_points, l2_points, 16, [256, 128], params, "fa_layer3")
+    l0_points = decoding_layer(l0_xyz, l1_xyz, l0_points, l1_points, 16, [128, 128, 128], params, "fa_layer4")
+    net = _layer(l0_points, params["fc1"], "relu")
+    return _layer(net, params["fc2"], None)
+
+
+def sem_seg_res_forward(point_cloud, params, num_class, dtype=np.float32):
+    """models/pointasnl_sem_seg_res.py:19-68, feature_channel=0."""
+    pc = point_cloud.astype(dtype)
+    n = pc.shape[1]
+    nps = [n // 8, n // 32, n // 128, n // 256]
+    l0_xyz = pc
+    _, l0_points = set_abstraction(l0_xyz, pc, n, 32, [16, 16, 32], params, "layer0", 0, NL=False)
+    l1_xyz, l1_1 = set_abstraction(l0_xyz, l0_points, nps[0], 32, [32, 32, 64], params, "layer1_1", 8)
+    _, l1_2 = set_abstraction(l0_xyz, l0_points, nps[0], 32, [64, 64], params, "layer1_2", 0, NL=False)
+    l1_2 = l1_2 + l1_1
+    l2_xyz, l2_1 = set_abstraction(l1_xyz, l1_2, nps[1], 32, [64, 64, 128], params, "layer2_1", 4)
+    _, l2_2 = set_abstraction(l2_xyz, l2_1, nps[1], 32, [128, 128], params, "layer2_2", 0, NL=False)
+    l2_2 = l2_2 + l2_1
+    l3_xyz, l3_1 = set_abstraction(l2_xyz, l2_2, nps[2], 32, [128, 128, 256], params, "layer3_1", 0)
+    _, l3_2 = set_abstraction(l3_xyz, l3_1, nps[2], 32, [256, 256], params, "layer3_2", 0, NL=False)
+    l3_2 = l3_2 + l3_1
+    l4_xyz, l4_1 = set_abstraction(l3_xyz, l3_1, nps[3], 32, [256, 256, 512], params, "layer4_1", 0)  # sic :50
+    _, l4_2 = set_abstraction(l4_xyz, l4_1, nps[3], 32, [512, 512], params, "layer4_2", 0, NL=False)
+    l4_2 = l4_2 + l4_1
+    l3_points = fp_module(l3_xyz, l4_xyz, l3_2, l4_2, [512, 512], params, "fa_layer1")
+    l2_points = fp_module(l2_xyz, l3_xyz, l2_2, l3_points, [256, 256], params, "fa_layer2")
+    l1_points = fp_module(l1_xyz, l2_xyz, l1_2, l2_points, [256, 128], params, "fa_layer3")
+    l0_points = fp_module(l0_xyz, l1_xyz, l0_points, l1_points, [128, 128, 128], params, "fa_layer4")
+    net = _layer(l0_points, params["fc1"], "leaky_relu")
+    return _layer(net, params["fc0"], None)
 
 
 def sa_group_all(xyz, points, mlp, params, scope):

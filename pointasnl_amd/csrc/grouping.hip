@@ -484,15 +484,33 @@ __global__ __launch_bounds__(T) void sa_group_kernel(int n, int c, int m, int k,
   const int t = threadIdx.x;
   for (int s = t; s < k; s += T) sidx[s] = idx[g * k + s];
   __syncthreads();
-  const int col = t % W, r0 = t / W;
-  const bool active = r0 < R;
   const float* cx = xyz + (size_t)bi * n * 3;
   const float* cf = feature + (size_t)bi * n * c;
+  float* out = new_point + (size_t)g * k * W;
+  if (W > T) {
+    // wide rows (C > T-6): a thread owns columns t, t+T, ... and walks all k rows of each
+    for (int col = t; col < W; col += T) {
+      const float centre = col < 3 ? new_xyz[g * 3 + col] : 0.f;
+      float mx = -INFINITY;
+      for (int s = 0; s < k; ++s) {
+        const int i = sidx[s];
+        float v;
+        if (col < 3) v = cx[(size_t)i * 3 + col] - centre;
+        else if (col < 6) v = cx[(size_t)i * 3 + (col - 3)];
+        else v = cf[(size_t)i * c + (col - 6)];
+        out[(size_t)s * W + col] = v;
+        mx = fmaxf(mx, v);
+      }
+      skip_max[g * W + col] = mx;
+    }
+    return;
+  }
+  const int col = t % W, r0 = t / W;
+  const bool active = r0 < R;
   float centre = 0.f;
   if (active && col < 3) centre = new_xyz[g * 3 + col];
   float mx = -INFINITY;
   if (active) {
-    float* out = new_point + (size_t)g * k * W;
     for (int s = r0; s < k; s += R) {
       const int i = sidx[s];
       float v;
@@ -667,7 +685,6 @@ extern "C" int pasnl_sa_group(int b, int n, int c, int m, int k, const float* xy
                               const float* new_xyz, float* new_point, float* skip_max, pasnl_stream_t stream) {
   PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && m >= 0 && k > 0, PASNL_EINVAL);
   const int W = 6 + c;
-  PASNL_REQUIRE(W <= 512, PASNL_EUNSUPPORTED);
   long groups = (long)b * m;
   if (groups == 0) return PASNL_OK;
   PASNL_REQUIRE(groups < (1L << 31), PASNL_EUNSUPPORTED);
@@ -678,7 +695,7 @@ extern "C" int pasnl_sa_group(int b, int n, int c, int m, int k, const float* xy
     hipLaunchKernelGGL(sa_group_kernel<256>, dim3((unsigned)groups), dim3(256), lds, st, n, c, m, k, xyz, feature, idx, new_xyz,
                        new_point, skip_max);
   } else {
-    size_t lds = (size_t)k * 4 + (size_t)(512 / W) * W * 4;
+    size_t lds = (size_t)k * 4 + (size_t)(W <= 512 ? (512 / W) * W : 0) * 4;
     hipLaunchKernelGGL(sa_group_kernel<512>, dim3((unsigned)groups), dim3(512), lds, st, n, c, m, k, xyz, feature, idx, new_xyz,
                        new_point, skip_max);
   }

@@ -1,0 +1,46 @@
+"""pointasnl_sem_seg -- inference graph of the reference's ScanNet segmentation model
+(models/pointasnl_sem_seg.py:18-50): 4 PointASNL set-abstraction layers + 4 PointASNL decoding layers
+(three_nn / three_interpolate + self-kNN local cell).  Same get_model signature; torch device tensors."""
+from pointasnl_amd.utils import tf_util
+from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction, PointASNLDecodingLayer
+
+
+def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=None, feature_channel=0):
+    """ Semantic segmentation PointNet, input is B x N x (3+feature_channel), output B x N x num_class """
+    end_points = {}
+    num_point = point_cloud.shape[1]
+    if feature_channel > 0:
+        l0_xyz = point_cloud[:, :, 0:3].contiguous()
+        l0_points = point_cloud[:, :, 3:3 + feature_channel].contiguous()
+    else:
+        l0_xyz = point_cloud
+        l0_points = point_cloud
+    end_points['l0_xyz'] = l0_xyz
+    num_points = [num_point // 8, num_point // 32, num_point // 128, num_point // 256]
+    kw = dict(is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay)
+    # Feature encoding layers
+    l1_xyz, l1_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=num_points[0], nsample=32, mlp=[32, 32, 64],
+                                                scope='layer1', as_neighbor=8, **kw)
+    l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=num_points[1], nsample=32, mlp=[64, 64, 128],
+                                                scope='layer2', as_neighbor=4, **kw)
+    l3_xyz, l3_points = PointASNLSetAbstraction(l2_xyz, l2_points, npoint=num_points[2], nsample=32, mlp=[128, 128, 256],
+                                                scope='layer3', as_neighbor=0, **kw)
+    l4_xyz, l4_points = PointASNLSetAbstraction(l3_xyz, l3_points, npoint=num_points[3], nsample=32, mlp=[256, 256, 512],
+                                                scope='layer4', as_neighbor=0, **kw)
+    end_points['l1_xyz'] = l1_xyz
+    # Feature decoding layers
+    l3_points = PointASNLDecodingLayer(l3_xyz, l4_xyz, l3_points, l4_points, 16, [512, 512], is_training, bn_decay,
+                                       weight_decay, scope='fa_layer1')
+    l2_points = PointASNLDecodingLayer(l2_xyz, l3_xyz, l2_points, l3_points, 16, [256, 256], is_training, bn_decay,
+                                       weight_decay, scope='fa_layer2')
+    l1_points = PointASNLDecodingLayer(l1_xyz, l2_xyz, l1_points, l2_points, 16, [256, 128], is_training, bn_decay,
+                                       weight_decay, scope='fa_layer3')
+    l0_points = PointASNLDecodingLayer(l0_xyz, l1_xyz, l0_points, l1_points, 16, [128, 128, 128], is_training, bn_decay,
+                                       weight_decay, scope='fa_layer4')
+    # FC layers
+    net = tf_util.conv1d(l0_points, 128, 1, padding='VALID', bn=True, is_training=is_training, scope='fc1',
+                         bn_decay=bn_decay, weight_decay=weight_decay)
+    end_points['feats'] = net
+    net = tf_util.dropout(net, keep_prob=0.5, is_training=is_training, scope='dp1')
+    net = tf_util.conv1d(net, num_class, 1, padding='VALID', activation_fn=None, weight_decay=weight_decay, scope='fc2')
+    return net, end_points

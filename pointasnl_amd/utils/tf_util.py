@@ -135,6 +135,8 @@ def _act(x, activation_fn):
         return torch.relu_(x)
     if activation_fn in ("sigmoid", torch.sigmoid):
         return torch.sigmoid_(x)
+    if activation_fn == "leaky_relu":  # tf.nn.leaky_relu default alpha = 0.2
+        return torch.nn.functional.leaky_relu(x, 0.2, inplace=True)
     return activation_fn(x)
 
 

@@ -148,3 +148,26 @@ def test_sa_local_cell(g, k, c, c1):
     scale = np.abs(want).max()
     assert np.abs(got - want).max() / scale < 1e-5
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * scale)
+
+
+@pytest.mark.parametrize("model", ["sem_seg", "sem_seg_res"])
+def test_seg_forward_matches_oracle(model):
+    """ScanNet / SemanticKITTI graphs (configs 4-5) at N=4096 (smallest size where every level still has >= 32
+    points): encoder + three_nn / three_interpolate decoders vs the numpy oracle."""
+    import importlib
+
+    M = importlib.import_module(f"pointasnl_amd.models.pointasnl_{model}")
+    st = _store(23)
+    # every level must keep >= nsample = 32 points: N/128 for sem_seg (4096), N/256 for sem_seg_res (8192)
+    npts = 4096 if model == "sem_seg" else 8192
+    pc = clouds(77, 1, npts)
+    with torch.no_grad():
+        logits, _ = M.get_model(dev(pc), False, 13)
+    params = st.export_numpy()
+    fwd = cells.sem_seg_forward if model == "sem_seg" else cells.sem_seg_res_forward
+    want = fwd(pc, params, 13, dtype=np.float64)
+    got = logits.cpu().numpy()
+    assert got.shape == (1, npts, 13)
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() / scale < 2e-4
+    assert (got.argmax(-1) == want.argmax(-1)).mean() > 0.999

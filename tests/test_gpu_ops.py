@@ -210,7 +210,7 @@ def test_empty(P):
 
 
 @pytest.mark.parametrize("b,n,c,m,k", [(4, 1024, 3, 512, 32), (2, 512, 128, 128, 64), (2, 64, 256, 32, 32), (1, 50, 7, 50, 5),
-                                       (2, 300, 300, 9, 3)])
+                                       (2, 300, 300, 9, 3), (1, 40, 512, 40, 32), (1, 33, 700, 5, 4)])
 def test_sa_group(P, b, n, c, m, k):
     # fused gather + centre + concat + max-over-K == the reference's op-by-op composition
     # (pointasnl_util.py:63-74, 248-249, 258), bit for bit (gathers, one subtraction, max)
