@@ -8,6 +8,7 @@
 // leaves the VALU free for the softmax); a vector-FMA variant of the non-local kernel is kept so the
 // choice is measured, not assumed (bench.py --ops, profiles/).
 #include <math.h>
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace pasnl {
@@ -18,34 +19,40 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// row index held in register r of lane-half h of a 32x32 MFMA C/D tile
+__device__ __forceinline__ int kappa(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
 // =============================================================================================
-// Non-local attention, MFMA variant ("swapped" flash form).
-//   A wave owns 32 queries.  For a sub-tile of 32 keys it forms S^T = K_tile . Q^T with cb/2
-//   32x32x2 MFMAs, so lane l holds, for ITS query (l & 31), the 16 keys kappa(r,h) =
-//   (r&3) + 8*(r>>2) + 4*h, h = l>>5: the softmax statistics of a query are 16 in-lane values plus
-//   one exchange with lane l^32 -- no transposes.  P^T is then already in B-operand position for
-//   O^T += V^T . P^T when MFMA step t is defined to contract key kappa(t,h): the A operand
+// Non-local attention, MFMA variant ("swapped" flash form, keys split across waves).
+//   A workgroup owns 32 queries; its SPLIT waves each walk every SPLIT-th block of 32 keys, so even a layer
+//   with few query tiles (cls layer2: 256) puts >= 2 waves on every SIMD and one wave's softmax (VALU)
+//   overlaps another's MFMAs.  Staging is wave-private (each wave copies its own 32 K/V rows into its own LDS
+//   region): no workgroup barrier inside the loop.  The partial (max, sum, O) of the SPLIT waves are merged
+//   through LDS at the end (one barrier).
+//   Per key block a wave forms S^T = K_blk . Q^T with cb/2 32x32x2 MFMAs, so lane l holds, for ITS query
+//   (l & 31), the 16 keys kappa(r,h) = (r&3) + 8*(r>>2) + 4*h, h = l>>5: the softmax statistics of a query are
+//   16 in-lane values plus one exchange with lane l^32 -- no transposes.  P^T is then already in B-operand
+//   position for O^T += V^T . P^T when MFMA step t is defined to contract key kappa(t,h): the A operand
 //   V[kappa(t,h)][c0 + (l&31)] is a conflict-free LDS row read.
 //   K rows are stored with stride CB+1 so that the A-operand read K[l&31][2t+h] is conflict-free.
 // =============================================================================================
-constexpr int NL_STAGE_KEYS = 64;  // keys staged in LDS per barrier pair
+constexpr int NL_KB = 32;  // keys per block
 
-template <int CB, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void nl_attention_mfma_kernel(int p, int n, float qscale,
+template <int CB, int SPLIT>
+__global__ __launch_bounds__(SPLIT * 64) void nl_attention_mfma_kernel(int p, int n, float qscale,
                                                                      const float* __restrict__ q,
                                                                      const float* __restrict__ kv,
                                                                      float* __restrict__ out) {
-  constexpr int KS = CB + 1;  // padded K row stride
+  constexpr int KS = CB + 1;                              // padded K row stride
+  constexpr int WAVE_FLOATS = NL_KB * KS + NL_KB * CB + 3;  // +3: room to align V to 16 bytes
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* Ks = reinterpret_cast<float*>(smem);  // [NL_STAGE_KEYS][KS]
-  // [NL_STAGE_KEYS][CB], rounded up to a 16-byte boundary for the float4 stores
-  float* Vs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(Ks + NL_STAGE_KEYS * KS) + 15) & ~uintptr_t(15));
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Ks = reinterpret_cast<float*>(smem) + (size_t)wave * ((WAVE_FLOATS + 3) & ~3);  // [NL_KB][KS]
+  float* Vs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(Ks + NL_KB * KS) + 15) & ~uintptr_t(15));  // [NL_KB][CB]
+
   const int h = lane >> 5, ql = lane & 31;
   const int bi = blockIdx.y;
-  const int q0 = (blockIdx.x * WAVES + wave) * 32;
+  const int q0 = blockIdx.x * 32;
   const int qi = min(q0 + ql, p - 1);
   const float* kvb = kv + (size_t)bi * n * 2 * CB;
 
@@ -63,14 +70,12 @@ __global__ __launch_bounds__(WAVES * 64) void nl_attention_mfma_kernel(int p, in
     for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
   float mrun = -INFINITY, lrun = 0.f;
 
-  for (int base = 0; base < n; base += NL_STAGE_KEYS) {
-    const int cnt = min(NL_STAGE_KEYS, n - base);
-    __syncthreads();
-    // stage [K | V] rows; global reads are coalesced float4.  Rows past cnt (only in the last stage) are
-    // zero-filled up to the 32-key sub-tile boundary: their probabilities are 0, and 0 * stale-LDS-NaN must
-    // not reach the accumulator.
-    const int fill = min(NL_STAGE_KEYS, (cnt + 31) & ~31);
-    for (int f = tid; f < fill * (2 * CB / 4); f += WAVES * 64) {
+  for (int base = wave * NL_KB; base < n; base += SPLIT * NL_KB) {
+    const int cnt = min(NL_KB, n - base);
+    // wave-private staging of 32 [K | V] rows (coalesced float4 reads); rows past cnt are zero-filled: their
+    // probabilities are 0, and 0 * stale-LDS-NaN must not reach the accumulator
+#pragma unroll 2
+    for (int f = lane; f < NL_KB * (2 * CB / 4); f += 64) {
       int row = f / (2 * CB / 4), c4 = (f - row * (2 * CB / 4)) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < cnt) v = *reinterpret_cast<const float4*>(kvb + (size_t)(base + row) * 2 * CB + c4);
@@ -81,51 +86,72 @@ __global__ __launch_bounds__(WAVES * 64) void nl_attention_mfma_kernel(int p, in
         *reinterpret_cast<float4*>(Vs + row * CB + (c4 - CB)) = v;
       }
     }
-    __syncthreads();
-    for (int sub = 0; sub < cnt; sub += 32) {
-      // ---- S^T = K_sub . Q^T
-      f32x16 S;
+    // (LDS operations of one wave execute in order: no barrier needed before reading the region back)
+    // ---- S^T = K_blk . Q^T
+    f32x16 S;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) S[r] = 0.f;
-      const float* krow = Ks + (sub + ql) * KS + h;  // rows beyond cnt hold stale data; masked below
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+    const float* krow = Ks + ql * KS + h;
 #pragma unroll
-      for (int t = 0; t < CB / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * t], qreg[t], S, 0, 0, 0);
-      // ---- online softmax over this lane's 16 keys (+ the other half-wave's 16)
-      const int valid = cnt - sub;  // keys kappa >= valid are padding
-      float tmax = -INFINITY;
+    for (int t = 0; t < CB / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * t], qreg[t], S, 0, 0, 0);
+    // ---- online softmax over this lane's 16 keys (+ the other half-wave's 16)
+    float tmax = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int kap = (r & 3) + 8 * (r >> 2) + 4 * h;
-        S[r] = kap < valid ? S[r] : -INFINITY;
-        tmax = fmaxf(tmax, S[r]);
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-      const float mnew = fmaxf(mrun, tmax);  // finite: every sub-tile has >= 1 valid key
-      const float alpha = fast_exp2(mrun - mnew);
-      float psum = 0.f;
+    for (int r = 0; r < 16; ++r) {
+      S[r] = kappa(r, h) < cnt ? S[r] : -INFINITY;
+      tmax = fmaxf(tmax, S[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float mnew = fmaxf(mrun, tmax);  // finite: every block has >= 1 valid key
+    const float alpha = fast_exp2(mrun - mnew);
+    float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        S[r] = fast_exp2(S[r] - mnew);
-        psum += S[r];
-      }
-      psum += __shfl_xor(psum, 32);
-      lrun = lrun * alpha + psum;
-      mrun = mnew;
-      // ---- O^T = alpha * O^T + V^T . P^T
+    for (int r = 0; r < 16; ++r) {
+      S[r] = fast_exp2(S[r] - mnew);
+      psum += S[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    lrun = lrun * alpha + psum;
+    mrun = mnew;
+    // ---- O^T = alpha * O^T + V^T . P^T
 #pragma unroll
-      for (int c = 0; c < CB / 32; ++c) {
+    for (int c = 0; c < CB / 32; ++c) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
-        const float* vcol = Vs + (size_t)sub * CB + c * 32 + ql;
+      for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
+      const float* vcol = Vs + c * 32 + ql;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-          int kap = (t & 3) + 8 * (t >> 2) + 4 * h;
-          O[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[kap * CB], S[t], O[c], 0, 0, 0);
-        }
-      }
+      for (int t = 0; t < 16; ++t) O[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[kappa(t, h) * CB], S[t], O[c], 0, 0, 0);
     }
   }
-  // O^T[channel = c*32 + (r&3) + 8*(r>>2) + 4*h][query = ql] / l
+
+  if constexpr (SPLIT > 1) {
+    // ---- merge the SPLIT partial results: wave w > 0 parks (m, l, O) in its own LDS region, wave 0 folds them in
+    float* park = Ks;  // [CB/2 + 2][64]
+    if (wave > 0) {
+#pragma unroll
+      for (int c = 0; c < CB / 32; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) park[(c * 16 + r) * 64 + lane] = O[c][r];
+      park[(CB / 2) * 64 + lane] = mrun;
+      park[(CB / 2 + 1) * 64 + lane] = lrun;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int w = 1; w < SPLIT; ++w) {
+      const float* pw = reinterpret_cast<const float*>(smem) + (size_t)w * ((WAVE_FLOATS + 3) & ~3);
+      const float mw = pw[(CB / 2) * 64 + lane], lw = pw[(CB / 2 + 1) * 64 + lane];
+      const float mnew = fmaxf(mrun, mw);  // a wave that saw no key block has m = -inf, l = 0, O = 0
+      const float a0 = mrun == -INFINITY ? 0.f : fast_exp2(mrun - mnew);
+      const float a1 = mw == -INFINITY ? 0.f : fast_exp2(mw - mnew);
+      lrun = lrun * a0 + lw * a1;
+      mrun = mnew;
+#pragma unroll
+      for (int c = 0; c < CB / 32; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[c][r] = O[c][r] * a0 + pw[(c * 16 + r) * 64 + lane] * a1;
+    }
+  }
+  // O^T[channel = c*32 + kappa(r,h)][query = ql] / l
   if (q0 + ql < p) {
     const float inv = 1.0f / lrun;
     float* op = out + ((size_t)bi * p + q0 + ql) * CB;
@@ -347,8 +373,6 @@ __global__ __launch_bounds__(256) void as_reweight_kernel(long groups, int as, i
 // LDS holds only the (BN-folded) weights, staged once per persistent workgroup.  fp32 in, fp32 accumulate
 // (the MFMA is an exact fp32 fmaf chain); tolerance vs the fp32 oracle 1e-5 relative.
 // =============================================================================================
-__device__ __forceinline__ int kappa(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
-
 template <int C1, int C2>
 __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, int w, const float* __restrict__ x,
                                                            const float* __restrict__ w0, const float* __restrict__ b0,
@@ -466,24 +490,34 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
 
 using namespace pasnl;
 
-template <int CB, int WAVES>
+template <int CB, int SPLIT>
 static int nl_mfma_launch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, hipStream_t st) {
-  size_t lds = (size_t)NL_STAGE_KEYS * (CB + 1) * 4 + 16 + (size_t)NL_STAGE_KEYS * CB * 4;
-  auto kern = nl_attention_mfma_kernel<CB, WAVES>;
+  constexpr int WAVE_FLOATS = NL_KB * (CB + 1) + NL_KB * CB + 3;
+  size_t lds = (size_t)SPLIT * ((WAVE_FLOATS + 3) & ~3) * 4 + 16;
+  auto kern = nl_attention_mfma_kernel<CB, SPLIT>;
+  if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
-  int qpb = WAVES * 32;
-  hipLaunchKernelGGL(kern, dim3((p + qpb - 1) / qpb, b), dim3(WAVES * 64), lds, st, p, n, qscale, q, kv, out);
+  hipLaunchKernelGGL(kern, dim3((p + 31) / 32, b), dim3(SPLIT * 64), lds, st, p, n, qscale, q, kv, out);
   return pasnl_launch_status();
 }
 
 template <int CB>
 static int nl_mfma_dispatch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, hipStream_t st) {
-  // fill the 256 CUs: fewer waves per workgroup when there are few query tiles
+  // split the keys over enough waves to put ~4 on every SIMD (4096 waves; measured best on all reference shapes:
+  // cls layer1 140 -> 82 us, cls layer2 128 -> 37 us, ScanNet layer1 1030 -> 279 us), bounded by the number of key
+  // blocks and by the LDS (cb = 128: 4 wave regions fit)
   long tiles = (long)b * ((p + 31) / 32);
-  if (tiles >= 4 * 512) return nl_mfma_launch<CB, 4>(b, p, n, qscale, q, kv, out, st);
-  if (tiles >= 2 * 512) return nl_mfma_launch<CB, 2>(b, p, n, qscale, q, kv, out, st);
+  long blocks = (n + NL_KB - 1) / NL_KB;
+  int want = 1;
+  while (want < 8 && tiles * want < 4096 && want * 2 <= blocks) want *= 2;
+  const char* force = getenv("PASNL_NL_SPLIT");  // tuning only
+  if (force && *force) want = atoi(force);
+  if (CB == 128 && want > 4) want = 4;
+  if (want >= 8) return nl_mfma_launch<CB, 8>(b, p, n, qscale, q, kv, out, st);
+  if (want >= 4) return nl_mfma_launch<CB, 4>(b, p, n, qscale, q, kv, out, st);
+  if (want >= 2) return nl_mfma_launch<CB, 2>(b, p, n, qscale, q, kv, out, st);
   return nl_mfma_launch<CB, 1>(b, p, n, qscale, q, kv, out, st);
 }
 
