@@ -92,6 +92,12 @@ def algorithmic(symbol, ints):
         g, k, w, c1, c2 = ints
         # reads the grouped points once, writes (c2 x 32) per group; weights are LDS-resident
         return 4 * (g * k * w + g * c2 * 32 + w * c1 + c1 * c2), g * (2 * k * (w * c1 + c1 * c2 + 3 * 32) + 2 * c2 * k * 32), "mfma"
+    if symbol == "pasnl_sa_cell":
+        b, n, c, m, k, c1, c2 = ints
+        g, w = b * m, 6 + c
+        # reads the tables, the indices and the centres once; writes (c2 x 32) per group + the skip maxima
+        return (4 * (b * n * (3 + c) + g * k + 3 * g + g * c2 * 32 + g * w + w * c1 + c1 * c2),
+                g * (2 * k * (w * c1 + c1 * c2 + 3 * 32) + 2 * c2 * k * 32), "mfma")
     if symbol == "pasnl_as_reweight":
         g, as_, ns, ch = ints
         return 4 * g * (as_ * (1 + ch) + as_ * (3 + ch) + 3 + ch), 4 * g * as_ * (1 + ch), "hbm"
@@ -159,6 +165,9 @@ def main():
                          "latency-bound prefix of one step (FPS: 512 dependent rounds on 64 CUs) runs under the GEMM/MFMA "
                          "work of the previous one.  1 = strictly serial steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--launch-order", action="store_true",
+                    help="add the per-forward sequence of C-ABI launches to the JSON line (profiles/pmc_to_traffic.py uses "
+                         "it to attribute rocprofv3 PMC rows to launches)")
     args = ap.parse_args()
 
     import torch
@@ -186,6 +195,8 @@ def main():
 
     import importlib
 
+    if args.model != "cls" and args.pipeline == 2:
+        args.pipeline = 1  # two concurrent replays of the ScanNet graph dead-lock on ROCm 7.2; serial replay
     default_pts = {"cls": 1024, "sem_seg": 8192, "sem_seg_res": 10240}[args.model]
     B, N = args.batch, (args.points or default_pts)
     if args.model != "cls" and args.batch == 64:
@@ -267,6 +278,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
+        # every pipeline lane computes the same function of the same input: their outputs must be bit-identical
+        lanes_agree = all(torch.equal(lanes[0][2], l[2]) for l in lanes[1:]) if len(lanes) > 1 else None
+
         # ---- per-kernel pass: the same forward, eager, every C-ABI launch bracketed by HIP events
         rows = []
         if rank == 0:
@@ -275,6 +289,8 @@ def main():
                 forward()
             torch.cuda.synchronize()
             rows = kernel_table(_hip.PROFILE)
+            per_fwd = len(_hip.PROFILE) // max(1, min(args.steps, 20))
+            launch_order = [[sym, list(ints)] for sym, ints, _, _ in _hip.PROFILE[:per_fwd]]
             _hip.PROFILE = None
 
     if rank != 0:
@@ -324,12 +340,14 @@ def main():
                                  "configs[1]: ModelNet40 pointasnl_cls, 1024 pts") if args.model == "cls" else
                                 f"configs[{cfg_index}]: pointasnl_{args.model}, {N} pts") + f", batch={B}/GPU, seeded random weights",
                    "global_batch": world * B, "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
-                   "hip_graph": graph is not None, "pipelined_graph_instances": len(lanes)},
+                   "hip_graph": graph is not None, "pipelined_graph_instances": len(lanes), "lanes_agree": lanes_agree},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "handwritten_kernel_us_per_step": round(handwritten_us, 1),
         "kernels": rows,
     }
+    if args.launch_order:
+        out["launch_order"] = launch_order
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -134,6 +134,23 @@ def main():
             q = torch.randn((g, a, cb), device="cuda")
             kv = torch.randn((g, a, 2 * cb), device="cuda")
             rows += timeit(lambda: U.as_attention(q, kv), f"as_attention {name}")
+    if want("sacell"):
+        from pointasnl_amd.utils import tf_util
+        tf_util.set_store(tf_util.VariableStore(seed=5))
+        for (b, n, c, m, k, c1, name) in [(64, 1024, 3, 512, 32, 64, "cls-L1"), (64, 512, 128, 128, 64, 128, "cls-L2"),
+                                          (16, 8192, 3, 1024, 32, 32, "scannet-L1"), (16, 1024, 64, 256, 32, 64, "scannet-L2"),
+                                          (8, 10240, 32, 1280, 32, 32, "kitti-L1")]:
+            xyz = cloud(b, n)
+            feat = torch.randn((b, n, c), device="cuda")
+            idx = torch.randint(0, n, (b, m, k), device="cuda", dtype=torch.int32)
+            nx = xyz[:, :m].contiguous()
+            with tf_util.variable_scope(name):
+                rows += timeit(lambda: U.sa_cell(xyz, feat, idx, nx, [c1, c1, 2 * c1], False, None, None, True), f"sa_cell {name} B={b}")
+                if args.sweep:
+                    def two():
+                        npnt, _ = U.sa_group(xyz, feat, idx, nx)
+                        U.sa_local_cell(npnt, [c1, c1, 2 * c1], False, None, None, True)
+                    rows += timeit(two, f"sa_group+local_cell {name} B={b}")
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
     json.dump(rows, open(args.out, "w"), indent=1)
 

@@ -169,6 +169,17 @@ int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, const float* x
                         const float* w1, const float* b1, const float* ww, const float* bw, float* out,
                         pasnl_stream_t stream);
 
+/* The same cell with the grouping fused in (pointasnl_util.py:63-74,248-249,258,264-274): row s of group (b,j) is
+ * [xyz[i]-new_xyz[b,j] | xyz[i] | feature[i]], i = idx[b,j,s], gathered straight from the (b,n,3) / (b,n,c) tables
+ * (L2-resident), so the (b,m,k,6+c) grouped tensor never exists in HBM.  Also returns the skip connection's
+ * reduce_max over the k neighbours: skip_max (b,m,6+c) -- bit-equal to pasnl_sa_group's.
+ * out (b*m, c2*32) as pasnl_sa_local_cell.  Replaces two tf.gather_nd, two concats, a subtraction, a reduce_max,
+ * three conv2d, a transpose and a batched matmul of the reference graph.  Same shape limits as above. */
+int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
+                  const int* idx, const float* new_xyz, const float* w0, const float* b0, const float* w1,
+                  const float* b1, const float* ww, const float* bw, float* out, float* skip_max,
+                  pasnl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

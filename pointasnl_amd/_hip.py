@@ -19,7 +19,7 @@ SYMBOLS = [
     "pasnl_farthest_point_sample", "pasnl_gather_point", "pasnl_gather_point_grad", "pasnl_prob_sample",
     "pasnl_query_ball_point", "pasnl_sa_group", "pasnl_group_point", "pasnl_group_point_grad", "pasnl_select_top_k", "pasnl_knn_batch",
     "pasnl_three_nn", "pasnl_three_interpolate", "pasnl_three_interpolate_grad", "pasnl_three_weights",
-    "pasnl_nl_attention", "pasnl_as_attention", "pasnl_as_reweight", "pasnl_sa_local_cell",
+    "pasnl_nl_attention", "pasnl_as_attention", "pasnl_as_reweight", "pasnl_sa_local_cell", "pasnl_sa_cell",
 ]
 
 
@@ -64,9 +64,22 @@ def ptr(t):
 PROFILE = None
 
 
+TRACE = bool(os.environ.get("PASNL_TRACE"))  # debugging: print + synchronise around every launch
+
+
 def launch(symbol, what, *args):
     """Call one pasnl_* entry point with the current stream appended; raise on a non-zero status."""
     fn = getattr(lib(), symbol)
+    if TRACE:
+        import sys
+        import time
+        ints = tuple(a for a in args if isinstance(a, (int, float)))
+        print(f"[pasnl] {symbol}{ints} ...", file=sys.stderr, flush=True)
+        t0 = time.perf_counter()
+        check(fn(*args, stream_ptr()), what)
+        torch.cuda.synchronize()
+        print(f"[pasnl]   done {1e3 * (time.perf_counter() - t0):.2f} ms", file=sys.stderr, flush=True)
+        return
     if PROFILE is None:
         check(fn(*args, stream_ptr()), what)
         return

@@ -8,7 +8,9 @@
 // leaves the VALU free for the softmax); a vector-FMA variant of the non-local kernel is kept so the
 // choice is measured, not assumed (bench.py --ops, profiles/).
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "common.hpp"
 
 namespace pasnl {
@@ -373,8 +375,37 @@ __global__ __launch_bounds__(256) void as_reweight_kernel(long groups, int as, i
 // LDS holds only the (BN-folded) weights, staged once per persistent workgroup.  fp32 in, fp32 accumulate
 // (the MFMA is an exact fp32 fmaf chain); tolerance vs the fp32 oracle 1e-5 relative.
 // =============================================================================================
-template <int C1, int C2>
+// GATHER = true is the same cell reading its input straight from the layer's tables instead of a materialised
+// new_point: row s of group (b,j) is [xyz[i]-new_xyz[j] | xyz[i] | feature[i]], i = idx[b,j,s]
+// (pointasnl_util.py:63-74,248-249).  The per-cloud tables (n x (3+C) floats: 12 KiB..270 KiB) stay L2-resident, so
+// the K-fold replicated grouped tensor (31 MB / 294 MB at cls B=64) is never written to or read from HBM.  The
+// skip connection's reduce_max over the K neighbours (:258) is taken on the fly from the same registers: a DPP
+// max over the 32 lanes of a half-wave per MFMA operand, folded into a wave-private LDS row.
+struct SaGatherSrc {
+  const float* xyz;      // (b,n,3)
+  const float* feature;  // (b,n,c), c = w - 6
+  const int* idx;        // (b,m,k)
+  const float* new_xyz;  // (b,m,3)
+  float* skip_max;       // (b,m,w)
+  int n, m;
+};
+
+// max over the 32 lanes of each half-wave; result in lane 31 (lanes 0..31) and lane 63 (lanes 32..63)
+__device__ __forceinline__ float half_wave_max(float v) {
+#define PASNL_HMAX(CTRL, RM)                                                                                  \
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, RM, 0xf, false)));
+  PASNL_HMAX(DPP_ROW_SHR1, 0xf)
+  PASNL_HMAX(DPP_ROW_SHR2, 0xf)
+  PASNL_HMAX(DPP_ROW_SHR4, 0xf)
+  PASNL_HMAX(DPP_ROW_SHR8, 0xf)
+  PASNL_HMAX(DPP_ROW_BCAST15, 0xa)
+#undef PASNL_HMAX
+  return v;
+}
+
+template <int C1, int C2, bool GATHER>
 __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, int w, const float* __restrict__ x,
+                                                           SaGatherSrc src,
                                                            const float* __restrict__ w0, const float* __restrict__ b0,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            const float* __restrict__ ww, const float* __restrict__ bw,
@@ -387,6 +418,7 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
   float* B0s = Wws + 4 * 32;                        // [C1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ql = lane & 31;
+  float* skp = B0s + C1 + (size_t)wave * wp;        // [4 waves][wp] running column maxima (GATHER only)
 
   for (int i = tid; i < wp * C1; i += 256) W0s[i] = (i / C1) < w ? w0[i] : 0.f;
   for (int i = tid; i < C1 * C2; i += 256) W1s[i] = w1[i];
@@ -407,8 +439,28 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) M[cb][r] = 0.f;
 
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    long bi = 0;
+    if constexpr (GATHER) {
+      bi = g / src.m;
+      cx = src.new_xyz[g * 3]; cy = src.new_xyz[g * 3 + 1]; cz = src.new_xyz[g * 3 + 2];
+      for (int c = lane; c < wp; c += 64) skp[c] = -INFINITY;
+    }
+
     for (int tile = 0; tile < k; tile += 32) {
-      const float* xrow = x + ((size_t)g * k + tile + ql) * w;  // this lane's neighbour row
+      const float* xrow;  // this lane's neighbour row; GATHER: feature row shifted so that column c >= 6 is xrow[c]
+      float x0 = 0.f, x1 = 0.f, x2 = 0.f;  // GATHER: columns (h, 2+h, 4+h) of the row = MFMA steps 0..2 of chunk 0
+      if constexpr (GATHER) {
+        const int i = src.idx[(size_t)g * k + tile + ql];
+        const float* pp = src.xyz + ((size_t)bi * src.n + i) * 3;
+        const float px = pp[0], py = pp[1], pz = pp[2];
+        x0 = h ? py - cy : px - cx;
+        x1 = h ? px : pz - cz;
+        x2 = h ? pz : py;
+        xrow = src.feature + ((size_t)bi * src.n + i) * (size_t)(w - 6) - 6;
+      } else {
+        xrow = x + ((size_t)g * k + tile + ql) * w;
+      }
       f32x16 H1T[C1 / 32];
 #pragma unroll
       for (int ob = 0; ob < C1 / 32; ++ob)
@@ -423,9 +475,22 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           int c = ch * 32 + 2 * t + h;
-          xr[t] = c < w ? xrow[c] : 0.f;
+          if constexpr (GATHER) xr[t] = (c >= 6 && c < w) ? xrow[c] : 0.f;
+          else xr[t] = c < w ? xrow[c] : 0.f;
         }
         const int live = min(16, (w - ch * 32 + 1) >> 1);  // MFMA steps with a non-zero k pair (uniform)
+        if constexpr (GATHER) {
+          if (ch == 0) { xr[0] = x0; xr[1] = x1; xr[2] = x2; }
+          // skip connection: column maxima over this tile's 32 rows, folded into the wave's LDS row by lanes 31 / 63
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            if (t < live) {
+              const float mx = half_wave_max(xr[t]);
+              const int c = ch * 32 + 2 * t + h;
+              if (ql == 31 && c < w) skp[c] = fmaxf(skp[c], mx);
+            }
+          }
+        }
         if (ch == 0) {
           // weight net: channels 0..2 are the centred coordinates
           G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0], Wws[h * 32 + ql], G, 0, 0, 0);
@@ -477,12 +542,228 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
         for (int t = 0; t < 16; ++t) M[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(H2[t], G[t], M[cb], 0, 0, 0);
       }
     }
+    if constexpr (GATHER) {
+      // the wave's LDS operations execute in order; the fence only keeps the compiler from moving the reads up
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int c = lane; c < w; c += 64) src.skip_max[(size_t)g * w + c] = skp[c];
+      __builtin_amdgcn_wave_barrier();
+    }
     // M[c2 = cb*32 + kappa(r,h)][j = ql] -> out[g][c2*32 + j]
     float* o = out + (size_t)g * C2 * 32;
 #pragma unroll
     for (int cb = 0; cb < C2 / 32; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[(size_t)(cb * 32 + kappa(r, h)) * 32 + ql] = M[cb][r];
+  }
+}
+
+
+// =============================================================================================
+// pasnl_sa_cell: grouping + skip maxima + local cell, NW waves per workgroup sharing one LDS copy of the weights.
+//   * NW = 8 puts TWO waves on every SIMD (<= 256 registers each): while one wave waits for its gathered rows or
+//     runs the bias/ReLU VALU passes between the chained products, the other one keeps the MFMA pipe busy.  With
+//     the weights filling the LDS there can be only one workgroup per CU, so the second wave has to come from
+//     inside the workgroup.
+//   * every global load is UNCONDITIONAL with a clamped address (a conditional load compiles to its own
+//     exec-masked basic block: serialised loads and vmcnt(0) at every join); values that must not be used are
+//     masked where they are consumed.
+//   * PF: the 16 operand values of the next 32-channel chunk are requested before the MFMAs of the current chunk.
+//   * skip connection: per chunk the 16 operand registers are reduced over the 32 rows of the tile with
+//     single-instruction v_max_f32_dpp steps and folded into a wave-private LDS row with ds_max_f32 (no return
+//     value: nothing waits for it); the row is written out once per group.
+// =============================================================================================
+__device__ __forceinline__ float vmaxf(float a, float b) {
+  // plain v_max_f32: fmaxf() would canonicalise both operands first (IEEE mode), 3 instructions instead of 1
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max over the 32 lanes of each half-wave of two independent values; results in lanes 31 / 63
+__device__ __forceinline__ void half_wave_max2(float& a, float& b) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1"
+      : "+v"(a), "+v"(b));
+}
+
+template <int C1, int C2, int NW, bool PF>
+__global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, int w, SaGatherSrc src,
+                                                         const float* __restrict__ w0, const float* __restrict__ b0,
+                                                         const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ ww, const float* __restrict__ bw,
+                                                         float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wp = (w + 31) & ~31;
+  float* W0s = reinterpret_cast<float*>(smem);      // [wp][C1]
+  float* W1s = W0s + (size_t)wp * C1;               // [C1][C2]
+  float* Wws = W1s + C1 * C2;                       // [4][32]
+  float* B0s = Wws + 4 * 32;                        // [C1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, ql = lane & 31;
+  float* skp = B0s + C1 + (size_t)wave * wp;        // [NW][wp] running column maxima of the current group
+
+  for (int i = tid; i < wp * C1; i += NW * 64) W0s[i] = (i / C1) < w ? w0[i] : 0.f;
+  for (int i = tid; i < C1 * C2; i += NW * 64) W1s[i] = w1[i];
+  for (int i = tid; i < 4 * 32; i += NW * 64) Wws[i] = i < 3 * 32 ? ww[i] : 0.f;
+  for (int i = tid; i < C1; i += NW * 64) B0s[i] = b0[i];
+  __syncthreads();
+
+  float b1r[C2 / 32];
+#pragma unroll
+  for (int cb = 0; cb < C2 / 32; ++cb) b1r[cb] = b1[cb * 32 + ql];
+  const float bwr = bw[ql];
+  const int nchunk = wp / 32;
+  const int cf = w - 6;
+
+  for (long g = (long)blockIdx.x * NW + wave; g < groups; g += (long)gridDim.x * NW) {
+    const long bi = (long)((int)g / src.m);
+    const float cx = src.new_xyz[g * 3], cy = src.new_xyz[g * 3 + 1], cz = src.new_xyz[g * 3 + 2];
+    for (int c = lane; c < wp; c += 64) skp[c] = -INFINITY;
+    f32x16 M[C2 / 32];
+#pragma unroll
+    for (int cb = 0; cb < C2 / 32; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) M[cb][r] = 0.f;
+
+    for (int tile = 0; tile < k; tile += 32) {
+      const int i = src.idx[(size_t)g * k + tile + ql];
+      const float* pp = src.xyz + ((size_t)bi * src.n + i) * 3;
+      const float px = pp[0], py = pp[1], pz = pp[2];
+      // feature row shifted by -6 floats: column c >= 6 of the cell input is frow[c]
+      const float* frow = src.feature + ((size_t)bi * src.n + i) * (size_t)cf - 6;
+      float xr[16], xn[16];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) xr[t] = frow[min(max(2 * t + h, 6), w - 1)];
+
+      f32x16 H1T[C1 / 32];
+#pragma unroll
+      for (int ob = 0; ob < C1 / 32; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1T[ob][r] = 0.f;
+      f32x16 G;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) G[r] = 0.f;
+
+      for (int ch = 0; ch < nchunk; ++ch) {
+        if constexpr (PF) {
+          // next chunk's operands in flight while this chunk's MFMAs run (the last request of a tile is a dummy)
+          const int cn = min(ch + 1, nchunk - 1) * 32;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) xn[t] = frow[min(max(cn + 2 * t + h, 6), w - 1)];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ch == 0) {
+          // columns 0..5 = [xyz - centre | xyz]: steps 0..2 of chunk 0 (column 2t+h)
+          xr[0] = h ? py - cy : px - cx;
+          xr[1] = h ? px : pz - cz;
+          xr[2] = h ? pz : py;
+          G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0], Wws[h * 32 + ql], G, 0, 0, 0);
+          G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[1], Wws[(2 + h) * 32 + ql], G, 0, 0, 0);
+        }
+        const int live = min(16, (w - ch * 32 + 1) >> 1);  // MFMA steps with a non-zero k pair (uniform)
+        if (live < 16) {
+          // last, partial chunk: columns >= w read column w-1 (clamped address): neutral for the max, zero for the MFMA
+#pragma unroll
+          for (int t = 0; t < 16; ++t) xr[t] = (ch * 32 + 2 * t + h) < w ? xr[t] : 0.f;
+        }
+        // skip connection: column maxima over the 32 rows, lanes 31 / 63 fold them into the wave's LDS row
+        {
+          float* srow = skp + ch * 32 + h;
+#pragma unroll
+          for (int t = 0; t < 16; t += 2) {
+            float a = xr[t], bb = xr[t + 1];
+            half_wave_max2(a, bb);
+            if (ql == 31) {
+              if (ch * 32 + 2 * t + h < w) __hip_atomic_fetch_max(srow + 2 * t, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              if (ch * 32 + 2 * t + 2 + h < w)
+                __hip_atomic_fetch_max(srow + 2 * t + 2, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+          }
+        }
+        const float* wbase = W0s + (size_t)(ch * 32 + h) * C1 + ql;
+        if (live == 16) {
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+#pragma unroll
+            for (int ob = 0; ob < C1 / 32; ++ob)
+              H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbase[(size_t)(2 * t) * C1 + ob * 32], xr[t], H1T[ob], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            if (t < live) {
+#pragma unroll
+              for (int ob = 0; ob < C1 / 32; ++ob)
+                H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbase[(size_t)(2 * t) * C1 + ob * 32], xr[t], H1T[ob], 0, 0, 0);
+            }
+          }
+        }
+        if constexpr (PF) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 16; ++t) xr[t] = xn[t];
+        } else {
+          const int cn = min(ch + 1, nchunk - 1) * 32;
+#pragma unroll
+          for (int t = 0; t < 16; ++t) xr[t] = frow[min(max(cn + 2 * t + h, 6), w - 1)];
+        }
+      }
+#pragma unroll
+      for (int ob = 0; ob < C1 / 32; ++ob)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1T[ob][r] = fmaxf(H1T[ob][r] + B0s[ob * 32 + kappa(r, h)], 0.f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) G[r] = fmaxf(G[r] + bwr, 0.f);
+
+#pragma unroll
+      for (int cb = 0; cb < C2 / 32; ++cb) {
+        f32x16 H2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H2[r] = 0.f;
+        float wv[2][16];
+        const float* w1p = W1s + (size_t)kappa(0, h) * C2 + cb * 32 + ql;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) wv[0][t] = w1p[(size_t)(kappa(t, 0)) * C2];
+#pragma unroll
+        for (int blk = 0; blk < C1 / 32; ++blk) {
+          if (blk + 1 < C1 / 32) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) wv[(blk + 1) & 1][t] = w1p[(size_t)((blk + 1) * 32 + kappa(t, 0)) * C2];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t = 0; t < 16; ++t) H2 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1T[blk][t], wv[blk & 1][t], H2, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H2[r] = fmaxf(H2[r] + b1r[cb], 0.f);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) M[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(H2[t], G[t], M[cb], 0, 0, 0);
+      }
+    }
+    // M[c2 = cb*32 + kappa(r,h)][j = ql] -> out[g][c2*32 + j]
+    float* o = out + (size_t)g * C2 * 32;
+#pragma unroll
+    for (int cb = 0; cb < C2 / 32; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(size_t)(cb * 32 + kappa(r, h)) * 32 + ql] = M[cb][r];
+    // the wave's LDS operations execute in order; the fences only keep the compiler from moving the reads up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int c = lane; c < w; c += 64) src.skip_max[(size_t)g * w + c] = skp[c];
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -574,13 +855,13 @@ extern "C" int pasnl_as_reweight(int g, int as, int nsample, int ch, const float
   return pasnl_launch_status();
 }
 
-template <int C1, int C2>
-static int local_cell_launch(long groups, int k, int w, const float* x, const float* w0, const float* b0, const float* w1,
-                             const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
+template <int C1, int C2, bool GATHER>
+static int local_cell_launch(long groups, int k, int w, const float* x, SaGatherSrc src, const float* w0, const float* b0,
+                             const float* w1, const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
   const int wp = (w + 31) & ~31;
-  size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 4 * 32 + C1) * sizeof(float);
+  size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 4 * 32 + C1 + (GATHER ? 4 * wp : 0)) * sizeof(float);
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
-  auto kern = sa_local_cell_kernel<C1, C2>;
+  auto kern = sa_local_cell_kernel<C1, C2, GATHER>;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
@@ -588,9 +869,48 @@ static int local_cell_launch(long groups, int k, int w, const float* x, const fl
   long wgs = (groups + 3) / 4;
   int per_cu = lds > 80 * 1024 ? 1 : (lds > 40 * 1024 ? 2 : 3);
   long cap = 256L * per_cu;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), lds, st, groups, k, w, x, w0, b0, w1, b1, ww, bw,
-                     out);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), lds, st, groups, k, w, x, src, w0, b0, w1, b1,
+                     ww, bw, out);
   return pasnl_launch_status();
+}
+
+template <bool GATHER>
+static int local_cell_dispatch(long groups, int k, int w, int c1, int c2, const float* x, SaGatherSrc src, const float* w0,
+                               const float* b0, const float* w1, const float* b1, const float* ww, const float* bw,
+                               float* out, hipStream_t st) {
+  if (c1 == 32 && c2 == 32) return local_cell_launch<32, 32, GATHER>(groups, k, w, x, src, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 64 && c2 == 64) return local_cell_launch<64, 64, GATHER>(groups, k, w, x, src, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 128 && c2 == 128) return local_cell_launch<128, 128, GATHER>(groups, k, w, x, src, w0, b0, w1, b1, ww, bw, out, st);
+  return PASNL_EUNSUPPORTED;
+}
+
+template <int C1, int C2, int NW, bool PF>
+static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0, const float* w1,
+                          const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
+  const int wp = (w + 31) & ~31;
+  size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 4 * 32 + C1 + (size_t)NW * wp) * sizeof(float);
+  if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
+  auto kern = sa_cell_kernel<C1, C2, NW, PF>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  // persistent workgroups (the weights are staged into LDS once per workgroup); 8 waves per CU at most
+  long wgs = (groups + NW - 1) / NW;
+  int per_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)(8 / NW));
+  if (per_cu < 1) per_cu = 1;
+  long cap = 256L * per_cu;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(NW * 64), lds, st, groups, k, w, src, w0, b0, w1, b1, ww,
+                     bw, out);
+  return pasnl_launch_status();
+}
+
+template <int C1, int C2>
+static int sa_cell_cfg(int nw, int pf, long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0,
+                       const float* w1, const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
+  if (nw == 8) return pf ? sa_cell_launch<C1, C2, 8, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
+                         : sa_cell_launch<C1, C2, 8, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  return pf ? sa_cell_launch<C1, C2, 4, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
+            : sa_cell_launch<C1, C2, 4, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
 }
 
 extern "C" int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, const float* x, const float* w0, const float* b0,
@@ -600,9 +920,31 @@ extern "C" int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, con
   PASNL_REQUIRE(k % 32 == 0, PASNL_EUNSUPPORTED);
   if (groups == 0) return PASNL_OK;
   PASNL_REQUIRE(x && w0 && b0 && w1 && b1 && ww && bw && out, PASNL_ENULL);
+  return local_cell_dispatch<false>(groups, k, w, c1, c2, x, SaGatherSrc{}, w0, b0, w1, b1, ww, bw, out, pasnl_hip_stream(stream));
+}
+
+extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
+                             const int* idx, const float* new_xyz, const float* w0, const float* b0, const float* w1,
+                             const float* b1, const float* ww, const float* bw, float* out, float* skip_max,
+                             pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && m >= 0 && k > 0 && c1 > 0 && c2 > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(k % 32 == 0, PASNL_EUNSUPPORTED);
+  const long groups = (long)b * m;
+  if (groups == 0) return PASNL_OK;
+  PASNL_REQUIRE(groups < (1L << 31), PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE(xyz && feature && idx && new_xyz && w0 && b0 && w1 && b1 && ww && bw && out && skip_max, PASNL_ENULL);
+  SaGatherSrc src{xyz, feature, idx, new_xyz, skip_max, n, m};
   hipStream_t st = pasnl_hip_stream(stream);
-  if (c1 == 32 && c2 == 32) return local_cell_launch<32, 32>(groups, k, w, x, w0, b0, w1, b1, ww, bw, out, st);
-  if (c1 == 64 && c2 == 64) return local_cell_launch<64, 64>(groups, k, w, x, w0, b0, w1, b1, ww, bw, out, st);
-  if (c1 == 128 && c2 == 128) return local_cell_launch<128, 128>(groups, k, w, x, w0, b0, w1, b1, ww, bw, out, st);
-  return PASNL_EUNSUPPORTED;
+  const int w = 6 + c;
+  // PASNL_SA_CELL_V1=1 selects the first (4-wave, LDS read-modify-write) gather variant; PASNL_SA_CELL_CFG="waves,prefetch"
+  // overrides the default configuration (both for A/B measurements only)
+  if (!getenv("PASNL_SA_CELL_V1")) {
+    int nw = 8, pf = 1;
+    if (const char* cfg = getenv("PASNL_SA_CELL_CFG")) sscanf(cfg, "%d,%d", &nw, &pf);
+    if (c1 == 32 && c2 == 32) return sa_cell_cfg<32, 32>(nw, pf, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+    if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(nw, pf, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+    if (c1 == 128 && c2 == 128) return sa_cell_cfg<128, 128>(nw, pf, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+    return PASNL_EUNSUPPORTED;
+  }
+  return local_cell_dispatch<true>(groups, k, w, c1, c2, nullptr, src, w0, b0, w1, b1, ww, bw, out, st);
 }

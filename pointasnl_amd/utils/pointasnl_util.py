@@ -84,6 +84,7 @@ def sa_group(xyz, feature, idx, new_xyz):
     return new_point, skip
 
 
+SA_CELL_GATHER = True    # grouping fused into the local cell (pasnl_sa_cell); False = pasnl_sa_group + pasnl_sa_local_cell
 LOCAL_CELL_FUSED = True  # False = the reference's op-by-op chain on the vendor BLAS (kept for A/B and as fallback)
 
 
@@ -112,6 +113,30 @@ def sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn):
     _hip.launch("pasnl_sa_local_cell", "sa_local_cell", b * p, k, w, c1, c2, _hip.ptr(new_point), _hip.ptr(w0), _hip.ptr(b0),
                 _hip.ptr(w1), _hip.ptr(b1), _hip.ptr(ww), _hip.ptr(bw), _hip.ptr(out))
     return out
+
+
+def sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay, bn):
+    """Grouping + local cell in ONE kernel (pointasnl_util.py:63-74,248-249,258,264-274): the (B,P,K,6+C) grouped
+    tensor is never materialised -- rows are gathered from the L2-resident per-cloud tables inside the MFMA
+    kernel, which also takes the skip connection's max over the K neighbours.
+    -> (B,P,mlp[1],32) = the input of after_conv,  skip (B,P,6+C)"""
+    b, n, c = feature.shape
+    _, p, k = idx.shape
+    c1, c2 = mlp[0], mlp[1]
+    st = tf_util.store()
+    with tf_util.variable_scope('conv0'):
+        w0, b0 = st.layer(6 + c, c1, bn)
+    with tf_util.variable_scope('conv1'):
+        w1, b1 = st.layer(c1, c2, bn)
+    with tf_util.variable_scope('weight_net'), tf_util.variable_scope('wconv0'):
+        ww, bw = st.layer(3, 32, True)
+    xyz, feature, idx, new_xyz = xyz.contiguous(), feature.contiguous(), idx.contiguous(), new_xyz.contiguous()
+    out = torch.empty((b, p, c2, 32), dtype=torch.float32, device=xyz.device)
+    skip = torch.empty((b, p, 6 + c), dtype=torch.float32, device=xyz.device)
+    _hip.launch("pasnl_sa_cell", "sa_cell", b, n, c, p, k, c1, c2, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx),
+                _hip.ptr(new_xyz), _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(w1), _hip.ptr(b1), _hip.ptr(ww), _hip.ptr(bw),
+                _hip.ptr(out), _hip.ptr(skip))
+    return out, skip
 
 
 def weight_net_hidden(xyz, hidden_units, scope, is_training, bn_decay=None, weight_decay=None, activation_fn="relu"):
@@ -272,9 +297,28 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
             g_pts = torch.cat([g_xyz, tf_grouping.group_point(feature, idx_as)], dim=-1)
             new_xyz, new_feature = AdaptiveSampling(g_xyz, g_pts, as_neighbor, is_training, bn_decay, weight_decay,
                                                     scope, bn)
-        # gather + translation normalisation + both concats + the skip connection's reduce_max: one kernel
-        new_point, skip_spatial = sa_group(xyz, feature, idx, new_xyz)
-        grouped_xyz = new_point[..., 0:3]
+        fused = _local_cell_supported(6 + num_channel, mlp, nsample)
+        if fused and SA_CELL_GATHER:
+            # grouping + skip max + local cell: one MFMA kernel reading the tables in place
+            tf_util._require_inference(is_training)
+            new_point, skip_spatial = sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay, bn)
+        else:
+            # gather + translation normalisation + both concats + the skip connection's reduce_max: one kernel
+            new_point, skip_spatial = sa_group(xyz, feature, idx, new_xyz)
+            grouped_xyz = new_point[..., 0:3]
+            if fused:
+                tf_util._require_inference(is_training)
+                new_point = sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn)
+            else:
+                for i, num_out_channel in enumerate(mlp):
+                    if i != len(mlp) - 1:
+                        new_point = tf_util.conv2d(new_point, num_out_channel, [1, 1], padding='VALID', stride=[1, 1],
+                                                   bn=bn, is_training=is_training, scope='conv%d' % (i),
+                                                   bn_decay=bn_decay, weight_decay=weight_decay)
+                weight = weight_net_hidden(grouped_xyz, [32], scope='weight_net', is_training=is_training,
+                                           bn_decay=bn_decay, weight_decay=weight_decay)
+                new_point = new_point.transpose(2, 3)
+                new_point = torch.matmul(new_point, weight)
 
         '''Point NonLocal Cell'''
         if NL:
@@ -287,20 +331,6 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                                       is_training=is_training, scope='skip', bn_decay=bn_decay,
                                       weight_decay=weight_decay)
 
-        '''Point Local Cell'''
-        if _local_cell_supported(new_point.shape[-1], mlp, nsample):
-            tf_util._require_inference(is_training)
-            new_point = sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn)
-        else:
-            for i, num_out_channel in enumerate(mlp):
-                if i != len(mlp) - 1:
-                    new_point = tf_util.conv2d(new_point, num_out_channel, [1, 1], padding='VALID', stride=[1, 1],
-                                               bn=bn, is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay,
-                                               weight_decay=weight_decay)
-            weight = weight_net_hidden(grouped_xyz, [32], scope='weight_net', is_training=is_training,
-                                       bn_decay=bn_decay, weight_decay=weight_decay)
-            new_point = new_point.transpose(2, 3)
-            new_point = torch.matmul(new_point, weight)
         new_point = tf_util.conv2d(new_point, mlp[-1], [1, new_point.shape[2]], padding='VALID', stride=[1, 1], bn=bn,
                                    is_training=is_training, scope='after_conv', bn_decay=bn_decay,
                                    weight_decay=weight_decay)

@@ -2,39 +2,79 @@
 
 Units and corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports
 half the bytes of a wide coalesced read stream, so the read side is doubled (an upper bound for narrow access
-patterns).  Kernels are matched to C-ABI symbols by name; launches of one kernel with different shapes are told
-apart by grid size order (largest first = largest shape).
+patterns; Infinity-Cache hits are counted too).  The two counters are collected in SEPARATE passes.
+
+Attribution: `bench.py --no-graph --launch-order` prints the per-forward sequence of C-ABI launches; every launch
+of the forward path starts exactly one `pasnl::` kernel, and every forward of the run is the same sequence, so the
+j-th pasnl dispatch of the trace (ordered by dispatch id) belongs to launch j mod len(sequence).  The script checks
+that the kernel name at each position is the same in every period before trusting the alignment.
+
+    bash profiles/collect_traffic.sh          (on the GPU box)
+    python profiles/pmc_to_traffic.py gpurun_out profiles/traffic.json
 """
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
 
 
-def load(pattern, counter):
-    per = defaultdict(list)
-    for f in glob.glob(pattern, recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == counter:
-                per[(r["Kernel_Name"], int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in per.items()}
-
-
-def main(out):
-    fetch = load("gpurun_out/pmc_FETCH_SIZE/**/*counter_collection.csv", "FETCH_SIZE")
-    write = load("gpurun_out/pmc_WRITE_SIZE/**/*counter_collection.csv", "WRITE_SIZE")
+def dispatches(root, counter):
     rows = {}
-    for (name, grid), kb in fetch.items():
-        if "pasnl::" not in name:
+    for f in glob.glob(os.path.join(root, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter and "pasnl::" in r["Kernel_Name"]:
+                rows[int(r["Dispatch_Id"])] = (r["Kernel_Name"].split("(")[0], float(r["Counter_Value"]))
+    return [rows[k] for k in sorted(rows)]
+
+
+def per_position(root, counter, order):
+    d = dispatches(root, counter)
+    n = len(order)
+    if not d or len(d) % n:
+        raise SystemExit(f"{counter}: {len(d)} pasnl dispatches is not a multiple of the {n} launches of one forward")
+    names = [None] * n
+    acc = defaultdict(list)
+    for j, (name, val) in enumerate(d):
+        p = j % n
+        if names[p] is None:
+            names[p] = name
+        elif names[p] != name:
+            raise SystemExit(f"{counter}: position {p} is {names[p]} in one forward and {name} in another")
+        acc[p].append(val)
+    return names, [sum(acc[p]) / len(acc[p]) for p in range(n)]
+
+
+def main(root, out):
+    order = None
+    for f in sorted(glob.glob(os.path.join(root, "**", "pmc_FETCH_SIZE.json"), recursive=True)):
+        try:
+            order = json.load(open(f))["launch_order"]
+        except Exception:
             continue
-        w = write.get((name, grid), 0.0)
-        rows[f"{name.split('(')[0]}|grid={grid}"] = {"fetch_KiB_raw": kb, "write_KiB": w,
-                                                      "hbm_bytes_corrected": int((2 * kb + w) * 1024)}
-    json.dump(rows, open(out, "w"), indent=1)
-    for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["hbm_bytes_corrected"]):
-        print(f"{k[:90]:90s} {v['hbm_bytes_corrected']/1e6:10.2f} MB")
+    if not order:
+        raise SystemExit("no bench line with launch_order found (run profiles/collect_traffic.sh)")
+    names, fetch = per_position(root, "FETCH_SIZE", order)
+    _, write = per_position(root, "WRITE_SIZE", order)
+    agg = defaultdict(list)
+    kern = {}
+    for p, (sym, dims) in enumerate(order):
+        key = sym + ":" + ",".join(map(str, dims))
+        agg[key].append((fetch[p], write[p]))
+        kern[key] = names[p]
+    traffic, detail = {}, {}
+    for key, v in agg.items():
+        f = sum(a for a, _ in v) / len(v)
+        w = sum(b for _, b in v) / len(v)
+        traffic[key] = int((2 * f + w) * 1024)
+        detail[key] = {"kernel": kern[key], "launches_per_forward": len(v), "fetch_KiB_raw": round(f, 1),
+                       "write_KiB": round(w, 1), "hbm_bytes_corrected": traffic[key]}
+    json.dump(traffic, open(out, "w"), indent=1, sort_keys=True)
+    json.dump(detail, open(out.replace(".json", "_detail.json"), "w"), indent=1, sort_keys=True)
+    for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]):
+        print(f"{k:60s} {v/1e6:10.2f} MB   {kern[k][:60]}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "profiles/traffic_raw.json")
+    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "profiles/traffic.json")

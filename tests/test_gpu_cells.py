@@ -150,6 +150,41 @@ def test_sa_local_cell(g, k, c, c1):
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * scale)
 
 
+@pytest.mark.parametrize("b,n,c,m,k,c1", [(2, 1024, 3, 512, 32, 64), (2, 512, 128, 128, 64, 128), (1, 256, 64, 37, 32, 32),
+                                         (1, 100, 30, 5, 96, 64), (3, 64, 3, 64, 32, 128), (1, 40, 250, 3, 32, 64)])
+def test_sa_cell_gather_fused(b, n, c, m, k, c1):
+    """pasnl_sa_cell = grouping + skip max + local cell in one kernel: `out` vs the fp64 restatement of
+    pointasnl_util.py:63-74,248-249,264-274 on the gathered rows; `skip` bit-equal to the gathered maximum (:258)."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    st = _store(b * 11 + c)
+    rng = np.random.default_rng(n + c)
+    xyz = clouds(5, b, n)
+    feat = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, k)).astype(np.int32)
+    new_xyz = clouds(6, b, m)
+    with st.scope("L"):
+        got, skip = U.sa_cell(dev(xyz), dev(feat), dev(idx), dev(new_xyz), [c1, c1, 2 * c1], False, None, None,
+                              True)
+    bi = np.arange(b)[:, None, None]
+    gx = xyz[bi, idx]
+    x = np.concatenate([gx - new_xyz[:, :, None, :], gx, feat[bi, idx]], axis=-1)  # (b,m,k,6+c) float32, exact
+    np.testing.assert_array_equal(skip.cpu().numpy(), x.max(axis=2))
+    p = st.export_numpy()
+    x64 = x.astype(np.float64)
+    h = cells._layer(cells._layer(x64, p["L/conv0"], "relu"), p["L/conv1"], "relu")
+    wn = cells._layer(x64[..., :3], p["L/weight_net/wconv0"], "relu")
+    want = np.swapaxes(h, 2, 3) @ wn  # (b,m,c1,32)
+    scale = np.abs(want).max()
+    assert np.abs(got.cpu().numpy() - want).max() / scale < 1e-5
+    # and it is the same function as the two-kernel path
+    with st.scope("L"):
+        np_, skip2 = U.sa_group(dev(xyz), dev(feat), dev(idx), dev(new_xyz))
+        two = U.sa_local_cell(np_, [c1, c1, 2 * c1], False, None, None, True)
+    np.testing.assert_array_equal(skip.cpu().numpy(), skip2.cpu().numpy())
+    np.testing.assert_allclose(got.cpu().numpy(), two.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+
+
 @pytest.mark.parametrize("model", ["sem_seg", "sem_seg_res"])
 def test_seg_forward_matches_oracle(model):
     """ScanNet / SemanticKITTI graphs (configs 4-5) at N=4096 (smallest size where every level still has >= 32

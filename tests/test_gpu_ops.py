@@ -72,6 +72,49 @@ def test_query_ball_point(P, b, n, m, ns, r, kind):
     np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
 
 
+@pytest.mark.parametrize("case", ["outside", "huge_radius", "degenerate", "plane", "many_queries", "nmax", "tiny", "dense",
+                                  "far_outlier", "odd_nsample"])
+def test_query_ball_point_grid_edges(P, case):
+    """Geometry the grid-pruned kernel must survive with bit-identical results: queries outside the cloud's bounding
+    box, a radius larger than the cloud (single cell), coincident points, flat clouds, more queries than one
+    workgroup handles, the largest LDS-resident cloud, clouds with an outlier that stretches the grid."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    b, n, m, ns, r = 2, 700, 300, 16, 0.15
+    xyz1 = clouds(31, b, n, "cube")
+    xyz2 = clouds(32, b, m, "cube")
+    if case == "outside":
+        xyz2 = (xyz2 * 3 - 1).astype(np.float32)  # two thirds of the queries lie outside [0,1)^3
+    elif case == "huge_radius":
+        r, ns = 5.0, 64
+    elif case == "degenerate":
+        xyz1 = np.repeat(xyz1[:, :1], n, axis=1).copy()
+        xyz2[:, ::2] = xyz1[:, :m:2] if m <= n else xyz2[:, ::2]
+    elif case == "plane":
+        xyz1[..., 2] = 0.25
+        xyz2[..., 2] = np.float32(0.25) + (rng.random((b, m)).astype(np.float32) - 0.5) * 0.2
+    elif case == "many_queries":
+        m = 1500
+        xyz2 = clouds(33, b, m, "cube")
+    elif case == "nmax":
+        n, ns, r = 2048, 40, 0.08
+        xyz1 = clouds(34, b, n, "cube")
+    elif case == "tiny":
+        n, m, ns = 3, 5, 4
+        xyz1, xyz2 = clouds(35, b, n, "cube"), clouds(36, b, m, "cube")
+        r = 0.6
+    elif case == "dense":
+        r, ns = 0.4, 8  # hundreds of hits per query, early exit in the brute-force kernel
+    elif case == "far_outlier":
+        xyz1[:, 5] = 1e6  # one point stretches the bounding box: everything else collapses into one cell
+        xyz2[:, 3] = 1e6
+    elif case == "odd_nsample":
+        ns = 37
+    want_idx, want_cnt = O.query_ball_point(r, ns, xyz1, xyz2)
+    idx, cnt = P.tf_grouping.query_ball_point(r, ns, dev(xyz1), dev(xyz2))
+    np.testing.assert_array_equal(cnt.cpu().numpy(), want_cnt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+
+
 def test_ball_radius_boundary(P):
     # points at distances straddling sqrt: radius 0.25 exactly representable, lattice of 1/8
     xyz1 = clouds(9, 1, 2000, "lattice")

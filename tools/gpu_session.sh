@@ -16,9 +16,6 @@ prof)  timeout 900 rocprofv3 --kernel-trace --stats -d $out/prof -o cls -- pytho
 seg)   timeout 600 python bench.py --model sem_seg --steps 10 --warmup 3 > $out/bench_sem_seg.json 2> $out/bench_sem_seg.err; cut -c1-300 $out/bench_sem_seg.json
        timeout 600 python bench.py --model sem_seg_res --steps 10 --warmup 3 > $out/bench_sem_seg_res.json 2> $out/bench_sem_seg_res.err; cut -c1-300 $out/bench_sem_seg_res.json;;
 ops)   timeout 900 python bench_ops.py --sweep --out $out/bench_ops.json > $out/bench_ops.log 2>&1; tail -60 $out/bench_ops.log;;
-pmc)   for c in FETCH_SIZE WRITE_SIZE; do
-         timeout 600 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_$c -o cls -f csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph > $out/pmc_$c.json 2> $out/pmc_$c.err || true
-       done
-       python profiles/pmc_to_traffic.py $out/traffic_raw.json | head -30;;
+pmc)   bash profiles/collect_traffic.sh; cp gpurun_out/pmc_FETCH_SIZE.json gpurun_out/pmc_WRITE_SIZE.json $out/ 2>/dev/null;;
 esac
 done
