@@ -597,26 +597,50 @@ __device__ __forceinline__ void half_wave_max2(float& a, float& b) {
       : "+v"(a), "+v"(b));
 }
 
-template <int C1, int C2, int NW, bool PF>
+// Internal column order of the cell input X (a permutation of the reference's [xyz-centre | xyz | feature], chosen
+// so that a lane's 16 operands of a chunk are 64 contiguous, 16-byte aligned bytes of a feature row):
+//     0..2 xyz - centre    3..5 xyz    6 the constant 1 (row 6 of W0 = b0: the conv0 bias rides on the MFMA)
+//     7 zero               8.. feature[0..cf)      then zeros up to a multiple of 32
+// VEC (cf % 4 == 0): MFMA step t of chunk ch contracts columns ch*32+t (lanes 0..31) and ch*32+16+t (lanes 32..63),
+// so lane (ql, h) needs X[row ql][ch*32 + 16h .. +16): FOUR global_load_dwordx4 per chunk.  The first kernels loaded
+// the same data as 16 scattered global_load_dword per chunk (80 per tile): the texture-addresser rate for 64
+// scattered dwords per instruction, not the matrix pipe, set their speed (57 % of the fp32 MFMA peak).
+// !VEC (cls layer1, cf = 3): step t contracts columns 2t (lanes 0..31) and 2t+1 (lanes 32..63), scalar loads.
+template <int C1, int C2, int NW, bool VEC>
 __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, int w, SaGatherSrc src,
                                                          const float* __restrict__ w0, const float* __restrict__ b0,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
                                                          const float* __restrict__ ww, const float* __restrict__ bw,
                                                          float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int wp = (w + 31) & ~31;
-  float* W0s = reinterpret_cast<float*>(smem);      // [wp][C1]
+  const int cf = w - 6;
+  const int wi = 8 + cf;                            // internal width
+  const int wp = (wi + 31) & ~31;
+  float* W0s = reinterpret_cast<float*>(smem);      // [wp][C1], rows in internal column order
   float* W1s = W0s + (size_t)wp * C1;               // [C1][C2]
-  float* Wws = W1s + C1 * C2;                       // [4][32]
-  float* B0s = Wws + 4 * 32;                        // [C1]
+  float* Wws = W1s + C1 * C2;                       // [3 steps][2 halves][32]: weight net, zero rows for the unused half
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ql = lane & 31;
-  float* skp = B0s + C1 + (size_t)wave * wp;        // [NW][wp] running column maxima of the current group
+  float* skp = Wws + 6 * 32 + (size_t)wave * wp;    // [NW][wp] running column maxima of the current group
 
-  for (int i = tid; i < wp * C1; i += NW * 64) W0s[i] = (i / C1) < w ? w0[i] : 0.f;
+  for (int i = tid; i < wp * C1; i += NW * 64) {
+    const int r = i / C1, c1 = i - r * C1;
+    float v = 0.f;
+    if (r < 6) v = w0[(size_t)r * C1 + c1];
+    else if (r == 6) v = b0[c1];
+    else if (r >= 8 && r < wi) v = w0[(size_t)(r - 2) * C1 + c1];
+    W0s[i] = v;
+  }
   for (int i = tid; i < C1 * C2; i += NW * 64) W1s[i] = w1[i];
-  for (int i = tid; i < 4 * 32; i += NW * 64) Wws[i] = i < 3 * 32 ? ww[i] : 0.f;
-  for (int i = tid; i < C1; i += NW * 64) B0s[i] = b0[i];
+  for (int i = tid; i < 6 * 32; i += NW * 64) {
+    const int t = i / 64, hh = (i >> 5) & 1, j = i & 31;
+    // VEC: step t pairs column t with column 16+t -> only the first half carries a coordinate.
+    // !VEC: step t pairs columns 2t, 2t+1: (0,1), (2,3): column 3 (xyz.x) is not a weight-net input.
+    float v = 0.f;
+    if (VEC) v = hh == 0 ? ww[t * 32 + j] : 0.f;
+    else v = (2 * t + hh) < 3 ? ww[(2 * t + hh) * 32 + j] : 0.f;
+    Wws[i] = v;
+  }
   __syncthreads();
 
   float b1r[C2 / 32];
@@ -624,7 +648,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   for (int cb = 0; cb < C2 / 32; ++cb) b1r[cb] = b1[cb * 32 + ql];
   const float bwr = bw[ql];
   const int nchunk = wp / 32;
-  const int cf = w - 6;
+  const int cf4 = cf >> 2;
 
   for (long g = (long)blockIdx.x * NW + wave; g < groups; g += (long)gridDim.x * NW) {
     const long bi = (long)((int)g / src.m);
@@ -640,11 +664,30 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       const int i = src.idx[(size_t)g * k + tile + ql];
       const float* pp = src.xyz + ((size_t)bi * src.n + i) * 3;
       const float px = pp[0], py = pp[1], pz = pp[2];
-      // feature row shifted by -6 floats: column c >= 6 of the cell input is frow[c]
-      const float* frow = src.feature + ((size_t)bi * src.n + i) * (size_t)cf - 6;
+      const float* frow = src.feature + ((size_t)bi * src.n + i) * (size_t)cf;
+      // operands of one chunk for this lane; every load is unconditional with a clamped address and masked where
+      // it is used (a conditional load compiles to its own exec-masked basic block)
       float xr[16], xn[16];
+      auto load_chunk = [&](int ch, float (&v)[16]) {
+        if constexpr (VEC) {
+          const int f0 = ch * 32 + 16 * h - 8;  // first feature of this lane's 16 columns (may be -8 or past the end)
 #pragma unroll
-      for (int t = 0; t < 16; ++t) xr[t] = frow[min(max(2 * t + h, 6), w - 1)];
+          for (int q = 0; q < 4; ++q) {
+            const int g4 = (f0 >> 2) + q;
+            const float4 t4 = reinterpret_cast<const float4*>(frow)[min(max(g4, 0), cf4 - 1)];
+            const bool ok = g4 >= 0 && g4 < cf4;
+            v[4 * q] = ok ? t4.x : 0.f; v[4 * q + 1] = ok ? t4.y : 0.f; v[4 * q + 2] = ok ? t4.z : 0.f; v[4 * q + 3] = ok ? t4.w : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 16; ++t) {
+            const int f = ch * 32 + 2 * t + h - 8;
+            const float x = frow[min(max(f, 0), cf - 1)];
+            v[t] = (f >= 0 && f < cf) ? x : 0.f;
+          }
+        }
+      };
+      load_chunk(0, xr);
 
       f32x16 H1T[C1 / 32];
 #pragma unroll
@@ -656,73 +699,98 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       for (int r = 0; r < 16; ++r) G[r] = 0.f;
 
       for (int ch = 0; ch < nchunk; ++ch) {
-        if constexpr (PF) {
-          // next chunk's operands in flight while this chunk's MFMAs run (the last request of a tile is a dummy)
-          const int cn = min(ch + 1, nchunk - 1) * 32;
-#pragma unroll
-          for (int t = 0; t < 16; ++t) xn[t] = frow[min(max(cn + 2 * t + h, 6), w - 1)];
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        // next chunk's operands in flight while this chunk's MFMAs run (the last request of a tile is a dummy)
+        load_chunk(min(ch + 1, nchunk - 1), xn);
+        __builtin_amdgcn_sched_barrier(0);
         if (ch == 0) {
-          // columns 0..5 = [xyz - centre | xyz]: steps 0..2 of chunk 0 (column 2t+h)
-          xr[0] = h ? py - cy : px - cx;
-          xr[1] = h ? px : pz - cz;
-          xr[2] = h ? pz : py;
-          G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0], Wws[h * 32 + ql], G, 0, 0, 0);
-          G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[1], Wws[(2 + h) * 32 + ql], G, 0, 0, 0);
-        }
-        const int live = min(16, (w - ch * 32 + 1) >> 1);  // MFMA steps with a non-zero k pair (uniform)
-        if (live < 16) {
-          // last, partial chunk: columns >= w read column w-1 (clamped address): neutral for the max, zero for the MFMA
-#pragma unroll
-          for (int t = 0; t < 16; ++t) xr[t] = (ch * 32 + 2 * t + h) < w ? xr[t] : 0.f;
-        }
-        // skip connection: column maxima over the 32 rows, lanes 31 / 63 fold them into the wave's LDS row
-        {
-          float* srow = skp + ch * 32 + h;
-#pragma unroll
-          for (int t = 0; t < 16; t += 2) {
-            float a = xr[t], bb = xr[t + 1];
-            half_wave_max2(a, bb);
-            if (ql == 31) {
-              if (ch * 32 + 2 * t + h < w) __hip_atomic_fetch_max(srow + 2 * t, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-              if (ch * 32 + 2 * t + 2 + h < w)
-                __hip_atomic_fetch_max(srow + 2 * t + 2, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          // internal columns 0..7 = [xyz - centre | xyz | 1 | 0]
+          if constexpr (VEC) {
+            if (h == 0) {
+              xr[0] = px - cx; xr[1] = py - cy; xr[2] = pz - cz; xr[3] = px;
+              xr[4] = py; xr[5] = pz; xr[6] = 1.f; xr[7] = 0.f;
             }
+          } else {
+            xr[0] = h ? py - cy : px - cx;
+            xr[1] = h ? px : pz - cz;
+            xr[2] = h ? pz : py;
+            xr[3] = h ? 0.f : 1.f;
           }
+#pragma unroll
+          for (int t = 0; t < (VEC ? 3 : 2); ++t)
+            G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[t], Wws[(t * 2 + h) * 32 + ql], G, 0, 0, 0);
         }
-        const float* wbase = W0s + (size_t)(ch * 32 + h) * C1 + ql;
+        // MFMA steps of this chunk that touch a column < wi (uniform)
+        const int rem = wi - ch * 32;
+        const int live = VEC ? min(16, rem) : min(16, (rem + 1) >> 1);
+        // skip connection: column maxima over the tile's 32 rows (single-instruction DPP steps, two columns per
+        // block), folded by lanes 31 / 63 into the wave's LDS row with ds_max_f32 (no return value)
+        float ma[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) ma[t] = xr[t];
+        const float* wbase = VEC ? W0s + (size_t)(ch * 32 + 16 * h) * C1 + ql : W0s + (size_t)(ch * 32 + h) * C1 + ql;
+        constexpr int RS = VEC ? 1 : 2;  // W0 row stride between consecutive MFMA steps
         if (live == 16) {
+          // full chunk: the W0 operands of batch j+1 (>= 4 MFMAs = 256 cycles of matrix-pipe time) are read from LDS
+          // while the MFMAs of batch j run; the DPP blocks of the skip maxima sit behind the MFMA batches and
+          // execute while the last MFMA of the batch occupies the pipe
+          constexpr int BT = C1 >= 128 ? 1 : 128 / C1;  // MFMA steps per batch
+          constexpr int NB = 16 / BT;
+          constexpr int PPB = NB >= 8 ? 1 : 8 / NB;     // column pairs reduced behind each batch
+          float wa[2][BT][C1 / 32];
 #pragma unroll
-          for (int t = 0; t < 16; ++t) {
+          for (int u = 0; u < BT; ++u)
 #pragma unroll
-            for (int ob = 0; ob < C1 / 32; ++ob)
-              H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbase[(size_t)(2 * t) * C1 + ob * 32], xr[t], H1T[ob], 0, 0, 0);
+            for (int ob = 0; ob < C1 / 32; ++ob) wa[0][u][ob] = wbase[(size_t)(RS * u) * C1 + ob * 32];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            if (j + 1 < NB) {
+#pragma unroll
+              for (int u = 0; u < BT; ++u)
+#pragma unroll
+                for (int ob = 0; ob < C1 / 32; ++ob)
+                  wa[(j + 1) & 1][u][ob] = wbase[(size_t)(RS * ((j + 1) * BT + u)) * C1 + ob * 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < BT; ++u)
+#pragma unroll
+              for (int ob = 0; ob < C1 / 32; ++ob)
+                H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j & 1][u][ob], xr[j * BT + u], H1T[ob], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < PPB; ++q) {
+              const int pr = j * PPB + q;
+              if (pr < 8) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         } else {
+#pragma unroll
+          for (int pr = 0; pr < 8; ++pr) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
 #pragma unroll
           for (int t = 0; t < 16; ++t) {
             if (t < live) {
 #pragma unroll
               for (int ob = 0; ob < C1 / 32; ++ob)
-                H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbase[(size_t)(2 * t) * C1 + ob * 32], xr[t], H1T[ob], 0, 0, 0);
+                H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbase[(size_t)(RS * t) * C1 + ob * 32], xr[t], H1T[ob], 0, 0, 0);
             }
           }
         }
-        if constexpr (PF) {
-          __builtin_amdgcn_sched_barrier(0);
+        if (ql == 31) {
+          // internal column of operand t: VEC ch*32 + 16h + t, !VEC ch*32 + 2t + h (padding columns get junk, unread)
+          float* srow = VEC ? skp + ch * 32 + 16 * h : skp + ch * 32 + h;
 #pragma unroll
-          for (int t = 0; t < 16; ++t) xr[t] = xn[t];
-        } else {
-          const int cn = min(ch + 1, nchunk - 1) * 32;
-#pragma unroll
-          for (int t = 0; t < 16; ++t) xr[t] = frow[min(max(cn + 2 * t + h, 6), w - 1)];
+          for (int t = 0; t < 16; ++t)
+            __hip_atomic_fetch_max(srow + RS * t, ma[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) xr[t] = xn[t];
       }
+      // ReLU (the bias came with the MFMA); G: bias + ReLU
 #pragma unroll
       for (int ob = 0; ob < C1 / 32; ++ob)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H1T[ob][r] = fmaxf(H1T[ob][r] + B0s[ob * 32 + kappa(r, h)], 0.f);
+        for (int r = 0; r < 16; ++r) H1T[ob][r] = fmaxf(H1T[ob][r], 0.f);
 #pragma unroll
       for (int r = 0; r < 16; ++r) G[r] = fmaxf(G[r] + bwr, 0.f);
 
@@ -762,7 +830,8 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    for (int c = lane; c < w; c += 64) src.skip_max[(size_t)g * w + c] = skp[c];
+    // reference column c of the skip maxima = internal column c (c < 6) or c + 2 (features)
+    for (int c = lane; c < w; c += 64) src.skip_max[(size_t)g * w + c] = skp[c < 6 ? c : c + 2];
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -884,20 +953,22 @@ static int local_cell_dispatch(long groups, int k, int w, int c1, int c2, const 
   return PASNL_EUNSUPPORTED;
 }
 
-template <int C1, int C2, int NW, bool PF>
+template <int C1, int C2, int NW, bool VEC>
 static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0, const float* w1,
                           const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
-  const int wp = (w + 31) & ~31;
-  size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 4 * 32 + C1 + (size_t)NW * wp) * sizeof(float);
+  const int wp = (8 + (w - 6) + 31) & ~31;  // internal width: [xyz-c | xyz | 1 | 0 | feature], padded to 32-chunks
+  size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 6 * 32 + (size_t)NW * wp) * sizeof(float);
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
-  auto kern = sa_cell_kernel<C1, C2, NW, PF>;
+  auto kern = sa_cell_kernel<C1, C2, NW, VEC>;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
-  // persistent workgroups (the weights are staged into LDS once per workgroup); 8 waves per CU at most
+  // persistent workgroups (the weights are staged into LDS once per workgroup): exactly as many as are resident at once
   long wgs = (groups + NW - 1) / NW;
-  int per_cu = (int)std::min<size_t>((160 * 1024) / lds, (size_t)(8 / NW));
-  if (per_cu < 1) per_cu = 1;
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NW * 64, lds) != hipSuccess ||
+      per_cu < 1)
+    per_cu = 1;
   long cap = 256L * per_cu;
   hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(NW * 64), lds, st, groups, k, w, src, w0, b0, w1, b1, ww,
                      bw, out);
@@ -905,12 +976,12 @@ static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const floa
 }
 
 template <int C1, int C2>
-static int sa_cell_cfg(int nw, int pf, long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0,
+static int sa_cell_cfg(int nw, bool vec, long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0,
                        const float* w1, const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
-  if (nw == 8) return pf ? sa_cell_launch<C1, C2, 8, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
-                         : sa_cell_launch<C1, C2, 8, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
-  return pf ? sa_cell_launch<C1, C2, 4, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
-            : sa_cell_launch<C1, C2, 4, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  if (nw == 8) return vec ? sa_cell_launch<C1, C2, 8, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
+                          : sa_cell_launch<C1, C2, 8, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  return vec ? sa_cell_launch<C1, C2, 4, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
+             : sa_cell_launch<C1, C2, 4, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
 }
 
 extern "C" int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, const float* x, const float* w0, const float* b0,
@@ -936,14 +1007,16 @@ extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, 
   SaGatherSrc src{xyz, feature, idx, new_xyz, skip_max, n, m};
   hipStream_t st = pasnl_hip_stream(stream);
   const int w = 6 + c;
-  // PASNL_SA_CELL_V1=1 selects the first (4-wave, LDS read-modify-write) gather variant; PASNL_SA_CELL_CFG="waves,prefetch"
-  // overrides the default configuration (both for A/B measurements only)
+  // PASNL_SA_CELL_V1=1 selects the first (scalar-load, LDS read-modify-write) gather variant; PASNL_SA_CELL_CFG=<waves per
+  // workgroup> overrides the default (both for A/B measurements only)
   if (!getenv("PASNL_SA_CELL_V1")) {
-    int nw = 8, pf = 1;
-    if (const char* cfg = getenv("PASNL_SA_CELL_CFG")) sscanf(cfg, "%d,%d", &nw, &pf);
-    if (c1 == 32 && c2 == 32) return sa_cell_cfg<32, 32>(nw, pf, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
-    if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(nw, pf, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
-    if (c1 == 128 && c2 == 128) return sa_cell_cfg<128, 128>(nw, pf, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+    // 16-byte operand loads need 16-byte aligned feature rows
+    const bool vec = (c % 4 == 0) && (reinterpret_cast<uintptr_t>(feature) % 16 == 0);
+    int nw = c1 <= 32 ? 8 : 4;  // two waves per SIMD where the registers allow it
+    if (const char* cfg = getenv("PASNL_SA_CELL_CFG")) nw = atoi(cfg);
+    if (c1 == 32 && c2 == 32) return sa_cell_cfg<32, 32>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+    if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+    if (c1 == 128 && c2 == 128) return sa_cell_cfg<128, 128>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
     return PASNL_EUNSUPPORTED;
   }
   return local_cell_dispatch<true>(groups, k, w, c1, c2, nullptr, src, w0, b0, w1, b1, ww, bw, out, st);

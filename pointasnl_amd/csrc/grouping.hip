@@ -253,11 +253,15 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int
 
   // ---- D. queries: one per lane; a wave never touches another wave's rows
   const int mw = (n + 31) >> 5;
-  const int swz = lane & min(rw - 1, 63);  // XOR swizzle of the word index: lane-private rows without padding
+  // XOR swizzle of the 16-byte group index: lane-private rows without padding, and 4 consecutive list entries stay
+  // contiguous so that the copy-out moves 16 bytes per lane
+  const int swmask = (min(rw >> 2, 8) - 1) << 2;
+  const int swz = (lane << 2) & swmask;
   uint32_t* row = rows + (size_t)tid * rw;
   const int qbase = blockIdx.x * BQG_QCHUNK;
   const int qend = min(m, qbase + BQG_QCHUNK);
   const int last = n > 0 ? n - 1 : 0;
+  const bool vec4 = (nsample & 3) == 0;
   for (int q0 = qbase + wave * 64; q0 < qend; q0 += BQG_THREADS) {
     const int j = q0 + lane;
     const bool live = j < qend;
@@ -299,12 +303,12 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int
         }
       }
     }
-    // ---- E. bit row -> ascending hit list (first nsample), in place (the words are cached in registers first)
+    // ---- E. bit row -> ascending hit list (first nsample, then the first hit as padding; zero-hit rows -> 0,
+    // SURVEY A.3), in place: the mask words are cached in registers first
     uint32_t wreg[MWT];
 #pragma unroll
     for (int w = 0; w < MWT; ++w) wreg[w] = w < mw ? row[w ^ swz] : 0u;
     int c = 0, first = 0;
-    unsigned short* lst = reinterpret_cast<unsigned short*>(row);
 #pragma unroll
     for (int w = 0; w < MWT; ++w) {
       uint32_t bits = wreg[w];
@@ -312,28 +316,39 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int
         const int k = w * 32 + (int)__builtin_ctz(bits);
         bits &= bits - 1u;
         if (c == 0) first = k;
-        lst[(((c >> 1) ^ swz) << 1) | (c & 1)] = (unsigned short)k;
+        row[c ^ swz] = (uint32_t)k;
         ++c;
       }
     }
-    // ---- F. the wave copies its 64 lists out, padded with the first hit (zero-hit rows -> 0)
+    for (int sp = c; sp < nsample; ++sp) row[sp ^ swz] = (uint32_t)first;
+    // ---- F. the wave copies its 64 lists out (16 bytes per lane and step when nsample % 4 == 0)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int nq = min(64, qend - q0);
     if (nq > 0) {
       int* o = idx + ((size_t)bi * m + q0) * nsample;
-      const int total = nq * nsample;
       const uint32_t* wrows = rows + (size_t)(wave * 64) * rw;
-      const int swmask = min(rw - 1, 63);
-      for (int e0 = 0; e0 < total; e0 += 64) {
-        const int e = min(e0 + lane, total - 1);
-        const int q = (int)__umulhi((uint32_t)e, ns_magic);  // e / nsample
-        const int sidx = e - q * nsample;
-        const int cq = __shfl(c, q), fq = __shfl(first, q);
-        const unsigned short* l = reinterpret_cast<const unsigned short*>(wrows + (size_t)q * rw);
-        const int v = l[(((sidx >> 1) ^ (q & swmask)) << 1) | (sidx & 1)];
-        if (e0 + lane < total) o[e0 + lane] = sidx < cq ? v : (cq > 0 ? fq : 0);
+      if (vec4) {
+        const int g4n = nsample >> 2, total = nq * g4n;
+#pragma unroll 2
+        for (int e0 = 0; e0 < total; e0 += 64) {
+          const int e = min(e0 + lane, total - 1);
+          const int q = ns_magic ? (int)__umulhi((uint32_t)e, ns_magic) : e;  // e / (nsample / 4)
+          const int g4 = e - q * g4n;
+          const uint4 v = *reinterpret_cast<const uint4*>(wrows + (size_t)q * rw + ((g4 << 2) ^ ((q << 2) & swmask)));
+          if (e0 + lane < total) *reinterpret_cast<uint4*>(o + (size_t)q * nsample + (g4 << 2)) = v;
+        }
+      } else {
+        const int total = nq * nsample;
+#pragma unroll 2
+        for (int e0 = 0; e0 < total; e0 += 64) {
+          const int e = min(e0 + lane, total - 1);
+          const int q = ns_magic ? (int)__umulhi((uint32_t)e, ns_magic) : e;  // e / nsample
+          const int sidx = e - q * nsample;
+          const uint32_t v = wrows[(size_t)q * rw + (sidx ^ ((q << 2) & swmask))];
+          if (e0 + lane < total) o[e0 + lane] = (int)v;
+        }
       }
       if (live) pts_cnt[(size_t)bi * m + j] = c;
     }
@@ -853,12 +868,14 @@ extern "C" int pasnl_query_ball_point(int b, int n, int m, float radius, int nsa
     // words per query row: the n-bit mask, later the nsample 16-bit hits; a power of two (XOR-swizzled, unpadded)
     int mwt = n <= 256 ? 8 : (n <= 512 ? 16 : (n <= 1024 ? 32 : 64));
     int rw = mwt;
-    while (rw * 2 < nsample) rw *= 2;
+    while (rw < nsample) rw *= 2;
     size_t glds = (size_t)n * 16 + (size_t)BQG_THREADS * rw * 4 + (size_t)((BQG_NC + 2 + 1) & ~1) * 2 + 32 * 4;
     if (glds <= 160 * 1024 && (size_t)BQG_THREADS * rw >= (size_t)BQG_NC) {
       dim3 grid((m + BQG_QCHUNK - 1) / BQG_QCHUNK, b);
       const float rpad = radius * 1.001f;
-      const uint32_t ns_magic = (uint32_t)((0x100000000ull / (unsigned)nsample) + 1ull);  // e / nsample for e < 2^16
+      // e / d for e < 2^16 as umulhi(e, magic); d = list entries (or 16-byte groups of entries) per query
+      const unsigned div = (nsample & 3) == 0 ? (unsigned)nsample / 4 : (unsigned)nsample;
+      const uint32_t ns_magic = div == 1 ? 0u : (uint32_t)((0x100000000ull / div) + 1ull);  // 0: divisor 1
 #define PASNL_BQG(MWT)                                                                                                  \
   {                                                                                                                     \
     auto gk = ball_query_grid_kernel<MWT>;                                                                              \
