@@ -98,6 +98,9 @@ def algorithmic(symbol, ints):
         # reads the tables, the indices and the centres once; writes (c2 x 32) per group + the skip maxima
         return (4 * (b * n * (3 + c) + g * k + 3 * g + g * c2 * 32 + g * w + w * c1 + c1 * c2),
                 g * (2 * k * (w * c1 + c1 * c2 + 3 * 32) + 2 * c2 * k * 32), "mfma")
+    if symbol == "pasnl_max_pool_rows":
+        b, n, c = ints
+        return 4 * b * c * (n + 1), 0, "hbm"
     if symbol == "pasnl_as_reweight":
         g, as_, ns, ch = ints
         return 4 * g * (as_ * (1 + ch) + as_ * (3 + ch) + 3 + ch), 4 * g * as_ * (1 + ch), "hbm"
@@ -195,7 +198,7 @@ def main():
 
     import importlib
 
-    if args.model != "cls" and args.pipeline == 2:
+    if args.model == "sem_seg" and args.pipeline == 2:
         args.pipeline = 1  # two concurrent replays of the ScanNet graph dead-lock on ROCm 7.2; serial replay
     default_pts = {"cls": 1024, "sem_seg": 8192, "sem_seg_res": 10240}[args.model]
     B, N = args.batch, (args.points or default_pts)

@@ -180,6 +180,10 @@ int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, const float
                   const float* b1, const float* ww, const float* bw, float* out, float* skip_max,
                   pasnl_stream_t stream);
 
+/* PointNet set-abstraction pooling (pointnet_util.py:137, tf.reduce_max(new_points, axis=[2], keep_dims=True)):
+ * out[b,ch] = max over the n points of x (b,n,c).  The two group_all modules of pointasnl_cls pool 67 + 34 MB. */
+int pasnl_max_pool_rows(int b, int n, int c, const float* x, float* out, pasnl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

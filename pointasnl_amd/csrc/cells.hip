@@ -53,8 +53,16 @@ __global__ __launch_bounds__(SPLIT * 64) void nl_attention_mfma_kernel(int p, in
   float* Vs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(Ks + NL_KB * KS) + 15) & ~uintptr_t(15));  // [NL_KB][CB]
 
   const int h = lane >> 5, ql = lane & 31;
-  const int bi = blockIdx.y;
-  const int q0 = blockIdx.x * 32;
+  // XCD-aware mapping: workgroups are dispatched round-robin over the 8 XCDs in linear order; all query tiles of a
+  // cloud go to ONE XCD (cloud % 8), so its K/V block (256 KiB at cls layer1) is fetched into one L2 once instead of
+  // into all eight (measured before: 143 MB of L2-miss fetches per launch for 17 MB of K/V)
+  int bi = blockIdx.y, qt = blockIdx.x;
+  if ((gridDim.y & 7) == 0) {
+    const int id = blockIdx.y * gridDim.x + blockIdx.x, slot = id >> 3;
+    bi = (id & 7) + 8 * (slot / (int)gridDim.x);
+    qt = slot % (int)gridDim.x;
+  }
+  const int q0 = qt * 32;
   const int qi = min(q0 + ql, p - 1);
   const float* kvb = kv + (size_t)bi * n * 2 * CB;
 
@@ -606,7 +614,9 @@ __device__ __forceinline__ void half_wave_max2(float& a, float& b) {
 // the same data as 16 scattered global_load_dword per chunk (80 per tile): the texture-addresser rate for 64
 // scattered dwords per instruction, not the matrix pipe, set their speed (57 % of the fp32 MFMA peak).
 // !VEC (cls layer1, cf = 3): step t contracts columns 2t (lanes 0..31) and 2t+1 (lanes 32..63), scalar loads.
-template <int C1, int C2, int NW, bool VEC>
+// LEAN: no operand prefetch buffer and the skip maxima reduced in place after the chunk's MFMAs -- 32 registers
+// less, which lets the 128-channel cell run two waves per SIMD (256 registers each) without spilling.
+template <int C1, int C2, int NW, bool VEC, bool LEAN>
 __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, int w, SaGatherSrc src,
                                                          const float* __restrict__ w0, const float* __restrict__ b0,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
@@ -650,8 +660,25 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   const int nchunk = wp / 32;
   const int cf4 = cf >> 2;
 
-  for (long g = (long)blockIdx.x * NW + wave; g < groups; g += (long)gridDim.x * NW) {
-    const long bi = (long)((int)g / src.m);
+  // XCD-aware work distribution: workgroup i runs on XCD i % 8 (round-robin dispatch) and every XCD has its own
+  // 4 MiB L2, so XCD x is given whole clouds (x, x+8, ...): the tables it gathers from (8 clouds x <= 270 KiB at
+  // cls B = 64) stay in ITS L2 instead of every XCD streaming every cloud's table through (measured: 368 MB of
+  // L2-miss fetches per launch for 17 MB of tables with the linear mapping).
+  const int nclouds = (int)(groups / src.m);
+  const bool xcd_map = (gridDim.x % 8 == 0) && nclouds >= 16;
+  const int xcd = blockIdx.x & 7;
+  const long my_groups = xcd_map ? (long)((nclouds - xcd + 7) >> 3) * src.m : groups;
+  const long first = xcd_map ? (long)(blockIdx.x >> 3) * NW + wave : (long)blockIdx.x * NW + wave;
+  const long step = xcd_map ? (long)(gridDim.x >> 3) * NW : (long)gridDim.x * NW;
+  for (long li = first; li < my_groups; li += step) {
+    long g = li, bi;
+    if (xcd_map) {
+      const int cl = (int)li / src.m;
+      bi = xcd + 8 * cl;
+      g = bi * src.m + ((int)li - cl * src.m);
+    } else {
+      bi = (long)((int)g / src.m);
+    }
     const float cx = src.new_xyz[g * 3], cy = src.new_xyz[g * 3 + 1], cz = src.new_xyz[g * 3 + 2];
     for (int c = lane; c < wp; c += 64) skp[c] = -INFINITY;
     f32x16 M[C2 / 32];
@@ -667,7 +694,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       const float* frow = src.feature + ((size_t)bi * src.n + i) * (size_t)cf;
       // operands of one chunk for this lane; every load is unconditional with a clamped address and masked where
       // it is used (a conditional load compiles to its own exec-masked basic block)
-      float xr[16], xn[16];
+      float xr[16], xn[LEAN ? 1 : 16];
       auto load_chunk = [&](int ch, float (&v)[16]) {
         if constexpr (VEC) {
           const int f0 = ch * 32 + 16 * h - 8;  // first feature of this lane's 16 columns (may be -8 or past the end)
@@ -699,9 +726,11 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       for (int r = 0; r < 16; ++r) G[r] = 0.f;
 
       for (int ch = 0; ch < nchunk; ++ch) {
-        // next chunk's operands in flight while this chunk's MFMAs run (the last request of a tile is a dummy)
-        load_chunk(min(ch + 1, nchunk - 1), xn);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LEAN) {
+          // next chunk's operands in flight while this chunk's MFMAs run (the last request of a tile is a dummy)
+          load_chunk(min(ch + 1, nchunk - 1), xn);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (ch == 0) {
           // internal columns 0..7 = [xyz - centre | xyz | 1 | 0]
           if constexpr (VEC) {
@@ -724,9 +753,12 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
         const int live = VEC ? min(16, rem) : min(16, (rem + 1) >> 1);
         // skip connection: column maxima over the tile's 32 rows (single-instruction DPP steps, two columns per
         // block), folded by lanes 31 / 63 into the wave's LDS row with ds_max_f32 (no return value)
-        float ma[16];
+        float mcopy[LEAN ? 1 : 16];
+        float (&ma)[16] = *reinterpret_cast<float (*)[16]>(LEAN ? xr : mcopy);
+        if constexpr (!LEAN) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) ma[t] = xr[t];
+          for (int t = 0; t < 16; ++t) ma[t] = xr[t];
+        }
         const float* wbase = VEC ? W0s + (size_t)(ch * 32 + 16 * h) * C1 + ql : W0s + (size_t)(ch * 32 + h) * C1 + ql;
         constexpr int RS = VEC ? 1 : 2;  // W0 row stride between consecutive MFMA steps
         if (live == 16) {
@@ -756,16 +788,24 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 #pragma unroll
               for (int ob = 0; ob < C1 / 32; ++ob)
                 H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j & 1][u][ob], xr[j * BT + u], H1T[ob], 0, 0, 0);
+            if constexpr (!LEAN) {
 #pragma unroll
-            for (int q = 0; q < PPB; ++q) {
-              const int pr = j * PPB + q;
-              if (pr < 8) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
+              for (int q = 0; q < PPB; ++q) {
+                const int pr = j * PPB + q;
+                if (pr < 8) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
+              }
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-        } else {
+          if constexpr (LEAN) {
 #pragma unroll
-          for (int pr = 0; pr < 8; ++pr) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
+            for (int pr = 0; pr < 8; ++pr) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
+          }
+        } else {
+          if constexpr (!LEAN) {
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
+          }
 #pragma unroll
           for (int t = 0; t < 16; ++t) {
             if (t < live) {
@@ -773,6 +813,11 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
               for (int ob = 0; ob < C1 / 32; ++ob)
                 H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbase[(size_t)(RS * t) * C1 + ob * 32], xr[t], H1T[ob], 0, 0, 0);
             }
+          }
+          if constexpr (LEAN) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
           }
         }
         if (ql == 31) {
@@ -783,8 +828,12 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
             __hip_atomic_fetch_max(srow + RS * t, ma[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LEAN) {
+          load_chunk(min(ch + 1, nchunk - 1), xr);
+        } else {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) xr[t] = xn[t];
+          for (int t = 0; t < 16; ++t) xr[t] = xn[t];
+        }
       }
       // ReLU (the bias came with the MFMA); G: bias + ReLU
 #pragma unroll
@@ -799,20 +848,34 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
         f32x16 H2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) H2[r] = 0.f;
-        float wv[2][16];
         const float* w1p = W1s + (size_t)kappa(0, h) * C2 + cb * 32 + ql;
+        if constexpr (LEAN) {
+          // single operand buffer: the other wave of the SIMD covers the LDS latency
 #pragma unroll
-        for (int t = 0; t < 16; ++t) wv[0][t] = w1p[(size_t)(kappa(t, 0)) * C2];
+          for (int blk = 0; blk < C1 / 32; ++blk) {
+            float wv1[16];
 #pragma unroll
-        for (int blk = 0; blk < C1 / 32; ++blk) {
-          if (blk + 1 < C1 / 32) {
+            for (int t = 0; t < 16; ++t) wv1[t] = w1p[(size_t)(blk * 32 + kappa(t, 0)) * C2];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int t = 0; t < 16; ++t) wv[(blk + 1) & 1][t] = w1p[(size_t)((blk + 1) * 32 + kappa(t, 0)) * C2];
+            for (int t = 0; t < 16; ++t) H2 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1T[blk][t], wv1[t], H2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          float wv[2][16];
 #pragma unroll
-          for (int t = 0; t < 16; ++t) H2 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1T[blk][t], wv[blk & 1][t], H2, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+          for (int t = 0; t < 16; ++t) wv[0][t] = w1p[(size_t)(kappa(t, 0)) * C2];
+#pragma unroll
+          for (int blk = 0; blk < C1 / 32; ++blk) {
+            if (blk + 1 < C1 / 32) {
+#pragma unroll
+              for (int t = 0; t < 16; ++t) wv[(blk + 1) & 1][t] = w1p[(size_t)((blk + 1) * 32 + kappa(t, 0)) * C2];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) H2 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1T[blk][t], wv[blk & 1][t], H2, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) H2[r] = fmaxf(H2[r] + b1r[cb], 0.f);
@@ -953,13 +1016,13 @@ static int local_cell_dispatch(long groups, int k, int w, int c1, int c2, const 
   return PASNL_EUNSUPPORTED;
 }
 
-template <int C1, int C2, int NW, bool VEC>
+template <int C1, int C2, int NW, bool VEC, bool LEAN>
 static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0, const float* w1,
                           const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
   const int wp = (8 + (w - 6) + 31) & ~31;  // internal width: [xyz-c | xyz | 1 | 0 | feature], padded to 32-chunks
   size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 6 * 32 + (size_t)NW * wp) * sizeof(float);
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
-  auto kern = sa_cell_kernel<C1, C2, NW, VEC>;
+  auto kern = sa_cell_kernel<C1, C2, NW, VEC, LEAN>;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
@@ -978,10 +1041,12 @@ static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const floa
 template <int C1, int C2>
 static int sa_cell_cfg(int nw, bool vec, long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0,
                        const float* w1, const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
-  if (nw == 8) return vec ? sa_cell_launch<C1, C2, 8, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
-                          : sa_cell_launch<C1, C2, 8, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
-  return vec ? sa_cell_launch<C1, C2, 4, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
-             : sa_cell_launch<C1, C2, 4, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  // two waves per SIMD (8 per workgroup) need <= 256 registers each: the lean variant where the full one would spill
+  constexpr bool LEAN8 = C1 >= 128;
+  if (nw == 8) return vec ? sa_cell_launch<C1, C2, 8, true, LEAN8>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
+                          : sa_cell_launch<C1, C2, 8, false, LEAN8>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  return vec ? sa_cell_launch<C1, C2, 4, true, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
+             : sa_cell_launch<C1, C2, 4, false, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
 }
 
 extern "C" int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, const float* x, const float* w0, const float* b0,
@@ -1012,7 +1077,11 @@ extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, 
   if (!getenv("PASNL_SA_CELL_V1")) {
     // 16-byte operand loads need 16-byte aligned feature rows
     const bool vec = (c % 4 == 0) && (reinterpret_cast<uintptr_t>(feature) % 16 == 0);
-    int nw = c1 <= 32 ? 8 : 4;  // two waves per SIMD where the registers allow it
+    // two waves per SIMD share one LDS copy of the weights where 256 registers per wave suffice (c1 <= 64: 201 vs 240 us
+    // at cls layer1, 44 vs 59 us at ScanNet layer2).  The 128-channel cell needs ~380: at 8 waves it is 3 % faster
+    // (411 vs 425 us) but spills, and the scratch traffic more than doubles its HBM bytes (PMC: 417 vs 175 MB) --
+    // one wave per SIMD, no spills.
+    int nw = c1 >= 128 ? 4 : 8;
     if (const char* cfg = getenv("PASNL_SA_CELL_CFG")) nw = atoi(cfg);
     if (c1 == 32 && c2 == 32) return sa_cell_cfg<32, 32>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
     if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);

@@ -785,6 +785,30 @@ __global__ __launch_bounds__(T) void sa_group_kernel(int n, int c, int m, int k,
 }
 
 // ---------------------------------------------------------------------------------------------
+// max_pool_rows: out[b, c] = max_s x[b, s, c]  -- the PointNet set-abstraction pooling over the points of a
+// region (pointnet_util.py:137, tf.reduce_max(new_points, axis=[2])).  One workgroup per (cloud, 64-channel
+// slab): lanes over channels (coalesced 256-byte rows), the 4 waves split the rows, partial maxima meet in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void max_pool_rows_kernel(int n, int c, const float* __restrict__ x, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const bool ok = col < c;
+  const float* p = x + (size_t)blockIdx.y * n * c + (ok ? col : 0);
+  float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+  int s = wave;
+  for (; s + 12 < n; s += 16) {  // four independent loads in flight per lane
+    float a = p[(size_t)s * c], b = p[(size_t)(s + 4) * c], d = p[(size_t)(s + 8) * c], e = p[(size_t)(s + 12) * c];
+    m0 = fmaxf(m0, a); m1 = fmaxf(m1, b); m2 = fmaxf(m2, d); m3 = fmaxf(m3, e);
+  }
+  for (; s < n; s += 4) m0 = fmaxf(m0, p[(size_t)s * c]);
+  part[wave][lane] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+  __syncthreads();
+  if (wave == 0 && ok)
+    out[(size_t)blockIdx.y * c + col] = fmaxf(fmaxf(part[0][lane], part[1][lane]), fmaxf(part[2][lane], part[3][lane]));
+}
+
+// ---------------------------------------------------------------------------------------------
 // select_top_k: one wave per (b,m) row; k rounds of "first strict minimum of the current row in
 // [s,n), swap with position s" (tf_grouping_g.cu:100-121), on the output arrays in global memory.
 // ---------------------------------------------------------------------------------------------
@@ -1000,6 +1024,15 @@ extern "C" int pasnl_group_point_grad(int b, int n, int c, int m, int nsample, c
   PASNL_REQUIRE(grad_out && idx, PASNL_ENULL);
   hipLaunchKernelGGL(group_point_grad_kernel, dim3(grid_for(total)), dim3(256), 0, st, n, c, rows_per_batch, total, grad_out,
                      idx, grad_points);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_max_pool_rows(int b, int n, int c, const float* x, float* out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0, PASNL_EINVAL);
+  if (b == 0) return PASNL_OK;
+  PASNL_REQUIRE(x && out, PASNL_ENULL);
+  PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
+  hipLaunchKernelGGL(max_pool_rows_kernel, dim3((c + 63) / 64, b), dim3(256), 0, pasnl_hip_stream(stream), n, c, x, out);
   return pasnl_launch_status();
 }
 

@@ -9,6 +9,7 @@ from pointasnl_amd.tf_sampling import farthest_point_sample, gather_point
 from pointasnl_amd.tf_grouping import query_ball_point, group_point, knn_point
 from pointasnl_amd.tf_interpolate import three_nn, three_interpolate, three_weights
 from pointasnl_amd.utils import tf_util
+from pointasnl_amd import _hip
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
@@ -40,13 +41,30 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
     return new_xyz, new_points, idx, grouped_xyz
 
 
+_GROUP_ALL_CONST = {}
+
+
+def max_pool_points(new_points):
+    """tf.reduce_max(new_points, axis=[2], keep_dims=True) for (B, npoint, nsample, C) (pointnet_util.py:137)."""
+    b, p, ns, c = new_points.shape
+    new_points = new_points.contiguous()
+    out = torch.empty((b, p, 1, c), dtype=torch.float32, device=new_points.device)
+    _hip.launch("pasnl_max_pool_rows", "max_pool_rows", b * p, ns, c, _hip.ptr(new_points), _hip.ptr(out))
+    return out
+
+
 def sample_and_group_all(xyz, points, use_xyz=True):
     '''
     Equivalent to sample_and_group with npoint=1, radius=inf, (0,0,0) as the centroid (pointnet_util.py:59-84).
     '''
     batch_size, nsample = xyz.shape[0], xyz.shape[1]
-    new_xyz = torch.zeros((batch_size, 1, 3), dtype=torch.float32, device=xyz.device)
-    idx = torch.arange(nsample, dtype=torch.int32, device=xyz.device).reshape(1, 1, nsample).repeat(batch_size, 1, 1)
+    # constants of the shape only (pointnet_util.py:72-73): built once per (B, nsample, device), not once per forward
+    key = (batch_size, nsample, str(xyz.device))
+    if key not in _GROUP_ALL_CONST:
+        new_xyz = torch.zeros((batch_size, 1, 3), dtype=torch.float32, device=xyz.device)
+        idx = torch.arange(nsample, dtype=torch.int32, device=xyz.device).reshape(1, 1, nsample).repeat(batch_size, 1, 1)
+        _GROUP_ALL_CONST[key] = (new_xyz, idx)
+    new_xyz, idx = _GROUP_ALL_CONST[key]
     grouped_xyz = xyz.reshape(batch_size, 1, nsample, 3)
     if points is not None:
         new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
@@ -74,7 +92,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         for i, num_out_channel in enumerate(mlp):
             new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
                                         is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay)
-        new_points = new_points.max(dim=2, keepdim=True).values
+        new_points = max_pool_points(new_points)
         if mlp2 is not None:
             for i, num_out_channel in enumerate(mlp2):
                 new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,

@@ -48,11 +48,10 @@ def per_position(root, counter, order):
 
 def main(root, out):
     order = None
-    for f in sorted(glob.glob(os.path.join(root, "**", "pmc_FETCH_SIZE.json"), recursive=True)):
-        try:
-            order = json.load(open(f))["launch_order"]
-        except Exception:
-            continue
+    try:  # the bench line printed under rocprofv3 by profiles/collect_traffic.sh
+        order = json.load(open(os.path.join(root, "pmc_FETCH_SIZE.json")))["launch_order"]
+    except Exception:
+        pass
     if not order:
         raise SystemExit("no bench line with launch_order found (run profiles/collect_traffic.sh)")
     names, fetch = per_position(root, "FETCH_SIZE", order)

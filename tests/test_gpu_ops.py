@@ -269,3 +269,13 @@ def test_sa_group(P, b, n, c, m, k):
     new_point, skip = U.sa_group(dev(xyz), dev(feat), dev(idx), dev(new_xyz))
     np.testing.assert_array_equal(new_point.cpu().numpy(), want)
     np.testing.assert_array_equal(skip.cpu().numpy(), want.max(axis=2))
+
+
+@pytest.mark.parametrize("b,p,ns,c", [(64, 1, 512, 512), (3, 1, 128, 1024), (2, 5, 7, 33), (1, 1, 1, 1), (2, 3, 1000, 70)])
+def test_max_pool_points(P, b, p, ns, c):
+    # pointnet_util.py:137: tf.reduce_max(new_points, axis=[2], keep_dims=True) -- bit-exact (a maximum has no rounding)
+    from pointasnl_amd.utils import pointnet_util as PU
+
+    x = np.random.default_rng(c).standard_normal((b, p, ns, c)).astype(np.float32)
+    got = PU.max_pool_points(dev(x)).cpu().numpy()
+    np.testing.assert_array_equal(got, x.max(axis=2, keepdims=True))
