@@ -168,6 +168,9 @@ def main():
                          "latency-bound prefix of one step (FPS: 512 dependent rounds on 64 CUs) runs under the GEMM/MFMA "
                          "work of the previous one.  1 = strictly serial steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the multi-rank code path (RCCL init, per-step all-gather, barriers, max-over-ranks) even with "
+                         "one rank: a 1-GPU box can then exercise everything but the wire")
     ap.add_argument("--launch-order", action="store_true",
                     help="add the per-forward sequence of C-ABI launches to the JSON line (profiles/pmc_to_traffic.py uses "
                          "it to attribute rocprofv3 PMC rows to launches)")
@@ -192,9 +195,11 @@ def main():
     _hip.lib()
     _hip.require_device()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import importlib
 
@@ -220,7 +225,7 @@ def main():
         return logits
 
     width = 40 if seg_model is None else N * 20
-    gathered = sharding.LogitsGather(world, B, width, x.device) if world > 1 else None  # eager path
+    gathered = sharding.LogitsGather(world, B, width, x.device, force=multi) if multi else None  # eager path
     lane_gather = []  # one gather buffer per pipeline lane
 
     with torch.no_grad():
@@ -239,10 +244,11 @@ def main():
                 st_l = torch.cuda.Stream()
                 st_l.wait_stream(torch.cuda.current_stream())
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=st_l):
+                # thread_local: the RCCL watchdog thread must not be able to invalidate the capture
+                with torch.cuda.graph(g, stream=st_l, capture_error_mode="thread_local"):
                     lg = forward()
                 lanes.append((st_l, g, lg))
-                lane_gather.append(sharding.LogitsGather(world, B, width, x.device) if world > 1 else None)
+                lane_gather.append(sharding.LogitsGather(world, B, width, x.device, force=multi) if multi else None)
             graph = lanes[0][1]
             logits = lanes[0][2]
         step_no = [0]
@@ -266,17 +272,17 @@ def main():
             step()
 
         # ---- timed region: barrier + sync on both sides, max over ranks
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             t = torch.tensor([elapsed], dtype=torch.float64, device=x.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -297,7 +303,7 @@ def main():
             _hip.PROFILE = None
 
     if rank != 0:
-        if world > 1:
+        if multi:
             dist.destroy_process_group()
         return
 
@@ -352,7 +358,7 @@ def main():
     if args.launch_order:
         out["launch_order"] = launch_order
     print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

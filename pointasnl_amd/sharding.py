@@ -20,12 +20,13 @@ def shard_range(rank, world, total):
 class LogitsGather:
     """Pre-allocated all-gather of equally sized per-rank logits (weak scaling: same batch on every rank)."""
 
-    def __init__(self, world, rows_per_rank, width, device, dtype=torch.float32):
+    def __init__(self, world, rows_per_rank, width, device, dtype=torch.float32, force=False):
         self.world = world
+        self.force = force  # issue the collective even with one rank (exercises the RCCL path on a 1-GPU box)
         self.out = torch.empty((world * rows_per_rank, width), dtype=dtype, device=device)
 
     def all_gather(self, local):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             self.out.copy_(local)
         else:
             dist.all_gather_into_tensor(self.out, local.contiguous())
