@@ -134,7 +134,12 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int
                                                                      int rw, uint32_t ns_magic,
                                                                      const float* __restrict__ xyz1,
                                                                      const float* __restrict__ xyz2, int* __restrict__ idx,
-                                                                     int* __restrict__ pts_cnt) {
+                                                                     int* __restrict__ pts_cnt, long long* __restrict__ dbg) {
+  // dbg != nullptr (PASNL_BALL_PROBE, diagnostics only): workgroup 0 records clock64() at the phase boundaries
+  long long tp[8];
+  int ntp = 0;
+#define PASNL_BQ_MARK() do { if (dbg) tp[ntp++ & 7] = clock64(); } while (0)
+  PASNL_BQ_MARK();
   constexpr int PPT = MWT * 32 / BQG_THREADS > 0 ? MWT * 32 / BQG_THREADS : 1;  // points per thread
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* spt = reinterpret_cast<float4*>(smem);                                   // [n] cell-sorted {x,y,z,index bits}
@@ -180,6 +185,7 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int
     lo[a] = fminf(fminf(red[a], red[6 + a]), fminf(red[12 + a], red[18 + a]));
     hi[a] = fmaxf(fmaxf(red[3 + a], red[9 + a]), fmaxf(red[15 + a], red[21 + a]));
   }
+  PASNL_BQ_MARK();
   // ---- B. grid geometry (identical in every thread)
   const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
   const float maxext = fmaxf(ex, fmaxf(ey, ez));
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int
     if (k < n) spt[(int)cstart[pcell[i]] + prank[i]] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
   }
   __syncthreads();  // last workgroup barrier: `ccount` (aliasing the rows) is dead, spt / cstart are complete
+  PASNL_BQ_MARK();
 
   // ---- D. queries: one per lane; a wave never touches another wave's rows
   const int mw = (n + 31) >> 5;
@@ -303,6 +310,7 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int
         }
       }
     }
+    PASNL_BQ_MARK();
     // ---- E. bit row -> ascending hit list (first nsample, then the first hit as padding; zero-hit rows -> 0,
     // SURVEY A.3), in place: the mask words are cached in registers first
     uint32_t wreg[MWT];
@@ -321,6 +329,7 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int
       }
     }
     for (int sp = c; sp < nsample; ++sp) row[sp ^ swz] = (uint32_t)first;
+    PASNL_BQ_MARK();
     // ---- F. the wave copies its 64 lists out (16 bytes per lane and step when nsample % 4 == 0)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -353,7 +362,11 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int
       if (live) pts_cnt[(size_t)bi * m + j] = c;
     }
     __builtin_amdgcn_wave_barrier();  // the rows are recycled by the next round
+    PASNL_BQ_MARK();
   }
+  if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+    for (int i = 0; i < 8; ++i) dbg[i] = tp[i];
+#undef PASNL_BQ_MARK
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -897,6 +910,9 @@ extern "C" int pasnl_query_ball_point(int b, int n, int m, float radius, int nsa
     if (glds <= 160 * 1024 && (size_t)BQG_THREADS * rw >= (size_t)BQG_NC) {
       dim3 grid((m + BQG_QCHUNK - 1) / BQG_QCHUNK, b);
       const float rpad = radius * 1.001f;
+      // diagnostics: PASNL_BALL_PROBE=<device pointer to 8 int64, hex> makes workgroup 0 record its phase clocks
+      long long* dbg = nullptr;
+      if (const char* pe = getenv("PASNL_BALL_PROBE")) dbg = reinterpret_cast<long long*>(strtoull(pe, nullptr, 16));
       // e / d for e < 2^16 as umulhi(e, magic); d = list entries (or 16-byte groups of entries) per query
       const unsigned div = (nsample & 3) == 0 ? (unsigned)nsample / 4 : (unsigned)nsample;
       const uint32_t ns_magic = div == 1 ? 0u : (uint32_t)((0x100000000ull / div) + 1ull);  // 0: divisor 1
@@ -907,7 +923,7 @@ extern "C" int pasnl_query_ball_point(int b, int n, int m, float radius, int nsa
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds) != hipSuccess)   \
       return PASNL_ELAUNCH;                                                                                             \
     hipLaunchKernelGGL(gk, grid, dim3(BQG_THREADS), glds, pasnl_hip_stream(stream), n, m, rpad, thr2, nsample, rw,      \
-                       ns_magic, xyz1, xyz2, idx, pts_cnt);                                                             \
+                       ns_magic, xyz1, xyz2, idx, pts_cnt, dbg);                                                        \
   }
       if (mwt == 8) PASNL_BQG(8)
       else if (mwt == 16) PASNL_BQG(16)
