@@ -184,6 +184,22 @@ int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, const float
  * out[b,ch] = max over the n points of x (b,n,c).  The two group_all modules of pointasnl_cls pool 67 + 34 MB. */
 int pasnl_max_pool_rows(int b, int n, int c, const float* x, float* out, pasnl_stream_t stream);
 
+/* Deterministic backward of gather_point / group_point / three_interpolate: the gradient row of a source point is
+ * the sum of its contributions in ascending order of the forward output element -- the order of the reference's
+ * sequential CPU loop (tf_interpolate.cpp:131-153) -- so results are bit-reproducible (the reference's GPU kernels,
+ * tf_sampling_g.cu:183-192 and tf_grouping_g.cu:61-78, scatter with atomicAdd and are not).  No fp atomics; every
+ * destination row is written (no memset needed).  Out-of-range indices are ignored.
+ * workspace: device memory of pasnl_grad_workspace_bytes(b, targets_per_cloud, contributions_per_cloud) bytes, where
+ * (targets, contributions) = (n, m) for gather_point, (n, m*nsample) for group_point, (m, 3*n) for three_interpolate.
+ * Argument meaning as the atomic versions above.  targets_per_cloud <= 38400 (LDS histogram). */
+size_t pasnl_grad_workspace_bytes(int b, int targets, long contributions);
+int pasnl_gather_point_grad_det(int b, int n, int m, const float* out_g, const int* idx, float* inp_g, void* workspace,
+                                size_t workspace_bytes, pasnl_stream_t stream);
+int pasnl_group_point_grad_det(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx,
+                               float* grad_points, void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
+int pasnl_three_interpolate_grad_det(int b, int n, int c, int m, const float* grad_out, const int* idx, const float* weight,
+                                     float* grad_points, void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

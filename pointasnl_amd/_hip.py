@@ -20,6 +20,7 @@ SYMBOLS = [
     "pasnl_query_ball_point", "pasnl_sa_group", "pasnl_group_point", "pasnl_group_point_grad", "pasnl_select_top_k", "pasnl_knn_batch",
     "pasnl_three_nn", "pasnl_three_interpolate", "pasnl_three_interpolate_grad", "pasnl_three_weights",
     "pasnl_nl_attention", "pasnl_as_attention", "pasnl_as_reweight", "pasnl_sa_local_cell", "pasnl_sa_cell", "pasnl_max_pool_rows",
+    "pasnl_grad_workspace_bytes", "pasnl_gather_point_grad_det", "pasnl_group_point_grad_det", "pasnl_three_interpolate_grad_det",
 ]
 
 
@@ -40,6 +41,7 @@ def lib():
                 "(or `make -C pointasnl_amd/csrc`).  pointasnl_amd has no CPU or eager fallback.")
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.pasnl_strerror.restype = ctypes.c_char_p
+        _lib.pasnl_grad_workspace_bytes.restype = ctypes.c_size_t
         for s in SYMBOLS:
             getattr(_lib, s)  # AttributeError here == header / library mismatch
     return _lib
@@ -111,3 +113,13 @@ def as_dev(x, dtype):
     import numpy as np
 
     return torch.from_numpy(np.ascontiguousarray(x)).to(device="cuda", dtype=dtype)
+
+
+DETERMINISTIC_GRADS = True  # backward of gather_point / group_point / three_interpolate: ordered segmented sums (no fp atomics)
+
+
+def grad_workspace(b, targets, contributions, device):
+    """(device buffer, byte count as c_size_t) for the pasnl_*_grad_det entry points."""
+    nbytes = int(lib().pasnl_grad_workspace_bytes(int(b), int(targets), ctypes.c_long(int(contributions))))
+    ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device)
+    return ws, ctypes.c_size_t(nbytes)

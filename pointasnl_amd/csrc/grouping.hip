@@ -798,6 +798,126 @@ __global__ __launch_bounds__(T) void sa_group_kernel(int n, int c, int m, int k,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Deterministic backward of the three gather-type ops (gather_point, group_point, three_interpolate).
+// The reference scatters with atomicAdd (tf_sampling_g.cu:183-192, tf_grouping_g.cu:61-78: run-to-run different
+// fp32 sums) or with a sequential CPU loop (tf_interpolate.cpp:131-153).  Here the gradient row of source point t
+// is the sum of its contributions in ASCENDING ORDER OF THE FORWARD OUTPUT ELEMENT -- exactly the sequential loop,
+// so the result is bit-reproducible and equals the oracle bit for bit.  No floating-point atomics:
+//   1. grad_lists_kernel (one workgroup per cloud): histogram of the targets in LDS (integer atomics), exclusive
+//      scan -> start[t], then every contribution e takes a slot of its target's list (order inside a list arbitrary);
+//   2. grad_segsum_kernel (one wave per target row): sorts the row's list (wave bitonic network; lists longer than
+//      64 are consumed 64 smallest at a time) and adds the source rows in that order, channels across the lanes.
+// ---------------------------------------------------------------------------------------------
+constexpr int GL_THREADS = 1024;
+
+__global__ __launch_bounds__(GL_THREADS) void grad_lists_kernel(int n, long entries, const int* __restrict__ idx,
+                                                               int* __restrict__ start, int* __restrict__ list) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* cnt = reinterpret_cast<int*>(smem);  // [n] counts, then cursors
+  __shared__ int wsum[GL_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long bi = blockIdx.x;
+  const int* ix = idx + bi * entries;
+  for (int t = tid; t < n; t += GL_THREADS) cnt[t] = 0;
+  __syncthreads();
+  for (long e = tid; e < entries; e += GL_THREADS) {
+    const int t = ix[e];
+    if (t >= 0 && t < n) atomicAdd(&cnt[t], 1);
+  }
+  __syncthreads();
+  // exclusive scan: thread t owns targets [t*per, t*per+per)
+  const int per = (n + GL_THREADS - 1) / GL_THREADS;
+  int sum = 0;
+  for (int j = 0; j < per; ++j) {
+    const int t = tid * per + j;
+    if (t < n) sum += cnt[t];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - sum;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  int* st = start + bi * (n + 1);
+  for (int j = 0; j < per; ++j) {
+    const int t = tid * per + j;
+    if (t < n) {
+      const int c = cnt[t];
+      cnt[t] = base;
+      st[t] = base;
+      base += c;
+    }
+  }
+  if (tid == GL_THREADS - 1) st[n] = base;  // the last thread's running total = number of valid contributions
+  __syncthreads();
+  int* ls = list + bi * entries;
+  for (long e = tid; e < entries; e += GL_THREADS) {
+    const int t = ix[e];
+    if (t >= 0 && t < n) ls[atomicAdd(&cnt[t], 1)] = (int)e;
+  }
+}
+
+// src row of contribution e of cloud bi: src + ((bi*entries + e) / rep) * c ; scale weight[bi*entries + e] (or none)
+__global__ __launch_bounds__(256) void grad_segsum_kernel(int n, int c, long entries, int rep, const float* __restrict__ src,
+                                                         const float* __restrict__ weight, const int* __restrict__ start,
+                                                         const int* __restrict__ list, float* __restrict__ dst, long rows) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const long bi = r / n;
+  const int t = (int)(r - bi * n);
+  const int lo = start[bi * (n + 1) + t], hi = start[bi * (n + 1) + t + 1];
+  const int* ls = list + bi * entries;
+  float* out = dst + r * c;
+  constexpr int CH = 8;  // 64-channel slabs accumulated per walk over the list
+  for (int c0 = 0; c0 < c; c0 += CH * 64) {
+    float acc[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) acc[q] = 0.f;
+    uint32_t prev = 0;
+    bool first = true;
+    for (int done = lo; done < hi;) {
+      // the 64 smallest not yet consumed contributions, ascending
+      uint32_t key[2];
+      key[0] = 0xffffffffu;
+      for (int base = lo; base < hi; base += 64) {
+        uint32_t cand = 0xffffffffu;
+        if (base + lane < hi) {
+          const uint32_t e = (uint32_t)ls[base + lane];
+          if (first || e > prev) cand = e;
+        }
+        key[1] = cand;
+        wave_bitonic_sort<2, uint32_t>(key, lane);
+      }
+      const int take = min(64, hi - done);
+      for (int j = 0; j < take; ++j) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)key[0], j);
+        const long ge = bi * entries + e;
+        const float* row = src + (ge / rep) * c + c0 + lane;
+        const float w = weight ? weight[ge] : 1.f;
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+          if (c0 + q * 64 + lane < c) {
+            const float v = row[q * 64];
+            acc[q] = acc[q] + (weight ? v * w : v);
+          }
+        }
+      }
+      prev = (uint32_t)__builtin_amdgcn_readlane((int)key[0], take - 1);
+      first = false;
+      done += take;
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q)
+      if (c0 + q * 64 + lane < c) out[c0 + q * 64 + lane] = acc[q];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // max_pool_rows: out[b, c] = max_s x[b, s, c]  -- the PointNet set-abstraction pooling over the points of a
 // region (pointnet_util.py:137, tf.reduce_max(new_points, axis=[2])).  One workgroup per (cloud, 64-channel
 // slab): lanes over channels (coalesced 256-byte rows), the 4 waves split the rows, partial maxima meet in LDS.
@@ -1041,6 +1161,57 @@ extern "C" int pasnl_group_point_grad(int b, int n, int c, int m, int nsample, c
   hipLaunchKernelGGL(group_point_grad_kernel, dim3(grid_for(total)), dim3(256), 0, st, n, c, rows_per_batch, total, grad_out,
                      idx, grad_points);
   return pasnl_launch_status();
+}
+
+static size_t grad_ws_bytes(int b, int n, long entries) {
+  return ((size_t)b * (n + 1) + (size_t)b * entries) * sizeof(int);
+}
+
+extern "C" size_t pasnl_grad_workspace_bytes(int b, int n, long entries) {
+  if (b <= 0 || n <= 0 || entries < 0) return 0;
+  return grad_ws_bytes(b, n, entries);
+}
+
+static int grad_det(int b, int n, int c, long entries, int rep, const float* src, const float* weight, const int* idx,
+                    float* dst, void* ws, size_t ws_bytes, hipStream_t st) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && entries >= 0, PASNL_EINVAL);
+  if (b == 0) return PASNL_OK;
+  PASNL_REQUIRE(dst, PASNL_ENULL);
+  PASNL_REQUIRE(entries == 0 || (src && idx), PASNL_ENULL);
+  PASNL_REQUIRE(ws && ws_bytes >= grad_ws_bytes(b, n, entries), PASNL_EWORKSPACE);
+  PASNL_REQUIRE((size_t)n * sizeof(int) <= 150 * 1024 && entries < (1L << 31), PASNL_EUNSUPPORTED);
+  int* start = static_cast<int*>(ws);
+  int* list = start + (size_t)b * (n + 1);
+  size_t lds = (size_t)n * sizeof(int);
+  if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(grad_lists_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  hipLaunchKernelGGL(grad_lists_kernel, dim3(b), dim3(GL_THREADS), lds, st, n, entries, idx, start, list);
+  long rows = (long)b * n;
+  hipLaunchKernelGGL(grad_segsum_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, n, c, entries, rep, src, weight, start,
+                     list, dst, rows);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_gather_point_grad_det(int b, int n, int m, const float* out_g, const int* idx, float* inp_g, void* ws,
+                                           size_t ws_bytes, pasnl_stream_t stream) {
+  PASNL_REQUIRE(m >= 0, PASNL_EINVAL);
+  return grad_det(b, n, 3, m, 1, out_g, nullptr, idx, inp_g, ws, ws_bytes, pasnl_hip_stream(stream));
+}
+
+extern "C" int pasnl_group_point_grad_det(int b, int n, int c, int m, int nsample, const float* grad_out, const int* idx,
+                                          float* grad_points, void* ws, size_t ws_bytes, pasnl_stream_t stream) {
+  PASNL_REQUIRE(m >= 0 && nsample >= 0, PASNL_EINVAL);
+  return grad_det(b, n, c, (long)m * nsample, 1, grad_out, nullptr, idx, grad_points, ws, ws_bytes, pasnl_hip_stream(stream));
+}
+
+extern "C" int pasnl_three_interpolate_grad_det(int b, int n, int c, int m, const float* grad_out, const int* idx,
+                                                const float* weight, float* grad_points, void* ws, size_t ws_bytes,
+                                                pasnl_stream_t stream) {
+  PASNL_REQUIRE(n >= 0, PASNL_EINVAL);
+  PASNL_REQUIRE(n == 0 || weight, PASNL_ENULL);
+  // targets are the m known points; contributions e = 3*i + k of unknown point i (tf_interpolate.cpp:137-151 order)
+  return grad_det(b, m, c, 3L * n, 3, grad_out, weight, idx, grad_points, ws, ws_bytes, pasnl_hip_stream(stream));
 }
 
 extern "C" int pasnl_max_pool_rows(int b, int n, int c, const float* x, float* out, pasnl_stream_t stream) {

@@ -48,8 +48,13 @@ class _ThreeInterpolate(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         b, n, c = grad_out.shape
         g = torch.empty((b, ctx.m, c), dtype=torch.float32, device=grad_out.device)
-        _hip.launch("pasnl_three_interpolate_grad", "ThreeInterpolateGrad", b, n, c, ctx.m, _hip.ptr(grad_out), _hip.ptr(idx),
-                                                           _hip.ptr(weight), _hip.ptr(g))
+        if _hip.DETERMINISTIC_GRADS:
+            ws, nbytes = _hip.grad_workspace(b, ctx.m, 3 * n, grad_out.device)
+            _hip.launch("pasnl_three_interpolate_grad_det", "ThreeInterpolateGrad", b, n, c, ctx.m, _hip.ptr(grad_out),
+                        _hip.ptr(idx), _hip.ptr(weight), _hip.ptr(g), _hip.ptr(ws), nbytes)
+        else:
+            _hip.launch("pasnl_three_interpolate_grad", "ThreeInterpolateGrad", b, n, c, ctx.m, _hip.ptr(grad_out), _hip.ptr(idx),
+                        _hip.ptr(weight), _hip.ptr(g))
         return g, None, None
 
 

@@ -73,7 +73,12 @@ class _GroupPoint(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         b, m, ns, c = grad_out.shape
         g = torch.empty((b, ctx.n, c), dtype=torch.float32, device=grad_out.device)
-        _hip.launch("pasnl_group_point_grad", "GroupPointGrad", b, ctx.n, c, m, ns, _hip.ptr(grad_out), _hip.ptr(idx), _hip.ptr(g))
+        if _hip.DETERMINISTIC_GRADS:
+            ws, nbytes = _hip.grad_workspace(b, ctx.n, m * ns, grad_out.device)
+            _hip.launch("pasnl_group_point_grad_det", "GroupPointGrad", b, ctx.n, c, m, ns, _hip.ptr(grad_out), _hip.ptr(idx),
+                        _hip.ptr(g), _hip.ptr(ws), nbytes)
+        else:
+            _hip.launch("pasnl_group_point_grad", "GroupPointGrad", b, ctx.n, c, m, ns, _hip.ptr(grad_out), _hip.ptr(idx), _hip.ptr(g))
         return g, None
 
 

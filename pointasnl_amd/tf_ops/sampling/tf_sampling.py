@@ -47,7 +47,12 @@ class _GatherPoint(torch.autograd.Function):
         out_g = out_g.contiguous()
         b, m, _ = out_g.shape
         inp_g = torch.empty((b, ctx.n, 3), dtype=torch.float32, device=out_g.device)
-        _hip.launch("pasnl_gather_point_grad", "GatherPointGrad", b, ctx.n, m, _hip.ptr(out_g), _hip.ptr(idx), _hip.ptr(inp_g))
+        if _hip.DETERMINISTIC_GRADS:
+            ws, nbytes = _hip.grad_workspace(b, ctx.n, m, out_g.device)
+            _hip.launch("pasnl_gather_point_grad_det", "GatherPointGrad", b, ctx.n, m, _hip.ptr(out_g), _hip.ptr(idx),
+                        _hip.ptr(inp_g), _hip.ptr(ws), nbytes)
+        else:
+            _hip.launch("pasnl_gather_point_grad", "GatherPointGrad", b, ctx.n, m, _hip.ptr(out_g), _hip.ptr(idx), _hip.ptr(inp_g))
         return inp_g, None
 
 

@@ -51,7 +51,8 @@ def test_gather_point_and_grad(P):
     out = P.tf_sampling.gather_point(x, dev(idx))
     g = np.random.default_rng(1).random((4, 333, 3), dtype=np.float32)
     out.backward(dev(g))
-    np.testing.assert_allclose(x.grad.cpu().numpy(), O.gather_point_grad(xyz, idx, g), rtol=1e-5, atol=1e-6)
+    # deterministic backward: contributions summed in ascending output order == the sequential loop, bit for bit
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), O.gather_point_grad(xyz, idx, g))
 
 
 @pytest.mark.parametrize("b,n,m,ns,r,kind", [
@@ -136,7 +137,7 @@ def test_group_point_and_grad(P, b, n, c, m, ns):
     x = dev(pts).requires_grad_(True)
     g = rng.random((b, m, ns, c), dtype=np.float32)
     P.tf_grouping.group_point(x, dev(idx)).backward(dev(g))
-    np.testing.assert_allclose(x.grad.cpu().numpy(), O.group_point_grad(pts, idx, g), rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), O.group_point_grad(pts, idx, g))
 
 
 @pytest.mark.parametrize("b,n,m,k,kind", [
@@ -211,7 +212,7 @@ def test_three_interpolate_and_grad(P, b, m, c, n):
     x = dev(pts).requires_grad_(True)
     g = rng.random((b, n, c), dtype=np.float32)
     P.tf_interpolate.three_interpolate(x, dev(i), dev(w)).backward(dev(g))
-    np.testing.assert_allclose(x.grad.cpu().numpy(), O.three_interpolate_grad(pts, i, w, g), rtol=1e-4, atol=1e-5)
+    np.testing.assert_array_equal(x.grad.cpu().numpy(), O.three_interpolate_grad(pts, i, w, g))
 
 
 @pytest.mark.parametrize("b,n,m", [(2, 100, 10), (3, 8192 + 1000, 2048), (2, 5, 100), (1, 20000, 64)])
@@ -279,3 +280,33 @@ def test_max_pool_points(P, b, p, ns, c):
     x = np.random.default_rng(c).standard_normal((b, p, ns, c)).astype(np.float32)
     got = PU.max_pool_points(dev(x)).cpu().numpy()
     np.testing.assert_array_equal(got, x.max(axis=2, keepdims=True))
+
+
+def test_deterministic_grads_long_lists_and_atomic_variants(P):
+    """Heavily repeated targets (lists far longer than one wave: the 64-smallest-at-a-time path), a cloud with an
+    untouched row (gradient must be an exact 0), and the atomic variants (same value up to summation order)."""
+    from pointasnl_amd import _hip
+
+    rng = np.random.default_rng(3)
+    b, n, c, m, ns = 2, 50, 70, 40, 33
+    pts = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, 4, (b, m, ns)).astype(np.int32)  # 1320 contributions onto 4 rows
+    idx[1, :5] = 49
+    g = rng.standard_normal((b, m, ns, c)).astype(np.float32)
+    want = O.group_point_grad(pts, idx, g)
+    for det in (True, False):
+        _hip.DETERMINISTIC_GRADS = det
+        try:
+            x = dev(pts).requires_grad_(True)
+            P.tf_grouping.group_point(x, dev(idx)).backward(dev(g))
+        finally:
+            _hip.DETERMINISTIC_GRADS = True
+        got = x.grad.cpu().numpy()
+        if det:
+            np.testing.assert_array_equal(got, want)
+            x2 = dev(pts).requires_grad_(True)
+            P.tf_grouping.group_point(x2, dev(idx)).backward(dev(g))
+            np.testing.assert_array_equal(x2.grad.cpu().numpy(), got)  # run-to-run identical
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-3)
+    assert (want[0, 10] == 0).all()
