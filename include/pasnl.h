@@ -200,6 +200,15 @@ int pasnl_group_point_grad_det(int b, int n, int c, int m, int nsample, const fl
 int pasnl_three_interpolate_grad_det(int b, int n, int c, int m, const float* grad_out, const int* idx, const float* weight,
                                      float* grad_points, void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
 
+/* Decoder local cell (PointASNLDecodingLayer, pointasnl_util.py:323-331): per point p of the dense level with its k
+ * nearest neighbours i_s = idx[b,p,s] (self-kNN on xyz):
+ *   F = [xyz[i_s] | feature[i_s]] (k,3+c);  G = relu((xyz[i_s]-xyz[p]) Ww + bw) (k,32);  out[b,p] = F^T G  (3+c,32)
+ * = the input of the [1,3+c] `decode_after_conv` GEMM.  feature = the three_interpolate output (b,n,c); Ww (3,32), bw
+ * (32) = decode_weight_net/wconv0 with inference BN folded.  Replaces two tf.gather_nd, a concat, a subtraction, a
+ * conv2d, a transpose and a batched matmul; no grouped tensor in HBM.  k in {16, 32}. */
+int pasnl_decode_cell(int b, int n, int c, int k, const float* xyz, const float* feature, const int* idx, const float* ww,
+                      const float* bw, float* out, pasnl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -247,3 +247,15 @@ def cls_forward(point_cloud, params, adaptive_sample=False, dtype=np.float32):
     net = _layer(net, params["fc2"], "relu")
     net = _layer(net, params["fc3"], None)
     return net, {"l1_xyz": l1_xyz, "l2_xyz": l2_xyz, "l1_points": l1_points, "l2_points": l2_points}
+
+
+def repulsion_loss(pred, nsample=20, radius=0.07, dtype=np.float64):
+    """utils/pointasnl_util.py:361-378: ball query -> group -> centre -> squared distances -> 5 smallest, drop the
+    first (the point itself) -> clamp -> mean(radius - dist * exp(-d2/h^2)).  Indices from the C oracle's ball query."""
+    idx, _ = ops.query_ball_point(radius, nsample, pred, pred)
+    grouped = batched_gather(pred, idx).astype(dtype) - pred[:, :, None, :].astype(dtype)
+    d2 = (grouped ** 2).sum(-1)
+    d2 = np.sort(d2, axis=-1)[:, :, 1:5]  # tf.nn.top_k(-d2, 5) then [:, :, 1:]
+    d2 = np.maximum(1e-12, d2)
+    h = 0.03
+    return float(np.mean(radius - np.sqrt(d2) * np.exp(-d2 / h ** 2)))

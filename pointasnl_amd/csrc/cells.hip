@@ -899,6 +899,88 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   }
 }
 
+
+// =============================================================================================
+// Decoder local cell (PointASNLDecodingLayer, pointasnl_util.py:323-331): for every point p of the dense level,
+//     F = [xyz[i_s] | feature[i_s]]            (k x (3+c))   i_s = idx[p, s], the point's k nearest neighbours
+//     G = relu((xyz[i_s] - xyz[p]) Ww + bw)     (k x 32)      weight net on the centred coordinates
+//     out[p] = F^T G                            ((3+c) x 32)  -> the input of `decode_after_conv`
+// The reference materialises both gathers (1.1 GB at ScanNet fa_layer4), a transpose and a batched matmul of
+// 131072 tiny matrices (4.4 ms in the vendor BLAS on MI355X).  Here one wave owns one point: G lives in 8 (k=16)
+// registers per lane, F^T is read straight from the L2-resident feature table as the A operand of
+// v_mfma_f32_32x32x2_f32 (lane = channel: 128-byte coalesced row segments), and each 32-channel output tile goes out as
+// 128-byte rows.  Bound: HBM writes (16.8 KB per point; 2.2 GB per launch at fa_layer4).
+// =============================================================================================
+template <int K>
+__global__ __launch_bounds__(256) void decode_cell_kernel(long points, int n, int c, const float* __restrict__ xyz,
+                                                         const float* __restrict__ feature, const int* __restrict__ idx,
+                                                         const float* __restrict__ ww, const float* __restrict__ bw,
+                                                         float* __restrict__ out) {
+  constexpr int T = K / 2;  // MFMA steps: step t contracts neighbours 2t (lanes 0..31) and 2t+1 (lanes 32..63)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, ql = lane & 31;
+  const int w = 3 + c, ntile = (w + 31) >> 5;
+  const float w0 = ww[ql], w1 = ww[32 + ql], w2 = ww[64 + ql], bj = bw[ql];
+
+  // XCD-aware: XCD x owns clouds x, x+8, ... (their feature tables stay in its L2)
+  const int nclouds = (int)(points / n);
+  const bool xcd_map = (gridDim.x % 8 == 0) && nclouds >= 8;
+  const int xcd = blockIdx.x & 7;
+  const long mine = xcd_map ? (long)((nclouds - xcd + 7) >> 3) * n : points;
+  const long first = xcd_map ? (long)(blockIdx.x >> 3) * 4 + wave : (long)blockIdx.x * 4 + wave;
+  const long step = xcd_map ? (long)(gridDim.x >> 3) * 4 : (long)gridDim.x * 4;
+  for (long li = first; li < mine; li += step) {
+    long p = li, bi;
+    if (xcd_map) {
+      const int cl = (int)(li / n);
+      bi = xcd + 8 * cl;
+      p = bi * n + (li - (long)cl * n);
+    } else {
+      bi = p / n;
+    }
+    const float cx = xyz[p * 3], cy = xyz[p * 3 + 1], cz = xyz[p * 3 + 2];
+    float G[T], qc[T];  // weight-net value of neighbour (2t+h) for column j = ql; coordinate ql (< 3) of that neighbour
+    const float* frow[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int is = idx[p * K + 2 * t + h];
+      const float* q = xyz + ((size_t)bi * n + is) * 3;
+      const float qx = q[0], qy = q[1], qz = q[2];
+      // conv accumulates in input-channel order, then the folded bias, then ReLU
+      G[t] = fmaxf(__builtin_fmaf(qz - cz, w2, __builtin_fmaf(qy - cy, w1, (qx - cx) * w0)) + bj, 0.f);
+      qc[t] = ql == 0 ? qx : (ql == 1 ? qy : qz);
+      frow[t] = feature + ((size_t)bi * n + is) * (size_t)c - 3;  // F column ch >= 3 is frow[ch]
+    }
+    float* o = out + (size_t)p * w * 32;
+    float a[T], an[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) a[t] = frow[t][min(max(ql, 3), w - 1)];
+    for (int ct = 0; ct < ntile; ++ct) {
+      // next tile's operands in flight during this tile's MFMAs and stores (clamped addresses, masked at use)
+      const int chn = min(ct + 1, ntile - 1) * 32 + ql;
+#pragma unroll
+      for (int t = 0; t < T; ++t) an[t] = frow[t][min(max(chn, 3), w - 1)];
+      const int ch = ct * 32 + ql;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float av = ch < 3 ? qc[t] : (ch < w ? a[t] : 0.f);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, G[t], acc, 0, 0, 0);
+      }
+      // acc[r] = out[channel ct*32 + kappa(r,h)][j = ql]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int oc = ct * 32 + kappa(r, h);
+        if (oc < w) o[(size_t)oc * 32 + ql] = acc[r];
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) a[t] = an[t];
+    }
+  }
+}
+
 }  // namespace pasnl
 
 using namespace pasnl;
@@ -1089,4 +1171,25 @@ extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, 
     return PASNL_EUNSUPPORTED;
   }
   return local_cell_dispatch<true>(groups, k, w, c1, c2, nullptr, src, w0, b0, w1, b1, ww, bw, out, st);
+}
+
+extern "C" int pasnl_decode_cell(int b, int n, int c, int k, const float* xyz, const float* feature, const int* idx,
+                                 const float* ww, const float* bw, float* out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && k > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(k == 16 || k == 32, PASNL_EUNSUPPORTED);
+  const long points = (long)b * n;
+  if (points == 0) return PASNL_OK;
+  PASNL_REQUIRE(xyz && feature && idx && ww && bw && out, PASNL_ENULL);
+  PASNL_REQUIRE(points * k < (1L << 40), PASNL_EUNSUPPORTED);
+  hipStream_t st = pasnl_hip_stream(stream);
+  // persistent workgroups, as many as are resident at once (a multiple of 8 keeps the XCD map on)
+  const void* kern = k == 16 ? reinterpret_cast<const void*>(decode_cell_kernel<16>) : reinterpret_cast<const void*>(decode_cell_kernel<32>);
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  long wgs = (points + 3) / 4;
+  const long cap = 256L * per_cu;
+  unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
+  if (k == 16) hipLaunchKernelGGL(decode_cell_kernel<16>, dim3(grid), dim3(256), 0, st, points, n, c, xyz, feature, idx, ww, bw, out);
+  else hipLaunchKernelGGL(decode_cell_kernel<32>, dim3(grid), dim3(256), 0, st, points, n, c, xyz, feature, idx, ww, bw, out);
+  return pasnl_launch_status();
 }

@@ -345,6 +345,23 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
         return new_xyz, new_point
 
 
+DECODE_CELL_FUSED = True  # False = the reference's op-by-op chain (gathers, concat, conv2d, transpose, batched matmul)
+
+
+def decode_cell(xyz, feature, idx):
+    """Decoder local cell (pointasnl_util.py:323-331) fused: (B,N,3), (B,N,C), (B,N,K) -> (B,N,3+C,32).
+    The variables are the ones the op-by-op chain creates (scope decode_weight_net/wconv0)."""
+    b, n, c = feature.shape
+    k = idx.shape[2]
+    with tf_util.variable_scope('decode_weight_net'), tf_util.variable_scope('wconv0'):
+        ww, bw = tf_util.store().layer(3, 32, True)
+    xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
+    out = torch.empty((b, n, 3 + c, 32), dtype=torch.float32, device=xyz.device)
+    _hip.launch("pasnl_decode_cell", "decode_cell", b, n, c, k, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx), _hip.ptr(ww),
+                _hip.ptr(bw), _hip.ptr(out))
+    return out
+
+
 def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_training, bn_decay, weight_decay, scope,
                            bn=True, use_xyz=True, use_knn=True, radius=None, dilate_rate=1, mode='concat', NL=False):
     ''' Input:
@@ -365,13 +382,18 @@ def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_traini
         interpolated_points = three_interpolate(points2, idx, weight)
 
         '''Point Local Cell'''
-        grouped_xyz, grouped_feature, idx = grouping(interpolated_points, nsample, xyz1, xyz1, use_xyz=use_xyz,
-                                                     use_knn=use_knn, radius=radius)
-        grouped_xyz = grouped_xyz - xyz1.unsqueeze(2)  # translation normalization
-        weight = weight_net_hidden(grouped_xyz, [32], scope='decode_weight_net', is_training=is_training,
-                                   bn_decay=bn_decay, weight_decay=weight_decay)
-        new_points = grouped_feature.transpose(2, 3)
-        new_points = torch.matmul(new_points, weight)
+        if DECODE_CELL_FUSED and use_xyz and use_knn and nsample in (16, 32):
+            # self-kNN, both gathers, the centring, the weight net and F^T.G in one kernel (no grouped tensors)
+            tf_util._require_inference(is_training)
+            new_points = decode_cell(xyz1, interpolated_points, knn_query(nsample, xyz1, xyz1))
+        else:
+            grouped_xyz, grouped_feature, idx = grouping(interpolated_points, nsample, xyz1, xyz1, use_xyz=use_xyz,
+                                                         use_knn=use_knn, radius=radius)
+            grouped_xyz = grouped_xyz - xyz1.unsqueeze(2)  # translation normalization
+            weight = weight_net_hidden(grouped_xyz, [32], scope='decode_weight_net', is_training=is_training,
+                                       bn_decay=bn_decay, weight_decay=weight_decay)
+            new_points = grouped_feature.transpose(2, 3)
+            new_points = torch.matmul(new_points, weight)
         new_points = tf_util.conv2d(new_points, mlp[0], [1, new_points.shape[2]], padding='VALID', stride=[1, 1], bn=bn,
                                     is_training=is_training, scope='decode_after_conv', bn_decay=bn_decay,
                                     weight_decay=weight_decay)

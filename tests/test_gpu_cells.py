@@ -206,3 +206,39 @@ def test_seg_forward_matches_oracle(model):
     scale = max(1.0, np.abs(want).max())
     assert np.abs(got - want).max() / scale < 2e-4
     assert (got.argmax(-1) == want.argmax(-1)).mean() > 0.999
+
+
+@pytest.mark.parametrize("n,radius", [(1024, 0.07), (1280, 0.2)])
+def test_repulsion_loss(n, radius):
+    """get_repulsion_loss (pointasnl_util.py:361-378), the only in-model consumer of query_ball_point / group_point:
+    ScanNet shape (l1_xyz 1024 pts, r=0.07) and SemanticKITTI shape (1280 pts, r=0.2), ns=20."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    pred = clouds(41, 3, n)
+    got = float(U.get_repulsion_loss(dev(pred), nsample=20, radius=radius))
+    want = cells.repulsion_loss(pred, nsample=20, radius=radius)
+    assert abs(got - want) < 1e-6 * max(1.0, abs(want))
+
+
+@pytest.mark.parametrize("b,n,c,k", [(2, 1024, 128, 16), (1, 300, 61, 16), (16, 64, 512, 16), (1, 40, 5, 32), (3, 17, 256, 16)])
+def test_decode_cell(b, n, c, k):
+    """pasnl_decode_cell = gathers + centring + weight net + F^T.G of PointASNLDecodingLayer (pointasnl_util.py:323-331)
+    vs the fp64 restatement; also against the op-by-op chain of the product."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    st = _store(n + c)
+    rng = np.random.default_rng(n * 3 + c)
+    xyz = clouds(8, b, n)
+    feat = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, n, k)).astype(np.int32)
+    with st.scope("D"):
+        got = U.decode_cell(dev(xyz), dev(feat), dev(idx)).cpu().numpy()
+    p = st.export_numpy()
+    bi = np.arange(b)[:, None, None]
+    gx = xyz[bi, idx].astype(np.float64)
+    F = np.concatenate([gx, feat[bi, idx].astype(np.float64)], axis=-1)                 # (b,n,k,3+c)
+    G = cells._layer(gx - xyz[:, :, None, :].astype(np.float64), p["D/decode_weight_net/wconv0"], "relu")  # (b,n,k,32)
+    want = np.swapaxes(F, 2, 3) @ G
+    assert got.shape == want.shape == (b, n, 3 + c, 32)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() / scale < 1e-5
