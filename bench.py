@@ -179,6 +179,11 @@ def main():
                          "it to attribute rocprofv3 PMC rows to launches)")
     args = ap.parse_args()
 
+    if os.environ.get("PASNL_BENCH_WATCHDOG"):  # diagnostics: dump every thread's Python stack and exit if the run stalls
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["PASNL_BENCH_WATCHDOG"]), exit=True)
+
     import torch
     import torch.distributed as dist
 
