@@ -6,8 +6,9 @@
 
 A "step" is one inference forward of models/pointasnl_cls.py over one batch of synthetic clouds
 (B=64 x 1024 x 3 per GPU, BASELINE.json configs[1]; --AS selects configs[2]); inputs are resident in HBM before
-the timed region.  The forward is captured once into a HIP graph and replayed; with N>1 every rank owns its own
-64 clouds (weak scaling, no data-path collective) and the per-shard logits are all-gathered over RCCL each step.
+the timed region.  The forward is captured into HIP graphs and replayed; consecutive forwards overlap on two
+streams (--pipeline).  With N>1 every rank owns its own 64 clouds (weak scaling, no data-path collective) and the
+per-shard logits are all-gathered over RCCL each step.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the hand-written kernel that takes the largest share of the
 step: algorithmic bytes/flops / its average launch duration, measured with HIP events on the
@@ -166,10 +167,15 @@ def main():
                          "(ScanNet 8192 pts / SemanticKITTI 10240 pts); own measurements, not the driver's metric")
     ap.add_argument("--points", type=int, default=0, help="points per cloud (default: 1024 cls, 8192 sem_seg, 10240 sem_seg_res)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
-    ap.add_argument("--pipeline", type=int, default=2,
-                    help="graph instances replayed round-robin on separate HIP streams: consecutive steps overlap, so the "
-                         "latency-bound prefix of one step (FPS: 512 dependent rounds on 64 CUs) runs under the GEMM/MFMA "
-                         "work of the previous one.  1 = strictly serial steps")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "lanes", "search", "serial", "1", "2"],
+                    help="how consecutive forwards overlap.  lanes = two graph instances of the whole forward replayed "
+                         "round-robin on two streams (the latency-bound kernels of one forward -- FPS: 512 dependent rounds on 64 "
+                         "CUs -- run under the MFMA/GEMM work of the other).  search = two-stage pipeline: only the search prefix "
+                         "of the first set-abstraction layer (FPS + gathers + kNN, no dense layer) of batch i+1 runs ahead on a "
+                         "second stream; the rest-graphs, which hold every vendor GEMM, stay serialised on one stream.  serial = "
+                         "one graph, one stream.  auto = lanes (stress-tested: 24k concurrent replays of the cls graph), except search for "
+                         "sem_seg, whose (4096 x 16480 x 256) hipBLASLt GEMM dead-locks the GPU when two instances of it run "
+                         "concurrently (tools/lanes_probe.py gemm_4096_16480_256; DESIGN.md 6).  1 / 2 = serial / auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (RCCL init, per-step all-gather, barriers, max-over-ranks) even with "
@@ -197,7 +203,7 @@ def main():
 
     from pointasnl_amd import _hip
     from pointasnl_amd.models import pointasnl_cls
-    from pointasnl_amd.utils import tf_util
+    from pointasnl_amd.utils import tf_util, pointasnl_util
     from pointasnl_amd import sharding
 
     _hip.lib()
@@ -211,8 +217,6 @@ def main():
 
     import importlib
 
-    if args.model == "sem_seg" and args.pipeline == 2:
-        args.pipeline = 1  # two concurrent replays of the ScanNet graph dead-lock on ROCm 7.2; serial replay
     default_pts = {"cls": 1024, "sem_seg": 8192, "sem_seg_res": 10240}[args.model]
     B, N = args.batch, (args.points or default_pts)
     if args.model != "cls" and args.batch == 64:
@@ -225,11 +229,18 @@ def main():
     x = torch.from_numpy(pc).cuda()
     store = tf_util.set_store(tf_util.VariableStore(seed=1234))  # identical weights on every rank
 
-    def forward():
+    model_mod = seg_model if seg_model is not None else pointasnl_cls
+    first_layer = model_mod.first_layer(N)
+
+    def search_prefix():
+        # FPS + gathers + kNN of the first set-abstraction layer: hand-written kernels only, no dense layer
+        return pointasnl_util.sa_search(x, x, **first_layer)
+
+    def forward(search=None):
         if seg_model is not None:
-            logits, _ = seg_model.get_model(x, False, 20)
+            logits, _ = seg_model.get_model(x, False, 20, search=search)
             return logits.reshape(B, -1)
-        logits, _ = pointasnl_cls.get_model(x, is_training=False, adaptive_sample=args.AS)
+        logits, _ = pointasnl_cls.get_model(x, is_training=False, adaptive_sample=args.AS, search=search)
         return logits
 
     width = 40 if seg_model is None else N * 20
@@ -246,31 +257,56 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = None
-        lanes = []  # (stream, graph, logits) per pipeline lane; every lane owns its intermediates
-        if not args.no_graph:
-            for lane_i in range(max(1, args.pipeline)):
-                st_l = torch.cuda.Stream()
-                st_l.wait_stream(torch.cuda.current_stream())
-                g = torch.cuda.CUDAGraph()
-                # thread_local: the RCCL watchdog thread must not be able to invalidate the capture
-                with torch.cuda.graph(g, stream=st_l, capture_error_mode="thread_local"):
-                    lg = forward()
-                lanes.append((st_l, g, lg))
-                lane_gather.append(sharding.LogitsGather(world, B, width, x.device, force=multi) if multi else None)
-            graph = lanes[0][1]
-            logits = lanes[0][2]
+        lanes = []  # one entry per buffer set: dict(P=search graph or None, R=graph, out=logits, stream, ...)
+        mode = {"1": "serial", "2": "auto"}.get(args.pipeline, args.pipeline)
+        if mode == "auto":
+            mode = "search" if args.model == "sem_seg" else "lanes"
+        if args.no_graph:
+            mode = "eager"
+        sp, sr = torch.cuda.Stream(), torch.cuda.Stream()  # search-prefix stream, rest-of-forward stream
+
+        def capture(fn, stream):
+            stream.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread must not be able to invalidate the capture
+            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
+                out = fn()
+            torch.cuda.current_stream().wait_stream(stream)
+            return g, out
+
+        if mode != "eager":
+            for li in range(1 if mode == "serial" else 2):
+                lane = {"gather": sharding.LogitsGather(world, B, width, x.device, force=multi) if multi else None, "P": None}
+                if mode == "search":
+                    lane["stream"] = sr
+                    lane["P"], srch = capture(search_prefix, sp)
+                    lane["R"], lane["out"] = capture(lambda: forward(search=srch), sr)
+                    lane["ev_p"], lane["ev_r"] = torch.cuda.Event(), torch.cuda.Event()
+                else:
+                    lane["stream"] = sr if li == 0 else sp  # lanes: every buffer set replays on its own stream
+                    lane["R"], lane["out"] = capture(forward, lane["stream"])
+                lanes.append(lane)
+            graph = lanes[0]["R"]
+            logits = lanes[0]["out"]
         step_no = [0]
 
         def step():
             if lanes:
-                li = step_no[0] % len(lanes)
-                st_l, g, lg = lanes[li]
+                lane = lanes[step_no[0] % len(lanes)]
                 step_no[0] += 1
-                with torch.cuda.stream(st_l):
-                    g.replay()
-                    if lane_gather[li] is not None:
-                        lane_gather[li].all_gather(lg)
-                return lg
+                if lane["P"] is not None:
+                    sp.wait_event(lane["ev_r"])  # the rest-graph of two steps ago has finished reading this buffer set
+                    with torch.cuda.stream(sp):
+                        lane["P"].replay()
+                        lane["ev_p"].record(sp)
+                    sr.wait_event(lane["ev_p"])
+                with torch.cuda.stream(lane["stream"]):
+                    lane["R"].replay()
+                    if lane["gather"] is not None:
+                        lane["gather"].all_gather(lane["out"])
+                    if lane["P"] is not None:
+                        lane["ev_r"].record(sr)
+                return lane["out"]
             out = forward()
             if gathered is not None:
                 gathered.all_gather(out)
@@ -295,8 +331,12 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
-        # every pipeline lane computes the same function of the same input: their outputs must be bit-identical
-        lanes_agree = all(torch.equal(lanes[0][2], l[2]) for l in lanes[1:]) if len(lanes) > 1 else None
+        # both buffer sets compute the same function of the same input, and so does the plain eager forward:
+        # the outputs must be bit-identical
+        lanes_agree = None
+        if lanes:
+            ref_out = forward()
+            lanes_agree = all(torch.equal(ref_out, l["out"]) for l in lanes)
 
         # ---- per-kernel pass: the same forward, eager, every C-ABI launch bracketed by HIP events
         rows = []
@@ -357,7 +397,7 @@ def main():
                                  "configs[1]: ModelNet40 pointasnl_cls, 1024 pts") if args.model == "cls" else
                                 f"configs[{cfg_index}]: pointasnl_{args.model}, {N} pts") + f", batch={B}/GPU, seeded random weights",
                    "global_batch": world * B, "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
-                   "hip_graph": graph is not None, "pipelined_graph_instances": len(lanes), "lanes_agree": lanes_agree},
+                   "hip_graph": graph is not None, "pipeline": mode, "outputs_agree": lanes_agree},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "handwritten_kernel_us_per_step": round(handwritten_us, 1),

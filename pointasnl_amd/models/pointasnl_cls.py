@@ -9,8 +9,13 @@ from pointasnl_amd.utils.pointnet_util import pointnet_sa_module
 from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction
 
 
+def first_layer(num_point=None):
+    """sa_search() arguments of layer1 (for callers that run the search ahead of the rest of the forward)"""
+    return dict(npoint=512, nsample=32)
+
+
 def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, weight_decay=None, num_class=40,
-              adaptive_sample=False):
+              adaptive_sample=False, search=None):
     """ Classification PointNet, input is BxNx3 (BxNx6 with normals), output Bx40 """
     batch_size = point_cloud.shape[0]
     end_points = {}
@@ -26,7 +31,7 @@ def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, w
     # Set abstraction layers
     l1_xyz, l1_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=512, nsample=32, mlp=[64, 64, 128],
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
-                                                scope='layer1', as_neighbor=as_neighbor[0])
+                                                scope='layer1', as_neighbor=as_neighbor[0], search=search)
     end_points['l1_xyz'] = l1_xyz
     l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=128, nsample=64, mlp=[128, 128, 256],
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,

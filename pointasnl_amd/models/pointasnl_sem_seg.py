@@ -5,7 +5,12 @@ from pointasnl_amd.utils import tf_util
 from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction, PointASNLDecodingLayer
 
 
-def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=None, feature_channel=0):
+def first_layer(num_point):
+    """sa_search() arguments of layer1 (for callers that run the search ahead of the rest of the forward)"""
+    return dict(npoint=num_point // 8, nsample=32)
+
+
+def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=None, feature_channel=0, search=None):
     """ Semantic segmentation PointNet, input is B x N x (3+feature_channel), output B x N x num_class """
     end_points = {}
     num_point = point_cloud.shape[1]
@@ -20,7 +25,7 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
     kw = dict(is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay)
     # Feature encoding layers
     l1_xyz, l1_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=num_points[0], nsample=32, mlp=[32, 32, 64],
-                                                scope='layer1', as_neighbor=8, **kw)
+                                                scope='layer1', as_neighbor=8, search=search, **kw)
     l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=num_points[1], nsample=32, mlp=[64, 64, 128],
                                                 scope='layer2', as_neighbor=4, **kw)
     l3_xyz, l3_points = PointASNLSetAbstraction(l2_xyz, l2_points, npoint=num_points[2], nsample=32, mlp=[128, 128, 256],

@@ -6,7 +6,12 @@ from pointasnl_amd.utils.pointnet_util import pointnet_fp_module
 from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction
 
 
-def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=None, feature_channel=0):
+def first_layer(num_point):
+    """sa_search() arguments of layer0 (npoint == num_point: no sampling, the kNN over the full cloud)"""
+    return dict(npoint=num_point, nsample=32)
+
+
+def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=None, feature_channel=0, search=None):
     """ Semantic segmentation PointNet, input is B x N x (3+feature_channel), output B x N x num_class """
     end_points = {}
     num_point = point_cloud.shape[1]
@@ -20,7 +25,7 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
     num_points = [num_point // 8, num_point // 32, num_point // 128, num_point // 256]
     kw = dict(is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay)
     _, l0_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=num_point, nsample=32, mlp=[16, 16, 32],
-                                           scope='layer0', as_neighbor=0, NL=False, **kw)
+                                           scope='layer0', as_neighbor=0, NL=False, search=search, **kw)
     # 1st Res Layer
     l1_xyz, l1_1_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=num_points[0], nsample=32, mlp=[32, 32, 64],
                                                   scope='layer1_1', as_neighbor=8, **kw)

@@ -259,8 +259,24 @@ def PointNonLocalCell(feature, new_point, mlp, is_training, bn_decay, weight_dec
         return new_nonlocal_point
 
 
+def sa_search(xyz, feature, npoint, nsample, use_knn=True, radius=None):
+    """The search prefix of a set-abstraction layer (pointasnl_util.py:236-242): farthest point sampling + gathers
+    (skipped when npoint == ndataset) and the neighbour search.  No dense layer is involved, so a serving loop can
+    run it for batch i+1 on a second stream while the rest of batch i computes (bench.py --pipeline 2).
+    -> (new_xyz (B,npoint,3), new_feature (B,npoint,C), idx (B,npoint,nsample))"""
+    if feature.shape[1] == npoint:
+        new_xyz, new_feature = xyz, feature
+    else:
+        new_xyz, new_feature = sampling(npoint, xyz, feature)
+    if use_knn:
+        idx = knn_query(nsample, xyz, new_xyz)
+    else:
+        idx, _ = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+    return new_xyz, new_feature, idx
+
+
 def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_decay, weight_decay, scope, bn=True,
-                            use_knn=True, radius=None, as_neighbor=8, NL=True):
+                            use_knn=True, radius=None, as_neighbor=8, NL=True, search=None):
     ''' Input:
             xyz: (batch_size, ndataset, 3) tensor
             feature: (batch_size, ndataset, channel) tensor
@@ -273,18 +289,9 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
     '''
     with tf_util.variable_scope(scope):
         batch_size, num_points, num_channel = feature.shape
-        '''Farthest Point Sampling'''
-        if num_points == npoint:
-            new_xyz = xyz
-            new_feature = feature
-        else:
-            new_xyz, new_feature = sampling(npoint, xyz, feature)
-
-        # neighbour search (the reference's grouping(): pointasnl_util.py:242 -> :51-76)
-        if use_knn:
-            idx = knn_query(nsample, xyz, new_xyz)
-        else:
-            idx, _ = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+        # Farthest point sampling + neighbour search (the reference's sampling() / grouping(): pointasnl_util.py:236-242);
+        # `search` = the result of sa_search() on the same inputs, computed ahead by the caller
+        new_xyz, new_feature, idx = search if search is not None else sa_search(xyz, feature, npoint, nsample, use_knn, radius)
         nl_channel = mlp[-1]
 
         '''Adaptive Sampling'''

@@ -26,10 +26,16 @@ if what.startswith("gemm"):
     shapes = [(131072, 4192, 128), (131072, 131, 128), (131072, 128, 128), (16384, 8288, 256), (16384, 320, 128)]
     if what == "gemm_bigk":  # fa_layer2 / fa_layer1 decode_after_conv: few rows, K = (3+c)*32
         shapes = [(4096, 16480, 256), (1024, 16480, 512), (4096, 384, 256), (16384, 8288, 256)]
+    if what.startswith("gemm_") and what[5:6].isdigit():  # gemm_M_K_N
+        shapes = [tuple(int(v) for v in what.split("_")[1:4])]
     if what == "gemm_small":
         shapes = [(32768, 2048, 128), (8192, 4096, 256), (32768, 131, 128), (32768, 128, 256), (32768, 256, 512)]
     GEMMS = [(torch.randn((m_, k_), device="cuda"), (torch.randn((k_, n_), device="cuda") * 0.01, torch.zeros(n_, device="cuda")))
              for (m_, k_, n_) in shapes]
+
+
+XC = torch.from_numpy(B.synth_clouds(5, 64, 1024)).cuda()
+XR = torch.from_numpy(B.synth_clouds(6, 8, 10240)).cuda() if what == "res" else None
 
 
 def fwd():
@@ -83,6 +89,15 @@ def fwd():
             lvl = 3 - di
             cur = U.PointASNLDecodingLayer(xs[lvl], xs[lvl + 1], ps[lvl], cur, 16, dm[di], False, None, None, scope='fa_layer%d' % (di + 1))
         return cur
+    if what == "res":
+        from pointasnl_amd.models import pointasnl_sem_seg_res
+        return pointasnl_sem_seg_res.get_model(XR, False, 20)[0]
+    if what == "cls":
+        from pointasnl_amd.models import pointasnl_cls
+        return pointasnl_cls.get_model(XC)[0]
+    if what == "cls_as":
+        from pointasnl_amd.models import pointasnl_cls
+        return pointasnl_cls.get_model(XC, adaptive_sample=True)[0]
     if what == "full":
         return pointasnl_sem_seg.get_model(x, False, 20)[0]
     raise SystemExit("unknown")
@@ -105,6 +120,8 @@ with torch.no_grad():
         st, g, _ = lanes[i % 2]
         with torch.cuda.stream(st):
             g.replay()
+            if os.environ.get("JITTER") and i % 7 == 3:
+                torch.cuda._sleep(int(2.4e3 * (37 * i % 400)))  # up to 400 us of idle on this lane: shifts the lanes' phase
         if os.environ.get("SYNC_EACH"):
             torch.cuda.synchronize()
         if i < 4 or os.environ.get("SYNC_EACH"):
