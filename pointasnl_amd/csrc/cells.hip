@@ -1114,7 +1114,12 @@ static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const floa
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), NW * 64, lds) != hipSuccess ||
       per_cu < 1)
     per_cu = 1;
-  long cap = 256L * per_cu;
+  // Over-subscribing the resident count (so that the hardware dispatcher balances the load when another stream's
+  // kernels keep some CUs busy) was measured and lost: staging the weights costs ~7 us per workgroup (cls layer2:
+  // 429 / 455 / 505 / 528 us at 1x / 2x / 4x / 8x, and the two-lane cls step 1.52 / 1.54 / 1.60 / 1.65 ms).
+  int os = 1;
+  if (const char* e = getenv("PASNL_SA_CELL_OS")) os = atoi(e) > 0 ? atoi(e) : 1;  // A/B measurements only
+  long cap = 256L * per_cu * os;
   hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(NW * 64), lds, st, groups, k, w, src, w0, b0, w1, b1, ww,
                      bw, out);
   return pasnl_launch_status();
