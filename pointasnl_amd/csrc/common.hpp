@@ -73,4 +73,26 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
   return (dx * dx + dy * dy) + dz * dz;
 }
 
+// The same canonical distance from one point to QW queries at once, written on 2-vectors so that the compiler emits
+// v_pk_add/mul_f32 (two queries per instruction; each component is the identical IEEE operation sequence, and
+// (p-q)^2 == (q-p)^2 bit for bit).
+typedef float pasnl_f32x2 __attribute__((ext_vector_type(2)));
+template <int QW>
+__device__ __forceinline__ void dist2_multi(const float (&qx)[QW], const float (&qy)[QW], const float (&qz)[QW], float x, float y,
+                                            float z, float (&d)[QW]) {
+  static_assert(QW % 2 == 0 || QW == 1, "queries are processed in pairs");
+  if constexpr (QW == 1) {
+    d[0] = dist2(qx[0], qy[0], qz[0], x, y, z);
+  } else {
+#pragma unroll
+    for (int i = 0; i < QW; i += 2) {
+      const pasnl_f32x2 dx = pasnl_f32x2{qx[i], qx[i + 1]} - x, dy = pasnl_f32x2{qy[i], qy[i + 1]} - y,
+                        dz = pasnl_f32x2{qz[i], qz[i + 1]} - z;
+      const pasnl_f32x2 r = (dx * dx + dy * dy) + dz * dz;
+      d[i] = r[0];
+      d[i + 1] = r[1];
+    }
+  }
+}
+
 }  // namespace pasnl

@@ -439,9 +439,11 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn_kernel(int n, int m, in
       int p = it + lane;
       bool in = p < tcnt;
       float x = in ? sx[p] : 0.f, y = in ? sy[p] : 0.f, z = in ? sz[p] : 0.f;
+      float dq[QW];
+      dist2_multi<QW>(qx, qy, qz, x, y, z, dq);
 #pragma unroll
       for (int q = 0; q < QW; ++q) {
-        float d = dist2(qx[q], qy[q], qz[q], x, y, z);
+        float d = dq[q];
         unsigned long long mask = __ballot(in && d < tau[q]);
         while (mask) {
           int src = (int)__builtin_ctzll(mask);
@@ -567,9 +569,11 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
       int p = it + lane;
       bool in = p < tcnt;
       float x = in ? sx[p] : 0.f, y = in ? sy[p] : 0.f, z = in ? sz[p] : 0.f;
+      float dq[QW];
+      dist2_multi<QW>(qx, qy, qz, x, y, z, dq);
 #pragma unroll
       for (int q = 0; q < QW; ++q) {
-        uint32_t di = in ? __float_as_uint(dist2(qx[q], qy[q], qz[q], x, y, z)) : INF_BITS;
+        uint32_t di = in ? __float_as_uint(dq[q]) : INF_BITS;
         if (R == 2) m2[q] = min(m2[q], max(m1[q], di));
         m1[q] = min(m1[q], di);
       }
@@ -604,9 +608,11 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
       int p = it + lane;
       bool in = p < tcnt;
       float x = in ? sx[p] : 0.f, y = in ? sy[p] : 0.f, z = in ? sz[p] : 0.f;
+      float dq[QW];
+      dist2_multi<QW>(qx, qy, qz, x, y, z, dq);
 #pragma unroll
       for (int q = 0; q < QW; ++q) {
-        uint32_t di = __float_as_uint(dist2(qx[q], qy[q], qz[q], x, y, z));
+        uint32_t di = __float_as_uint(dq[q]);
         bool c = in && di <= U[q];
         unsigned long long mask = __ballot(c);
         if (mask) {
