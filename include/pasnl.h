@@ -209,6 +209,11 @@ int pasnl_three_interpolate_grad_det(int b, int n, int c, int m, const float* gr
 int pasnl_decode_cell(int b, int n, int c, int k, const float* xyz, const float* feature, const int* idx, const float* ww,
                       const float* bw, float* out, pasnl_stream_t stream);
 
+/* AdaptiveSampling with as_neighbor == 0 (pointasnl_util.py:161-164): new_xyz (b,m,3) = xyz[idx[b,j,0]] and
+ * new_feature (b,m,3+c) = [xyz | feature][idx[b,j,0]], idx (b,m,k) the neighbour indices of the layer. */
+int pasnl_take_neighbor0(int b, int n, int c, int m, int k, const float* xyz, const float* feature, const int* idx,
+                         float* new_xyz, float* new_feature, pasnl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -924,6 +924,27 @@ __global__ __launch_bounds__(256) void grad_segsum_kernel(int n, int c, long ent
 }
 
 // ---------------------------------------------------------------------------------------------
+// AdaptiveSampling with as_neighbor == 0 (pointasnl_util.py:161-164): the sampled point is replaced by its nearest
+// neighbour (index idx[b,j,0] -- normally itself, a lower-indexed duplicate otherwise):
+//     new_xyz[b,j] = xyz[b,i],   new_feature[b,j] = [xyz[b,i] | feature[b,i]],   i = idx[b,j,0]
+// One launch instead of the reference's slice + two gathers + concat + two slices.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void take_neighbor0_kernel(int n, int c, int m, int k, long total, const float* __restrict__ xyz,
+                                                            const float* __restrict__ feature, const int* __restrict__ idx,
+                                                            float* __restrict__ new_xyz, float* __restrict__ new_feature) {
+  const int w = 3 + c;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long row = e / w;  // (b, j)
+    const int col = (int)(e - row * w);
+    const long bi = row / m;
+    const int i = idx[row * k];
+    const float v = col < 3 ? xyz[((size_t)bi * n + i) * 3 + col] : feature[((size_t)bi * n + i) * c + (col - 3)];
+    new_feature[e] = v;
+    if (col < 3) new_xyz[row * 3 + col] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // max_pool_rows: out[b, c] = max_s x[b, s, c]  -- the PointNet set-abstraction pooling over the points of a
 // region (pointnet_util.py:137, tf.reduce_max(new_points, axis=[2])).  One workgroup per (cloud, 64-channel
 // slab): lanes over channels (coalesced 256-byte rows), the 4 waves split the rows, partial maxima meet in LDS.
@@ -1097,7 +1118,7 @@ extern "C" int pasnl_knn_batch(int b, int n, int m, int k, const float* support,
   // Two-pass selection wins wherever selection dominates (measured: 2.6x at N=1024,K=32; 3.7x at N=512,K=64); for
   // small K over large clouds both kernels are bound by the distance loop and the single pass is ahead
   // (N=8192,K=16: 795 vs 982 us).  PASNL_KNN_INSERTION=1 forces the insertion kernel (A/B measurements).
-  if (k <= 64 && !(k <= 16 && n > 2048) && !getenv("PASNL_KNN_INSERTION")) {
+  if (k <= 64 && (!(k <= 16 && n > 2048) || getenv("PASNL_KNN_TWO_PASS")) && !getenv("PASNL_KNN_INSERTION")) {
     constexpr int QW = 4;
     dim3 grid((m + SEARCH_WAVES * QW - 1) / (SEARCH_WAVES * QW), b), block(SEARCH_WAVES * 64);
 #define PASNL_KNN2(RR, T) hipLaunchKernelGGL((knn2_kernel<RR, QW, T>), grid, block, 0, st, n, m, k, support, queries, static_cast<T*>(idx), dist2)
@@ -1218,6 +1239,17 @@ extern "C" int pasnl_three_interpolate_grad_det(int b, int n, int c, int m, cons
   PASNL_REQUIRE(n == 0 || weight, PASNL_ENULL);
   // targets are the m known points; contributions e = 3*i + k of unknown point i (tf_interpolate.cpp:137-151 order)
   return grad_det(b, m, c, 3L * n, 3, grad_out, weight, idx, grad_points, ws, ws_bytes, pasnl_hip_stream(stream));
+}
+
+extern "C" int pasnl_take_neighbor0(int b, int n, int c, int m, int k, const float* xyz, const float* feature, const int* idx,
+                                    float* new_xyz, float* new_feature, pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && m >= 0 && k > 0, PASNL_EINVAL);
+  long total = (long)b * m * (3 + c);
+  if (total == 0) return PASNL_OK;
+  PASNL_REQUIRE(xyz && feature && idx && new_xyz && new_feature, PASNL_ENULL);
+  hipLaunchKernelGGL(take_neighbor0_kernel, dim3(grid_for(total)), dim3(256), 0, pasnl_hip_stream(stream), n, c, m, k, total, xyz,
+                     feature, idx, new_xyz, new_feature);
+  return pasnl_launch_status();
 }
 
 extern "C" int pasnl_max_pool_rows(int b, int n, int c, const float* x, float* out, pasnl_stream_t stream) {

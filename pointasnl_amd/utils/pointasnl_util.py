@@ -295,9 +295,16 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
         nl_channel = mlp[-1]
 
         '''Adaptive Sampling'''
-        if num_points != npoint:
-            # AdaptiveSampling only ever reads the first `as_neighbor` neighbours (:165-166; neighbour 0 when
-            # as_neighbor == 0, :161-164): gather just those instead of slicing the full grouped tensors
+        if num_points != npoint and as_neighbor == 0:
+            # AdaptiveSampling with num_neighbor == 0 takes neighbour 0 of every group (:161-164): one gather kernel
+            xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
+            new_xyz = torch.empty((batch_size, npoint, 3), dtype=torch.float32, device=xyz.device)
+            new_feature = torch.empty((batch_size, npoint, 3 + num_channel), dtype=torch.float32, device=xyz.device)
+            _hip.launch("pasnl_take_neighbor0", "take_neighbor0", batch_size, num_points, num_channel, npoint, nsample,
+                        _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx), _hip.ptr(new_xyz), _hip.ptr(new_feature))
+        elif num_points != npoint:
+            # AdaptiveSampling only ever reads the first `as_neighbor` neighbours (:165-166): gather just those
+            # instead of slicing the full grouped tensors
             k_as = max(1, as_neighbor)
             idx_as = idx[:, :, :k_as].contiguous()
             g_xyz = tf_grouping.group_point(xyz, idx_as)
