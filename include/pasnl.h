@@ -214,6 +214,18 @@ int pasnl_decode_cell(int b, int n, int c, int k, const float* xyz, const float*
 int pasnl_take_neighbor0(int b, int n, int c, int m, int k, const float* xyz, const float* feature, const int* idx,
                          float* new_xyz, float* new_feature, pasnl_stream_t stream);
 
+/* AdaptiveSampling without the grouped tensors (pointasnl_util.py:121-171):
+ *   pasnl_as_gather: x (b,m,as,6+c) = [xyz[i_s]-xyz[i_0] | xyz[i_s] | feature[i_s]], i_s = idx[b,j,s], s < as -- the
+ *     input of conv_kv_ds / conv_query_ds (concat(normalized_xyz, shift_group_points)); idx (b,m,k) with k >= as.
+ *   pasnl_as_attention_qkv: as pasnl_as_attention on ONE tensor kvq (g,as,3*cb) = [K | V | Q] per row (the output of
+ *     a single GEMM with the conv_kv_ds and conv_query_ds weights side by side).
+ *   pasnl_as_reweight_x: as pasnl_as_reweight, reading coordinates and (xyz | feature) rows (ch = 3+c channels) from x. */
+int pasnl_as_gather(int b, int n, int c, int m, int k, int as, const float* xyz, const float* feature, const int* idx, float* out,
+                    pasnl_stream_t stream);
+int pasnl_as_attention_qkv(int g, int as, int cb, const float* kvq, float* out, pasnl_stream_t stream);
+int pasnl_as_reweight_x(int g, int as, int ch, const float* logits, const float* x, float* new_xyz, float* new_feature,
+                        pasnl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -261,22 +261,23 @@ __global__ __launch_bounds__(TB) void nl_attention_valu_kernel(int p, int n, flo
 //   softmax over keys = 4 in-lane values + exchanges with lanes l^16, l^32
 //   O^T[ch][query] += V^T . P^T with step t contracting key 4*(l>>4)+t
 // =============================================================================================
-__global__ __launch_bounds__(256) void as_attention_kernel(long groups, int as, int cb, float qscale,
+__global__ __launch_bounds__(256) void as_attention_kernel(long groups, int as, int cb, float qscale, int qs, int kvs,
                                                           const float* __restrict__ q, const float* __restrict__ kv,
                                                           float* __restrict__ out) {
+  // qs / kvs = row strides of q and kv in floats (cb and 2cb for separate tensors; 3cb for one [K|V|Q] tensor)
   const int lane = threadIdx.x & 63;
   const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (g >= groups) return;
   const int col = lane & 15, grp = lane >> 4;
-  const float* qg = q + (size_t)g * as * cb;
-  const float* kg = kv + (size_t)g * as * 2 * cb;
+  const float* qg = q + (size_t)g * as * qs;
+  const float* kg = kv + (size_t)g * as * kvs;
   const bool rowok = col < as;  // this lane's key row (as A operand) / query (as B operand) exists
   f32x4 S = {0.f, 0.f, 0.f, 0.f};
   for (int c0 = 0; c0 < cb; c0 += 4) {
     int c = c0 + grp;
     bool okc = rowok && c < cb;
-    float a = okc ? kg[(size_t)col * 2 * cb + c] : 0.f;
-    float b = okc ? qg[(size_t)col * cb + c] * qscale : 0.f;
+    float a = okc ? kg[(size_t)col * kvs + c] : 0.f;
+    float b = okc ? qg[(size_t)col * qs + c] * qscale : 0.f;
     S = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, S, 0, 0, 0);
   }
   float tmax = -INFINITY;
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(256) void as_attention_kernel(long groups, int as, 
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       int key = 4 * grp + t;
-      float a = (key < as && ch < cb) ? vg[(size_t)key * 2 * cb + ch] : 0.f;
+      float a = (key < as && ch < cb) ? vg[(size_t)key * kvs + ch] : 0.f;
       O = __builtin_amdgcn_mfma_f32_16x16x4f32(a, S[t], O, 0, 0, 0);
     }
     // O^T[ch = c0 + 4*grp + r][query = col]
@@ -321,10 +322,11 @@ __global__ __launch_bounds__(256) void as_attention_kernel(long groups, int as, 
 // One thread per (group, column) of the (1+ch)-wide logits; column 0 re-weights xyz.
 // =============================================================================================
 constexpr int AS_MAX = 16;
-__global__ __launch_bounds__(256) void as_reweight_kernel(long groups, int as, int nsample, int ch,
+__global__ __launch_bounds__(256) void as_reweight_kernel(long groups, int as, int nsample, int ch, int xs, int fs,
                                                          const float* __restrict__ logits,
                                                          const float* __restrict__ gxyz, const float* __restrict__ gfeat,
                                                          float* __restrict__ new_xyz, float* __restrict__ new_feature) {
+  // xs / fs = row strides of the grouped coordinates / features in floats (3 and ch for separate tensors)
   const int w = 1 + ch;
   const long total = groups * w;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -345,20 +347,20 @@ __global__ __launch_bounds__(256) void as_reweight_kernel(long groups, int as, i
     }
     if (c == 0) {
       float ax = 0.f, ay = 0.f, az = 0.f;
-      const float* xp = gxyz + (size_t)g * nsample * 3;
+      const float* xp = gxyz + (size_t)g * nsample * xs;
 #pragma unroll
       for (int k = 0; k < AS_MAX; ++k)
         if (k < as) {
           float wk = v[k] / sum;
-          ax += xp[k * 3] * wk; ay += xp[k * 3 + 1] * wk; az += xp[k * 3 + 2] * wk;
+          ax += xp[k * xs] * wk; ay += xp[k * xs + 1] * wk; az += xp[k * xs + 2] * wk;
         }
       new_xyz[g * 3] = ax; new_xyz[g * 3 + 1] = ay; new_xyz[g * 3 + 2] = az;
     } else {
       float a = 0.f;
-      const float* fp = gfeat + (size_t)g * nsample * ch + (c - 1);
+      const float* fp = gfeat + (size_t)g * nsample * fs + (c - 1);
 #pragma unroll
       for (int k = 0; k < AS_MAX; ++k)
-        if (k < as) a += fp[(size_t)k * ch] * (v[k] / sum);
+        if (k < as) a += fp[(size_t)k * fs] * (v[k] / sum);
       new_feature[(size_t)g * ch + (c - 1)] = a;
     }
   }
@@ -901,6 +903,37 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 
 
 // =============================================================================================
+// AdaptiveSampling input (pointasnl_util.py:121-124,165-166): for every group the first `as` neighbours as rows
+//     [xyz[i_s] - xyz[i_0] | xyz[i_s] | feature[i_s]]   (as x (6+C)),   i_s = idx[b,j,s]
+// = concat(normalized_xyz, shift_group_points) of the reference, gathered straight from the tables (one launch
+// instead of two gathers, a slice, a subtraction and two concats).  Columns 3.. are also the (xyz | feature) rows
+// the re-weighting tail needs, so nothing else of the grouped tensors is ever materialised.
+// =============================================================================================
+__global__ __launch_bounds__(256) void as_gather_kernel(int n, int c, int m, int k, int as, long total,
+                                                       const float* __restrict__ xyz, const float* __restrict__ feature,
+                                                       const int* __restrict__ idx, float* __restrict__ out) {
+  const int w = 6 + c;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long row = e / w;  // (b, j, s)
+    const int col = (int)(e - row * w);
+    const long gj = row / as;  // (b, j)
+    const int sidx = (int)(row - gj * as);
+    const long bi = gj / m;
+    const int i = idx[gj * k + sidx];
+    float v;
+    if (col < 3) {
+      const int i0 = idx[gj * k];
+      v = xyz[((size_t)bi * n + i) * 3 + col] - xyz[((size_t)bi * n + i0) * 3 + col];
+    } else if (col < 6) {
+      v = xyz[((size_t)bi * n + i) * 3 + (col - 3)];
+    } else {
+      v = feature[((size_t)bi * n + i) * c + (col - 6)];
+    }
+    out[e] = v;
+  }
+}
+
+// =============================================================================================
 // Decoder local cell (PointASNLDecodingLayer, pointasnl_util.py:323-331): for every point p of the dense level,
 //     F = [xyz[i_s] | feature[i_s]]            (k x (3+c))   i_s = idx[p, s], the point's k nearest neighbours
 //     G = relu((xyz[i_s] - xyz[p]) Ww + bw)     (k x 32)      weight net on the centred coordinates
@@ -1052,7 +1085,30 @@ extern "C" int pasnl_as_attention(int g, int as, int cb, const float* q, const f
   PASNL_REQUIRE(q && kv && out, PASNL_ENULL);
   const float qscale = LOG2E / sqrtf((float)cb);
   hipLaunchKernelGGL(as_attention_kernel, dim3((unsigned)(((long)g + 3) / 4)), dim3(256), 0, pasnl_hip_stream(stream), (long)g,
-                     as, cb, qscale, q, kv, out);
+                     as, cb, qscale, cb, 2 * cb, q, kv, out);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_as_attention_qkv(int g, int as, int cb, const float* kvq, float* out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(g >= 0 && as > 0 && cb > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(as <= 16 && cb <= 256, PASNL_EUNSUPPORTED);
+  if (g == 0) return PASNL_OK;
+  PASNL_REQUIRE(kvq && out, PASNL_ENULL);
+  const float qscale = LOG2E / sqrtf((float)cb);
+  hipLaunchKernelGGL(as_attention_kernel, dim3((unsigned)(((long)g + 3) / 4)), dim3(256), 0, pasnl_hip_stream(stream), (long)g,
+                     as, cb, qscale, 3 * cb, 3 * cb, kvq + 2 * cb, kvq, out);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_as_gather(int b, int n, int c, int m, int k, int as, const float* xyz, const float* feature, const int* idx,
+                               float* out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && m >= 0 && k > 0 && as > 0 && as <= k, PASNL_EINVAL);
+  long total = (long)b * m * as * (6 + c);
+  if (total == 0) return PASNL_OK;
+  PASNL_REQUIRE(xyz && feature && idx && out, PASNL_ENULL);
+  long grid = (total + 255) / 256;
+  hipLaunchKernelGGL(as_gather_kernel, dim3((unsigned)(grid > 16384 ? 16384 : grid)), dim3(256), 0, pasnl_hip_stream(stream), n, c,
+                     m, k, as, total, xyz, feature, idx, out);
   return pasnl_launch_status();
 }
 
@@ -1065,7 +1121,22 @@ extern "C" int pasnl_as_reweight(int g, int as, int nsample, int ch, const float
   long total = (long)g * (1 + ch);
   long grid = (total + 255) / 256;
   hipLaunchKernelGGL(as_reweight_kernel, dim3((unsigned)(grid > 16384 ? 16384 : grid)), dim3(256), 0, pasnl_hip_stream(stream),
-                     (long)g, as, nsample, ch, logits, grouped_xyz, grouped_feature, new_xyz, new_feature);
+                     (long)g, as, nsample, ch, 3, ch, logits, grouped_xyz, grouped_feature, new_xyz, new_feature);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_as_reweight_x(int g, int as, int ch, const float* logits, const float* x, float* new_xyz,
+                                   float* new_feature, pasnl_stream_t stream) {
+  PASNL_REQUIRE(g >= 0 && as > 0 && ch > 3, PASNL_EINVAL);
+  PASNL_REQUIRE(as <= AS_MAX, PASNL_EUNSUPPORTED);
+  if (g == 0) return PASNL_OK;
+  PASNL_REQUIRE(logits && x && new_xyz && new_feature, PASNL_ENULL);
+  // x rows = [xyz - xyz0 | xyz | feature] (3 + ch floats): coordinates and the (xyz | feature) rows both start at column 3
+  const int w = 3 + ch;
+  long total = (long)g * (1 + ch);
+  long grid = (total + 255) / 256;
+  hipLaunchKernelGGL(as_reweight_kernel, dim3((unsigned)(grid > 16384 ? 16384 : grid)), dim3(256), 0, pasnl_hip_stream(stream),
+                     (long)g, as, as, ch, w, w, logits, x + 3, x + 3, new_xyz, new_feature);
   return pasnl_launch_status();
 }
 

@@ -218,6 +218,45 @@ def AdaptiveSampling(group_xyz, group_feature, num_neighbor, is_training, bn_dec
         return new_xyz, new_feature
 
 
+AS_FUSED = True  # False = the reference's op-by-op AdaptiveSampling / SampleWeights chain on gathered tensors
+
+
+def adaptive_sampling_fused(xyz, feature, idx, num_neighbor, scope, bn):
+    """AdaptiveSampling + SampleWeights (pointasnl_util.py:112-173) without the grouped tensors: one gather builds the
+    (B,P,as,6+C) input of the two projections, ONE GEMM produces [K | V | Q], the micro attention reads it in place,
+    and the re-weighting tail reads coordinates and features from the same gathered rows.  Same variables as the
+    op-by-op chain (scopes <scope>/<scope>/conv_kv_ds, conv_query_ds, mlp2_0, mlp2_1)."""
+    b, n, c = feature.shape
+    _, p, k = idx.shape
+    as_ = int(num_neighbor)
+    channel = 3 + c
+    cb = max(32, channel // 2)
+    xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
+    x = torch.empty((b, p, as_, 6 + c), dtype=torch.float32, device=xyz.device)
+    _hip.launch("pasnl_as_gather", "as_gather", b, n, c, p, k, as_, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx), _hip.ptr(x))
+    st = tf_util.store()
+    with tf_util.variable_scope(scope), tf_util.variable_scope(scope):  # AdaptiveSampling's and SampleWeights' scopes
+        key = st.path("kvq_fused")
+        if key not in st._folded:
+            with tf_util.variable_scope('conv_kv_ds'):
+                wkv, bkv = st.layer(6 + c, 2 * cb, bn)
+            with tf_util.variable_scope('conv_query_ds'):
+                wq, bq = st.layer(6 + c, cb, bn)
+            st._folded[key] = (torch.cat([wkv, wq], dim=1).contiguous(), torch.cat([bkv, bq]).contiguous())
+        wkvq, bkvq = st._folded[key]
+        kvq = torch.addmm(bkvq, x.reshape(-1, 6 + c), wkvq)  # (B*P*as, 3cb) = [K | V | Q]
+        att = torch.empty((b, p, as_, cb), dtype=torch.float32, device=xyz.device)
+        _hip.launch("pasnl_as_attention_qkv", "as_attention", b * p, as_, cb, _hip.ptr(kvq), _hip.ptr(att))
+        hid = tf_util.conv2d(att, 32, [1, 1], padding='VALID', stride=[1, 1], bn=bn, is_training=False, scope='mlp2_0')
+        logits = tf_util.conv2d(hid, 1 + channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn, is_training=False,
+                                scope='mlp2_1', activation_fn=None).contiguous()
+    new_xyz = torch.empty((b, p, 3), dtype=torch.float32, device=xyz.device)
+    new_feature = torch.empty((b, p, channel), dtype=torch.float32, device=xyz.device)
+    _hip.launch("pasnl_as_reweight_x", "as_reweight", b * p, as_, channel, _hip.ptr(logits), _hip.ptr(x), _hip.ptr(new_xyz),
+                _hip.ptr(new_feature))
+    return new_xyz, new_feature
+
+
 def nl_attention(q, kv, variant=None):
     """softmax(q k^T / sqrt(cb)) v with K,V = halves of kv; q (B,P,cb), kv (B,N,2cb) -> (B,P,cb).  Fused."""
     b, p, cb = q.shape
@@ -302,6 +341,9 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
             new_feature = torch.empty((batch_size, npoint, 3 + num_channel), dtype=torch.float32, device=xyz.device)
             _hip.launch("pasnl_take_neighbor0", "take_neighbor0", batch_size, num_points, num_channel, npoint, nsample,
                         _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx), _hip.ptr(new_xyz), _hip.ptr(new_feature))
+        elif num_points != npoint and AS_FUSED and as_neighbor <= 16:
+            tf_util._require_inference(is_training)
+            new_xyz, new_feature = adaptive_sampling_fused(xyz, feature, idx, as_neighbor, scope, bn)
         elif num_points != npoint:
             # AdaptiveSampling only ever reads the first `as_neighbor` neighbours (:165-166): gather just those
             # instead of slicing the full grouped tensors
