@@ -242,3 +242,25 @@ def test_decode_cell(b, n, c, k):
     assert got.shape == want.shape == (b, n, 3 + c, 32)
     scale = np.abs(want).max()
     assert np.abs(got - want).max() / scale < 1e-5
+
+
+@pytest.mark.parametrize("b,n,c,m,k,as_", [(2, 1024, 3, 512, 32, 12), (2, 512, 128, 128, 64, 12), (1, 300, 3, 77, 32, 8),
+                                          (1, 200, 64, 50, 32, 4), (1, 64, 32, 9, 16, 16)])
+def test_adaptive_sampling_fused(b, n, c, m, k, as_):
+    """AdaptiveSampling + SampleWeights (pointasnl_util.py:112-173) without grouped tensors (as_gather + one [K|V|Q]
+    GEMM + strided micro attention + re-weighting) vs the fp64 restatement on explicitly gathered groups."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    st = _store(n + c + as_)
+    rng = np.random.default_rng(c * 5 + as_)
+    xyz = clouds(12, b, n)
+    feat = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, k)).astype(np.int32)
+    with st.scope("layerA"):
+        new_xyz, new_feat = U.adaptive_sampling_fused(dev(xyz), dev(feat), dev(idx), as_, "layerA", True)
+    bi = np.arange(b)[:, None, None]
+    gx = xyz[bi, idx].astype(np.float64)
+    gf = np.concatenate([gx, feat[bi, idx].astype(np.float64)], axis=-1)
+    want_xyz, want_feat = cells.adaptive_sampling(gx, gf, as_, st.export_numpy(), "layerA", outer="layerA")
+    np.testing.assert_allclose(new_xyz.cpu().numpy(), want_xyz, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(new_feat.cpu().numpy(), want_feat, rtol=1e-5, atol=2e-5)
