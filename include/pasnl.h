@@ -226,6 +226,18 @@ int pasnl_as_attention_qkv(int g, int as, int cb, const float* kvq, float* out, 
 int pasnl_as_reweight_x(int g, int as, int ch, const float* logits, const float* x, float* new_xyz, float* new_feature,
                         pasnl_stream_t stream);
 
+/* Voxel-grid subsampling (utils/cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp:4-106), the input
+ * stage of the ScanNet / SemanticKITTI "grid" pipelines: points (n,3) [+ features (n,fdim)] [+ classes (n,ldim)] ->
+ * one row per occupied voxel of edge sample_dl: barycentre, feature mean, majority label.  Voxel keys, fp32 sums in
+ * input order and the barycentre / mean arithmetic follow the reference bit for bit; rows come out in ASCENDING VOXEL
+ * KEY (the reference emits unordered_map iteration order) and a label tie goes to the smallest label (the reference:
+ * first maximum in hash order).  Outputs are sized for n rows; out_count (device int) receives the number of voxels.
+ * workspace: pasnl_grid_subsample_workspace_bytes(n) bytes of device memory.  No host synchronisation. */
+size_t pasnl_grid_subsample_workspace_bytes(long n);
+int pasnl_grid_subsample(long n, int fdim, int ldim, const float* points, const float* features, const int* classes,
+                         float sample_dl, float* out_points, float* out_features, int* out_classes, int* out_count,
+                         void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,3 +193,23 @@ class ops:
         w = np.zeros_like(dist)
         lib().oracle_three_weights(ctypes.c_long(dist.size // 3), _p(dist), _p(w))
         return w
+
+    @staticmethod
+    def grid_subsample(points, features=None, classes=None, sampleDl=0.1):
+        """-> (points[, features][, classes]) in ascending voxel-key order (oracle_grid_subsample)"""
+        points = _f32(points)
+        n = points.shape[0]
+        feats = _f32(features) if features is not None else np.zeros((n, 0), np.float32)
+        cls = _i32(classes) if classes is not None else np.zeros((n, 0), np.int32)
+        fdim, ldim = feats.shape[1], cls.shape[1]
+        op, of, oc = np.zeros((n, 3), np.float32), np.zeros((n, fdim), np.float32), np.zeros((n, ldim), np.int32)
+        fn = lib().oracle_grid_subsample
+        m = fn(ctypes.c_long(n), fdim, ldim, _p(points), _p(feats), _p(cls), ctypes.c_float(sampleDl), _p(op), _p(of), _p(oc))
+        out = [op[:m]]
+        if features is not None:
+            out.append(of[:m])
+        if classes is not None:
+            out.append(oc[:m])
+        return out[0] if len(out) == 1 else tuple(out)
+
+

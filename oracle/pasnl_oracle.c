@@ -320,3 +320,67 @@ API void oracle_three_weights(long rows, const float* dist, float* weight) {
     weight[r * 3 + 2] = r2 / norm;
   }
 }
+
+/* ---- utils/cpp_wrappers/cpp_subsampling/grid_subsampling/grid_subsampling.cpp:4-106.
+ * Same voxel keys, same fp32 sums in input order, same barycentre / mean arithmetic; rows are emitted in ASCENDING
+ * VOXEL KEY (the reference emits unordered_map iteration order) and a label tie goes to the smallest label (the
+ * reference: first maximum in hash order).  Returns the number of voxels. */
+typedef struct { unsigned long long key; long i; } gs_pair;
+static int gs_cmp(const void* a, const void* b) {
+  const gs_pair *x = (const gs_pair*)a, *y = (const gs_pair*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->i < y->i ? -1 : (x->i > y->i);
+}
+API int oracle_grid_subsample(long n, int fdim, int ldim, const float* pts, const float* feats, const int* cls, float dl,
+                              float* out_pts, float* out_feats, int* out_cls) {
+  if (n <= 0) return 0;
+  float mn[3] = {pts[0], pts[1], pts[2]}, mx[3] = {pts[0], pts[1], pts[2]};
+  for (long i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      float v = pts[i * 3 + a];
+      if (v < mn[a]) mn[a] = v;
+      if (v > mx[a]) mx[a] = v;
+    }
+  float inv = 1 / dl; /* :25 */
+  float ox = floorf(mn[0] * inv) * dl, oy = floorf(mn[1] * inv) * dl, oz = floorf(mn[2] * inv) * dl;
+  unsigned long long nx = (unsigned long long)floorf((mx[0] - ox) / dl) + 1; /* :28 */
+  unsigned long long ny = (unsigned long long)floorf((mx[1] - oy) / dl) + 1;
+  gs_pair* pr = (gs_pair*)malloc(sizeof(gs_pair) * (size_t)n);
+  for (long i = 0; i < n; ++i) {
+    unsigned long long ix = (unsigned long long)floorf((pts[i * 3] - ox) / dl); /* :52-55 */
+    unsigned long long iy = (unsigned long long)floorf((pts[i * 3 + 1] - oy) / dl);
+    unsigned long long iz = (unsigned long long)floorf((pts[i * 3 + 2] - oz) / dl);
+    pr[i].key = ix + nx * iy + nx * ny * iz;
+    pr[i].i = i;
+  }
+  qsort(pr, (size_t)n, sizeof(gs_pair), gs_cmp);
+  int m = 0;
+  for (long lo = 0; lo < n;) {
+    long hi = lo;
+    while (hi < n && pr[hi].key == pr[lo].key) ++hi;
+    int count = (int)(hi - lo);
+    for (int a = 0; a < 3; ++a) {
+      float s = 0.f;
+      for (long j = lo; j < hi; ++j) s += pts[pr[j].i * 3 + a];
+      out_pts[(size_t)m * 3 + a] = s * (float)(1.0 / count); /* :86 */
+    }
+    for (int f = 0; f < fdim; ++f) {
+      float s = 0.f;
+      for (long j = lo; j < hi; ++j) s += feats[pr[j].i * fdim + f];
+      out_feats[(size_t)m * fdim + f] = s / (float)count; /* :89-93 */
+    }
+    for (int l = 0; l < ldim; ++l) {
+      int best = 0, best_count = 0;
+      for (long j = lo; j < hi; ++j) {
+        int lab = cls[pr[j].i * ldim + l], cnt = 0;
+        for (long j2 = lo; j2 < hi; ++j2) cnt += cls[pr[j2].i * ldim + l] == lab;
+        if (cnt > best_count || (cnt == best_count && lab < best)) { best = lab; best_count = cnt; }
+      }
+      out_cls[(size_t)m * ldim + l] = best;
+    }
+    ++m;
+    lo = hi;
+  }
+  free(pr);
+  return m;
+}

@@ -180,3 +180,27 @@ class HipRef:
         self.lib.ref_select_top_k(b, n, m, int(k), self._ptr(dist), self._ptr(outi), self._ptr(out))
         self._sync()
         return outi, out
+
+
+_gridsub = None
+
+
+def grid_subsample(points, features=None, classes=None, sampleDl=0.1):
+    """reference grid_subsampling (grid_subsampling.cpp:4-106); rows in unordered_map iteration order"""
+    global _gridsub
+    if _gridsub is None:
+        _gridsub = _load("libref_gridsub.so")
+    points = _f32(points)
+    n = points.shape[0]
+    feats = _f32(features) if features is not None else np.zeros((n, 0), np.float32)
+    cls = np.ascontiguousarray(classes, dtype=np.int32) if classes is not None else np.zeros((n, 0), np.int32)
+    fdim, ldim = feats.shape[1], cls.shape[1]
+    op, of, oc = np.zeros((n, 3), np.float32), np.zeros((n, fdim), np.float32), np.zeros((n, ldim), np.int32)
+    m = _gridsub.ref_grid_subsample(ctypes.c_long(n), fdim, ldim, _p(points), _p(feats), _p(cls), ctypes.c_float(sampleDl),
+                                    _p(op), _p(of), _p(oc))
+    out = [op[:m]]
+    if features is not None:
+        out.append(of[:m])
+    if classes is not None:
+        out.append(oc[:m])
+    return out[0] if len(out) == 1 else tuple(out)

@@ -25,7 +25,18 @@ KNN_CASES = [  # (seed, b, n, m, k, kind)
 ]
 NN_CASES = [(401, 4, 512, 128, "cube"), (402, 2, 2048, 256, "ball"), (403, 2, 320, 80, "lattice"), (404, 2, 10, 2, "cube")]
 FPS_CASES = [(501, 4, 1024, 512, "ball"), (502, 3, 1024, 512, "lattice"), (503, 2, 2500, 300, "lattice"), (504, 6, 512, 128, "cube")]
+GRIDSUB_CASES = [(701, 6000, 0.1, 3, 1), (702, 2500, 0.03, 0, 0), (703, 1500, 0.4, 5, 2)]  # seed, n, sampleDl, fdim, ldim
 BALL_CASES = [(601, 8, 512, 128, 64, 0.1, "cube"), (602, 2, 1024, 512, 32, 0.2, "ball"), (603, 2, 700, 90, 16, 0.25, "lattice")]
+
+
+def gridsub_inputs(seed, n, dl, fdim, ldim):
+    """points in an anisotropic box, random features, labels that are a function of the voxel (no vote ties)"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    p = (rng.random((n, 3)) * np.array([3.0, 2.0, 1.0]) - 0.7).astype(np.float32)
+    f = rng.random((n, fdim)).astype(np.float32) if fdim else None
+    vox = np.floor(p / np.float32(dl)).astype(np.int64)
+    c = np.stack([(vox[:, 0] * 7 + vox[:, 1] * 3 + vox[:, 2] + l) % 5 for l in range(ldim)], 1).astype(np.int32) if ldim else None
+    return p, f, c
 
 
 def make_cpu():
@@ -48,7 +59,16 @@ def make_cpu():
         g = np.random.Generator(np.random.PCG64(seed + 1)).random((b, n, 16), dtype=np.float32)
         out[f"interp_grad_{seed}"] = ref.three_interpolate_grad(pts, i, w.astype(np.float32), g)
     np.savez_compressed(os.path.join(HERE, "ref_interp.npz"), **out)
-    print("wrote ref_knn.npz, ref_interp.npz")
+    out = {}
+    for seed, n, dl, fdim, ldim in GRIDSUB_CASES:
+        p, f, c = gridsub_inputs(seed, n, dl, fdim, ldim)
+        res = ref.grid_subsample(p, f, c, dl)
+        res = res if isinstance(res, tuple) else (res,)
+        order = np.lexsort(res[0].T[::-1])  # the reference emits hash-table order: store the rows sorted by (x, y, z)
+        for name, arr in zip(["pts"] + (["feat"] if fdim else []) + (["cls"] if ldim else []), res):
+            out[f"{name}_{seed}"] = arr[order]
+    np.savez_compressed(os.path.join(HERE, "ref_gridsub.npz"), **out)
+    print("wrote ref_knn.npz, ref_interp.npz, ref_gridsub.npz")
 
 
 def make_gpu():

@@ -310,3 +310,29 @@ def test_deterministic_grads_long_lists_and_atomic_variants(P):
         else:
             np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-3)
     assert (want[0, 10] == 0).all()
+
+
+@pytest.mark.parametrize("n,dl,fdim,ldim,kind", [(200000, 0.04, 3, 1, "room"), (5000, 0.1, 0, 0, "cube"), (3000, 0.5, 6, 2, "cube"),
+                                                 (1, 0.1, 2, 1, "cube"), (4096, 10.0, 1, 1, "cube"), (10000, 0.06, 0, 1, "neg")])
+def test_grid_subsampling(P, n, dl, fdim, ldim, kind):
+    """pasnl_grid_subsample through the reference's module interface (cpp_subsampling.compute) vs the C restatement of
+    grid_subsampling.cpp:4-106: same voxels in the same (ascending-key) order, bit-equal barycentres and feature means
+    (fp32 sums in input order), majority labels with the smallest-label tie rule (random labels: ties do occur)."""
+    from pointasnl_amd.utils.cpp_wrappers.cpp_subsampling import grid_subsampling as cpp_subsampling
+
+    rng = np.random.default_rng(n + fdim)
+    p = rng.random((n, 3)).astype(np.float32)
+    if kind == "room":
+        p = (p * np.array([6.0, 4.0, 2.5], dtype=np.float32)).astype(np.float32)
+        p[::3, 2] = 0.0  # a floor: dense voxels with hundreds of members
+    elif kind == "neg":
+        p = (p * 4 - 2).astype(np.float32)
+    f = rng.random((n, fdim)).astype(np.float32) if fdim else None
+    c = rng.integers(0, 4, (n, ldim)).astype(np.int32) if ldim else None
+    want = O.grid_subsample(p, f, c, dl)
+    got = cpp_subsampling.compute(p, features=f, classes=c, sampleDl=dl, verbose=0)
+    want = want if isinstance(want, tuple) else (want,)
+    got = got if isinstance(got, tuple) else (got,)
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        np.testing.assert_array_equal(g, w)

@@ -51,6 +51,19 @@ def test_three_nn_interpolate_match_reference(interp_gold, case):
     np.testing.assert_array_equal(O.three_interpolate_grad(pts, i, w, g), interp_gold[f"interp_grad_{seed}"])
 
 
+@pytest.mark.parametrize("case", G.GRIDSUB_CASES)
+def test_grid_subsample_matches_reference(case):
+    """oracle_grid_subsample vs outputs of the reference's own grid_subsampling.cpp (fixture rows sorted by x,y,z)"""
+    seed, n, dl, fdim, ldim = case
+    gold = np.load(os.path.join(HERE, "ref_gridsub.npz"))
+    p, f, c = G.gridsub_inputs(seed, n, dl, fdim, ldim)
+    res = O.grid_subsample(p, f, c, dl)
+    res = res if isinstance(res, tuple) else (res,)
+    order = np.lexsort(res[0].T[::-1])
+    for name, arr in zip(["pts"] + (["feat"] if fdim else []) + (["cls"] if ldim else []), res):
+        np.testing.assert_array_equal(arr[order], gold[f"{name}_{seed}"])
+
+
 @pytest.mark.parametrize("case", G.FPS_CASES)
 def test_fps_matches_reference_kernel(hip_gold, case):
     seed, b, n, m, kind = case
