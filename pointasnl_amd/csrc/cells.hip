@@ -385,12 +385,8 @@ __global__ __launch_bounds__(256) void as_reweight_kernel(long groups, int as, i
 // LDS holds only the (BN-folded) weights, staged once per persistent workgroup.  fp32 in, fp32 accumulate
 // (the MFMA is an exact fp32 fmaf chain); tolerance vs the fp32 oracle 1e-5 relative.
 // =============================================================================================
-// GATHER = true is the same cell reading its input straight from the layer's tables instead of a materialised
-// new_point: row s of group (b,j) is [xyz[i]-new_xyz[j] | xyz[i] | feature[i]], i = idx[b,j,s]
-// (pointasnl_util.py:63-74,248-249).  The per-cloud tables (n x (3+C) floats: 12 KiB..270 KiB) stay L2-resident, so
-// the K-fold replicated grouped tensor (31 MB / 294 MB at cls B=64) is never written to or read from HBM.  The
-// skip connection's reduce_max over the K neighbours (:258) is taken on the fly from the same registers: a DPP
-// max over the 32 lanes of a half-wave per MFMA operand, folded into a wave-private LDS row.
+// Sources of the gather-fused cell (pasnl_sa_cell): row s of group (b,j) is [xyz[i]-new_xyz[j] | xyz[i] | feature[i]],
+// i = idx[b,j,s] (pointasnl_util.py:63-74,248-249)
 struct SaGatherSrc {
   const float* xyz;      // (b,n,3)
   const float* feature;  // (b,n,c), c = w - 6
@@ -400,22 +396,8 @@ struct SaGatherSrc {
   int n, m;
 };
 
-// max over the 32 lanes of each half-wave; result in lane 31 (lanes 0..31) and lane 63 (lanes 32..63)
-__device__ __forceinline__ float half_wave_max(float v) {
-#define PASNL_HMAX(CTRL, RM)                                                                                  \
-  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, RM, 0xf, false)));
-  PASNL_HMAX(DPP_ROW_SHR1, 0xf)
-  PASNL_HMAX(DPP_ROW_SHR2, 0xf)
-  PASNL_HMAX(DPP_ROW_SHR4, 0xf)
-  PASNL_HMAX(DPP_ROW_SHR8, 0xf)
-  PASNL_HMAX(DPP_ROW_BCAST15, 0xa)
-#undef PASNL_HMAX
-  return v;
-}
-
-template <int C1, int C2, bool GATHER>
+template <int C1, int C2>
 __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, int w, const float* __restrict__ x,
-                                                           SaGatherSrc src,
                                                            const float* __restrict__ w0, const float* __restrict__ b0,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            const float* __restrict__ ww, const float* __restrict__ bw,
@@ -428,7 +410,6 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
   float* B0s = Wws + 4 * 32;                        // [C1]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ql = lane & 31;
-  float* skp = B0s + C1 + (size_t)wave * wp;        // [4 waves][wp] running column maxima (GATHER only)
 
   for (int i = tid; i < wp * C1; i += 256) W0s[i] = (i / C1) < w ? w0[i] : 0.f;
   for (int i = tid; i < C1 * C2; i += 256) W1s[i] = w1[i];
@@ -449,28 +430,8 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) M[cb][r] = 0.f;
 
-    float cx = 0.f, cy = 0.f, cz = 0.f;
-    long bi = 0;
-    if constexpr (GATHER) {
-      bi = g / src.m;
-      cx = src.new_xyz[g * 3]; cy = src.new_xyz[g * 3 + 1]; cz = src.new_xyz[g * 3 + 2];
-      for (int c = lane; c < wp; c += 64) skp[c] = -INFINITY;
-    }
-
     for (int tile = 0; tile < k; tile += 32) {
-      const float* xrow;  // this lane's neighbour row; GATHER: feature row shifted so that column c >= 6 is xrow[c]
-      float x0 = 0.f, x1 = 0.f, x2 = 0.f;  // GATHER: columns (h, 2+h, 4+h) of the row = MFMA steps 0..2 of chunk 0
-      if constexpr (GATHER) {
-        const int i = src.idx[(size_t)g * k + tile + ql];
-        const float* pp = src.xyz + ((size_t)bi * src.n + i) * 3;
-        const float px = pp[0], py = pp[1], pz = pp[2];
-        x0 = h ? py - cy : px - cx;
-        x1 = h ? px : pz - cz;
-        x2 = h ? pz : py;
-        xrow = src.feature + ((size_t)bi * src.n + i) * (size_t)(w - 6) - 6;
-      } else {
-        xrow = x + ((size_t)g * k + tile + ql) * w;
-      }
+      const float* xrow = x + ((size_t)g * k + tile + ql) * w;  // this lane's neighbour row
       f32x16 H1T[C1 / 32];
 #pragma unroll
       for (int ob = 0; ob < C1 / 32; ++ob)
@@ -485,22 +446,9 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
           int c = ch * 32 + 2 * t + h;
-          if constexpr (GATHER) xr[t] = (c >= 6 && c < w) ? xrow[c] : 0.f;
-          else xr[t] = c < w ? xrow[c] : 0.f;
+          xr[t] = c < w ? xrow[c] : 0.f;
         }
         const int live = min(16, (w - ch * 32 + 1) >> 1);  // MFMA steps with a non-zero k pair (uniform)
-        if constexpr (GATHER) {
-          if (ch == 0) { xr[0] = x0; xr[1] = x1; xr[2] = x2; }
-          // skip connection: column maxima over this tile's 32 rows, folded into the wave's LDS row by lanes 31 / 63
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            if (t < live) {
-              const float mx = half_wave_max(xr[t]);
-              const int c = ch * 32 + 2 * t + h;
-              if (ql == 31 && c < w) skp[c] = fmaxf(skp[c], mx);
-            }
-          }
-        }
         if (ch == 0) {
           // weight net: channels 0..2 are the centred coordinates
           G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0], Wws[h * 32 + ql], G, 0, 0, 0);
@@ -551,14 +499,6 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
 #pragma unroll
         for (int t = 0; t < 16; ++t) M[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(H2[t], G[t], M[cb], 0, 0, 0);
       }
-    }
-    if constexpr (GATHER) {
-      // the wave's LDS operations execute in order; the fence only keeps the compiler from moving the reads up
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (int c = lane; c < w; c += 64) src.skip_max[(size_t)g * w + c] = skp[c];
-      __builtin_amdgcn_wave_barrier();
     }
     // M[c2 = cb*32 + kappa(r,h)][j = ql] -> out[g][c2*32 + j]
     float* o = out + (size_t)g * C2 * 32;
@@ -1140,13 +1080,13 @@ extern "C" int pasnl_as_reweight_x(int g, int as, int ch, const float* logits, c
   return pasnl_launch_status();
 }
 
-template <int C1, int C2, bool GATHER>
-static int local_cell_launch(long groups, int k, int w, const float* x, SaGatherSrc src, const float* w0, const float* b0,
+template <int C1, int C2>
+static int local_cell_launch(long groups, int k, int w, const float* x, const float* w0, const float* b0,
                              const float* w1, const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
   const int wp = (w + 31) & ~31;
-  size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 4 * 32 + C1 + (GATHER ? 4 * wp : 0)) * sizeof(float);
+  size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 4 * 32 + C1) * sizeof(float);
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
-  auto kern = sa_local_cell_kernel<C1, C2, GATHER>;
+  auto kern = sa_local_cell_kernel<C1, C2>;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
@@ -1154,18 +1094,17 @@ static int local_cell_launch(long groups, int k, int w, const float* x, SaGather
   long wgs = (groups + 3) / 4;
   int per_cu = lds > 80 * 1024 ? 1 : (lds > 40 * 1024 ? 2 : 3);
   long cap = 256L * per_cu;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), lds, st, groups, k, w, x, src, w0, b0, w1, b1,
+  hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(256), lds, st, groups, k, w, x, w0, b0, w1, b1,
                      ww, bw, out);
   return pasnl_launch_status();
 }
 
-template <bool GATHER>
-static int local_cell_dispatch(long groups, int k, int w, int c1, int c2, const float* x, SaGatherSrc src, const float* w0,
+static int local_cell_dispatch(long groups, int k, int w, int c1, int c2, const float* x, const float* w0,
                                const float* b0, const float* w1, const float* b1, const float* ww, const float* bw,
                                float* out, hipStream_t st) {
-  if (c1 == 32 && c2 == 32) return local_cell_launch<32, 32, GATHER>(groups, k, w, x, src, w0, b0, w1, b1, ww, bw, out, st);
-  if (c1 == 64 && c2 == 64) return local_cell_launch<64, 64, GATHER>(groups, k, w, x, src, w0, b0, w1, b1, ww, bw, out, st);
-  if (c1 == 128 && c2 == 128) return local_cell_launch<128, 128, GATHER>(groups, k, w, x, src, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 32 && c2 == 32) return local_cell_launch<32, 32>(groups, k, w, x, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 64 && c2 == 64) return local_cell_launch<64, 64>(groups, k, w, x, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 128 && c2 == 128) return local_cell_launch<128, 128>(groups, k, w, x, w0, b0, w1, b1, ww, bw, out, st);
   return PASNL_EUNSUPPORTED;
 }
 
@@ -1214,7 +1153,7 @@ extern "C" int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, con
   PASNL_REQUIRE(k % 32 == 0, PASNL_EUNSUPPORTED);
   if (groups == 0) return PASNL_OK;
   PASNL_REQUIRE(x && w0 && b0 && w1 && b1 && ww && bw && out, PASNL_ENULL);
-  return local_cell_dispatch<false>(groups, k, w, c1, c2, x, SaGatherSrc{}, w0, b0, w1, b1, ww, bw, out, pasnl_hip_stream(stream));
+  return local_cell_dispatch(groups, k, w, c1, c2, x, w0, b0, w1, b1, ww, bw, out, pasnl_hip_stream(stream));
 }
 
 extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
@@ -1230,23 +1169,18 @@ extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, 
   SaGatherSrc src{xyz, feature, idx, new_xyz, skip_max, n, m};
   hipStream_t st = pasnl_hip_stream(stream);
   const int w = 6 + c;
-  // PASNL_SA_CELL_V1=1 selects the first (scalar-load, LDS read-modify-write) gather variant; PASNL_SA_CELL_CFG=<waves per
-  // workgroup> overrides the default (both for A/B measurements only)
-  if (!getenv("PASNL_SA_CELL_V1")) {
-    // 16-byte operand loads need 16-byte aligned feature rows
-    const bool vec = (c % 4 == 0) && (reinterpret_cast<uintptr_t>(feature) % 16 == 0);
-    // two waves per SIMD share one LDS copy of the weights where 256 registers per wave suffice (c1 <= 64: 201 vs 240 us
-    // at cls layer1, 44 vs 59 us at ScanNet layer2).  The 128-channel cell needs ~380: at 8 waves it is 3 % faster
-    // (411 vs 425 us) but spills, and the scratch traffic more than doubles its HBM bytes (PMC: 417 vs 175 MB) --
-    // one wave per SIMD, no spills.
-    int nw = c1 >= 128 ? 4 : 8;
-    if (const char* cfg = getenv("PASNL_SA_CELL_CFG")) nw = atoi(cfg);
-    if (c1 == 32 && c2 == 32) return sa_cell_cfg<32, 32>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
-    if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
-    if (c1 == 128 && c2 == 128) return sa_cell_cfg<128, 128>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
-    return PASNL_EUNSUPPORTED;
-  }
-  return local_cell_dispatch<true>(groups, k, w, c1, c2, nullptr, src, w0, b0, w1, b1, ww, bw, out, st);
+  // 16-byte operand loads need 16-byte aligned feature rows
+  const bool vec = (c % 4 == 0) && (reinterpret_cast<uintptr_t>(feature) % 16 == 0);
+  // two waves per SIMD share one LDS copy of the weights where 256 registers per wave suffice (c1 <= 64: 201 vs 240 us
+  // at cls layer1, 44 vs 59 us at ScanNet layer2).  The 128-channel cell needs ~380: at 8 waves it is 3 % faster
+  // (411 vs 425 us) but spills, and the scratch traffic more than doubles its HBM bytes (PMC: 417 vs 175 MB) --
+  // one wave per SIMD, no spills.  PASNL_SA_CELL_CFG=<waves per workgroup> overrides (A/B measurements only).
+  int nw = c1 >= 128 ? 4 : 8;
+  if (const char* cfg = getenv("PASNL_SA_CELL_CFG")) nw = atoi(cfg) == 4 ? 4 : 8;
+  if (c1 == 32 && c2 == 32) return sa_cell_cfg<32, 32>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 128 && c2 == 128) return sa_cell_cfg<128, 128>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  return PASNL_EUNSUPPORTED;
 }
 
 extern "C" int pasnl_decode_cell(int b, int n, int c, int k, const float* xyz, const float* feature, const int* idx,
