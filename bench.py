@@ -15,10 +15,17 @@ step: algorithmic bytes/flops / its average launch duration, me
 launch stream in an event-instrumented pass of the same forward.  `cpu_baseline` times the CPU restatement of
 the same forward (oracle/, "port") on the host cores over a bounded sample.  `kernels` lists every hand-written
 kernel the same way (extra, for the record).
+
+Every rank's measurement runs in a worker process under a thin supervisor (`supervise`): the worker reports its phase over
+a pipe, and a worker that makes no progress for the phase's allowance (a GPU dead-lock between concurrently replayed
+graphs) is killed and re-run once with --pipeline serial, so that a stall costs a retry instead of the run.
 """
 import argparse
 import json
 import os
+import select
+import signal
+import subprocess
 import sys
 import time
 
@@ -154,8 +161,85 @@ def cpu_baseline(pc_all, params, adaptive, seconds_budget=25.0):
                       f"numpy fp32 dense layers; median {med:.3f} s/forward"}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# supervisor: progress-watched worker process, one serial retry
+# ---------------------------------------------------------------------------------------------------------------
+HEARTBEAT_ENV = "PASNL_BENCH_HEARTBEAT_FD"
+# seconds without a heartbeat that count as a stall, per phase the worker announces.  start: interpreter + first
+# `import torch` on a fresh box (minutes) + RCCL init; setup: eager forwards, BLAS heuristics, graph capture;
+# run: warm-up + timed steps (+ per step, see beat()); post: event-instrumented pass + CPU baseline sample
+ALLOWANCE = {"start": 900.0, "setup": 600.0, "run": 120.0, "post": 900.0}
+
+
+def beat(phase, extra=0.0):
+    """worker side: announce a phase; the supervisor expects the next announcement within ALLOWANCE[phase]+extra s"""
+    fd = os.environ.get(HEARTBEAT_ENV)
+    if fd:
+        scale = float(os.environ.get("PASNL_BENCH_STALL_SCALE", "1"))  # tests shrink the allowances
+        os.write(int(fd), f"{phase} {(ALLOWANCE[phase] + extra) * scale:.3f}\n".encode())
+
+
+def watch(cmd, env, first_allowance=ALLOWANCE["start"]):
+    """Run `cmd` with a heartbeat pipe; returns (returncode, None) or (None, stalled_phase) after killing a stalled child."""
+    r, w = os.pipe()
+    env = dict(env)
+    env[HEARTBEAT_ENV] = str(w)
+    proc = subprocess.Popen(cmd, env=env, pass_fds=(w,))
+    os.close(w)
+
+    def forward_signal(signum, _frame):  # the driver stops the supervisor: take the worker along
+        proc.kill()
+        proc.wait()
+        sys.exit(128 + signum)
+
+    old = {sig: signal.signal(sig, forward_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
+    phase, allowance, buf = "start", first_allowance, b""
+    try:
+        while True:
+            ready, _, _ = select.select([r], [], [], allowance)
+            if not ready:
+                proc.kill()  # exactly the process started above
+                proc.wait()
+                return None, phase
+            data = os.read(r, 4096)
+            if not data:  # every write end closed: the worker has exited
+                return proc.wait(), None
+            buf += data
+            lines = buf.split(b"\n")
+            buf = lines.pop()
+            if lines:
+                name, secs = lines[-1].decode().split()
+                phase, allowance = name, float(secs)
+    finally:
+        os.close(r)
+        for sig, h in old.items():
+            signal.signal(sig, h)
+
+
+def supervise(argv):
+    """Supervisor side of every rank: worker with the given flags; on a stall one more worker with --pipeline serial."""
+    base = [sys.executable, os.path.abspath(__file__), "--worker"]
+    scale = float(os.environ.get("PASNL_BENCH_STALL_SCALE", "1"))
+    rc, stalled = watch(base + argv, os.environ, ALLOWANCE["start"] * scale)
+    if stalled is None:
+        return rc
+    print(f"bench.py: worker made no progress in phase '{stalled}' and was killed; retrying with --pipeline serial",
+          file=sys.stderr, flush=True)
+    rc, stalled2 = watch(base + argv + ["--pipeline", "serial", "--retry-of", stalled], os.environ, ALLOWANCE["start"] * scale)
+    if stalled2 is None:
+        return rc
+    print(f"bench.py: the serial retry stalled in phase '{stalled2}' as well; giving up", file=sys.stderr, flush=True)
+    return 3
+
+
 def main():
+    if "--worker" not in sys.argv[1:] and os.environ.get("PASNL_BENCH_SUPERVISE", "1") != "0":
+        sys.exit(supervise(sys.argv[1:]))
+    beat("start")
     ap = argparse.ArgumentParser()
+    ap.add_argument("--worker", action="store_true", help="run the measurement in this process without a supervisor (the supervisor passes it; use it under profilers)")
+    ap.add_argument("--retry-of", default=None,
+                    help="(internal) phase in which the first worker stalled; this worker is its serial retry")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
@@ -185,6 +269,15 @@ def main():
                          "it to attribute rocprofv3 PMC rows to launches)")
     args = ap.parse_args()
 
+    if args.worker:  # do not outlive the supervisor (PR_SET_PDEATHSIG)
+        import ctypes
+
+        ctypes.CDLL(None).prctl(1, signal.SIGKILL)
+
+    def fake_stall(phase):  # supervisor test hook: the first worker hangs in the named phase
+        if os.environ.get("PASNL_BENCH_FAKE_STALL") == phase and not args.retry_of:
+            time.sleep(1e6)
+
     if os.environ.get("PASNL_BENCH_WATCHDOG"):  # diagnostics: dump every thread's Python stack and exit if the run stalls
         import faulthandler
 
@@ -213,7 +306,12 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        store = None
+        if args.retry_of:  # the first worker's rendezvous keys may still sit in the launcher's store: fresh key space
+            base_store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world))
+            store = dist.PrefixStore("pasnl_retry/", base_store)
+        dist.init_process_group("nccl", store=store, rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
 
     import importlib
 
@@ -247,6 +345,7 @@ def main():
     gathered = sharding.LogitsGather(world, B, width, x.device, force=multi) if multi else None  # eager path
     lane_gather = []  # one gather buffer per pipeline lane
 
+    beat("setup")
     with torch.no_grad():
         # ---- warm-up (eager: creates weights, BLAS workspaces), then capture
         side = torch.cuda.Stream()
@@ -312,6 +411,10 @@ def main():
                 gathered.all_gather(out)
             return out
 
+        if multi:
+            dist.barrier()  # ranks enter the watched region together, so a stall expires every rank's allowance together
+        beat("run", 0.25 * (args.warmup + args.steps))
+        fake_stall("run")
         for _ in range(args.warmup):
             step()
 
@@ -326,6 +429,7 @@ def main():
         if multi:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        beat("post")
         if multi:
             t = torch.tensor([elapsed], dtype=torch.float64, device=x.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -397,7 +501,8 @@ def main():
                                  "configs[1]: ModelNet40 pointasnl_cls, 1024 pts") if args.model == "cls" else
                                 f"configs[{cfg_index}]: pointasnl_{args.model}, {N} pts") + f", batch={B}/GPU, seeded random weights",
                    "global_batch": world * B, "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
-                   "hip_graph": graph is not None, "pipeline": mode, "outputs_agree": lanes_agree},
+                   "hip_graph": graph is not None, "pipeline": mode, "outputs_agree": lanes_agree,
+                   "retry_of_stalled_phase": args.retry_of},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "handwritten_kernel_us_per_step": round(handwritten_us, 1),

@@ -8,6 +8,6 @@ mkdir -p gpurun_out
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_$c
   timeout 600 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_$c -o cls -f csv -- \
-    python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-graph --launch-order "$@" > gpurun_out/pmc_$c.json 2> gpurun_out/pmc_$c.err || true
+    python bench.py --worker --steps 3 --warmup 1 --no-cpu-baseline --no-graph --launch-order "$@" > gpurun_out/pmc_$c.json 2> gpurun_out/pmc_$c.err || true
 done
 find gpurun_out -name "*counter_collection.csv" | head
