@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.hpp"
 
 namespace pasnl {
@@ -558,6 +559,39 @@ __device__ __forceinline__ void half_wave_max2(float& a, float& b) {
 // !VEC (cls layer1, cf = 3): step t contracts columns 2t (lanes 0..31) and 2t+1 (lanes 32..63), scalar loads.
 // LEAN: no operand prefetch buffer and the skip maxima reduced in place after the chunk's MFMAs -- 32 registers
 // less, which lets the 128-channel cell run two waves per SIMD (256 registers each) without spilling.
+// Diagnostic builds only (make probe: -DPASNL_SA_CELL_PROBE=<level> [-DPASNL_SA_ABLATE=<mask>] -> libpasnl_hip_probe*.so,
+// tools/sa_cell_probe.py): s_memtime marks at the phase boundaries of a tile, summed over all waves into sa_probe[].
+// Level 2 adds marks around explicit vmcnt(0) waits (tile start, every chunk), which separates "waiting for gathered
+// rows" from matrix work at the price of perturbing the LDS prefetch.  The ablation mask removes one ingredient at a
+// time (results are then wrong; only the time matters): 1 skip maxima, 2 global operand loads, 4 output stores.
+#ifdef PASNL_SA_CELL_PROBE
+__device__ unsigned long long sa_probe[16];
+#define SA_MARK0(t) do { __builtin_amdgcn_sched_barrier(0); t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#if PASNL_SA_CELL_PROBE >= 1
+#define SA_MARK(t) SA_MARK0(t)
+#else
+#define SA_MARK(t) t = 0   /* level 0: only the wave's total (two marks per wave: the code is the production code) */
+#endif
+#define SA_PROBE(...) __VA_ARGS__
+#if PASNL_SA_CELL_PROBE >= 2
+#define SA_MARK2(t) SA_MARK(t)
+#define SA_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define SA_MARK2(t) t = 0
+#define SA_WAIT_VM()
+#endif
+#else
+#define SA_MARK(t)
+#define SA_MARK2(t)
+#define SA_WAIT_VM()
+#define SA_PROBE(...)
+#endif
+#ifndef PASNL_SA_ABLATE
+#define PASNL_SA_ABLATE 0
+#endif
+
+constexpr int SA_SKIP_REP = 4;
+
 template <int C1, int C2, int NW, bool VEC, bool LEAN>
 __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, int w, SaGatherSrc src,
                                                          const float* __restrict__ w0, const float* __restrict__ b0,
@@ -565,6 +599,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
                                                          const float* __restrict__ ww, const float* __restrict__ bw,
                                                          float* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  SA_PROBE(unsigned long long pentry; SA_MARK0(pentry);)
   const int cf = w - 6;
   const int wi = 8 + cf;                            // internal width
   const int wp = (wi + 31) & ~31;
@@ -573,17 +608,52 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   float* Wws = W1s + C1 * C2;                       // [3 steps][2 halves][32]: weight net, zero rows for the unused half
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, ql = lane & 31;
-  float* skp = Wws + 6 * 32 + (size_t)wave * wp;    // [NW][wp] running column maxima of the current group
+  // running column maxima of the current group: [NW][SA_SKIP_REP][sks]; row ql of a tile folds into replica ql % 4
+  // (8 lanes per address instead of 32), sks = wp + 4 puts the 8 addresses of one ds_max_f32 on 8 different banks
+  const int sks = wp + 4;
+  float* skp = Wws + 6 * 32 + (size_t)wave * SA_SKIP_REP * sks;
+  float* skl = skp + (ql & (SA_SKIP_REP - 1)) * sks + (VEC ? 16 * h : h);  // this lane's replica, its first column
 
-  for (int i = tid; i < wp * C1; i += NW * 64) {
-    const int r = i / C1, c1 = i - r * C1;
-    float v = 0.f;
-    if (r < 6) v = w0[(size_t)r * C1 + c1];
-    else if (r == 6) v = b0[c1];
-    else if (r >= 8 && r < wi) v = w0[(size_t)(r - 2) * C1 + c1];
-    W0s[i] = v;
+  // ---- weights into LDS, once per (persistent) workgroup.  16-byte loads, SB of them in flight per thread before the
+  // first LDS store: the copy is latency-bound (144 KiB per workgroup at C = 128: 57 k cycles = 7 % of the launch with
+  // one dependent dword load + store per iteration, conditional on the row kind)
+  constexpr int T = NW * 64;
+  if (((reinterpret_cast<uintptr_t>(w0) | reinterpret_cast<uintptr_t>(w1) | reinterpret_cast<uintptr_t>(b0)) & 15) == 0) {
+    constexpr int Q = C1 / 4, SB = 8;
+    const int n0 = wp * Q;  // float4 items of W0s; row r of W0s = w0 row r (r < 6) | b0 (6) | 0 (7) | w0 row r - 2 | 0 (r >= wi)
+    for (int base = tid; base < n0; base += SB * T) {
+      float4 v[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int i = min(base + u * T, n0 - 1), r = i / Q, q = i - r * Q;
+        const float* srow = r == 6 ? b0 : w0 + (size_t)(r < 6 ? r : min(max(r, 8), wi - 1) - 2) * C1;
+        v[u] = reinterpret_cast<const float4*>(srow)[q];
+        if (r == 7 || r >= wi) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u)
+        if (base + u * T < n0) reinterpret_cast<float4*>(W0s)[base + u * T] = v[u];
+    }
+    constexpr int N1 = C1 * C2 / 4;
+    for (int base = tid; base < N1; base += SB * T) {
+      float4 v[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) v[u] = reinterpret_cast<const float4*>(w1)[min(base + u * T, N1 - 1)];
+#pragma unroll
+      for (int u = 0; u < SB; ++u)
+        if (base + u * T < N1) reinterpret_cast<float4*>(W1s)[base + u * T] = v[u];
+    }
+  } else {
+    for (int i = tid; i < wp * C1; i += T) {
+      const int r = i / C1, c1 = i - r * C1;
+      float v = 0.f;
+      if (r < 6) v = w0[(size_t)r * C1 + c1];
+      else if (r == 6) v = b0[c1];
+      else if (r >= 8 && r < wi) v = w0[(size_t)(r - 2) * C1 + c1];
+      W0s[i] = v;
+    }
+    for (int i = tid; i < C1 * C2; i += T) W1s[i] = w1[i];
   }
-  for (int i = tid; i < C1 * C2; i += NW * 64) W1s[i] = w1[i];
   for (int i = tid; i < 6 * 32; i += NW * 64) {
     const int t = i / 64, hh = (i >> 5) & 1, j = i & 31;
     // VEC: step t pairs column t with column 16+t -> only the first half carries a coordinate.
@@ -612,7 +682,11 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   const long my_groups = xcd_map ? (long)((nclouds - xcd + 7) >> 3) * src.m : groups;
   const long first = xcd_map ? (long)(blockIdx.x >> 3) * NW + wave : (long)blockIdx.x * NW + wave;
   const long step = xcd_map ? (long)(gridDim.x >> 3) * NW : (long)gridDim.x * NW;
+  SA_PROBE(unsigned long long pk0, pg0, pt0, pt1, pt2, pt3, pc0, pc1;
+           unsigned long long a_pro = 0, a_start = 0, a_conv0 = 0, a_cwait = 0, a_conv1 = 0, a_epi = 0, a_tiles = 0;)
+  SA_PROBE(SA_MARK0(pk0);)
   for (long li = first; li < my_groups; li += step) {
+    SA_MARK(pg0);
     long g = li, bi;
     if (xcd_map) {
       const int cl = (int)li / src.m;
@@ -622,7 +696,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       bi = (long)((int)g / src.m);
     }
     const float cx = src.new_xyz[g * 3], cy = src.new_xyz[g * 3 + 1], cz = src.new_xyz[g * 3 + 2];
-    for (int c = lane; c < wp; c += 64) skp[c] = -INFINITY;
+    for (int c = lane; c < SA_SKIP_REP * sks; c += 64) skp[c] = -INFINITY;
     f32x16 M[C2 / 32];
 #pragma unroll
     for (int cb = 0; cb < C2 / 32; ++cb)
@@ -630,158 +704,175 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       for (int r = 0; r < 16; ++r) M[cb][r] = 0.f;
 
     for (int tile = 0; tile < k; tile += 32) {
+#pragma unroll
+      for (int cb = 0; cb < C2 / 32; ++cb) asm volatile("" : "+a"(M[cb]));  // M lives in AccVGPRs: no VALU ever reads it
+      SA_MARK(pt0);
+      SA_PROBE(if (tile == 0) a_pro += pt0 - pg0;)
       const int i = src.idx[(size_t)g * k + tile + ql];
       const float* pp = src.xyz + ((size_t)bi * src.n + i) * 3;
       const float px = pp[0], py = pp[1], pz = pp[2];
       const float* frow = src.feature + ((size_t)bi * src.n + i) * (size_t)cf;
-      // operands of one chunk for this lane; every load is unconditional with a clamped address and masked where
-      // it is used (a conditional load compiles to its own exec-masked basic block)
-      float xr[16], xn[LEAN ? 1 : 16];
-      auto load_chunk = [&](int ch, float (&v)[16]) {
+      // Operands of one chunk for this lane.  Every load is unconditional with a clamped address (a conditional load
+      // compiles to its own exec-masked basic block); columns outside the feature row exist only in the LAST chunk of
+      // a row that is not a multiple of 32 wide (and in chunk 0's first 8 columns, which are overwritten below), so
+      // only that chunk is masked.
+      float xr[16];
+      // operands [u0, u1) of chunk ch (VEC: whole 16-byte groups); the loops unroll, u0 / u1 are constants at every call
+      auto load_part = [&](int ch, int u0, int u1) {
+        if constexpr ((PASNL_SA_ABLATE & 2) != 0) {
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            if (t >= u0 && t < u1) xr[t] = (float)(ch + t) * px;
+        } else if constexpr (VEC) {
+          const int g0 = ch * 8 + 4 * h - 2;  // first 16-byte group of this lane's 16 columns (-2 in chunk 0)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (4 * q >= u0 && 4 * q < u1) {
+              const float4 t4 = reinterpret_cast<const float4*>(frow)[min(max(g0 + q, 0), cf4 - 1)];
+              xr[4 * q] = t4.x; xr[4 * q + 1] = t4.y; xr[4 * q + 2] = t4.z; xr[4 * q + 3] = t4.w;
+            }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 16; ++t)
+            if (t >= u0 && t < u1) xr[t] = frow[min(max(ch * 32 + 2 * t + h - 8, 0), cf - 1)];
+        }
+      };
+      auto load_chunk = [&](int ch, float (&)[16]) { load_part(ch, 0, 16); };
+      auto mask_chunk = [&](int ch, float (&v)[16]) {
         if constexpr (VEC) {
-          const int f0 = ch * 32 + 16 * h - 8;  // first feature of this lane's 16 columns (may be -8 or past the end)
+          const int g0 = ch * 8 + 4 * h - 2;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int g4 = (f0 >> 2) + q;
-            const float4 t4 = reinterpret_cast<const float4*>(frow)[min(max(g4, 0), cf4 - 1)];
-            const bool ok = g4 >= 0 && g4 < cf4;
-            v[4 * q] = ok ? t4.x : 0.f; v[4 * q + 1] = ok ? t4.y : 0.f; v[4 * q + 2] = ok ? t4.z : 0.f; v[4 * q + 3] = ok ? t4.w : 0.f;
+            const bool ok = g0 + q >= 0 && g0 + q < cf4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q + e] = ok ? v[4 * q + e] : 0.f;
           }
         } else {
 #pragma unroll
           for (int t = 0; t < 16; ++t) {
             const int f = ch * 32 + 2 * t + h - 8;
-            const float x = frow[min(max(f, 0), cf - 1)];
-            v[t] = (f >= 0 && f < cf) ? x : 0.f;
+            v[t] = (f >= 0 && f < cf) ? v[t] : 0.f;
           }
         }
       };
       load_chunk(0, xr);
+      SA_WAIT_VM();
+      SA_MARK(pt1);
+      SA_PROBE(a_start += pt1 - pt0;)
 
       f32x16 H1T[C1 / 32];
 #pragma unroll
       for (int ob = 0; ob < C1 / 32; ++ob)
 #pragma unroll
         for (int r = 0; r < 16; ++r) H1T[ob][r] = 0.f;
+#pragma unroll
+      for (int ob = 0; ob < C1 / 32; ++ob) asm volatile("" : "+a"(H1T[ob]));
       f32x16 G;
 #pragma unroll
       for (int r = 0; r < 16; ++r) G[r] = 0.f;
 
-      for (int ch = 0; ch < nchunk; ++ch) {
-        if constexpr (!LEAN) {
-          // next chunk's operands in flight while this chunk's MFMAs run (the last request of a tile is a dummy)
-          load_chunk(min(ch + 1, nchunk - 1), xn);
-          __builtin_amdgcn_sched_barrier(0);
+      const int nfull = wi >> 5;  // chunks whose 32 columns all exist
+      if (nfull == 0) mask_chunk(0, xr);
+      // internal columns 0..7 = [xyz - centre | xyz | 1 | 0]; the weight net (3 -> 32) rides on the same operands
+      if constexpr (VEC) {
+        if (h == 0) {
+          xr[0] = px - cx; xr[1] = py - cy; xr[2] = pz - cz; xr[3] = px;
+          xr[4] = py; xr[5] = pz; xr[6] = 1.f; xr[7] = 0.f;
         }
-        if (ch == 0) {
-          // internal columns 0..7 = [xyz - centre | xyz | 1 | 0]
-          if constexpr (VEC) {
-            if (h == 0) {
-              xr[0] = px - cx; xr[1] = py - cy; xr[2] = pz - cz; xr[3] = px;
-              xr[4] = py; xr[5] = pz; xr[6] = 1.f; xr[7] = 0.f;
-            }
-          } else {
-            xr[0] = h ? py - cy : px - cx;
-            xr[1] = h ? px : pz - cz;
-            xr[2] = h ? pz : py;
-            xr[3] = h ? 0.f : 1.f;
-          }
+      } else {
+        xr[0] = h ? py - cy : px - cx;
+        xr[1] = h ? px : pz - cz;
+        xr[2] = h ? pz : py;
+        xr[3] = h ? 0.f : 1.f;
+      }
 #pragma unroll
-          for (int t = 0; t < (VEC ? 3 : 2); ++t)
-            G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[t], Wws[(t * 2 + h) * 32 + ql], G, 0, 0, 0);
-        }
-        // MFMA steps of this chunk that touch a column < wi (uniform)
-        const int rem = wi - ch * 32;
-        const int live = VEC ? min(16, rem) : min(16, (rem + 1) >> 1);
-        // skip connection: column maxima over the tile's 32 rows (single-instruction DPP steps, two columns per
-        // block), folded by lanes 31 / 63 into the wave's LDS row with ds_max_f32 (no return value)
-        float mcopy[LEAN ? 1 : 16];
-        float (&ma)[16] = *reinterpret_cast<float (*)[16]>(LEAN ? xr : mcopy);
-        if constexpr (!LEAN) {
+      for (int t = 0; t < (VEC ? 3 : 2); ++t)
+        G = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[t], Wws[(t * 2 + h) * 32 + ql], G, 0, 0, 0);
+
+      constexpr int RS = VEC ? 1 : 2;  // W0 row / column stride between consecutive MFMA steps
+      // Skip connection: the column maxima over the group's rows.  The fp32 MFMA runs on the SIMD's vector lanes, so
+      // every VALU instruction of this wave costs matrix time (tools/mfmaprobe.hip: 64 -> 88 cycles per MFMA with 4
+      // VALU ops behind each); LDS instructions do not.  Each lane therefore folds its 16 operands straight into its
+      // replica row with ds_max_f32 (no return value, nothing waits for it) instead of reducing over the 32 rows
+      // with 80 DPP steps per chunk first.  Padding columns receive zeros: unread.
+      // NS MFMA steps of chunk ch: the W0 operands of batch j+1 (BT steps x C1/32 blocks) are read from LDS while the
+      // MFMAs of batch j run
+      // STREAM: the operand registers of a finished group of steps are refilled in place with the same columns of
+      // the next chunk (12 steps = 48 MFMAs of matrix time before they are used again): no second buffer, no copies.
+      auto chunk_steps = [&](int ch, auto ns_c, auto stream_c) {
+        constexpr int NS = decltype(ns_c)::value;
+        constexpr bool STREAM = decltype(stream_c)::value;
+        if constexpr (!(PASNL_SA_ABLATE & 1)) {
+          // an opaque LDS address: one address register + immediate offsets instead of one address add per ds_max
+          // (the row lies past the 64 KiB an immediate offset could reach from the start of the LDS)
+          typedef __attribute__((address_space(3))) float lds_float;
+          lds_float* srow = (lds_float*)(skl + ch * 32);
+          asm volatile("" : "+v"(srow));
 #pragma unroll
-          for (int t = 0; t < 16; ++t) ma[t] = xr[t];
+          for (int t = 0; t < NS; ++t)
+            __hip_atomic_fetch_max(srow + RS * t, xr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
+#ifdef PASNL_SA_BT
+        constexpr int BT = PASNL_SA_BT;
+#else
+        constexpr int BT = C1 >= 128 ? 1 : 128 / C1;  // MFMA steps per batch
+#endif
+        constexpr int NB = NS / BT;
         const float* wbase = VEC ? W0s + (size_t)(ch * 32 + 16 * h) * C1 + ql : W0s + (size_t)(ch * 32 + h) * C1 + ql;
-        constexpr int RS = VEC ? 1 : 2;  // W0 row stride between consecutive MFMA steps
-        if (live == 16) {
-          // full chunk: the W0 operands of batch j+1 (>= 4 MFMAs = 256 cycles of matrix-pipe time) are read from LDS
-          // while the MFMAs of batch j run; the DPP blocks of the skip maxima sit behind the MFMA batches and
-          // execute while the last MFMA of the batch occupies the pipe
-          constexpr int BT = C1 >= 128 ? 1 : 128 / C1;  // MFMA steps per batch
-          constexpr int NB = 16 / BT;
-          constexpr int PPB = NB >= 8 ? 1 : 8 / NB;     // column pairs reduced behind each batch
-          float wa[2][BT][C1 / 32];
+        float wa[2][BT][C1 / 32];
 #pragma unroll
-          for (int u = 0; u < BT; ++u)
+        for (int u = 0; u < BT; ++u)
 #pragma unroll
-            for (int ob = 0; ob < C1 / 32; ++ob) wa[0][u][ob] = wbase[(size_t)(RS * u) * C1 + ob * 32];
+          for (int ob = 0; ob < C1 / 32; ++ob) wa[0][u][ob] = wbase[(size_t)(RS * u) * C1 + ob * 32];
 #pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            if (j + 1 < NB) {
-#pragma unroll
-              for (int u = 0; u < BT; ++u)
-#pragma unroll
-                for (int ob = 0; ob < C1 / 32; ++ob)
-                  wa[(j + 1) & 1][u][ob] = wbase[(size_t)(RS * ((j + 1) * BT + u)) * C1 + ob * 32];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < NB; ++j) {
+          if (j + 1 < NB) {
 #pragma unroll
             for (int u = 0; u < BT; ++u)
 #pragma unroll
               for (int ob = 0; ob < C1 / 32; ++ob)
-                H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j & 1][u][ob], xr[j * BT + u], H1T[ob], 0, 0, 0);
-            if constexpr (!LEAN) {
-#pragma unroll
-              for (int q = 0; q < PPB; ++q) {
-                const int pr = j * PPB + q;
-                if (pr < 8) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
-              }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                wa[(j + 1) & 1][u][ob] = wbase[(size_t)(RS * ((j + 1) * BT + u)) * C1 + ob * 32];
           }
-          if constexpr (LEAN) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
+          for (int u = 0; u < BT; ++u)
+#pragma unroll
+            for (int ob = 0; ob < C1 / 32; ++ob)
+              H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j & 1][u][ob], xr[j * BT + u], H1T[ob], 0, 0, 0);
+          if constexpr (STREAM) {
+            constexpr int GR = VEC ? 4 : 1;  // operands per load
+            // the load groups whose last step this batch finished: [floor(j*BT / GR), floor((j+1)*BT / GR)) * GR
+            load_part(min(ch + 1, nchunk - 1), j * BT / GR * GR, (j + 1) * BT / GR * GR);
           }
-        } else {
-          if constexpr (!LEAN) {
-#pragma unroll
-            for (int pr = 0; pr < 8; ++pr) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
-          }
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            if (t < live) {
-#pragma unroll
-              for (int ob = 0; ob < C1 / 32; ++ob)
-                H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wbase[(size_t)(RS * t) * C1 + ob * 32], xr[t], H1T[ob], 0, 0, 0);
-            }
-          }
-          if constexpr (LEAN) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int pr = 0; pr < 8; ++pr) half_wave_max2(ma[2 * pr], ma[2 * pr + 1]);
-          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        if (ql == 31) {
-          // internal column of operand t: VEC ch*32 + 16h + t, !VEC ch*32 + 2t + h (padding columns get junk, unread)
-          float* srow = VEC ? skp + ch * 32 + 16 * h : skp + ch * 32 + h;
-#pragma unroll
-          for (int t = 0; t < 16; ++t)
-            __hip_atomic_fetch_max(srow + RS * t, ma[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (LEAN) {
-          load_chunk(min(ch + 1, nchunk - 1), xr);
-        } else {
-#pragma unroll
-          for (int t = 0; t < 16; ++t) xr[t] = xn[t];
-        }
+      };
+
+      // ---- full chunks: one code path, so that the accumulators stay where they are across iterations
+      for (int ch = 0; ch < nfull; ++ch) {
+        chunk_steps(ch, std::integral_constant<int, 16>{}, std::true_type{});  // (the last refill of a tile is a dummy)
+        SA_MARK2(pc0);
+        SA_WAIT_VM();
+        SA_MARK2(pc1);
+        SA_PROBE(a_cwait += pc1 - pc0;)
       }
+      // ---- the last chunk of a row whose width is not a multiple of 32: 8 or 16 steps (rows of W0 past the width and
+      // the masked operands are zero, so steps past the last live column add nothing)
+      if (nfull < nchunk) {
+        const int ch = nfull;
+        if (nfull > 0) mask_chunk(ch, xr);
+        const int rem = wi - ch * 32;
+        const int live = VEC ? min(16, rem) : min(16, (rem + 1) >> 1);  // MFMA steps that touch a column < wi
+        if (live <= 8) chunk_steps(ch, std::integral_constant<int, 8>{}, std::false_type{});
+        else chunk_steps(ch, std::integral_constant<int, 16>{}, std::false_type{});
+      }
+      SA_MARK(pt2);
+      SA_PROBE(a_conv0 += pt2 - pt1;)
       // ReLU (the bias came with the MFMA); G: bias + ReLU
 #pragma unroll
       for (int ob = 0; ob < C1 / 32; ++ob)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H1T[ob][r] = fmaxf(H1T[ob][r], 0.f);
+        for (int r = 0; r < 16; ++r) H1T[ob][r] = vmaxf(H1T[ob][r], 0.f);
 #pragma unroll
       for (int r = 0; r < 16; ++r) G[r] = fmaxf(G[r] + bwr, 0.f);
 
@@ -824,9 +915,13 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 #pragma unroll
         for (int t = 0; t < 16; ++t) M[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(H2[t], G[t], M[cb], 0, 0, 0);
       }
+      SA_MARK(pt3);
+      SA_PROBE(a_conv1 += pt3 - pt2; a_tiles += 1;)
     }
     // M[c2 = cb*32 + kappa(r,h)][j = ql] -> out[g][c2*32 + j]
     float* o = out + (size_t)g * C2 * 32;
+    if ((PASNL_SA_ABLATE & 4) && cx == 12345.f) o = nullptr;  // ablation: keep M alive, store (almost) never
+    if (!(PASNL_SA_ABLATE & 4) || o == nullptr)
 #pragma unroll
     for (int cb = 0; cb < C2 / 32; ++cb)
 #pragma unroll
@@ -836,10 +931,36 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // reference column c of the skip maxima = internal column c (c < 6) or c + 2 (features)
-    for (int c = lane; c < w; c += 64) src.skip_max[(size_t)g * w + c] = skp[c < 6 ? c : c + 2];
+    for (int c = lane; c < w; c += 64) {
+      const float* sc = skp + (c < 6 ? c : c + 2);
+      src.skip_max[(size_t)g * w + c] = fmaxf(fmaxf(sc[0], sc[sks]), fmaxf(sc[2 * sks], sc[3 * sks]));
+    }
     __builtin_amdgcn_wave_barrier();
+    SA_MARK(pt0);
+    SA_PROBE(a_epi += pt0 - pt3;)
   }
+#ifdef PASNL_SA_CELL_PROBE
+  SA_MARK0(pt0);
+  if (lane == 0) {
+    atomicAdd(&sa_probe[0], a_pro); atomicAdd(&sa_probe[1], a_start); atomicAdd(&sa_probe[2], a_conv0);
+    atomicAdd(&sa_probe[3], a_cwait); atomicAdd(&sa_probe[4], a_conv1); atomicAdd(&sa_probe[5], a_epi);
+    atomicAdd(&sa_probe[6], a_tiles); atomicAdd(&sa_probe[7], pt0 - pk0); atomicAdd(&sa_probe[8], 1ull);
+    atomicAdd(&sa_probe[9], pk0 - pentry);
+  }
+#endif
 }
+
+#ifdef PASNL_SA_CELL_PROBE
+}  // namespace pasnl
+// [prologue, start wait, conv0 (incl. chunk wait), chunk wait, conv1 + matmul, epilogue, tiles, wave total, waves,
+// weight staging] cycles
+extern "C" int pasnl_sa_cell_probe_read(unsigned long long* host16) {
+  if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(pasnl::sa_probe), sizeof(pasnl::sa_probe)) != hipSuccess) return -1;
+  unsigned long long zero[16] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(pasnl::sa_probe), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+namespace pasnl {
+#endif
 
 
 // =============================================================================================
@@ -1112,7 +1233,7 @@ template <int C1, int C2, int NW, bool VEC, bool LEAN>
 static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0, const float* w1,
                           const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
   const int wp = (8 + (w - 6) + 31) & ~31;  // internal width: [xyz-c | xyz | 1 | 0 | feature], padded to 32-chunks
-  size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 6 * 32 + (size_t)NW * wp) * sizeof(float);
+  size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 6 * 32 + (size_t)NW * SA_SKIP_REP * (wp + 4)) * sizeof(float);
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
   auto kern = sa_cell_kernel<C1, C2, NW, VEC, LEAN>;
   if (lds > 48 * 1024 &&

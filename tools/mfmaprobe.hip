@@ -3,20 +3,30 @@
 //   mode 1: 1 accumulator, 64-deep dependent chain, operands in registers
 //   mode 2: 4 independent accumulators, A operand read from LDS one batch ahead (conv0 pattern)
 //   mode 3: 1 accumulator chain, B operands read from LDS one batch of 16 ahead (conv1 pattern)
+//   mode 4: as 0, with 4 independent plain VALU ops (v_max_f32) pinned behind every MFMA
+//   mode 5: as 1 (chain), with 4 VALU ops behind every MFMA
+//   mode 6: as 0, with a cluster of 16 VALU ops behind every 4th MFMA
+//   mode 7: as 0, with 2 DPP ops (v_max_f32_dpp row_shr) behind every MFMA
+//   mode 8: as 0, with 12 VALU ops behind every MFMA (48 issue cycles of a 64-cycle MFMA)
 // Prints cycles per MFMA (clock64), TFLOP/s over the whole chip (HIP events) and the implied clock.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int MODE>
+template <int MODE, bool RND = false>
 __global__ void probe(float* out, long long* t, int iters) {
   __shared__ float lds[8192];
-  for (int i = threadIdx.x; i < 8192; i += blockDim.x) lds[i] = 1e-6f * i;
+  for (int i = threadIdx.x; i < 8192; i += blockDim.x) {
+    unsigned hsh = (unsigned)i * 2654435761u + 12345u;   // RND: operands with random mantissas (toggle rate of real data)
+    hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+    lds[i] = RND ? (float)(int)(hsh >> 8) * (1.0f / 8388608.0f) - 1.0f : 1e-6f * i;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   f32x16 acc[4];
   for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-  float x[16];
-  for (int i = 0; i < 16; ++i) x[i] = 1e-3f * (lane + i);
+  float x[16], y[8];
+  for (int i = 0; i < 16; ++i) x[i] = RND ? lds[(lane * 16 + i) & 8191] : 1e-3f * (lane + i);
+  for (int i = 0; i < 8; ++i) y[i] = 1e-2f * (lane - i);
   const float* wp = lds + lane;
   long long c0 = clock64();
   for (int it = 0; it < iters; ++it) {
@@ -28,6 +38,24 @@ __global__ void probe(float* out, long long* t, int iters) {
     } else if (MODE == 1) {
 #pragma unroll
       for (int tt = 0; tt < 64; ++tt) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[tt & 15], x[(tt + 3) & 15], acc[0], 0, 0, 0);
+    } else if (MODE >= 4) {
+      constexpr int NV = MODE == 8 ? 12 : MODE == 7 ? 2 : 4;
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int ai = MODE == 5 ? 0 : a;
+          acc[ai] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[tt], x[(tt + a) & 15], acc[ai], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (MODE != 6 || a == 3) {
+#pragma unroll
+            for (int v = 0; v < (MODE == 6 ? 16 : NV); ++v) {
+              if (MODE == 7) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(y[v & 7]));
+              else asm volatile("v_max_f32 %0, %0, %1" : "+v"(y[v & 7]) : "v"(y[(v + 3) & 7]));
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
     } else if (MODE == 2) {
       float wa[2][4];
 #pragma unroll
@@ -64,14 +92,15 @@ __global__ void probe(float* out, long long* t, int iters) {
   if (threadIdx.x == 0) t[blockIdx.x] = c1 - c0;
   float s = 0;
   for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+  for (int i = 0; i < 8; ++i) s += y[i];
   out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
-template <int MODE> void run(const char* name, float* out, long long* t, int threads, int iters) {
+template <int MODE, bool RND = false> void run(const char* name, float* out, long long* t, int threads, int iters) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  probe<MODE><<<256, threads>>>(out, t, 10);
+  probe<MODE, RND><<<256, threads>>>(out, t, 10);
   (void)hipEventRecord(e0);
-  probe<MODE><<<256, threads>>>(out, t, iters);
+  probe<MODE, RND><<<256, threads>>>(out, t, iters);
   (void)hipEventRecord(e1);
   (void)hipDeviceSynchronize();
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
@@ -91,6 +120,17 @@ int main() {
       run<1>("1 accumulator chain, register operands", out, t, threads, iters);
       run<2>("4 accumulators, A from LDS one batch ahead", out, t, threads, iters);
       run<3>("1 accumulator chain, B from LDS 16 ahead", out, t, threads, iters);
+      if (iters == 40000) {
+        run<2, true>("4 accumulators, A from LDS, RANDOM operand data", out, t, threads, iters);
+        run<3, true>("1 chain, B from LDS 16 ahead, RANDOM operand data", out, t, threads, iters);
+      }
+      if (iters == 2000) {
+        run<4>("4 accumulators + 4 VALU behind every MFMA", out, t, threads, iters);
+        run<5>("1 chain + 4 VALU behind every MFMA", out, t, threads, iters);
+        run<6>("4 accumulators + 16 VALU behind every 4th MFMA", out, t, threads, iters);
+        run<7>("4 accumulators + 2 DPP behind every MFMA", out, t, threads, iters);
+        run<8>("4 accumulators + 12 VALU behind every MFMA", out, t, threads, iters);
+      }
     }
   }
   return 0;
