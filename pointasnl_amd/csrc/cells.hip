@@ -557,8 +557,9 @@ __device__ __forceinline__ void half_wave_max2(float& a, float& b) {
 // the same data as 16 scattered global_load_dword per chunk (80 per tile): the texture-addresser rate for 64
 // scattered dwords per instruction, not the matrix pipe, set their speed (57 % of the fp32 MFMA peak).
 // !VEC (cls layer1, cf = 3): step t contracts columns 2t (lanes 0..31) and 2t+1 (lanes 32..63), scalar loads.
-// LEAN: no operand prefetch buffer and the skip maxima reduced in place after the chunk's MFMAs -- 32 registers
-// less, which lets the 128-channel cell run two waves per SIMD (256 registers each) without spilling.
+// TAIL8: the row ends with exactly one partial chunk of <= 8 live steps (every shape of the three models: 8 + cf is
+// 8 mod 32 for cf = 32, 64, 128 and 11 for cf = 3).  Known at compile time, the conv0 code is one straight path:
+// [full-chunk loop][8-step tail], and the accumulators are not copied where paths would merge.
 // Diagnostic builds only (make probe: -DPASNL_SA_CELL_PROBE=<level> [-DPASNL_SA_ABLATE=<mask>] -> libpasnl_hip_probe*.so,
 // tools/sa_cell_probe.py): s_memtime marks at the phase boundaries of a tile, summed over all waves into sa_probe[].
 // Level 2 adds marks around explicit vmcnt(0) waits (tile start, every chunk), which separates "waiting for gathered
@@ -592,7 +593,7 @@ __device__ unsigned long long sa_probe[16];
 
 constexpr int SA_SKIP_REP = 4;
 
-template <int C1, int C2, int NW, bool VEC, bool LEAN>
+template <int C1, int C2, int NW, bool VEC, bool TAIL8>
 __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, int w, SaGatherSrc src,
                                                          const float* __restrict__ w0, const float* __restrict__ b0,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
@@ -606,7 +607,8 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   float* W0s = reinterpret_cast<float*>(smem);      // [wp][C1], rows in internal column order
   float* W1s = W0s + (size_t)wp * C1;               // [C1][C2]
   float* Wws = W1s + C1 * C2;                       // [3 steps][2 halves][32]: weight net, zero rows for the unused half
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: the group bookkeeping below is scalar work
   const int h = lane >> 5, ql = lane & 31;
   // running column maxima of the current group: [NW][SA_SKIP_REP][sks]; row ql of a tile folds into replica ql % 4
   // (8 lanes per address instead of 32), sks = wp + 4 puts the 8 addresses of one ds_max_f32 on 8 different banks
@@ -676,25 +678,27 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   // 4 MiB L2, so XCD x is given whole clouds (x, x+8, ...): the tables it gathers from (8 clouds x <= 270 KiB at
   // cls B = 64) stay in ITS L2 instead of every XCD streaming every cloud's table through (measured: 368 MB of
   // L2-miss fetches per launch for 17 MB of tables with the linear mapping).
-  const int nclouds = (int)(groups / src.m);
+  // All of it is wave-uniform and kept in SGPRs (scalar instructions do not occupy the vector/matrix pipe); the
+  // (cloud, point) pair advances incrementally, one division per wave instead of one per group.
+  const int m = src.m;
+  const int nclouds = (int)(groups / m);
   const bool xcd_map = (gridDim.x % 8 == 0) && nclouds >= 16;
   const int xcd = blockIdx.x & 7;
-  const long my_groups = xcd_map ? (long)((nclouds - xcd + 7) >> 3) * src.m : groups;
-  const long first = xcd_map ? (long)(blockIdx.x >> 3) * NW + wave : (long)blockIdx.x * NW + wave;
-  const long step = xcd_map ? (long)(gridDim.x >> 3) * NW : (long)gridDim.x * NW;
+  const int my_groups = xcd_map ? ((nclouds - xcd + 7) >> 3) * m : (int)groups;
+  const int first = xcd_map ? (int)(blockIdx.x >> 3) * NW + wave : (int)blockIdx.x * NW + wave;
+  const int step = xcd_map ? (int)(gridDim.x >> 3) * NW : (int)gridDim.x * NW;
+  const int step_q = step / m, step_r = step - step_q * m;
+  int cl = first / m, pj = first - cl * m;  // position in this workgroup's list: cloud slot, point
   SA_PROBE(unsigned long long pk0, pg0, pt0, pt1, pt2, pt3, pc0, pc1;
            unsigned long long a_pro = 0, a_start = 0, a_conv0 = 0, a_cwait = 0, a_conv1 = 0, a_epi = 0, a_tiles = 0;)
   SA_PROBE(SA_MARK0(pk0);)
-  for (long li = first; li < my_groups; li += step) {
+  for (int li = first; li < my_groups; li += step) {
     SA_MARK(pg0);
-    long g = li, bi;
-    if (xcd_map) {
-      const int cl = (int)li / src.m;
-      bi = xcd + 8 * cl;
-      g = bi * src.m + ((int)li - cl * src.m);
-    } else {
-      bi = (long)((int)g / src.m);
-    }
+    const long bi = xcd_map ? xcd + 8 * cl : cl;
+    const long g = bi * m + pj;
+    pj += step_r;
+    cl += step_q;
+    if (pj >= m) { pj -= m; ++cl; }
     const float cx = src.new_xyz[g * 3], cy = src.new_xyz[g * 3 + 1], cz = src.new_xyz[g * 3 + 2];
     for (int c = lane; c < SA_SKIP_REP * sks; c += 64) skp[c] = -INFINITY;
     f32x16 M[C2 / 32];
@@ -755,7 +759,8 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
           }
         }
       };
-      load_chunk(0, xr);
+      if (TAIL8 && wi < 32) load_part(0, 0, 8);  // a one-chunk row: only 8 steps exist
+      else load_chunk(0, xr);
       SA_WAIT_VM();
       SA_MARK(pt1);
       SA_PROBE(a_start += pt1 - pt0;)
@@ -858,7 +863,10 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       }
       // ---- the last chunk of a row whose width is not a multiple of 32: 8 or 16 steps (rows of W0 past the width and
       // the masked operands are zero, so steps past the last live column add nothing)
-      if (nfull < nchunk) {
+      if constexpr (TAIL8) {
+        if (nfull > 0) mask_chunk(nfull, xr);
+        chunk_steps(nfull, std::integral_constant<int, 8>{}, std::false_type{});
+      } else if (nfull < nchunk) {
         const int ch = nfull;
         if (nfull > 0) mask_chunk(ch, xr);
         const int rem = wi - ch * 32;
@@ -882,19 +890,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 #pragma unroll
         for (int r = 0; r < 16; ++r) H2[r] = 0.f;
         const float* w1p = W1s + (size_t)kappa(0, h) * C2 + cb * 32 + ql;
-        if constexpr (LEAN) {
-          // single operand buffer: the other wave of the SIMD covers the LDS latency
-#pragma unroll
-          for (int blk = 0; blk < C1 / 32; ++blk) {
-            float wv1[16];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) wv1[t] = w1p[(size_t)(blk * 32 + kappa(t, 0)) * C2];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 16; ++t) H2 = __builtin_amdgcn_mfma_f32_32x32x2f32(H1T[blk][t], wv1[t], H2, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        } else {
+        {
           float wv[2][16];
 #pragma unroll
           for (int t = 0; t < 16; ++t) wv[0][t] = w1p[(size_t)(kappa(t, 0)) * C2];
@@ -1229,13 +1225,13 @@ static int local_cell_dispatch(long groups, int k, int w, int c1, int c2, const 
   return PASNL_EUNSUPPORTED;
 }
 
-template <int C1, int C2, int NW, bool VEC, bool LEAN>
+template <int C1, int C2, int NW, bool VEC, bool TAIL8>
 static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0, const float* w1,
                           const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
   const int wp = (8 + (w - 6) + 31) & ~31;  // internal width: [xyz-c | xyz | 1 | 0 | feature], padded to 32-chunks
   size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 6 * 32 + (size_t)NW * SA_SKIP_REP * (wp + 4)) * sizeof(float);
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
-  auto kern = sa_cell_kernel<C1, C2, NW, VEC, LEAN>;
+  auto kern = sa_cell_kernel<C1, C2, NW, VEC, TAIL8>;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
@@ -1246,25 +1242,25 @@ static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const floa
       per_cu < 1)
     per_cu = 1;
   // Over-subscribing the resident count (so that the hardware dispatcher balances the load when another stream's
-  // kernels keep some CUs busy) was measured and lost: staging the weights costs ~7 us per workgroup (cls layer2:
-  // 429 / 455 / 505 / 528 us at 1x / 2x / 4x / 8x, and the two-lane cls step 1.52 / 1.54 / 1.60 / 1.65 ms).
-  int os = 1;
-  if (const char* e = getenv("PASNL_SA_CELL_OS")) os = atoi(e) > 0 ? atoi(e) : 1;  // A/B measurements only
-  long cap = 256L * per_cu * os;
+  // kernels keep some CUs busy) was measured and lost (cls layer2: 429 / 455 / 505 / 528 us at 1x / 2x / 4x / 8x, and
+  // the two-lane cls step 1.52 / 1.54 / 1.60 / 1.65 ms).
+  long cap = 256L * per_cu;
   hipLaunchKernelGGL(kern, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(NW * 64), lds, st, groups, k, w, src, w0, b0, w1, b1, ww,
                      bw, out);
   return pasnl_launch_status();
 }
 
+// Waves per workgroup: two waves per SIMD (8 per workgroup, one LDS copy of the weights) where 256 registers per wave
+// suffice (c1 <= 64; 201 vs 240 us at cls layer1, 44 vs 59 us at ScanNet layer2 when measured); the 128-channel cell
+// needs ~350 registers (at 8 waves it spilled: 3 % faster, 2.4x the HBM bytes) and runs one wave per SIMD.
 template <int C1, int C2>
-static int sa_cell_cfg(int nw, bool vec, long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0,
+static int sa_cell_cfg(bool vec, bool tail8, long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0,
                        const float* w1, const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
-  // two waves per SIMD (8 per workgroup) need <= 256 registers each: the lean variant where the full one would spill
-  constexpr bool LEAN8 = C1 >= 128;
-  if (nw == 8) return vec ? sa_cell_launch<C1, C2, 8, true, LEAN8>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
-                          : sa_cell_launch<C1, C2, 8, false, LEAN8>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
-  return vec ? sa_cell_launch<C1, C2, 4, true, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
-             : sa_cell_launch<C1, C2, 4, false, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  constexpr int NW = C1 >= 128 ? 4 : 8;
+  if (vec) return tail8 ? sa_cell_launch<C1, C2, NW, true, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
+                        : sa_cell_launch<C1, C2, NW, true, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  return tail8 ? sa_cell_launch<C1, C2, NW, false, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
+               : sa_cell_launch<C1, C2, NW, false, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
 }
 
 extern "C" int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, const float* x, const float* w0, const float* b0,
@@ -1292,15 +1288,12 @@ extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, 
   const int w = 6 + c;
   // 16-byte operand loads need 16-byte aligned feature rows
   const bool vec = (c % 4 == 0) && (reinterpret_cast<uintptr_t>(feature) % 16 == 0);
-  // two waves per SIMD share one LDS copy of the weights where 256 registers per wave suffice (c1 <= 64: 201 vs 240 us
-  // at cls layer1, 44 vs 59 us at ScanNet layer2).  The 128-channel cell needs ~380: at 8 waves it is 3 % faster
-  // (411 vs 425 us) but spills, and the scratch traffic more than doubles its HBM bytes (PMC: 417 vs 175 MB) --
-  // one wave per SIMD, no spills.  PASNL_SA_CELL_CFG=<waves per workgroup> overrides (A/B measurements only).
-  int nw = c1 >= 128 ? 4 : 8;
-  if (const char* cfg = getenv("PASNL_SA_CELL_CFG")) nw = atoi(cfg) == 4 ? 4 : 8;
-  if (c1 == 32 && c2 == 32) return sa_cell_cfg<32, 32>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
-  if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
-  if (c1 == 128 && c2 == 128) return sa_cell_cfg<128, 128>(nw, vec, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  // the row's last chunk: live MFMA steps (0 = the width is a multiple of 32); see TAIL8
+  const int wi = 8 + c, rem = wi & 31;
+  const bool tail8 = rem != 0 && (vec ? rem : (rem + 1) >> 1) <= 8;
+  if (c1 == 32 && c2 == 32) return sa_cell_cfg<32, 32>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  if (c1 == 128 && c2 == 128) return sa_cell_cfg<128, 128>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   return PASNL_EUNSUPPORTED;
 }
 
