@@ -692,6 +692,10 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   SA_PROBE(unsigned long long pk0, pg0, pt0, pt1, pt2, pt3, pc0, pc1;
            unsigned long long a_pro = 0, a_start = 0, a_conv0 = 0, a_cwait = 0, a_conv1 = 0, a_epi = 0, a_tiles = 0;)
   SA_PROBE(SA_MARK0(pk0);)
+  // The neighbour index of a tile row is requested one tile ahead (one register): a tile then starts with ONE
+  // dependent round trip (its rows) instead of two (index, then rows).
+  int inext = 0;
+  if (first < my_groups) inext = src.idx[((xcd_map ? xcd + 8L * cl : (long)cl) * m + pj) * k + ql];
   for (int li = first; li < my_groups; li += step) {
     SA_MARK(pg0);
     const long bi = xcd_map ? xcd + 8 * cl : cl;
@@ -699,6 +703,8 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
     pj += step_r;
     cl += step_q;
     if (pj >= m) { pj -= m; ++cl; }
+    // the group after this one (this one again when it is the last: a dummy request)
+    const long g_next = li + step < my_groups ? (xcd_map ? xcd + 8L * cl : (long)cl) * m + pj : g;
     const float cx = src.new_xyz[g * 3], cy = src.new_xyz[g * 3 + 1], cz = src.new_xyz[g * 3 + 2];
     for (int c = lane; c < SA_SKIP_REP * sks; c += 64) skp[c] = -INFINITY;
     f32x16 M[C2 / 32];
@@ -712,7 +718,8 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       for (int cb = 0; cb < C2 / 32; ++cb) asm volatile("" : "+a"(M[cb]));  // M lives in AccVGPRs: no VALU ever reads it
       SA_MARK(pt0);
       SA_PROBE(if (tile == 0) a_pro += pt0 - pg0;)
-      const int i = src.idx[(size_t)g * k + tile + ql];
+      const int i = inext;
+      inext = src.idx[(tile + 32 < k ? (size_t)g * k + tile + 32 : (size_t)g_next * k) + ql];
       const float* pp = src.xyz + ((size_t)bi * src.n + i) * 3;
       const float px = pp[0], py = pp[1], pz = pp[2];
       const float* frow = src.feature + ((size_t)bi * src.n + i) * (size_t)cf;
