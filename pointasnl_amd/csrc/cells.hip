@@ -513,17 +513,19 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
 
 // =============================================================================================
 // pasnl_sa_cell: grouping + skip maxima + local cell, NW waves per workgroup sharing one LDS copy of the weights.
-//   * NW = 8 puts TWO waves on every SIMD (<= 256 registers each): while one wave waits for its gathered rows or
-//     runs the bias/ReLU VALU passes between the chained products, the other one keeps the MFMA pipe busy.  With
-//     the weights filling the LDS there can be only one workgroup per CU, so the second wave has to come from
-//     inside the workgroup.
+//   * The fp32 MFMA executes on the SIMD's vector lanes: VALU instructions do not overlap with it (tools/mfmaprobe.hip:
+//     4 VALU ops behind every MFMA -> 88 instead of 64 cycles per MFMA, with one or two waves per SIMD), LDS and
+//     global-memory instructions do.  The kernel is therefore written to MINIMISE VALU INSTRUCTIONS: reductions go
+//     through LDS atomics, accumulators stay where they are (single-path loops, M pinned in AccVGPRs), operands are
+//     refilled in place, group bookkeeping is scalar.
+//   * NW = 8 puts TWO waves on every SIMD (<= 256 registers each): while one wave waits for its gathered rows the
+//     other one keeps the pipe busy (latency only -- see above).  With the weights filling the LDS there can be only
+//     one workgroup per CU, so the second wave has to come from inside the workgroup.
 //   * every global load is UNCONDITIONAL with a clamped address (a conditional load compiles to its own
 //     exec-masked basic block: serialised loads and vmcnt(0) at every join); values that must not be used are
 //     masked where they are consumed.
-//   * PF: the 16 operand values of the next 32-channel chunk are requested before the MFMAs of the current chunk.
-//   * skip connection: per chunk the 16 operand registers are reduced over the 32 rows of the tile with
-//     single-instruction v_max_f32_dpp steps and folded into a wave-private LDS row with ds_max_f32 (no return
-//     value: nothing waits for it); the row is written out once per group.
+//   * skip connection: every lane folds its operands into one of 4 replica rows of the wave with ds_max_f32 (no return
+//     value: nothing waits for it); the rows are combined and written out once per group.
 // =============================================================================================
 __device__ __forceinline__ float vmaxf(float a, float b) {
   // plain v_max_f32: fmaxf() would canonicalise both operands first (IEEE mode), 3 instructions instead of 1
@@ -531,23 +533,6 @@ __device__ __forceinline__ float vmaxf(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-// max over the 32 lanes of each half-wave of two independent values; results in lanes 31 / 63
-__device__ __forceinline__ void half_wave_max2(float& a, float& b) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1"
-      : "+v"(a), "+v"(b));
-}
-
 // Internal column order of the cell input X (a permutation of the reference's [xyz-centre | xyz | feature], chosen
 // so that a lane's 16 operands of a chunk are 64 contiguous, 16-byte aligned bytes of a feature row):
 //     0..2 xyz - centre    3..5 xyz    6 the constant 1 (row 6 of W0 = b0: the conv0 bias rides on the MFMA)

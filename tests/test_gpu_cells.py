@@ -150,8 +150,14 @@ def test_sa_local_cell(g, k, c, c1):
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-5 * scale)
 
 
-@pytest.mark.parametrize("b,n,c,m,k,c1", [(2, 1024, 3, 512, 32, 64), (2, 512, 128, 128, 64, 128), (1, 256, 64, 37, 32, 32),
-                                         (1, 100, 30, 5, 96, 64), (3, 64, 3, 64, 32, 128), (1, 40, 250, 3, 32, 64)])
+@pytest.mark.parametrize("b,n,c,m,k,c1", [
+    (2, 1024, 3, 512, 32, 64), (2, 512, 128, 128, 64, 128), (1, 256, 64, 37, 32, 32),   # the models' shapes (8-step tail)
+    (1, 100, 30, 5, 96, 64), (3, 64, 3, 64, 32, 128), (1, 40, 250, 3, 32, 64),           # scalar loads, 3 tiles, 9 chunks
+    (19, 96, 24, 33, 32, 32),    # row width 32: no partial chunk; 19 clouds: the XCD map with a ragged last round
+    (17, 64, 56, 16, 32, 64),    # row width 64: two full chunks, no partial chunk
+    (2, 128, 16, 40, 64, 64),    # partial chunk with 16 live steps (16-byte loads)
+    (1, 77, 11, 9, 32, 32),      # partial chunk with 10 live steps (scalar loads)
+    (1, 50, 4, 1, 32, 128)])     # one group: fewer groups than waves
 def test_sa_cell_gather_fused(b, n, c, m, k, c1):
     """pasnl_sa_cell = grouping + skip max + local cell in one kernel: `out` vs the fp64 restatement of
     pointasnl_util.py:63-74,248-249,264-274 on the gathered rows; `skip` bit-equal to the gathered maximum (:258)."""
@@ -183,6 +189,38 @@ def test_sa_cell_gather_fused(b, n, c, m, k, c1):
         two = U.sa_local_cell(np_, [c1, c1, 2 * c1], False, None, None, True)
     np.testing.assert_array_equal(skip.cpu().numpy(), skip2.cpu().numpy())
     np.testing.assert_allclose(got.cpu().numpy(), two.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+
+
+def test_sa_cell_unaligned_weights_take_the_scalar_staging_path():
+    """The C-ABI takes any float pointers: weights that are not 16-byte aligned are staged with dword copies and give
+    bit-identical results."""
+    from pointasnl_amd import _hip
+
+    b, n, c, m, k, c1 = 2, 200, 64, 24, 32, 64
+    g = torch.Generator(device="cuda").manual_seed(3)
+    r = lambda *sh: torch.randn(sh, device="cuda", generator=g)
+    xyz, feat, new_xyz = r(b, n, 3), r(b, n, c), r(b, m, 3)
+    idx = torch.randint(0, n, (b, m, k), device="cuda", dtype=torch.int32, generator=g)
+    ws = [r(6 + c, c1) * 0.1, r(c1) * 0.1, r(c1, c1) * 0.1, r(c1) * 0.1, r(3, 32), r(32)]
+
+    def run(weights):
+        out = torch.empty((b, m, c1, 32), device="cuda")
+        skip = torch.empty((b, m, 6 + c), device="cuda")
+        _hip.launch("pasnl_sa_cell", "sa_cell", b, n, c, m, k, c1, c1, _hip.ptr(xyz), _hip.ptr(feat), _hip.ptr(idx),
+                    _hip.ptr(new_xyz), *[_hip.ptr(t) for t in weights], _hip.ptr(out), _hip.ptr(skip))
+        return out, skip
+
+    def misaligned(t):  # the same values, 4 bytes past a 16-byte boundary
+        buf = torch.empty(t.numel() + 4, device="cuda")
+        v = buf[1:1 + t.numel()].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 == 4
+        return v
+
+    out_a, skip_a = run(ws)
+    out_u, skip_u = run([misaligned(t) for t in ws])
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_u) and torch.equal(skip_a, skip_u)
 
 
 @pytest.mark.parametrize("model", ["sem_seg", "sem_seg_res"])
