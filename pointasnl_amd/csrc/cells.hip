@@ -677,10 +677,70 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   SA_PROBE(unsigned long long pk0, pg0, pt0, pt1, pt2, pt3, pc0, pc1;
            unsigned long long a_pro = 0, a_start = 0, a_conv0 = 0, a_cwait = 0, a_conv1 = 0, a_epi = 0, a_tiles = 0;)
   SA_PROBE(SA_MARK0(pk0);)
-  // The neighbour index of a tile row is requested one tile ahead (one register): a tile then starts with ONE
-  // dependent round trip (its rows) instead of two (index, then rows).
+  // Operands of one chunk for this lane.  Every load is unconditional with a clamped address (a conditional load
+  // compiles to its own exec-masked basic block); columns outside the feature row exist only in the LAST chunk of
+  // a row that is not a multiple of 32 wide (and in chunk 0's first 8 columns, which are overwritten below), so
+  // only that chunk is masked.
+  float xr[16];
+  float px = 0.f, py = 0.f, pz = 0.f;   // the tile's neighbour coordinates (one row per lane pair)
+  const float* frow = src.feature;       // and its feature row
+  // operands [u0, u1) of chunk ch (VEC: whole 16-byte groups); the loops unroll, u0 / u1 are constants at every call
+  auto load_part = [&](int ch, int u0, int u1) {
+    if constexpr ((PASNL_SA_ABLATE & 2) != 0) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (t >= u0 && t < u1) xr[t] = (float)(ch + t) * px;
+    } else if constexpr (VEC) {
+      const int g0 = ch * 8 + 4 * h - 2;  // first 16-byte group of this lane's 16 columns (-2 in chunk 0)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (4 * q >= u0 && 4 * q < u1) {
+          const float4 t4 = reinterpret_cast<const float4*>(frow)[min(max(g0 + q, 0), cf4 - 1)];
+          xr[4 * q] = t4.x; xr[4 * q + 1] = t4.y; xr[4 * q + 2] = t4.z; xr[4 * q + 3] = t4.w;
+        }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t)
+        if (t >= u0 && t < u1) xr[t] = frow[min(max(ch * 32 + 2 * t + h - 8, 0), cf - 1)];
+    }
+  };
+  auto mask_chunk = [&](int ch, float (&v)[16]) {
+    if constexpr (VEC) {
+      const int g0 = ch * 8 + 4 * h - 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = g0 + q >= 0 && g0 + q < cf4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * q + e] = ok ? v[4 * q + e] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int f = ch * 32 + 2 * t + h - 8;
+        v[t] = (f >= 0 && f < cf) ? v[t] : 0.f;
+      }
+    }
+  };
+  // Request everything a tile starts with -- its rows' coordinates and the first chunk of operands -- for neighbour
+  // index i of cloud bc.  Called while the PREVIOUS tile still has its conv1 / matmul phase ahead (the operand
+  // registers are dead there), so that a tile starts without waiting for memory.
+  auto request_rows = [&](long bc, int i) {
+    const float* pp = src.xyz + ((size_t)bc * src.n + i) * 3;
+    px = pp[0]; py = pp[1]; pz = pp[2];
+    frow = src.feature + ((size_t)bc * src.n + i) * (size_t)cf;
+    if (TAIL8 && wi < 32) load_part(0, 0, 8);  // a one-chunk row: only 8 steps exist
+    else load_part(0, 0, 16);
+  };
+  // Software pipeline over tiles: the neighbour indices of tile t+1 are requested when tile t starts, its rows when
+  // tile t has finished conv0; the centre of the next group when a group starts.  Only a wave's first tile waits
+  // for the two dependent round trips (index, then rows).
   int inext = 0;
-  if (first < my_groups) inext = src.idx[((xcd_map ? xcd + 8L * cl : (long)cl) * m + pj) * k + ql];
+  float cxn = 0.f, cyn = 0.f, czn = 0.f;
+  if (first < my_groups) {
+    const long b0 = xcd_map ? xcd + 8L * cl : (long)cl, g0 = b0 * m + pj;
+    request_rows(b0, src.idx[g0 * k + ql]);
+    cxn = src.new_xyz[g0 * 3]; cyn = src.new_xyz[g0 * 3 + 1]; czn = src.new_xyz[g0 * 3 + 2];
+  }
   for (int li = first; li < my_groups; li += step) {
     SA_MARK(pg0);
     const long bi = xcd_map ? xcd + 8 * cl : cl;
@@ -689,8 +749,10 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
     cl += step_q;
     if (pj >= m) { pj -= m; ++cl; }
     // the group after this one (this one again when it is the last: a dummy request)
-    const long g_next = li + step < my_groups ? (xcd_map ? xcd + 8L * cl : (long)cl) * m + pj : g;
-    const float cx = src.new_xyz[g * 3], cy = src.new_xyz[g * 3 + 1], cz = src.new_xyz[g * 3 + 2];
+    const long bi_next = li + step < my_groups ? (xcd_map ? xcd + 8L * cl : (long)cl) : bi;
+    const long g_next = li + step < my_groups ? bi_next * m + pj : g;
+    const float cx = cxn, cy = cyn, cz = czn;
+    cxn = src.new_xyz[g_next * 3]; cyn = src.new_xyz[g_next * 3 + 1]; czn = src.new_xyz[g_next * 3 + 2];
     for (int c = lane; c < SA_SKIP_REP * sks; c += 64) skp[c] = -INFINITY;
     f32x16 M[C2 / 32];
 #pragma unroll
@@ -703,56 +765,8 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       for (int cb = 0; cb < C2 / 32; ++cb) asm volatile("" : "+a"(M[cb]));  // M lives in AccVGPRs: no VALU ever reads it
       SA_MARK(pt0);
       SA_PROBE(if (tile == 0) a_pro += pt0 - pg0;)
-      const int i = inext;
+      // (this tile's rows were requested during the previous tile; now the indices of the following tile)
       inext = src.idx[(tile + 32 < k ? (size_t)g * k + tile + 32 : (size_t)g_next * k) + ql];
-      const float* pp = src.xyz + ((size_t)bi * src.n + i) * 3;
-      const float px = pp[0], py = pp[1], pz = pp[2];
-      const float* frow = src.feature + ((size_t)bi * src.n + i) * (size_t)cf;
-      // Operands of one chunk for this lane.  Every load is unconditional with a clamped address (a conditional load
-      // compiles to its own exec-masked basic block); columns outside the feature row exist only in the LAST chunk of
-      // a row that is not a multiple of 32 wide (and in chunk 0's first 8 columns, which are overwritten below), so
-      // only that chunk is masked.
-      float xr[16];
-      // operands [u0, u1) of chunk ch (VEC: whole 16-byte groups); the loops unroll, u0 / u1 are constants at every call
-      auto load_part = [&](int ch, int u0, int u1) {
-        if constexpr ((PASNL_SA_ABLATE & 2) != 0) {
-#pragma unroll
-          for (int t = 0; t < 16; ++t)
-            if (t >= u0 && t < u1) xr[t] = (float)(ch + t) * px;
-        } else if constexpr (VEC) {
-          const int g0 = ch * 8 + 4 * h - 2;  // first 16-byte group of this lane's 16 columns (-2 in chunk 0)
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            if (4 * q >= u0 && 4 * q < u1) {
-              const float4 t4 = reinterpret_cast<const float4*>(frow)[min(max(g0 + q, 0), cf4 - 1)];
-              xr[4 * q] = t4.x; xr[4 * q + 1] = t4.y; xr[4 * q + 2] = t4.z; xr[4 * q + 3] = t4.w;
-            }
-        } else {
-#pragma unroll
-          for (int t = 0; t < 16; ++t)
-            if (t >= u0 && t < u1) xr[t] = frow[min(max(ch * 32 + 2 * t + h - 8, 0), cf - 1)];
-        }
-      };
-      auto load_chunk = [&](int ch, float (&)[16]) { load_part(ch, 0, 16); };
-      auto mask_chunk = [&](int ch, float (&v)[16]) {
-        if constexpr (VEC) {
-          const int g0 = ch * 8 + 4 * h - 2;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const bool ok = g0 + q >= 0 && g0 + q < cf4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * q + e] = ok ? v[4 * q + e] : 0.f;
-          }
-        } else {
-#pragma unroll
-          for (int t = 0; t < 16; ++t) {
-            const int f = ch * 32 + 2 * t + h - 8;
-            v[t] = (f >= 0 && f < cf) ? v[t] : 0.f;
-          }
-        }
-      };
-      if (TAIL8 && wi < 32) load_part(0, 0, 8);  // a one-chunk row: only 8 steps exist
-      else load_chunk(0, xr);
       SA_WAIT_VM();
       SA_MARK(pt1);
       SA_PROBE(a_start += pt1 - pt0;)
@@ -866,6 +880,8 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
         if (live <= 8) chunk_steps(ch, std::integral_constant<int, 8>{}, std::false_type{});
         else chunk_steps(ch, std::integral_constant<int, 16>{}, std::false_type{});
       }
+      // rows of the following tile (same group, or the first tile of the next one): they arrive during conv1
+      request_rows(tile + 32 < k ? bi : bi_next, inext);
       SA_MARK(pt2);
       SA_PROBE(a_conv0 += pt2 - pt1;)
       // ReLU (the bias came with the MFMA); G: bias + ReLU
