@@ -510,9 +510,15 @@ def main():
     }
     if args.launch_order:
         out["launch_order"] = launch_order
-    print(json.dumps(out))
     if multi:
         dist.destroy_process_group()
+    # the JSON line is the LAST line on stdout: RCCL leaves a version banner in the C stdio buffer, which would otherwise
+    # be flushed after it when the process exits
+    import ctypes
+
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
