@@ -479,7 +479,7 @@ def main():
                     "alg_bytes": dom["alg_bytes"], "alg_flops": dom["alg_flops"]}
 
     cpu = None
-    if not args.no_cpu_baseline and args.model == "cls":
+    if not args.no_cpu_baseline and args.model == "cls" and world == 1:  # rank 0 at N=1 only
         cpu = cpu_baseline(pc, store.export_numpy(), args.AS)
 
     handwritten_us = sum(r["avg_us"] for r in rows)
