@@ -9,7 +9,6 @@ What changes underneath (and nothing else):
     of pointasnl_util.py:199-212 is never written to HBM;
   * 1x1 convolutions + inference BN are folded GEMMs on the vendor BLAS (tf_util.py here).
 """
-import ctypes
 
 import torch
 
