@@ -39,6 +39,38 @@ __device__ __forceinline__ int kappa(int t, int h) { return (t & 3) + 8 * (t >> 
 //   V[kappa(t,h)][c0 + (l&31)] is a conflict-free LDS row read.
 //   K rows are stored with stride CB+1 so that the A-operand read K[l&31][2t+h] is conflict-free.
 // =============================================================================================
+// Diagnostic builds only (make probe: -DPASNL_SA_CELL_PROBE=<level> [-DPASNL_SA_ABLATE=<mask>] -> libpasnl_hip_probe*.so,
+// tools/sa_cell_probe.py): s_memtime marks at the phase boundaries of a tile, summed over all waves into sa_probe[].
+// Level 2 adds marks around explicit vmcnt(0) waits (tile start, every chunk), which separates "waiting for gathered
+// rows" from matrix work at the price of perturbing the LDS prefetch.  The ablation mask removes one ingredient at a
+// time (results are then wrong; only the time matters): 1 skip maxima, 2 global operand loads, 4 output stores.
+#ifdef PASNL_SA_CELL_PROBE
+__device__ unsigned long long sa_probe[16];
+__device__ unsigned long long nl_probe[16];
+#define SA_MARK0(t) do { __builtin_amdgcn_sched_barrier(0); t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#if PASNL_SA_CELL_PROBE >= 1
+#define SA_MARK(t) SA_MARK0(t)
+#else
+#define SA_MARK(t) t = 0   /* level 0: only the wave's total (two marks per wave: the code is the production code) */
+#endif
+#define SA_PROBE(...) __VA_ARGS__
+#if PASNL_SA_CELL_PROBE >= 2
+#define SA_MARK2(t) SA_MARK(t)
+#define SA_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define SA_MARK2(t) t = 0
+#define SA_WAIT_VM()
+#endif
+#else
+#define SA_MARK(t)
+#define SA_MARK2(t)
+#define SA_WAIT_VM()
+#define SA_PROBE(...)
+#endif
+#ifndef PASNL_SA_ABLATE
+#define PASNL_SA_ABLATE 0
+#endif
+
 constexpr int NL_KB = 32;  // keys per block
 
 template <int CB, int SPLIT>
@@ -80,9 +112,50 @@ __global__ __launch_bounds__(SPLIT * 64) void nl_attention_mfma_kernel(int p, in
 #pragma unroll
     for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
   float mrun = -INFINITY, lrun = 0.f;
+  SA_PROBE(unsigned long long n0, n1, n2, n3, n4, nk0, a_st = 0, a_s = 0, a_sm = 0, a_pv = 0, a_blk = 0; SA_MARK0(nk0);)
+
+  // Register prefetch (cb <= 64): the [K | V] rows of block i+1 are requested before the products of block i and written
+  // to the wave's LDS region after them, so a wave overlaps ITS OWN memory round trip with its own matrix work.  (More
+  // waves per SIMD do not: the waves of a launch start together and run phases of identical length, so they wait for
+  // memory together and compete for the pipe together -- the loop took the same 249 k cycles per SIMD with 1, 2 or 4
+  // waves on it.)  Lane l always copies float4 column l % F4 of rows l / F4 + i * RPI: offsets are loop constants.
+  constexpr bool PF = CB <= 64;
+  constexpr int F4 = 2 * CB / 4, RPI = PF ? 64 / F4 : 1, NIT = PF ? NL_KB / RPI : 1;
+  const int pr0 = lane / F4, pc4 = (lane - pr0 * F4) * 4;
+  float4 pf[NIT];
+  auto request_block = [&](int base) {
+    const int cnt = min(NL_KB, n - base);
+#pragma unroll
+    for (int i = 0; i < NIT; ++i)
+      pf[i] = *reinterpret_cast<const float4*>(kvb + (size_t)(base + min(pr0 + i * RPI, cnt - 1)) * 2 * CB + pc4);
+  };
+  if constexpr (PF) {
+    if (wave * NL_KB < n) request_block(wave * NL_KB);
+  }
 
   for (int base = wave * NL_KB; base < n; base += SPLIT * NL_KB) {
+    SA_MARK(n0);
     const int cnt = min(NL_KB, n - base);
+    if constexpr (PF) {
+      // rows past cnt are zero-filled: their probabilities are 0, and 0 * stale-LDS-NaN must not reach the accumulator
+      if (cnt < NL_KB) {  // only the last block of a cloud whose size is not a multiple of 32
+#pragma unroll
+        for (int i = 0; i < NIT; ++i)
+          if (pr0 + i * RPI >= cnt) pf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      if (pc4 < CB) {
+        float* d = Ks + pr0 * KS + pc4;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+          d[i * RPI * KS] = pf[i].x; d[i * RPI * KS + 1] = pf[i].y; d[i * RPI * KS + 2] = pf[i].z; d[i * RPI * KS + 3] = pf[i].w;
+        }
+      } else {
+        float* d = Vs + pr0 * CB + (pc4 - CB);
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) *reinterpret_cast<float4*>(d + i * RPI * CB) = pf[i];
+      }
+      if (base + SPLIT * NL_KB < n) request_block(base + SPLIT * NL_KB);
+    } else {
     // wave-private staging of 32 [K | V] rows (coalesced float4 reads); rows past cnt are zero-filled: their
     // probabilities are 0, and 0 * stale-LDS-NaN must not reach the accumulator
 #pragma unroll 2
@@ -97,7 +170,9 @@ __global__ __launch_bounds__(SPLIT * 64) void nl_attention_mfma_kernel(int p, in
         *reinterpret_cast<float4*>(Vs + row * CB + (c4 - CB)) = v;
       }
     }
+    }
     // (LDS operations of one wave execute in order: no barrier needed before reading the region back)
+    SA_MARK(n1);
     // ---- S^T = K_blk . Q^T
     f32x16 S;
 #pragma unroll
@@ -105,13 +180,22 @@ __global__ __launch_bounds__(SPLIT * 64) void nl_attention_mfma_kernel(int p, in
     const float* krow = Ks + ql * KS + h;
 #pragma unroll
     for (int t = 0; t < CB / 2; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * t], qreg[t], S, 0, 0, 0);
+    // the V operands of the first 32-channel block are requested now: they arrive under the softmax
+    float vop[16];
+    {
+      const float* vcol0 = Vs + ql;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) vop[t] = vcol0[kappa(t, h) * CB];
+    }
+    SA_MARK(n2);
     // ---- online softmax over this lane's 16 keys (+ the other half-wave's 16)
     float tmax = -INFINITY;
+    if (cnt < NL_KB) {  // keys to mask exist only in the last block of a cloud whose size is not a multiple of 32
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      S[r] = kappa(r, h) < cnt ? S[r] : -INFINITY;
-      tmax = fmaxf(tmax, S[r]);
+      for (int r = 0; r < 16; ++r) S[r] = kappa(r, h) < cnt ? S[r] : -INFINITY;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, S[r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
     const float mnew = fmaxf(mrun, tmax);  // finite: every block has >= 1 valid key
     const float alpha = fast_exp2(mrun - mnew);
@@ -124,6 +208,7 @@ __global__ __launch_bounds__(SPLIT * 64) void nl_attention_mfma_kernel(int p, in
     psum += __shfl_xor(psum, 32);
     lrun = lrun * alpha + psum;
     mrun = mnew;
+    SA_MARK(n3);
     // ---- O^T = alpha * O^T + V^T . P^T
 #pragma unroll
     for (int c = 0; c < CB / 32; ++c) {
@@ -131,9 +216,20 @@ __global__ __launch_bounds__(SPLIT * 64) void nl_attention_mfma_kernel(int p, in
       for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
       const float* vcol = Vs + c * 32 + ql;
 #pragma unroll
-      for (int t = 0; t < 16; ++t) O[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[kappa(t, h) * CB], S[t], O[c], 0, 0, 0);
+      for (int t = 0; t < 16; ++t)
+        O[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(c == 0 ? vop[t] : vcol[kappa(t, h) * CB], S[t], O[c], 0, 0, 0);
     }
+    SA_MARK(n4);
+    SA_PROBE(a_st += n1 - n0; a_s += n2 - n1; a_sm += n3 - n2; a_pv += n4 - n3; a_blk += 1;)
   }
+#ifdef PASNL_SA_CELL_PROBE
+  SA_MARK0(n4);
+  if (lane == 0) {
+    atomicAdd(&nl_probe[0], a_st); atomicAdd(&nl_probe[1], a_s); atomicAdd(&nl_probe[2], a_sm); atomicAdd(&nl_probe[3], a_pv);
+    atomicAdd(&nl_probe[4], a_blk); atomicAdd(&nl_probe[5], n4 - nk0); atomicAdd(&nl_probe[6], 1ull);
+  }
+  SA_MARK0(nk0);
+#endif
 
   if constexpr (SPLIT > 1) {
     // ---- merge the SPLIT partial results: wave w > 0 parks (m, l, O) in its own LDS region, wave 0 folds them in
@@ -545,36 +641,6 @@ __device__ __forceinline__ float vmaxf(float a, float b) {
 // TAIL8: the row ends with exactly one partial chunk of <= 8 live steps (every shape of the three models: 8 + cf is
 // 8 mod 32 for cf = 32, 64, 128 and 11 for cf = 3).  Known at compile time, the conv0 code is one straight path:
 // [full-chunk loop][8-step tail], and the accumulators are not copied where paths would merge.
-// Diagnostic builds only (make probe: -DPASNL_SA_CELL_PROBE=<level> [-DPASNL_SA_ABLATE=<mask>] -> libpasnl_hip_probe*.so,
-// tools/sa_cell_probe.py): s_memtime marks at the phase boundaries of a tile, summed over all waves into sa_probe[].
-// Level 2 adds marks around explicit vmcnt(0) waits (tile start, every chunk), which separates "waiting for gathered
-// rows" from matrix work at the price of perturbing the LDS prefetch.  The ablation mask removes one ingredient at a
-// time (results are then wrong; only the time matters): 1 skip maxima, 2 global operand loads, 4 output stores.
-#ifdef PASNL_SA_CELL_PROBE
-__device__ unsigned long long sa_probe[16];
-#define SA_MARK0(t) do { __builtin_amdgcn_sched_barrier(0); t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#if PASNL_SA_CELL_PROBE >= 1
-#define SA_MARK(t) SA_MARK0(t)
-#else
-#define SA_MARK(t) t = 0   /* level 0: only the wave's total (two marks per wave: the code is the production code) */
-#endif
-#define SA_PROBE(...) __VA_ARGS__
-#if PASNL_SA_CELL_PROBE >= 2
-#define SA_MARK2(t) SA_MARK(t)
-#define SA_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define SA_MARK2(t) t = 0
-#define SA_WAIT_VM()
-#endif
-#else
-#define SA_MARK(t)
-#define SA_MARK2(t)
-#define SA_WAIT_VM()
-#define SA_PROBE(...)
-#endif
-#ifndef PASNL_SA_ABLATE
-#define PASNL_SA_ABLATE 0
-#endif
 
 constexpr int SA_SKIP_REP = 4;
 
@@ -958,6 +1024,12 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 }  // namespace pasnl
 // [prologue, start wait, conv0 (incl. chunk wait), chunk wait, conv1 + matmul, epilogue, tiles, wave total, waves,
 // weight staging] cycles
+// [staging, S = K.Q^T, softmax, O += V^T.P^T, blocks, wave loop total, waves] cycles
+extern "C" int pasnl_nl_probe_read(unsigned long long* host16) {
+  if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(pasnl::nl_probe), sizeof(pasnl::nl_probe)) != hipSuccess) return -1;
+  unsigned long long zero[16] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(pasnl::nl_probe), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
 extern "C" int pasnl_sa_cell_probe_read(unsigned long long* host16) {
   if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(pasnl::sa_probe), sizeof(pasnl::sa_probe)) != hipSuccess) return -1;
   unsigned long long zero[16] = {};
