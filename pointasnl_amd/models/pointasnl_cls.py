@@ -6,7 +6,7 @@ import torch
 
 from pointasnl_amd.utils import tf_util
 from pointasnl_amd.utils.pointnet_util import pointnet_sa_module
-from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction
+from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction, get_repulsion_loss
 
 
 def first_layer(num_point=None):
@@ -57,3 +57,15 @@ def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, w
     end_points['l2_points'] = l2_points
     end_points['l2_xyz_true'] = l2_xyz
     return net, end_points
+
+
+def get_loss(pred, label, end_points, uniform_weight=0, weights_decay=1e-4):
+    """ pred: B*NUM_CLASSES, label: B  (pointasnl_cls.py:55-70) """
+    regularization_loss = tf_util.regularization_loss(weights_decay)
+    loss = torch.nn.functional.cross_entropy(pred, label.long(), reduction='none')
+    classify_loss = loss.mean()
+    if uniform_weight > 0:
+        uniform_loss = get_repulsion_loss(end_points['l1_xyz'], nsample=20, radius=0.07)
+    else:
+        uniform_loss = classify_loss
+    return classify_loss + uniform_weight * uniform_loss + regularization_loss

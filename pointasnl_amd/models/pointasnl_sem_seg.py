@@ -1,8 +1,9 @@
 """pointasnl_sem_seg -- inference graph of the reference's ScanNet segmentation model
 (models/pointasnl_sem_seg.py:18-50): 4 PointASNL set-abstraction layers + 4 PointASNL decoding layers
 (three_nn / three_interpolate + self-kNN local cell).  Same get_model signature; torch device tensors."""
+import torch
 from pointasnl_amd.utils import tf_util
-from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction, PointASNLDecodingLayer
+from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction, PointASNLDecodingLayer, get_repulsion_loss
 
 
 def first_layer(num_point):
@@ -49,3 +50,15 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
     net = tf_util.dropout(net, keep_prob=0.5, is_training=is_training, scope='dp1')
     net = tf_util.conv1d(net, num_class, 1, padding='VALID', activation_fn=None, weight_decay=weight_decay, scope='fc2')
     return net, end_points
+
+
+def get_loss(pred, label, end_points, smpw=1.0, uniform_weight=0.01, weights_decay=1e-4, radius=0.07):
+    """ pred: BxNxC, label: BxN, smpw: BxN  (pointasnl_sem_seg.py get_loss) """
+    regularization_loss = tf_util.regularization_loss(weights_decay)
+    # tf.losses.sparse_softmax_cross_entropy(weights=smpw): sum(w * ce) / number of non-zero weights
+    ce = torch.nn.functional.cross_entropy(pred.reshape(-1, pred.shape[-1]), label.reshape(-1).long(), reduction='none')
+    w = torch.as_tensor(smpw, dtype=ce.dtype, device=ce.device).expand(label.shape).reshape(-1)
+    classify_loss = (ce * w).sum() / torch.count_nonzero(w).clamp(min=1)
+    uniform_loss = get_repulsion_loss(end_points['l1_xyz'], nsample=20, radius=radius)
+    weight_reg = tf_util.collection_losses()
+    return classify_loss + weight_reg + uniform_weight * uniform_loss + regularization_loss

@@ -102,11 +102,11 @@ def sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn):
     c1, c2 = mlp[0], mlp[1]
     st = tf_util.store()
     with tf_util.variable_scope('conv0'):
-        w0, b0 = st.layer(w, c1, bn)
+        w0, b0 = st.layer(w, c1, bn, weight_decay)
     with tf_util.variable_scope('conv1'):
-        w1, b1 = st.layer(c1, c2, bn)
+        w1, b1 = st.layer(c1, c2, bn, weight_decay)
     with tf_util.variable_scope('weight_net'), tf_util.variable_scope('wconv0'):
-        ww, bw = st.layer(3, 32, True)
+        ww, bw = st.layer(3, 32, True, weight_decay)
     new_point = new_point.contiguous()
     out = torch.empty((b, p, c2, 32), dtype=torch.float32, device=new_point.device)
     _hip.launch("pasnl_sa_local_cell", "sa_local_cell", b * p, k, w, c1, c2, _hip.ptr(new_point), _hip.ptr(w0), _hip.ptr(b0),
@@ -124,11 +124,11 @@ def sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay
     c1, c2 = mlp[0], mlp[1]
     st = tf_util.store()
     with tf_util.variable_scope('conv0'):
-        w0, b0 = st.layer(6 + c, c1, bn)
+        w0, b0 = st.layer(6 + c, c1, bn, weight_decay)
     with tf_util.variable_scope('conv1'):
-        w1, b1 = st.layer(c1, c2, bn)
+        w1, b1 = st.layer(c1, c2, bn, weight_decay)
     with tf_util.variable_scope('weight_net'), tf_util.variable_scope('wconv0'):
-        ww, bw = st.layer(3, 32, True)
+        ww, bw = st.layer(3, 32, True, weight_decay)
     xyz, feature, idx, new_xyz = xyz.contiguous(), feature.contiguous(), idx.contiguous(), new_xyz.contiguous()
     out = torch.empty((b, p, c2, 32), dtype=torch.float32, device=xyz.device)
     skip = torch.empty((b, p, 6 + c), dtype=torch.float32, device=xyz.device)
@@ -220,7 +220,7 @@ def AdaptiveSampling(group_xyz, group_feature, num_neighbor, is_training, bn_dec
 AS_FUSED = True  # False = the reference's op-by-op AdaptiveSampling / SampleWeights chain on gathered tensors
 
 
-def adaptive_sampling_fused(xyz, feature, idx, num_neighbor, scope, bn):
+def adaptive_sampling_fused(xyz, feature, idx, num_neighbor, scope, bn, weight_decay=None):
     """AdaptiveSampling + SampleWeights (pointasnl_util.py:112-173) without the grouped tensors: one gather builds the
     (B,P,as,6+C) input of the two projections, ONE GEMM produces [K | V | Q], the micro attention reads it in place,
     and the re-weighting tail reads coordinates and features from the same gathered rows.  Same variables as the
@@ -238,17 +238,18 @@ def adaptive_sampling_fused(xyz, feature, idx, num_neighbor, scope, bn):
         key = st.path("kvq_fused")
         if key not in st._folded:
             with tf_util.variable_scope('conv_kv_ds'):
-                wkv, bkv = st.layer(6 + c, 2 * cb, bn)
+                wkv, bkv = st.layer(6 + c, 2 * cb, bn, weight_decay)
             with tf_util.variable_scope('conv_query_ds'):
-                wq, bq = st.layer(6 + c, cb, bn)
+                wq, bq = st.layer(6 + c, cb, bn, weight_decay)
             st._folded[key] = (torch.cat([wkv, wq], dim=1).contiguous(), torch.cat([bkv, bq]).contiguous())
         wkvq, bkvq = st._folded[key]
         kvq = torch.addmm(bkvq, x.reshape(-1, 6 + c), wkvq)  # (B*P*as, 3cb) = [K | V | Q]
         att = torch.empty((b, p, as_, cb), dtype=torch.float32, device=xyz.device)
         _hip.launch("pasnl_as_attention_qkv", "as_attention", b * p, as_, cb, _hip.ptr(kvq), _hip.ptr(att))
-        hid = tf_util.conv2d(att, 32, [1, 1], padding='VALID', stride=[1, 1], bn=bn, is_training=False, scope='mlp2_0')
+        hid = tf_util.conv2d(att, 32, [1, 1], padding='VALID', stride=[1, 1], bn=bn, is_training=False, scope='mlp2_0',
+                             weight_decay=weight_decay)
         logits = tf_util.conv2d(hid, 1 + channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn, is_training=False,
-                                scope='mlp2_1', activation_fn=None).contiguous()
+                                scope='mlp2_1', activation_fn=None, weight_decay=weight_decay).contiguous()
     new_xyz = torch.empty((b, p, 3), dtype=torch.float32, device=xyz.device)
     new_feature = torch.empty((b, p, channel), dtype=torch.float32, device=xyz.device)
     _hip.launch("pasnl_as_reweight_x", "as_reweight", b * p, as_, channel, _hip.ptr(logits), _hip.ptr(x), _hip.ptr(new_xyz),
@@ -342,7 +343,7 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                         _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx), _hip.ptr(new_xyz), _hip.ptr(new_feature))
         elif num_points != npoint and AS_FUSED and as_neighbor <= 16:
             tf_util._require_inference(is_training)
-            new_xyz, new_feature = adaptive_sampling_fused(xyz, feature, idx, as_neighbor, scope, bn)
+            new_xyz, new_feature = adaptive_sampling_fused(xyz, feature, idx, as_neighbor, scope, bn, weight_decay)
         elif num_points != npoint:
             # AdaptiveSampling only ever reads the first `as_neighbor` neighbours (:165-166): gather just those
             # instead of slicing the full grouped tensors
@@ -403,13 +404,13 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
 DECODE_CELL_FUSED = True  # False = the reference's op-by-op chain (gathers, concat, conv2d, transpose, batched matmul)
 
 
-def decode_cell(xyz, feature, idx):
+def decode_cell(xyz, feature, idx, weight_decay=None):
     """Decoder local cell (pointasnl_util.py:323-331) fused: (B,N,3), (B,N,C), (B,N,K) -> (B,N,3+C,32).
     The variables are the ones the op-by-op chain creates (scope decode_weight_net/wconv0)."""
     b, n, c = feature.shape
     k = idx.shape[2]
     with tf_util.variable_scope('decode_weight_net'), tf_util.variable_scope('wconv0'):
-        ww, bw = tf_util.store().layer(3, 32, True)
+        ww, bw = tf_util.store().layer(3, 32, True, weight_decay)
     xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
     out = torch.empty((b, n, 3 + c, 32), dtype=torch.float32, device=xyz.device)
     _hip.launch("pasnl_decode_cell", "decode_cell", b, n, c, k, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx), _hip.ptr(ww),
@@ -440,7 +441,7 @@ def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_traini
         if DECODE_CELL_FUSED and use_xyz and use_knn and nsample in (16, 32):
             # self-kNN, both gathers, the centring, the weight net and F^T.G in one kernel (no grouped tensors)
             tf_util._require_inference(is_training)
-            new_points = decode_cell(xyz1, interpolated_points, knn_query(nsample, xyz1, xyz1))
+            new_points = decode_cell(xyz1, interpolated_points, knn_query(nsample, xyz1, xyz1), weight_decay)
         else:
             grouped_xyz, grouped_feature, idx = grouping(interpolated_points, nsample, xyz1, xyz1, use_xyz=use_xyz,
                                                          use_knn=use_knn, radius=radius)

@@ -30,6 +30,7 @@ class VariableStore:
         self.device = device
         self.randomize_bn = randomize_bn  # non-trivial gamma/beta/mean/var so that BN folding is actually tested
         self.vars = {}
+        self.decays = {}  # weights variable -> wd: the reference's 'losses' collection (tf_util.py:30-49: wd * l2_loss(var))
         self._folded = {}
         self._scope = []
 
@@ -71,8 +72,11 @@ class VariableStore:
             self.vars[full] = torch.tensor(v, dtype=torch.float32, device=self.device)
         return self.vars[full]
 
-    def layer(self, cin, cout, bn):
-        """(W', b') of the layer at the current scope, BN folded, cached."""
+    def layer(self, cin, cout, bn, weight_decay=None):
+        """(W', b') of the layer at the current scope, BN folded, cached.  weight_decay: as the reference's
+        _variable_with_weight_decay, a layer built with one contributes wd * l2_loss(weights) to get_loss()."""
+        if weight_decay is not None:
+            self.decays[self.path("weights")] = float(weight_decay)
         key = self.path("")
         if key not in self._folded:
             w = self.get("weights", (cin, cout), "xavier")
@@ -140,10 +144,10 @@ def _act(x, activation_fn):
     return activation_fn(x)
 
 
-def _dense(inputs, num_output_channels, scope, bn, activation_fn):
+def _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay=None):
     cin = inputs.shape[-1]
     with variable_scope(scope):
-        w, b = store().layer(cin, num_output_channels, bn)
+        w, b = store().layer(cin, num_output_channels, bn, weight_decay)
     x2d = inputs.reshape(-1, cin)
     if activation_fn in ("relu", torch.relu, torch.nn.functional.relu) and FUSE_RELU_EPILOGUE:
         # bias + ReLU in the GEMM epilogue (hipBLASLt) instead of a second pass over the output
@@ -160,7 +164,7 @@ def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='S
     _require_inference(is_training)
     if kernel_size != 1 or data_format != 'NHWC':
         raise NotImplementedError("conv1d mirror supports kernel_size=1, NHWC")
-    return _dense(inputs, num_output_channels, scope, bn, activation_fn)
+    return _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay)
 
 
 def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], padding='SAME', data_format='NHWC',
@@ -173,11 +177,11 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], paddi
     if data_format != 'NHWC' or kh != 1:
         raise NotImplementedError("conv2d mirror supports NHWC, kernel height 1")
     if kw == 1:
-        return _dense(inputs, num_output_channels, scope, bn, activation_fn)
+        return _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay)
     if padding != 'VALID' or kw != inputs.shape[2]:
         raise NotImplementedError("conv2d mirror supports [1,1] or the full-width VALID kernel")
     b, h, w, c = inputs.shape
-    out = _dense(inputs.reshape(b, h, w * c), num_output_channels, scope, bn, activation_fn)
+    out = _dense(inputs.reshape(b, h, w * c), num_output_channels, scope, bn, activation_fn, weight_decay)
     return out.reshape(b, h, 1, num_output_channels)
 
 
@@ -185,10 +189,30 @@ def fully_connected(inputs, num_outputs, scope, use_xavier=True, stddev=1e-3, we
                     activation_fn="relu", bn=False, bn_decay=None, is_training=None):
     """tf_util.py:327-365"""
     _require_inference(is_training)
-    return _dense(inputs, num_outputs, scope, bn, activation_fn)
+    return _dense(inputs, num_outputs, scope, bn, activation_fn, weight_decay)
 
 
 def dropout(inputs, is_training, scope, keep_prob=0.5, noise_shape=None):
     """tf_util.py:594-615: identity at inference."""
     _require_inference(is_training)
     return inputs
+
+
+def l2_loss(t):
+    """tf.nn.l2_loss: sum(t ** 2) / 2"""
+    return (t * t).sum() * 0.5
+
+
+def regularization_loss(weights_decay):
+    """weights_decay * sum of l2_loss over every variable whose name contains 'weights' (the models' get_loss)."""
+    st = store()
+    return weights_decay * sum(l2_loss(v) for name, v in st.vars.items() if 'weights' in name)
+
+
+def collection_losses():
+    """tf.add_n(tf.get_collection('losses')): the wd * l2_loss(weights) terms of the layers built with a weight_decay.
+    Like tf.add_n it refuses an empty collection (a graph built with weight_decay=None)."""
+    st = store()
+    if not st.decays:
+        raise ValueError("the 'losses' collection is empty: build the model with a weight_decay")
+    return sum(wd * l2_loss(st.vars[name]) for name, wd in st.decays.items())
