@@ -273,6 +273,162 @@ __global__ __launch_bounds__(SPLIT * 64) void nl_attention_mfma_kernel(int p, in
 }
 
 // =============================================================================================
+// Non-local attention, MFMA variant WITHOUT LDS staging (cb <= 64).
+//   A key block is used by exactly one wave, so the LDS round trip of the kernel above only re-distributes data
+//   between lanes -- and both products can take their A operands from global memory in the layout the loads
+//   deliver:
+//     * S^T = K . Q^T: the pairing of channels inside an MFMA step is free as long as K and Q agree on it.  Step t
+//       contracts channel t (lanes 0..31) and channel cb/2 + t (lanes 32..63): lane (ql, h) needs the cb/2
+//       CONTIGUOUS floats K[key ql][h*cb/2 ..] -- cb/8 16-byte loads, no transposition, no bank-conflict padding;
+//     * O^T += V^T . P^T: step t contracts key kappa(t, h), its A operand V[key][c*32 + ql] is a coalesced 128-byte
+//       row read (lanes over channels) straight from L2.
+//   The operand registers are refilled IN PLACE with the next key block as soon as the products that read them
+//   have been issued (K under the softmax and P.V, V under the next block's K.Q and softmax): the wave overlaps
+//   its own round trips, which more waves per SIMD do not do for it (equal-length phases).
+//   LDS only for the final merge of the SPLIT partial results.
+// =============================================================================================
+template <int CB, int SPLIT>
+__global__ __launch_bounds__(SPLIT * 64) void nl_attention_direct_kernel(int p, int n, float qscale,
+                                                                       const float* __restrict__ q,
+                                                                       const float* __restrict__ kv,
+                                                                       float* __restrict__ out) {
+  constexpr int HC = CB / 2;                       // MFMA steps of S = channels per half-wave
+  constexpr int PARK = (CB / 2 + 2) * 64;          // floats a wave parks for the merge
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, ql = lane & 31;
+  int bi = blockIdx.y, qt = blockIdx.x;  // XCD-aware mapping as in nl_attention_mfma_kernel
+  if ((gridDim.y & 7) == 0) {
+    const int id = blockIdx.y * gridDim.x + blockIdx.x, slot = id >> 3;
+    bi = (id & 7) + 8 * (slot / (int)gridDim.x);
+    qt = slot % (int)gridDim.x;
+  }
+  const int q0 = qt * 32;
+  const int qi = min(q0 + ql, p - 1);
+  const float* kvb = kv + (size_t)bi * n * 2 * CB;
+
+  float qreg[HC];  // B[k = h][j = ql] = Q[query][h*HC + t] * (log2e / sqrt(cb))
+  {
+    const float* qp = q + ((size_t)bi * p + qi) * CB + HC * h;
+#pragma unroll
+    for (int t = 0; t < HC; ++t) qreg[t] = qp[t] * qscale;
+  }
+  f32x16 O[CB / 32];
+#pragma unroll
+  for (int c = 0; c < CB / 32; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+
+  // rows past the end of a ragged last block are clamped to its last row: finite values, their probabilities are 0
+  float kreg[HC], vreg[CB / 32][16];
+  auto load_k = [&](int base) {
+    const int cnt = min(NL_KB, n - base);
+    const float4* kp = reinterpret_cast<const float4*>(kvb + (size_t)(base + min(ql, cnt - 1)) * 2 * CB + HC * h);
+#pragma unroll
+    for (int g = 0; g < HC / 4; ++g) {
+      const float4 v = kp[g];
+      kreg[4 * g] = v.x; kreg[4 * g + 1] = v.y; kreg[4 * g + 2] = v.z; kreg[4 * g + 3] = v.w;
+    }
+  };
+  auto load_v = [&](int base, int c) {
+    const int cnt = min(NL_KB, n - base);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) vreg[c][t] = kvb[(size_t)(base + min(kappa(t, h), cnt - 1)) * 2 * CB + CB + c * 32 + ql];
+  };
+  const int first = wave * NL_KB;
+  if (first < n) {
+    load_k(first);
+#pragma unroll
+    for (int c = 0; c < CB / 32; ++c) load_v(first, c);
+  }
+
+  for (int base = first; base < n; base += SPLIT * NL_KB) {
+    const int cnt = min(NL_KB, n - base);
+    const int nxt = base + SPLIT * NL_KB < n ? base + SPLIT * NL_KB : base;  // the last refill of a wave is a dummy
+    // ---- S^T = K_blk . Q^T
+    f32x16 S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) S[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < HC; ++t) S = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[t], qreg[t], S, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_k(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- online softmax over this lane's 16 keys (+ the other half-wave's 16)
+    if (cnt < NL_KB) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[r] = kappa(r, h) < cnt ? S[r] : -INFINITY;
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, S[r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    const float mnew = fmaxf(mrun, tmax);  // finite: every block has >= 1 valid key
+    const float alpha = fast_exp2(mrun - mnew);
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      S[r] = fast_exp2(S[r] - mnew);
+      psum += S[r];
+    }
+    psum += __shfl_xor(psum, 32);
+    lrun = lrun * alpha + psum;
+    mrun = mnew;
+    // ---- O^T = alpha * O^T + V^T . P^T
+#pragma unroll
+    for (int c = 0; c < CB / 32; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) O[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[c][t], S[t], O[c], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_v(nxt, c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  if constexpr (SPLIT > 1) {
+    // ---- merge the SPLIT partial results: wave w > 0 parks (m, l, O) in its LDS region, wave 0 folds them in
+    float* park = reinterpret_cast<float*>(smem) + (size_t)wave * PARK;
+    if (wave > 0) {
+#pragma unroll
+      for (int c = 0; c < CB / 32; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) park[(c * 16 + r) * 64 + lane] = O[c][r];
+      park[(CB / 2) * 64 + lane] = mrun;
+      park[(CB / 2 + 1) * 64 + lane] = lrun;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    for (int w = 1; w < SPLIT; ++w) {
+      const float* pw = reinterpret_cast<const float*>(smem) + (size_t)w * PARK;
+      const float mw = pw[(CB / 2) * 64 + lane], lw = pw[(CB / 2 + 1) * 64 + lane];
+      const float mnew = fmaxf(mrun, mw);  // a wave that saw no key block has m = -inf, l = 0, O = 0
+      const float a0 = mrun == -INFINITY ? 0.f : fast_exp2(mrun - mnew);
+      const float a1 = mw == -INFINITY ? 0.f : fast_exp2(mw - mnew);
+      lrun = lrun * a0 + lw * a1;
+      mrun = mnew;
+#pragma unroll
+      for (int c = 0; c < CB / 32; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[c][r] = O[c][r] * a0 + pw[(c * 16 + r) * 64 + lane] * a1;
+    }
+  }
+  if (q0 + ql < p) {  // O^T[channel = c*32 + kappa(r,h)][query = ql] / l
+    const float inv = 1.0f / lrun;
+    float* op = out + ((size_t)bi * p + q0 + ql) * CB;
+#pragma unroll
+    for (int c = 0; c < CB / 32; ++c)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(O[c][4 * g] * inv, O[c][4 * g + 1] * inv, O[c][4 * g + 2] * inv, O[c][4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + c * 32 + 8 * g + 4 * h) = v;
+      }
+  }
+}
+
+// =============================================================================================
 // Non-local attention, vector-FMA variant: one query per lane, K/V rows broadcast from LDS.
 // Kept for the MFMA-vs-FMA comparison (cb <= 64: q and the accumulator live in VGPRs).
 // =============================================================================================
@@ -1157,6 +1313,14 @@ using namespace pasnl;
 
 template <int CB, int SPLIT>
 static int nl_mfma_launch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, hipStream_t st) {
+  if constexpr (CB <= 64) {
+    if (!getenv("PASNL_NL_LDS")) {  // (the LDS-staged kernel stays selectable for A/B measurements)
+      const size_t lds = (size_t)SPLIT * (CB / 2 + 2) * 64 * sizeof(float);
+      hipLaunchKernelGGL((nl_attention_direct_kernel<CB, SPLIT>), dim3((p + 31) / 32, b), dim3(SPLIT * 64), lds, st, p, n, qscale,
+                         q, kv, out);
+      return pasnl_launch_status();
+    }
+  }
   constexpr int WAVE_FLOATS = NL_KB * (CB + 1) + NL_KB * CB + 3;
   size_t lds = (size_t)SPLIT * ((WAVE_FLOATS + 3) & ~3) * 4 + 16;
   auto kern = nl_attention_mfma_kernel<CB, SPLIT>;
@@ -1171,12 +1335,13 @@ static int nl_mfma_launch(int b, int p, int n, float qscale, const float* q, con
 template <int CB>
 static int nl_mfma_dispatch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, hipStream_t st) {
   // split the keys over enough waves to put ~4 on every SIMD (4096 waves; measured best on all reference shapes:
-  // cls layer1 140 -> 82 us, cls layer2 128 -> 37 us, ScanNet layer1 1030 -> 279 us), bounded by the number of key
-  // blocks and by the LDS (cb = 128: 4 wave regions fit)
+  // cls layer1 140 -> 82 us, cls layer2 128 -> 37 us, ScanNet layer1 1030 -> 279 us with the LDS-staged kernel), but
+  // keep >= 4 key blocks per wave (cls layer2, 16 blocks: 19 us at 4 waves, 23 us at 8: the merge is not free) and
+  // stay within the LDS (cb = 128: 4 wave regions fit)
   long tiles = (long)b * ((p + 31) / 32);
   long blocks = (n + NL_KB - 1) / NL_KB;
   int want = 1;
-  while (want < 8 && tiles * want < 4096 && want * 2 <= blocks) want *= 2;
+  while (want < 8 && tiles * want < 4096 && want * 2 * 4 <= blocks) want *= 2;
   const char* force = getenv("PASNL_NL_SPLIT");  // tuning only
   if (force && *force) want = atoi(force);
   if (CB == 128 && want > 4) want = 4;

@@ -40,6 +40,21 @@ def test_nl_attention(b, p, n, cb, variant):
     np.testing.assert_allclose(got, want64, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("b,p,n,cb", [(2, 128, 512, 64), (2, 45, 77, 32)])
+def test_nl_attention_lds_staged_kernel_still_agrees(b, p, n, cb, monkeypatch):
+    """cb <= 64 runs the kernel that takes its operands straight from global memory; the LDS-staged one (the only one
+    for cb = 128) stays selectable (PASNL_NL_LDS) and must give the same answer."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    rng = np.random.default_rng(n)
+    q = rng.standard_normal((b, p, cb)).astype(np.float32)
+    kv = rng.standard_normal((b, n, 2 * cb)).astype(np.float32)
+    want = cells.nl_attention_core(q.astype(np.float64), kv.astype(np.float64), cb)
+    monkeypatch.setenv("PASNL_NL_LDS", "1")
+    got = U.nl_attention(dev(q), dev(kv), variant=2).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
 def test_nl_attention_spike():
     # one key dominates from a late tile: forces the online-softmax rescale branch with a large max jump
     from pointasnl_amd.utils import pointasnl_util as U
