@@ -538,6 +538,16 @@ __device__ __forceinline__ void wave_bitonic_sort(KeyT (&v)[NREG], int lane) {
 
 constexpr int KNN2_CAP = 128;  // candidate buffer per query (keys)
 
+// Diagnostic build only (-DPASNL_KNN_PROBE, tools/knn_probe.py): s_memtime marks between the phases, summed over waves
+#ifdef PASNL_KNN_PROBE
+__device__ unsigned long long knn_probe[8];
+#define KNN_MARK(t) do { __builtin_amdgcn_sched_barrier(0); t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define KNN_PROBE(...) __VA_ARGS__
+#else
+#define KNN_MARK(t)
+#define KNN_PROBE(...)
+#endif
+
 template <int R, int QW, typename IdxT>
 __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, int k, const float* __restrict__ support,
                                                                 const float* __restrict__ queries, IdxT* __restrict__ idx,
@@ -559,6 +569,7 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
     qx[q] = p[0]; qy[q] = p[1]; qz[q] = p[2];
     m1[q] = INF_BITS; m2[q] = INF_BITS;
   }
+  KNN_PROBE(unsigned long long k0, k1, k2, k3, k4; KNN_MARK(k0);)
   // ---- pass 1: per-lane R smallest distances
   for (int base = 0; base < n; base += SEARCH_TILE) {
     int tcnt = min(SEARCH_TILE, n - base);
@@ -579,6 +590,7 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
       }
     }
   }
+  KNN_MARK(k1);
   // ---- bound U = K-th smallest of the lane minima
   uint32_t U[QW];
 #pragma unroll
@@ -593,6 +605,7 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
       if (r == ((k - 1) >> 6)) u = (uint32_t)__builtin_amdgcn_readlane((int)mv[r], (k - 1) & 63);
     U[q] = u;
   }
+  KNN_MARK(k2);
   // ---- pass 2: collect candidates d <= U in index order
   int cnt[QW];
 #pragma unroll
@@ -624,6 +637,7 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
       }
     }
   }
+  KNN_MARK(k3);
   // ---- sort + emit; overflowing queries are flagged for the fallback pass
   bool overflow = false;
 #pragma unroll
@@ -653,6 +667,13 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
       }
     }
   }
+#ifdef PASNL_KNN_PROBE
+  KNN_MARK(k4);
+  if (lane == 0) {
+    atomicAdd(&knn_probe[0], k1 - k0); atomicAdd(&knn_probe[1], k2 - k1); atomicAdd(&knn_probe[2], k3 - k2);
+    atomicAdd(&knn_probe[3], k4 - k3); atomicAdd(&knn_probe[4], 1ull);
+  }
+#endif
   // ---- fallback (rare): sorted-list insertion for the flagged queries; every wave helps staging the tiles
   if (!__syncthreads_or(overflow ? 1 : 0)) return;
   float tau[QW];
@@ -1105,6 +1126,15 @@ static int knn_launch(int b, int n, int m, int k, const float* support, const fl
                        dist2);
   return pasnl_launch_status();
 }
+
+#ifdef PASNL_KNN_PROBE
+// [pass 1 (incl. staging), bound, pass 2, emit, waves] cycles summed over waves
+extern "C" int pasnl_knn_probe_read(unsigned long long* host8) {
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(pasnl::knn_probe), sizeof(pasnl::knn_probe)) != hipSuccess) return -1;
+  unsigned long long zero[8] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(pasnl::knn_probe), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int pasnl_knn_batch(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
                                int idx_is_i64, float* dist2, pasnl_stream_t stream) {
