@@ -223,6 +223,11 @@ int pasnl_take_neighbor0(int b, int n, int c, int m, int k, const float* xyz, co
 int pasnl_as_gather(int b, int n, int c, int m, int k, int as, const float* xyz, const float* feature, const int* idx, float* out,
                     pasnl_stream_t stream);
 int pasnl_as_attention_qkv(int g, int as, int cb, const float* kvq, float* out, pasnl_stream_t stream);
+/*   pasnl_as_attention_proj: the same attention with the projections fused in, for narrow inputs (w <= 15, cb = 32 or 64):
+ *   x (g,as,w) = the rows pasnl_as_gather produces, wkvq (w,3*cb) / bkvq (3*cb) = the BN-folded [conv_kv_ds | conv_query_ds]
+ *   weights (pointasnl_util.py:126-135); K, V, Q = x.wkvq + bkvq never reach memory. */
+int pasnl_as_attention_proj(int g, int as, int cb, int w, const float* x, const float* wkvq, const float* bkvq, float* out,
+                            pasnl_stream_t stream);
 int pasnl_as_reweight_x(int g, int as, int ch, const float* logits, const float* x, float* new_xyz, float* new_feature,
                         pasnl_stream_t stream);
 

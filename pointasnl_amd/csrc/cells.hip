@@ -1379,6 +1379,121 @@ extern "C" int pasnl_nl_attention(int b, int p, int n, int cb, const float* q, c
   return nl_mfma_dispatch<128>(b, p, n, qscale, q, kv, out, st);
 }
 
+namespace pasnl {
+// ---------------------------------------------------------------------------------------------
+// AdaptiveSampling micro attention with the K / V / Q projections computed on the fly (narrow inputs: w <= 15, the
+// xyz-only first layers, w = 9).  The projection output would be (groups*as, 3cb) floats -- 151 MB at cls layer1,
+// written by a GEMM that is pure HBM traffic at K = 9 and read once by the attention.  Here everything is a chain of
+// v_mfma_f32_16x16x4_f32 whose D layouts are already the next product's operand layouts (lane = (col, grp)):
+//     K^T = Wk'^T . X'^T  and  Q^T = Wq'^T . X'^T   -> lane (row = col, grp) holds channels 4*grp + r of a 16-block
+//     V   = X' . Wv'                                -> lane (channel = col, grp) holds keys 4*grp + r
+//     S   = sum over (block, r) of K^T[r] (A) x Q^T[r] (B): the pairing of channels inside a step is free as long
+//           as K and Q agree on it               -> lane (query = col, grp) holds keys 4*grp + r
+//     O^T = V[t] (A) x P[t] (B)
+// X' = [x | 1 | 0..] (the constant column carries the biases), W' = the BN-folded weights with the bias as row w;
+// the log2e/sqrt(cb) scale is folded into Wq'.  A lane's weights (<= 48 values) live in registers for the whole kernel.
+//   one wave per group, persistent over groups
+// ---------------------------------------------------------------------------------------------
+constexpr int AS_PROJ_MAXW = 15;
+template <int KS, int CBLK>  // k-steps of 4 inputs (w + 1 <= 4 KS), 16-channel blocks (cb = 16 CBLK)
+__global__ __launch_bounds__(256) void as_attention_proj_kernel(long groups, int as, int w, float qscale,
+                                                               const float* __restrict__ x, const float* __restrict__ wkvq,
+                                                               const float* __restrict__ bkvq, float* __restrict__ out) {
+  constexpr int CB = 16 * CBLK;
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 15, grp = lane >> 4;
+  // W'[k][c] for this lane's k = 4s + grp, c = cb*16 + col; columns of wkvq: [K | V | Q]
+  float wk[KS][CBLK], wv[KS][CBLK], wq[KS][CBLK];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 4 * s + grp;
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) {
+      const int c = cb * 16 + col;
+      const float* wrow = wkvq + (size_t)min(k, w - 1) * 3 * CB;
+      const float k_ = k < w ? wrow[c] : (k == w ? bkvq[c] : 0.f);
+      const float v_ = k < w ? wrow[CB + c] : (k == w ? bkvq[CB + c] : 0.f);
+      const float q_ = k < w ? wrow[2 * CB + c] : (k == w ? bkvq[2 * CB + c] : 0.f);
+      wk[s][cb] = k_; wv[s][cb] = v_; wq[s][cb] = q_ * qscale;
+    }
+  }
+  const long nwaves = (long)gridDim.x * 4;
+  for (long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += nwaves) {
+    // X'[row = col][k = 4s + grp]; rows past `as` are zero rows (their keys are masked, their queries not stored)
+    float xv[KS];
+    const float* xp = x + ((size_t)g * as + min(col, as - 1)) * w;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 4 * s + grp;
+      const float v = xp[min(k, w - 1)];
+      xv[s] = col < as ? (k < w ? v : (k == w ? 1.f : 0.f)) : 0.f;
+    }
+    f32x4 Kt[CBLK], Qt[CBLK], V[CBLK];
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) {
+      Kt[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; Qt[cb] = Kt[cb]; V[cb] = Kt[cb];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        Kt[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[s][cb], xv[s], Kt[cb], 0, 0, 0);
+        Qt[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s][cb], xv[s], Qt[cb], 0, 0, 0);
+        V[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s], wv[s][cb], V[cb], 0, 0, 0);
+      }
+    }
+    f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S = __builtin_amdgcn_mfma_f32_16x16x4f32(Kt[cb][r], Qt[cb][r], S, 0, 0, 0);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      S[r] = (4 * grp + r) < as ? S[r] : -INFINITY;
+      tmax = fmaxf(tmax, S[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      S[r] = fast_exp2(S[r] - tmax);
+      psum += S[r];
+    }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    const float inv = 1.0f / psum;
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) {
+      f32x4 O = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) O = __builtin_amdgcn_mfma_f32_16x16x4f32(V[cb][t], S[t], O, 0, 0, 0);
+      if (col < as)  // O^T[ch = cb*16 + 4*grp + r][query = col]
+        *reinterpret_cast<float4*>(out + ((size_t)g * as + col) * CB + cb * 16 + 4 * grp) =
+            make_float4(O[0] * inv, O[1] * inv, O[2] * inv, O[3] * inv);
+    }
+  }
+}
+}  // namespace pasnl
+
+extern "C" int pasnl_as_attention_proj(int g, int as, int cb, int w, const float* x, const float* wkvq, const float* bkvq,
+                                       float* out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(g >= 0 && as > 0 && cb > 0 && w > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(as <= 16 && w <= pasnl::AS_PROJ_MAXW && (cb == 32 || cb == 64), PASNL_EUNSUPPORTED);
+  if (g == 0) return PASNL_OK;
+  PASNL_REQUIRE(x && wkvq && bkvq && out, PASNL_ENULL);
+  PASNL_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, PASNL_EINVAL);
+  const float qscale = LOG2E / sqrtf((float)cb);
+  const long wgs = ((long)g + 3) / 4;
+  const dim3 grid((unsigned)(wgs < 2048 ? wgs : 2048)), block(256);  // persistent: a lane's weights are loaded once
+  hipStream_t st = pasnl_hip_stream(stream);
+  const int ks = (w + 1 + 3) / 4;
+#define PASNL_AS_GO(KS, CBLK) \
+  hipLaunchKernelGGL((pasnl::as_attention_proj_kernel<KS, CBLK>), grid, block, 0, st, (long)g, as, w, qscale, x, wkvq, bkvq, out)
+  if (cb == 32) { if (ks <= 2) PASNL_AS_GO(2, 2); else if (ks == 3) PASNL_AS_GO(3, 2); else PASNL_AS_GO(4, 2); }
+  else { if (ks <= 2) PASNL_AS_GO(2, 4); else if (ks == 3) PASNL_AS_GO(3, 4); else PASNL_AS_GO(4, 4); }
+#undef PASNL_AS_GO
+  return pasnl_launch_status();
+}
+
 extern "C" int pasnl_as_attention(int g, int as, int cb, const float* q, const float* kv, float* out,
                                   pasnl_stream_t stream) {
   PASNL_REQUIRE(g >= 0 && as > 0 && cb > 0, PASNL_EINVAL);

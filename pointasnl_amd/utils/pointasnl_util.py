@@ -220,6 +220,9 @@ def AdaptiveSampling(group_xyz, group_feature, num_neighbor, is_training, bn_dec
 AS_FUSED = True  # False = the reference's op-by-op AdaptiveSampling / SampleWeights chain on gathered tensors
 
 
+AS_PROJ_FUSED = True  # False = the projections as one vendor GEMM in front of the attention kernel (any width)
+
+
 def adaptive_sampling_fused(xyz, feature, idx, num_neighbor, scope, bn, weight_decay=None):
     """AdaptiveSampling + SampleWeights (pointasnl_util.py:112-173) without the grouped tensors: one gather builds the
     (B,P,as,6+C) input of the two projections, ONE GEMM produces [K | V | Q], the micro attention reads it in place,
@@ -243,9 +246,15 @@ def adaptive_sampling_fused(xyz, feature, idx, num_neighbor, scope, bn, weight_d
                 wq, bq = st.layer(6 + c, cb, bn, weight_decay)
             st._folded[key] = (torch.cat([wkv, wq], dim=1).contiguous(), torch.cat([bkv, bq]).contiguous())
         wkvq, bkvq = st._folded[key]
-        kvq = torch.addmm(bkvq, x.reshape(-1, 6 + c), wkvq)  # (B*P*as, 3cb) = [K | V | Q]
         att = torch.empty((b, p, as_, cb), dtype=torch.float32, device=xyz.device)
-        _hip.launch("pasnl_as_attention_qkv", "as_attention", b * p, as_, cb, _hip.ptr(kvq), _hip.ptr(att))
+        if AS_PROJ_FUSED and 6 + c <= 15 and cb in (32, 64):
+            # narrow rows (the xyz-only first layers): K, V, Q are built inside the attention kernel; the (B*P*as, 3cb)
+            # projection -- 151 MB at cls layer1, written by a GEMM with K = 9 and read once -- never exists
+            _hip.launch("pasnl_as_attention_proj", "as_attention", b * p, as_, cb, 6 + c, _hip.ptr(x), _hip.ptr(wkvq),
+                        _hip.ptr(bkvq), _hip.ptr(att))
+        else:
+            kvq = torch.addmm(bkvq, x.reshape(-1, 6 + c), wkvq)  # (B*P*as, 3cb) = [K | V | Q]
+            _hip.launch("pasnl_as_attention_qkv", "as_attention", b * p, as_, cb, _hip.ptr(kvq), _hip.ptr(att))
         hid = tf_util.conv2d(att, 32, [1, 1], padding='VALID', stride=[1, 1], bn=bn, is_training=False, scope='mlp2_0',
                              weight_decay=weight_decay)
         logits = tf_util.conv2d(hid, 1 + channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn, is_training=False,

@@ -319,6 +319,28 @@ def test_adaptive_sampling_fused(b, n, c, m, k, as_):
     np.testing.assert_allclose(new_feat.cpu().numpy(), want_feat, rtol=1e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("g,as_,cb,w", [(4096, 12, 32, 9), (300, 8, 32, 9), (65, 4, 32, 15), (7, 16, 64, 1), (129, 12, 64, 13), (9000, 12, 32, 6)])
+def test_as_attention_proj(g, as_, cb, w):
+    """pasnl_as_attention_proj (projections built inside the attention kernel) == the fp64 attention on the projected
+    rows, and == the GEMM + pasnl_as_attention_qkv path it replaces for narrow inputs."""
+    from pointasnl_amd import _hip
+
+    rng = np.random.default_rng(g + w)
+    x = rng.standard_normal((g, as_, w)).astype(np.float32)
+    wkvq = (rng.standard_normal((w, 3 * cb)) * 0.5).astype(np.float32)
+    bkvq = (rng.standard_normal(3 * cb) * 0.1).astype(np.float32)
+    kvq64 = x.astype(np.float64) @ wkvq.astype(np.float64) + bkvq
+    want = cells.nl_attention_core(kvq64[..., 2 * cb:], kvq64[..., :2 * cb], cb)
+    xd, wd, bd = dev(x), dev(wkvq), dev(bkvq)
+    got = torch.empty((g, as_, cb), device="cuda")
+    _hip.launch("pasnl_as_attention_proj", "as_attention", g, as_, cb, w, _hip.ptr(xd), _hip.ptr(wd), _hip.ptr(bd), _hip.ptr(got))
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    kvq = torch.addmm(bd, xd.reshape(-1, w), wd).contiguous()
+    two = torch.empty_like(got)
+    _hip.launch("pasnl_as_attention_qkv", "as_attention", g, as_, cb, _hip.ptr(kvq), _hip.ptr(two))
+    np.testing.assert_allclose(got.cpu().numpy(), two.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
 def _np_ce(logits, labels):
     z = logits.astype(np.float64)
     z = z - z.max(axis=-1, keepdims=True)
