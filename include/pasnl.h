@@ -228,6 +228,13 @@ int pasnl_as_attention_qkv(int g, int as, int cb, const float* kvq, float* out, 
  *   weights (pointasnl_util.py:126-135); K, V, Q = x.wkvq + bkvq never reach memory. */
 int pasnl_as_attention_proj(int g, int as, int cb, int w, const float* x, const float* wkvq, const float* bkvq, float* out,
                             pasnl_stream_t stream);
+/*   pasnl_as_cell_narrow: the whole AdaptiveSampling cell of a narrow layer after the gather (pointasnl_util.py:112-173): the
+ *   projections and the attention as above, then mlp2 (cb -> 32 -> 1+ch; wa (cb,32), ba (32), wb (32,1+ch), bb (1+ch), BN
+ *   folded), the softmax over the neighbours and the re-weighted sums.  x (g,as,w) with w = 3 + ch <= 15 ->
+ *   new_xyz (g,3), new_feature (g,ch). */
+int pasnl_as_cell_narrow(int g, int as, int cb, int w, int ch, const float* x, const float* wkvq, const float* bkvq,
+                         const float* wa, const float* ba, const float* wb, const float* bb, float* new_xyz, float* new_feature,
+                         pasnl_stream_t stream);
 int pasnl_as_reweight_x(int g, int as, int ch, const float* logits, const float* x, float* new_xyz, float* new_feature,
                         pasnl_stream_t stream);
 

@@ -1498,6 +1498,206 @@ __global__ __launch_bounds__(256) void as_attention_proj_kernel(long groups, int
 }
 }  // namespace pasnl
 
+namespace pasnl {
+// all-reduce over the 16 lanes of a DPP row (quad xor 1, xor 2, then the two mirrors); every lane ends with the result
+__device__ __forceinline__ float row16_max(float v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+      : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+      : "+v"(v));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The whole AdaptiveSampling cell of a narrow layer (w = 6 + c <= 15 inputs, 1 + ch <= 16 weights per neighbour) in ONE
+// kernel after the gather (pointasnl_util.py:112-173): projections + micro attention as in as_attention_proj_kernel, then
+//     hid^T    = relu(Wa'^T . att^T + ba)   (cb -> 32; the attention output O^T is already the B operand, the bias
+//                                            is the accumulator's initial value)
+//     logit^T  = Wb'^T . hid^T + bb         (32 -> 1 + ch)   -> lane (neighbour s = col, grp) holds outputs o = 4*grp + r
+//     softmax over the neighbours = over the 16 lanes of a DPP row; weighted sums of the gathered rows the same way.
+// Nothing but the gathered rows is read and only new_xyz (g,3) / new_feature (g,ch) are written: the (groups*as, cb),
+// (.., 32) and (.., 1+ch) intermediates of the op-by-op chain (50 + 50 + 11 MB at cls layer1) never exist.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int CBLK>
+__global__ __launch_bounds__(256) void as_cell_narrow_kernel(long groups, int as, int w, int ch, float qscale,
+                                                            const float* __restrict__ x, const float* __restrict__ wkvq,
+                                                            const float* __restrict__ bkvq, const float* __restrict__ wa,
+                                                            const float* __restrict__ ba, const float* __restrict__ wb,
+                                                            const float* __restrict__ bb, float* __restrict__ new_xyz,
+                                                            float* __restrict__ new_feature) {
+  constexpr int CB = 16 * CBLK;
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 15, grp = lane >> 4;
+  const int nout = 1 + ch;
+  float wk[KS][CBLK], wv[KS][CBLK], wq[KS][CBLK];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 4 * s + grp;
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) {
+      const int c = cb * 16 + col;
+      const float* wrow = wkvq + (size_t)min(k, w - 1) * 3 * CB;
+      wk[s][cb] = k < w ? wrow[c] : (k == w ? bkvq[c] : 0.f);
+      wv[s][cb] = k < w ? wrow[CB + c] : (k == w ? bkvq[CB + c] : 0.f);
+      wq[s][cb] = (k < w ? wrow[2 * CB + c] : (k == w ? bkvq[2 * CB + c] : 0.f)) * qscale;
+    }
+  }
+  // mlp2_0: A[m = h][k-slot grp] of step (cb, r) = Wa[cb*16 + 4*grp + r][hb*16 + col]; its bias as accumulator start
+  float wa_r[CBLK][4][2];
+  f32x4 ba_r[2];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ba_r[hb][r] = ba[hb * 16 + 4 * grp + r];
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wa_r[cb][r][hb] = wa[(size_t)(cb * 16 + 4 * grp + r) * 32 + hb * 16 + col];
+  }
+  // mlp2_1: A[m = o][k-slot grp] of step (hb, r) = Wb[hb*16 + 4*grp + r][o = col]
+  float wb_r[2][4];
+  f32x4 bb_r;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bb_r[r] = 4 * grp + r < nout ? bb[4 * grp + r] : 0.f;
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) wb_r[hb][r] = col < nout ? wb[(size_t)(hb * 16 + 4 * grp + r) * nout + col] : 0.f;
+
+  const long nwaves = (long)gridDim.x * 4;
+  for (long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += nwaves) {
+    float xv[KS];
+    const float* xp = x + ((size_t)g * as + min(col, as - 1)) * w;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 4 * s + grp;
+      const float v = xp[min(k, w - 1)];
+      xv[s] = col < as ? (k < w ? v : (k == w ? 1.f : 0.f)) : 0.f;
+    }
+    // the columns this lane re-weights: output o = 4*grp + r multiplies x column 3 + (o - 1) (o >= 1), output 0 the xyz
+    float xo[4], xc[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xo[r] = xp[min(max(2 + 4 * grp + r, 3), w - 1)];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) xc[d] = xp[3 + d];
+
+    f32x4 Kt[CBLK], Qt[CBLK], V[CBLK];
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) {
+      Kt[cb] = f32x4{0.f, 0.f, 0.f, 0.f}; Qt[cb] = Kt[cb]; V[cb] = Kt[cb];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        Kt[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wk[s][cb], xv[s], Kt[cb], 0, 0, 0);
+        Qt[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s][cb], xv[s], Qt[cb], 0, 0, 0);
+        V[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[s], wv[s][cb], V[cb], 0, 0, 0);
+      }
+    }
+    f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) S = __builtin_amdgcn_mfma_f32_16x16x4f32(Kt[cb][r], Qt[cb][r], S, 0, 0, 0);
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      S[r] = (4 * grp + r) < as ? S[r] : -INFINITY;
+      tmax = fmaxf(tmax, S[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      S[r] = fast_exp2(S[r] - tmax);
+      psum += S[r];
+    }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    const float inv = 1.0f / psum;
+    // att^T blocks (O^T / l) feed mlp2_0 directly
+    f32x4 H[2] = {ba_r[0], ba_r[1]};
+#pragma unroll
+    for (int cb = 0; cb < CBLK; ++cb) {
+      f32x4 O = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) O = __builtin_amdgcn_mfma_f32_16x16x4f32(V[cb][t], S[t], O, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = O[r] * inv;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) H[hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_r[cb][r][hb], a, H[hb], 0, 0, 0);
+      }
+    }
+    f32x4 L = bb_r;
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L = __builtin_amdgcn_mfma_f32_16x16x4f32(wb_r[hb][r], fmaxf(H[hb][r], 0.f), L, 0, 0, 0);
+    // L[r] = logit of neighbour `col` for output o = 4*grp + r; softmax over the neighbours = over the row's lanes
+    float wgt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = col < as ? L[r] : -INFINITY;
+      const float mx = row16_max(v);
+      const float e = col < as ? fast_exp2((v - mx) * LOG2E) : 0.f;
+      wgt[r] = e / row16_sum(e);
+    }
+    // weighted sums over the neighbours; lane col == 0 of every row writes its outputs
+    float sx[3], sf[4];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) sx[d] = row16_sum(col < as ? wgt[0] * xc[d] : 0.f);  // (only grp 0 holds output 0)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sf[r] = row16_sum(col < as ? wgt[r] * xo[r] : 0.f);
+    if (col == 0) {
+      if (grp == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) new_xyz[g * 3 + d] = sx[d];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = 4 * grp + r;
+        if (o >= 1 && o < nout) new_feature[(size_t)g * ch + (o - 1)] = sf[r];
+      }
+    }
+  }
+}
+}  // namespace pasnl
+
+extern "C" int pasnl_as_cell_narrow(int g, int as, int cb, int w, int ch, const float* x, const float* wkvq, const float* bkvq,
+                                    const float* wa, const float* ba, const float* wb, const float* bb, float* new_xyz,
+                                    float* new_feature, pasnl_stream_t stream) {
+  PASNL_REQUIRE(g >= 0 && as > 0 && cb > 0 && w > 0 && ch > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(as <= 16 && w <= pasnl::AS_PROJ_MAXW && (cb == 32 || cb == 64) && 1 + ch <= 16 && w == 3 + ch,
+                PASNL_EUNSUPPORTED);
+  if (g == 0) return PASNL_OK;
+  PASNL_REQUIRE(x && wkvq && bkvq && wa && ba && wb && bb && new_xyz && new_feature, PASNL_ENULL);
+  const float qscale = LOG2E / sqrtf((float)cb);
+  const long wgs = ((long)g + 3) / 4;
+  const dim3 grid((unsigned)(wgs < 2048 ? wgs : 2048)), block(256);
+  hipStream_t st = pasnl_hip_stream(stream);
+  const int ks = (w + 1 + 3) / 4;
+#define PASNL_AS_GO(KS, CBLK)                                                                                            \
+  hipLaunchKernelGGL((pasnl::as_cell_narrow_kernel<KS, CBLK>), grid, block, 0, st, (long)g, as, w, ch, qscale, x, wkvq, bkvq, wa, \
+                     ba, wb, bb, new_xyz, new_feature)
+  if (cb == 32) { if (ks <= 2) PASNL_AS_GO(2, 2); else if (ks == 3) PASNL_AS_GO(3, 2); else PASNL_AS_GO(4, 2); }
+  else { if (ks <= 2) PASNL_AS_GO(2, 4); else if (ks == 3) PASNL_AS_GO(3, 4); else PASNL_AS_GO(4, 4); }
+#undef PASNL_AS_GO
+  return pasnl_launch_status();
+}
+
 extern "C" int pasnl_as_attention_proj(int g, int as, int cb, int w, const float* x, const float* wkvq, const float* bkvq,
                                        float* out, pasnl_stream_t stream) {
   PASNL_REQUIRE(g >= 0 && as > 0 && cb > 0 && w > 0, PASNL_EINVAL);

@@ -220,6 +220,7 @@ def AdaptiveSampling(group_xyz, group_feature, num_neighbor, is_training, bn_dec
 AS_FUSED = True  # False = the reference's op-by-op AdaptiveSampling / SampleWeights chain on gathered tensors
 
 
+AS_CELL_NARROW = True  # narrow layers: the whole cell after the gather in one kernel (pasnl_as_cell_narrow)
 AS_PROJ_FUSED = True  # False = the projections as one vendor GEMM in front of the attention kernel (any width)
 
 
@@ -234,6 +235,7 @@ def adaptive_sampling_fused(xyz, feature, idx, num_neighbor, scope, bn, weight_d
     channel = 3 + c
     cb = max(32, channel // 2)
     xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
+    narrow = AS_CELL_NARROW and 6 + c <= 15 and 1 + channel <= 16 and cb in (32, 64)
     x = torch.empty((b, p, as_, 6 + c), dtype=torch.float32, device=xyz.device)
     _hip.launch("pasnl_as_gather", "as_gather", b, n, c, p, k, as_, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx), _hip.ptr(x))
     st = tf_util.store()
@@ -246,6 +248,20 @@ def adaptive_sampling_fused(xyz, feature, idx, num_neighbor, scope, bn, weight_d
                 wq, bq = st.layer(6 + c, cb, bn, weight_decay)
             st._folded[key] = (torch.cat([wkv, wq], dim=1).contiguous(), torch.cat([bkv, bq]).contiguous())
         wkvq, bkvq = st._folded[key]
+        if narrow:
+            # narrow rows (the xyz-only first layers): projections, attention, mlp2, the softmax over the neighbours and the
+            # re-weighted sums in ONE kernel on the gathered rows -- no (B*P*as, .) intermediate at all.  (Folding the gather
+            # in as well was measured: 77 us instead of 18 + 53 -- its two dependent loads per row are exposed there.)
+            with tf_util.variable_scope('mlp2_0'):
+                wa, ba = st.layer(cb, 32, bn, weight_decay)
+            with tf_util.variable_scope('mlp2_1'):
+                wb, bb = st.layer(32, 1 + channel, bn, weight_decay)
+            new_xyz = torch.empty((b, p, 3), dtype=torch.float32, device=xyz.device)
+            new_feature = torch.empty((b, p, channel), dtype=torch.float32, device=xyz.device)
+            _hip.launch("pasnl_as_cell_narrow", "as_cell", b * p, as_, cb, 6 + c, channel, _hip.ptr(x), _hip.ptr(wkvq),
+                        _hip.ptr(bkvq), _hip.ptr(wa), _hip.ptr(ba), _hip.ptr(wb), _hip.ptr(bb), _hip.ptr(new_xyz),
+                        _hip.ptr(new_feature))
+            return new_xyz, new_feature
         att = torch.empty((b, p, as_, cb), dtype=torch.float32, device=xyz.device)
         if AS_PROJ_FUSED and 6 + c <= 15 and cb in (32, 64):
             # narrow rows (the xyz-only first layers): K, V, Q are built inside the attention kernel; the (B*P*as, 3cb)

@@ -299,11 +299,17 @@ def test_decode_cell(b, n, c, k):
 
 @pytest.mark.parametrize("b,n,c,m,k,as_", [(2, 1024, 3, 512, 32, 12), (2, 512, 128, 128, 64, 12), (1, 300, 3, 77, 32, 8),
                                           (1, 200, 64, 50, 32, 4), (1, 64, 32, 9, 16, 16)])
-def test_adaptive_sampling_fused(b, n, c, m, k, as_):
+@pytest.mark.parametrize("narrow_cell,proj", [(True, True), (False, True), (False, False)])
+def test_adaptive_sampling_fused(b, n, c, m, k, as_, narrow_cell, proj, monkeypatch):
     """AdaptiveSampling + SampleWeights (pointasnl_util.py:112-173) without grouped tensors (as_gather + one [K|V|Q]
     GEMM + strided micro attention + re-weighting) vs the fp64 restatement on explicitly gathered groups."""
     from pointasnl_amd.utils import pointasnl_util as U
 
+    # narrow layers have three implementations of the same cell: one kernel / attention with fused projections / GEMM first
+    monkeypatch.setattr(U, "AS_CELL_NARROW", narrow_cell)
+    monkeypatch.setattr(U, "AS_PROJ_FUSED", proj)
+    if c > 9 and not (narrow_cell and proj):
+        pytest.skip("wide rows have one implementation")
     st = _store(n + c + as_)
     rng = np.random.default_rng(c * 5 + as_)
     xyz = clouds(12, b, n)
