@@ -298,7 +298,10 @@ def test_decode_cell(b, n, c, k):
 
 
 @pytest.mark.parametrize("b,n,c,m,k,as_", [(2, 1024, 3, 512, 32, 12), (2, 512, 128, 128, 64, 12), (1, 300, 3, 77, 32, 8),
-                                          (1, 200, 64, 50, 32, 4), (1, 64, 32, 9, 16, 16)])
+                                          (1, 200, 64, 50, 32, 4), (1, 64, 32, 9, 16, 16),
+                                          (1, 64, 3, 9, 16, 16), (1, 50, 2, 7, 8, 1),   # narrow rows: full / single neighbour
+                                          (3, 4000, 3, 3000, 16, 12),                    # more groups than resident waves
+                                          (1, 80, 9, 11, 16, 5)])                        # the widest narrow row (15 columns)
 @pytest.mark.parametrize("narrow_cell,proj", [(True, True), (False, True), (False, False)])
 def test_adaptive_sampling_fused(b, n, c, m, k, as_, narrow_cell, proj, monkeypatch):
     """AdaptiveSampling + SampleWeights (pointasnl_util.py:112-173) without grouped tensors (as_gather + one [K|V|Q]
