@@ -235,6 +235,10 @@ int pasnl_as_attention_proj(int g, int as, int cb, int w, const float* x, const 
 int pasnl_as_cell_narrow(int g, int as, int cb, int w, int ch, const float* x, const float* wkvq, const float* bkvq,
                          const float* wa, const float* ba, const float* wb, const float* bb, float* new_xyz, float* new_feature,
                          pasnl_stream_t stream);
+/*   pasnl_as_cell_wide: the same cell for wide layers, after their projection GEMM: kvq (g,as,3*cb) = [K | V | Q] rows
+ *   (any cb <= 144: the reference's widths are (3 + c) / 2 = 33, 65, ...), x (g,as,w) the gathered rows (for the re-weighted sums) -> new_xyz (g,3), new_feature (g,ch). */
+int pasnl_as_cell_wide(int g, int as, int cb, int w, int ch, const float* kvq, const float* x, const float* wa, const float* ba,
+                       const float* wb, const float* bb, float* new_xyz, float* new_feature, pasnl_stream_t stream);
 int pasnl_as_reweight_x(int g, int as, int ch, const float* logits, const float* x, float* new_xyz, float* new_feature,
                         pasnl_stream_t stream);
 

@@ -1676,6 +1676,164 @@ __global__ __launch_bounds__(256) void as_cell_narrow_kernel(long groups, int as
 }
 }  // namespace pasnl
 
+namespace pasnl {
+// ---------------------------------------------------------------------------------------------
+// The AdaptiveSampling cell of a WIDE layer after its projection GEMM (w = 6 + c > 15: K = w is a GEMM worth running):
+// kvq (g, as, 3cb) = [K | V | Q] rows -> attention -> mlp2 -> softmax over the neighbours -> re-weighted sums, as in
+// as_cell_narrow_kernel, with the projected operands read from memory in the layouts that kernel computes them in
+// (K^T / Q^T: 16-byte loads of 4 consecutive channels; V: coalesced row reads).  Wb (32 x (1+ch)) sits in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int CBLK>  // cb <= 16 * CBLK (the reference's bottleneck widths are (3 + c) / 2: 33, 65, ... -- any cb works)
+__global__ __launch_bounds__(256) void as_cell_wide_kernel(long groups, int as, int cb, int w, int ch, float qscale,
+                                                          const float* __restrict__ kvq, const float* __restrict__ x,
+                                                          const float* __restrict__ wa, const float* __restrict__ ba,
+                                                          const float* __restrict__ wb, const float* __restrict__ bb,
+                                                          float* __restrict__ new_xyz, float* __restrict__ new_feature) {
+  const int cb3 = 3 * cb;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* Wbs = reinterpret_cast<float*>(smem);  // [32][nout]
+  const int nout = 1 + ch;
+  for (int i = threadIdx.x; i < 32 * nout; i += 256) Wbs[i] = wb[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 15, grp = lane >> 4;
+  float wa_r[CBLK][4][2];
+  f32x4 ba_r[2];
+#pragma unroll
+  for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ba_r[hb][r] = ba[hb * 16 + 4 * grp + r];
+#pragma unroll
+    for (int cbk = 0; cbk < CBLK; ++cbk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = cbk * 16 + 4 * grp + r;  // rows past cb are zero: the padded channels contribute nothing
+        wa_r[cbk][r][hb] = c < cb ? wa[(size_t)c * 32 + hb * 16 + col] : 0.f;
+      }
+  }
+  const int noblk = (nout + 15) >> 4;
+  const long nwaves = (long)gridDim.x * 4;
+  for (long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += nwaves) {
+    const float* kq = kvq + ((size_t)g * as + min(col, as - 1)) * cb3;  // this lane's [K | V | Q] row
+    const float* vb = kvq + (size_t)g * as * cb3 + cb;                  // V rows of the group
+    f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cbk = 0; cbk < CBLK; ++cbk)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = cbk * 16 + 4 * grp + r;
+        const float kk = kq[min(c, cb - 1)], qq = kq[2 * cb + min(c, cb - 1)];  // unconditional loads, clamped
+        const bool ok = col < as && c < cb;
+        S = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? kk : 0.f, ok ? qq * qscale : 0.f, S, 0, 0, 0);
+      }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      S[r] = (4 * grp + r) < as ? S[r] : -INFINITY;
+      tmax = fmaxf(tmax, S[r]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      S[r] = fast_exp2(S[r] - tmax);
+      psum += S[r];
+    }
+    psum += __shfl_xor(psum, 16);
+    psum += __shfl_xor(psum, 32);
+    const float inv = 1.0f / psum;
+    f32x4 H[2] = {ba_r[0], ba_r[1]};
+#pragma unroll
+    for (int cbk = 0; cbk < CBLK; ++cbk) {
+      f32x4 O = {0.f, 0.f, 0.f, 0.f};
+      const int vc = cbk * 16 + col;  // V[key][vc]: lanes over channels
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int key = 4 * grp + t;
+        const float v = vb[(size_t)min(key, as - 1) * cb3 + min(vc, cb - 1)];
+        O = __builtin_amdgcn_mfma_f32_16x16x4f32(key < as && vc < cb ? v : 0.f, S[t], O, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = O[r] * inv;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) H[hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_r[cbk][r][hb], a, H[hb], 0, 0, 0);
+      }
+    }
+    float hr[2][4];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hr[hb][r] = fmaxf(H[hb][r], 0.f);
+    const float* xp = x + ((size_t)g * as + min(col, as - 1)) * w;  // the row this lane re-weights
+    for (int ob = 0; ob < noblk; ++ob) {
+      // logits of outputs o = ob*16 + 4*grp + r for neighbour `col`
+      f32x4 L;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L[r] = ob * 16 + 4 * grp + r < nout ? bb[ob * 16 + 4 * grp + r] : 0.f;
+      const int oc = min(ob * 16 + col, nout - 1);
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float wv_ = Wbs[(hb * 16 + 4 * grp + r) * nout + oc];
+          L = __builtin_amdgcn_mfma_f32_16x16x4f32(ob * 16 + col < nout ? wv_ : 0.f, hr[hb][r], L, 0, 0, 0);
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = ob * 16 + 4 * grp + r;
+        const float v = col < as ? L[r] : -INFINITY;
+        const float mx = row16_max(v);
+        const float e = col < as ? fast_exp2((v - mx) * LOG2E) : 0.f;
+        const float wgt = e / row16_sum(e);
+        if (o == 0) {  // (uniform per 16-lane row: only grp 0 of block 0)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const float sx = row16_sum(col < as ? wgt * xp[3 + d] : 0.f);
+            if (col == 0) new_xyz[g * 3 + d] = sx;
+          }
+        } else {
+          const float sf = row16_sum(col < as ? wgt * xp[min(2 + o, w - 1)] : 0.f);
+          if (col == 0 && o < nout) new_feature[(size_t)g * ch + (o - 1)] = sf;
+        }
+      }
+    }
+  }
+}
+}  // namespace pasnl
+
+extern "C" int pasnl_as_cell_wide(int g, int as, int cb, int w, int ch, const float* kvq, const float* x, const float* wa,
+                                  const float* ba, const float* wb, const float* bb, float* new_xyz, float* new_feature,
+                                  pasnl_stream_t stream) {
+  PASNL_REQUIRE(g >= 0 && as > 0 && cb > 0 && w > 0 && ch > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(as <= 16 && cb <= 144 && w == 3 + ch, PASNL_EUNSUPPORTED);
+  if (g == 0) return PASNL_OK;
+  PASNL_REQUIRE(kvq && x && wa && ba && wb && bb && new_xyz && new_feature, PASNL_ENULL);
+  const size_t lds = (size_t)32 * (1 + ch) * sizeof(float);
+  PASNL_REQUIRE(lds <= 64 * 1024, PASNL_EUNSUPPORTED);
+  const float qscale = LOG2E / sqrtf((float)cb);
+  const long wgs = ((long)g + 3) / 4;
+  long cap = 768;  // persistent workgroups: a wave's weights (registers) and the workgroup's Wb (LDS) are loaded once
+  if (const char* e = getenv("PASNL_AS_GRID")) cap = atol(e) > 0 ? atol(e) : cap;  // tuning only
+  const dim3 grid((unsigned)(wgs < cap ? wgs : cap)), block(256);
+  hipStream_t st = pasnl_hip_stream(stream);
+#define PASNL_AS_GO(CBLK)                                                                                                  \
+  do {                                                                                                                     \
+    auto kern = pasnl::as_cell_wide_kernel<CBLK>;                                                                          \
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)lds) != hipSuccess)                                                    \
+      return PASNL_ELAUNCH;                                                                                                \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, (long)g, as, cb, w, ch, qscale, kvq, x, wa, ba, wb, bb, new_xyz,        \
+                       new_feature);                                                                                       \
+  } while (0)
+  const int cblk = (cb + 15) / 16;
+  if (cblk <= 2) PASNL_AS_GO(2); else if (cblk == 3) PASNL_AS_GO(3); else if (cblk == 4) PASNL_AS_GO(4);
+  else if (cblk == 5) PASNL_AS_GO(5); else if (cblk <= 7) PASNL_AS_GO(7); else PASNL_AS_GO(9);
+#undef PASNL_AS_GO
+  return pasnl_launch_status();
+}
+
 extern "C" int pasnl_as_cell_narrow(int g, int as, int cb, int w, int ch, const float* x, const float* wkvq, const float* bkvq,
                                     const float* wa, const float* ba, const float* wb, const float* bb, float* new_xyz,
                                     float* new_feature, pasnl_stream_t stream) {

@@ -220,6 +220,7 @@ def AdaptiveSampling(group_xyz, group_feature, num_neighbor, is_training, bn_dec
 AS_FUSED = True  # False = the reference's op-by-op AdaptiveSampling / SampleWeights chain on gathered tensors
 
 
+AS_CELL_WIDE = True    # wide layers: one kernel after the projection GEMM (pasnl_as_cell_wide)
 AS_CELL_NARROW = True  # narrow layers: the whole cell after the gather in one kernel (pasnl_as_cell_narrow)
 AS_PROJ_FUSED = True  # False = the projections as one vendor GEMM in front of the attention kernel (any width)
 
@@ -261,6 +262,18 @@ def adaptive_sampling_fused(xyz, feature, idx, num_neighbor, scope, bn, weight_d
             _hip.launch("pasnl_as_cell_narrow", "as_cell", b * p, as_, cb, 6 + c, channel, _hip.ptr(x), _hip.ptr(wkvq),
                         _hip.ptr(bkvq), _hip.ptr(wa), _hip.ptr(ba), _hip.ptr(wb), _hip.ptr(bb), _hip.ptr(new_xyz),
                         _hip.ptr(new_feature))
+            return new_xyz, new_feature
+        if AS_CELL_WIDE and not narrow and cb <= 144 and 32 * (1 + channel) * 4 <= 64 * 1024:
+            # wide rows: the projections are a GEMM worth running (K = 6 + c); everything after it is one kernel
+            with tf_util.variable_scope('mlp2_0'):
+                wa, ba = st.layer(cb, 32, bn, weight_decay)
+            with tf_util.variable_scope('mlp2_1'):
+                wb, bb = st.layer(32, 1 + channel, bn, weight_decay)
+            kvq = torch.addmm(bkvq, x.reshape(-1, 6 + c), wkvq)  # (B*P*as, 3cb) = [K | V | Q]
+            new_xyz = torch.empty((b, p, 3), dtype=torch.float32, device=xyz.device)
+            new_feature = torch.empty((b, p, channel), dtype=torch.float32, device=xyz.device)
+            _hip.launch("pasnl_as_cell_wide", "as_cell", b * p, as_, cb, 6 + c, channel, _hip.ptr(kvq), _hip.ptr(x), _hip.ptr(wa),
+                        _hip.ptr(ba), _hip.ptr(wb), _hip.ptr(bb), _hip.ptr(new_xyz), _hip.ptr(new_feature))
             return new_xyz, new_feature
         att = torch.empty((b, p, as_, cb), dtype=torch.float32, device=xyz.device)
         if AS_PROJ_FUSED and 6 + c <= 15 and cb in (32, 64):

@@ -311,8 +311,10 @@ def test_adaptive_sampling_fused(b, n, c, m, k, as_, narrow_cell, proj, monkeypa
     # narrow layers have three implementations of the same cell: one kernel / attention with fused projections / GEMM first
     monkeypatch.setattr(U, "AS_CELL_NARROW", narrow_cell)
     monkeypatch.setattr(U, "AS_PROJ_FUSED", proj)
-    if c > 9 and not (narrow_cell and proj):
-        pytest.skip("wide rows have one implementation")
+    if c > 9:  # wide rows: one kernel after the projection GEMM / the few-kernel chain
+        if not proj:
+            pytest.skip("wide rows have two implementations")
+        monkeypatch.setattr(U, "AS_CELL_WIDE", narrow_cell)
     st = _store(n + c + as_)
     rng = np.random.default_rng(c * 5 + as_)
     xyz = clouds(12, b, n)
