@@ -26,10 +26,12 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ int kappa(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
 // =============================================================================================
-// Non-local attention, MFMA variant ("swapped" flash form, keys split across waves).
+// Non-local attention, MFMA variant with LDS staging ("swapped" flash form, keys split across waves).  The kernel
+// for cb = 128; cb <= 64 runs nl_attention_direct_kernel (below), which takes its operands straight from L2.
 //   A workgroup owns 32 queries; its SPLIT waves each walk every SPLIT-th block of 32 keys, so even a layer
-//   with few query tiles (cls layer2: 256) puts >= 2 waves on every SIMD and one wave's softmax (VALU)
-//   overlaps another's MFMAs.  Staging is wave-private (each wave copies its own 32 K/V rows into its own LDS
+//   with few query tiles (cls layer2: 256) has enough waves in flight.  (More waves do NOT overlap one wave's
+//   softmax with another's MFMAs -- both run on the SIMD's vector lanes -- nor, as it turned out, its memory
+//   round trips: DESIGN.md 4.)  Staging is wave-private (each wave copies its own 32 K/V rows into its own LDS
 //   region): no workgroup barrier inside the loop.  The partial (max, sum, O) of the SPLIT waves are merged
 //   through LDS at the end (one barrier).
 //   Per key block a wave forms S^T = K_blk . Q^T with cb/2 32x32x2 MFMAs, so lane l holds, for ITS query
