@@ -50,14 +50,60 @@ def synth_clouds(seed, b, n):
     return pc.astype(np.float32)
 
 
+def normalize_data(batch):
+    """provider.normalize_data (utils/provider.py:8-24): per cloud, centroid to the origin, max norm 1."""
+    batch = np.asarray(batch, dtype=np.float64)
+    batch = batch - batch.mean(axis=1, keepdims=True)
+    return batch / np.sqrt((batch ** 2).sum(-1)).max(axis=1)[:, None, None]
+
+
 def add_noise(pc, noise, seed):
-    """configs[2]: overwrite the first `noise` points per cloud with uniform outliers (test.py:128-132)."""
+    """configs[2]: overwrite the first `noise` points per cloud with uniform outliers, normalised among themselves
+    like the reference does (test.py:128-132: np.random.random((bsize, noise, 3)) -> provider.normalize_data)."""
     if noise <= 0:
         return pc
     rng = np.random.Generator(np.random.PCG64(seed + 1000))
     pc = pc.copy()
-    pc[:, :noise, :] = rng.random((pc.shape[0], noise, 3), dtype=np.float32) * 2 - 1
+    pc[:, :noise, :] = normalize_data(rng.random((pc.shape[0], noise, 3))).astype(np.float32)
     return pc
+
+
+def synth_scannet(seed, b, n):
+    """SURVEY 8(d) C4 (configs[3]): xyz uniform in a 1.5 x 1.5 x 3 m block then normalize_data (train_scannet.py:301),
+    rgb uniform in [0,1) -> (b, n, 6) float32."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    xyz = rng.random((b, n, 3)) * np.array([1.5, 1.5, 3.0])
+    rgb = rng.random((b, n, 3))
+    return np.concatenate([normalize_data(xyz), rgb], axis=-1).astype(np.float32)
+
+
+def synth_kitti(seed, b, n):
+    """SURVEY 8(d) C5 (configs[4]): per cloud the n points nearest to a random centre of a synthetic lidar scan
+    (ground z ~ N(0, 0.02) with 1/r density + a few vertical walls), voxel-snapped at 0.06 m to one point per voxel
+    (mimics grid_subsampling + crop_pc, semantic_kitti_dataset_grid.py:265-286); metres, NOT normalised -> (b, n, 3)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = np.zeros((b, n, 3), np.float32)
+    for i in range(b):
+        m = 6 * n
+        r = 2.0 + 38.0 * rng.random(m) ** 2          # dense near the sensor
+        th = rng.random(m) * 2 * np.pi
+        pts = np.stack([r * np.cos(th), r * np.sin(th), rng.standard_normal(m) * 0.02], 1)
+        for _ in range(6):                            # walls / car sides: vertical rectangles
+            c = (rng.random(2) - 0.5) * 40
+            d = rng.random() * np.pi
+            u = (rng.random(m // 12) - 0.5) * 8
+            w = np.stack([c[0] + u * np.cos(d), c[1] + u * np.sin(d), rng.random(m // 12) * 2.0], 1)
+            pts = np.concatenate([pts, w])
+        vox = np.floor(pts / 0.06).astype(np.int64)
+        _, first = np.unique(vox, axis=0, return_index=True)
+        pts = pts[np.sort(first)]
+        centre = pts[rng.integers(0, len(pts))]
+        near = np.argsort(((pts - centre) ** 2).sum(1), kind="stable")[:n]
+        sel = pts[near[rng.permutation(len(near))]]   # crop_pc shuffles the selection
+        if len(sel) < n:
+            sel = np.concatenate([sel, sel[rng.integers(0, len(sel), n - len(sel))]])
+        out[i] = sel.astype(np.float32)
+    return out
 
 
 # ---- algorithmic work per launch, SURVEY.md 8(d).  ints = the integer arguments of the C-ABI call.

@@ -1,11 +1,13 @@
-"""oracle.cells -- numpy restatement of the PointASNL cells and of the classification graph around them.
+"""oracle.cells -- numpy restatement of the PointASNL cells and of the three model graphs around them.
 
-TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED: the arithmetic of these cells lives in
-TensorFlow 1.13 core ops (tf.nn.conv2d, tf.matmul, tf.nn.softmax, tf.contrib.layers.batch_norm), an
-un-vendored dependency that is not installable here, and the reference holds no test or golden vector for
-them.  The restatement follows the reference call sites line by line (cited below), is
-evaluated in fp32 like the reference, and every test also evaluates it in fp64 as a cross-check; the
-tolerance against the HIP path is 1e-5.
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PINNED: every function below is checked, in fp64, against the
+outputs of the REFERENCE'S OWN PYTHON (utils/pointasnl_util.py, utils/pointnet_util.py, utils/tf_util.py,
+models/pointasnl_*.py) imported and executed under oracle/tf_shim -- tests/golden/make_golden.py {cells,models,losses}
+-> tests/golden/ref_{cells,models,losses}.npz, asserted by tests/test_oracle_cells_pinned.py at 1e-9 (measured
+~1e-13).  What remains outside the pin is TensorFlow's own arithmetic inside tf.nn.conv2d / tf.matmul / tf.nn.softmax /
+tf.contrib.layers.batch_norm (an un-vendored dependency): the shim implements their documented semantics.
+The restatement is evaluated in fp32 like the reference and in fp64 as a cross-check; the tolerance against the HIP
+path is 1e-5.
 
 Weights are passed in as ``params``: a mapping  scope -> {"w": (cin,cout), "b": (cout,), and when the layer
 has batch norm "gamma","beta","mean","var"}  (utils/tf_util.py:120-185 conv2d = conv, bias, BN, activation;
@@ -111,8 +113,9 @@ def knn_query(k, support, query):
     return ops.knn_batch(support, query, k, omp=True).astype(np.int32)
 
 
-def set_abstraction(xyz, feature, npoint, nsample, mlp, params, scope, as_neighbor=8, NL=True):
-    """PointASNLSetAbstraction, pointasnl_util.py:221-292 (use_knn=True, bn=True)."""
+def set_abstraction(xyz, feature, npoint, nsample, mlp, params, scope, as_neighbor=8, NL=True, knn_idx=None):
+    """PointASNLSetAbstraction, pointasnl_util.py:221-292 (use_knn=True, bn=True).  knn_idx: neighbour lists to use instead
+    of the oracle's kNN (tests on clouds with equidistant neighbours pass the reference nanoflann's own lists)."""
     dt = feature.dtype
     num_points, num_channel = feature.shape[1:]
     if num_points == npoint:  # :236-240
@@ -120,7 +123,7 @@ def set_abstraction(xyz, feature, npoint, nsample, mlp, params, scope, as_neighb
     else:
         fps_idx = ops.farthest_point_sample(npoint, xyz.astype(np.float32))
         new_xyz, new_feature = batched_gather(xyz, fps_idx), batched_gather(feature, fps_idx)
-    idx = knn_query(nsample, xyz.astype(np.float32), new_xyz.astype(np.float32))  # :242 -> :62
+    idx = knn_query(nsample, xyz.astype(np.float32), new_xyz.astype(np.float32)) if knn_idx is None else knn_idx  # :242 -> :62
     grouped_xyz = batched_gather(xyz, idx)
     new_point = np.concatenate([grouped_xyz, batched_gather(feature, idx)], axis=-1)  # :71-74
     if num_points != npoint:  # :246-247
@@ -145,13 +148,27 @@ def set_abstraction(xyz, feature, npoint, nsample, mlp, params, scope, as_neighb
     return new_xyz.astype(dt), new_point
 
 
+def _three_weights(dist, dtype):
+    """pointasnl_util.py:308-311 / pointnet_util.py:212-215 on the op's float32 squared distances, in the graph's dtype"""
+    if dtype == np.float32:
+        return ops.three_weights(dist)
+    d = np.maximum(dist.astype(dtype), 1e-10)
+    return (1.0 / d) / (1.0 / d).sum(axis=2, keepdims=True)
+
+
+def _three_interpolate(points, idx, w):
+    """tf_interpolate.cpp:107-127: (p[i1]*w1 + p[i2]*w2) + p[i3]*w3"""
+    if points.dtype == np.float32:
+        return ops.three_interpolate(points, idx, w)
+    g = batched_gather(points, idx)
+    return (g[:, :, 0] * w[:, :, 0:1] + g[:, :, 1] * w[:, :, 1:2]) + g[:, :, 2] * w[:, :, 2:3]
+
+
 def decoding_layer(xyz1, xyz2, points1, points2, nsample, mlp, params, scope):
     """PointASNLDecodingLayer, pointasnl_util.py:294-351 (NL=False, use_xyz=True, use_knn=True)."""
     dist, idx = ops.three_nn(xyz1.astype(np.float32), xyz2.astype(np.float32))  # :307
-    w = ops.three_weights(dist).astype(points2.dtype)  # :308-311
-    bi = np.arange(xyz1.shape[0])[:, None, None]
-    interpolated = (points2[bi, idx] * w[..., None]).sum(axis=2) if points2.dtype != np.float32 else \
-        ops.three_interpolate(points2, idx, w)  # :320
+    w = _three_weights(dist, points2.dtype)  # :308-311
+    interpolated = _three_interpolate(points2, idx, w)  # :320
     kidx = knn_query(nsample, xyz1.astype(np.float32), xyz1.astype(np.float32))  # :323
     grouped_xyz = batched_gather(xyz1, kidx)
     grouped_feature = np.concatenate([grouped_xyz, batched_gather(interpolated, kidx)], axis=-1)
@@ -170,22 +187,27 @@ def decoding_layer(xyz1, xyz2, points1, points2, nsample, mlp, params, scope):
 def fp_module(xyz1, xyz2, points1, points2, mlp, params, scope):
     """pointnet_fp_module, utils/pointnet_util.py:199-229."""
     dist, idx = ops.three_nn(xyz1.astype(np.float32), xyz2.astype(np.float32))
-    w = ops.three_weights(dist).astype(points2.dtype)
-    bi = np.arange(xyz1.shape[0])[:, None, None]
-    interpolated = (points2[bi, idx] * w[..., None]).sum(axis=2) if points2.dtype != np.float32 else \
-        ops.three_interpolate(points2, idx, w)
+    w = _three_weights(dist, points2.dtype)
+    interpolated = _three_interpolate(points2, idx, w)
     x = np.concatenate([interpolated, points1], axis=2) if points1 is not None else interpolated
     for i in range(len(mlp)):
         x = _layer(x, params[scope + "/conv_%d" % i], "relu")
     return x
 
 
-def sem_seg_forward(point_cloud, params, num_class, dtype=np.float32):
-    """models/pointasnl_sem_seg.py:18-50, feature_channel=0."""
+def _split_input(pc, feature_channel):
+    """tf.slice of the input into coordinates and features (pointasnl_sem_seg.py:22-27); feature_channel == 0: both = pc"""
+    if feature_channel > 0:
+        return pc[:, :, 0:3], pc[:, :, 3:3 + feature_channel]
+    return pc, pc
+
+
+def sem_seg_forward(point_cloud, params, num_class, dtype=np.float32, feature_channel=0, return_l1=False):
+    """models/pointasnl_sem_seg.py:18-50."""
     pc = point_cloud.astype(dtype)
     n = pc.shape[1]
     nps = [n // 8, n // 32, n // 128, n // 256]
-    l0_xyz, l0_points = pc, pc
+    l0_xyz, l0_points = _split_input(pc, feature_channel)
     l1_xyz, l1_points = set_abstraction(l0_xyz, l0_points, nps[0], 32, [32, 32, 64], params, "layer1", 8)
     l2_xyz, l2_points = set_abstraction(l1_xyz, l1_points, nps[1], 32, [64, 64, 128], params, "layer2", 4)
     l3_xyz, l3_points = set_abstraction(l2_xyz, l2_points, nps[2], 32, [128, 128, 256], params, "layer3", 0)
@@ -195,16 +217,17 @@ def sem_seg_forward(point_cloud, params, num_class, dtype=np.float32):
     l1_points = decoding_layer(l1_xyz, l2_xyz, l1_points, l2_points, 16, [256, 128], params, "fa_layer3")
     l0_points = decoding_layer(l0_xyz, l1_xyz, l0_points, l1_points, 16, [128, 128, 128], params, "fa_layer4")
     net = _layer(l0_points, params["fc1"], "relu")
-    return _layer(net, params["fc2"], None)
+    net = _layer(net, params["fc2"], None)
+    return (net, l1_xyz) if return_l1 else net
 
 
-def sem_seg_res_forward(point_cloud, params, num_class, dtype=np.float32):
-    """models/pointasnl_sem_seg_res.py:19-68, feature_channel=0."""
+def sem_seg_res_forward(point_cloud, params, num_class, dtype=np.float32, feature_channel=0, return_l1=False):
+    """models/pointasnl_sem_seg_res.py:19-68."""
     pc = point_cloud.astype(dtype)
     n = pc.shape[1]
     nps = [n // 8, n // 32, n // 128, n // 256]
-    l0_xyz = pc
-    _, l0_points = set_abstraction(l0_xyz, pc, n, 32, [16, 16, 32], params, "layer0", 0, NL=False)
+    l0_xyz, l0_feat = _split_input(pc, feature_channel)
+    _, l0_points = set_abstraction(l0_xyz, l0_feat, n, 32, [16, 16, 32], params, "layer0", 0, NL=False)
     l1_xyz, l1_1 = set_abstraction(l0_xyz, l0_points, nps[0], 32, [32, 32, 64], params, "layer1_1", 8)
     _, l1_2 = set_abstraction(l0_xyz, l0_points, nps[0], 32, [64, 64], params, "layer1_2", 0, NL=False)
     l1_2 = l1_2 + l1_1
@@ -222,7 +245,8 @@ def sem_seg_res_forward(point_cloud, params, num_class, dtype=np.float32):
     l1_points = fp_module(l1_xyz, l2_xyz, l1_2, l2_points, [256, 128], params, "fa_layer3")
     l0_points = fp_module(l0_xyz, l1_xyz, l0_points, l1_points, [128, 128, 128], params, "fa_layer4")
     net = _layer(l0_points, params["fc1"], "leaky_relu")
-    return _layer(net, params["fc0"], None)
+    net = _layer(net, params["fc0"], None)
+    return (net, l1_xyz) if return_l1 else net
 
 
 def sa_group_all(xyz, points, mlp, params, scope):
@@ -259,3 +283,59 @@ def repulsion_loss(pred, nsample=20, radius=0.07, dtype=np.float64):
     d2 = np.maximum(1e-12, d2)
     h = 0.03
     return float(np.mean(radius - np.sqrt(d2) * np.exp(-d2 / h ** 2)))
+
+
+def params_from_tf(variables):
+    """{TF variable name: array} (names as the reference graph creates them, e.g. 'layer1/layer1/conv_kv/bn/gamma';
+    weights [kh,kw,cin,cout] or [k,cin,cout] or [cin,cout]) -> the scope -> {"w","b","gamma","beta","mean","var"} mapping
+    used above.  Kernels are flattened to (kh*kw*cin, cout): a [1,W] VALID kernel over a (B,P,W,C) map is one matmul over
+    the row-major (W,C) window (tf_util.py:170-175)."""
+    out = {}
+    for full, a in variables.items():
+        parts = full.split("/")
+        a = np.asarray(a)
+        if len(parts) >= 2 and parts[-2] == "bn":
+            sc = "/".join(parts[:-2])
+            key = {"gamma": "gamma", "beta": "beta", "moving_mean": "mean", "moving_variance": "var"}[parts[-1]]
+        else:
+            sc = "/".join(parts[:-1])
+            key = {"weights": "w", "biases": "b"}[parts[-1]]
+            if key == "w":
+                a = a.reshape(-1, a.shape[-1])
+        out.setdefault(sc, {})[key] = a
+    return out
+
+
+def _xent(logits, labels):
+    z = logits - logits.max(axis=-1, keepdims=True)
+    return np.log(np.exp(z).sum(axis=-1)) - np.take_along_axis(z, labels[..., None].astype(np.int64), axis=-1)[..., 0]
+
+
+def _l2_all_weights(params, dtype):
+    """sum of tf.nn.l2_loss(v) over tf.global_variables() with 'weights' in the name"""
+    return sum((p["w"].astype(dtype) ** 2).sum() / 2 for p in params.values() if "w" in p)
+
+
+def cls_loss(pred, label, l1_xyz, params, uniform_weight=0, weights_decay=1e-4, dtype=np.float64):
+    """models/pointasnl_cls.py:55-70.  uniform_weight == 0: the 'uniform' term is the classify loss times zero."""
+    classify = _xent(pred.astype(dtype), label).mean()
+    uniform = repulsion_loss(l1_xyz, nsample=20, radius=0.07, dtype=dtype) if uniform_weight > 0 else classify
+    return classify + uniform_weight * uniform + weights_decay * _l2_all_weights(params, dtype)
+
+
+def seg_loss(pred, label, l1_xyz, params, weight_decay, smpw=1.0, uniform_weight=0.01, weights_decay=1e-4, radius=0.07,
+             dtype=np.float64, decayed=lambda scope: True):
+    """models/pointasnl_sem_seg.py:53-68 == pointasnl_sem_seg_res.py:70-85.  tf.losses.sparse_softmax_cross_entropy
+    reduces with SUM_BY_NONZERO_WEIGHTS and ADDS ITS RESULT to the 'losses' collection -- the collection tf_util's
+    wd * l2_loss(weights) terms live in (tf_util.py:47-48) -- so tf.add_n(tf.get_collection('losses')) (:63) contains the
+    classify loss once more: total = 2 * classify + sum(wd * l2) + uniform_weight * uniform + weights_decay * sum(l2).
+    `decayed(scope)`: which layers were built with the weight_decay -- all of them in pointasnl_sem_seg.py; in
+    pointasnl_sem_seg_res.py the pointnet_fp_module decoders take none (:57-60), so 'fa_layer*' is excluded there."""
+    ce = _xent(pred.astype(dtype), label)
+    w = np.broadcast_to(np.asarray(smpw, dtype=dtype), ce.shape)
+    classify = (ce * w).sum() / np.count_nonzero(w)
+    l2 = _l2_all_weights(params, dtype)
+    l2_decayed = sum((p["w"].astype(dtype) ** 2).sum() / 2 for sc, p in params.items() if "w" in p and decayed(sc))
+    weight_reg = (weight_decay * l2_decayed if weight_decay is not None else 0.0) + classify
+    uniform = repulsion_loss(l1_xyz, nsample=20, radius=radius, dtype=dtype)
+    return classify + weight_reg + uniform_weight * uniform + weights_decay * l2

@@ -55,10 +55,13 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
 def get_loss(pred, label, end_points, smpw=1.0, uniform_weight=0.01, weights_decay=1e-4, radius=0.07):
     """ pred: BxNxC, label: BxN, smpw: BxN  (pointasnl_sem_seg.py get_loss) """
     regularization_loss = tf_util.regularization_loss(weights_decay)
-    # tf.losses.sparse_softmax_cross_entropy(weights=smpw): sum(w * ce) / number of non-zero weights
+    # tf.losses.sparse_softmax_cross_entropy(weights=smpw): sum(w * ce) / number of non-zero weights -- and the result
+    # joins the 'losses' collection (tf.GraphKeys.LOSSES), the one tf.add_n(tf.get_collection('losses')) sums below: the
+    # reference's total therefore holds the classify loss TWICE (checked against the reference's Python executed under
+    # oracle/tf_shim: tests/golden/ref_losses.npz)
     ce = torch.nn.functional.cross_entropy(pred.reshape(-1, pred.shape[-1]), label.reshape(-1).long(), reduction='none')
     w = torch.as_tensor(smpw, dtype=ce.dtype, device=ce.device).expand(label.shape).reshape(-1)
     classify_loss = (ce * w).sum() / torch.count_nonzero(w).clamp(min=1)
     uniform_loss = get_repulsion_loss(end_points['l1_xyz'], nsample=20, radius=radius)
-    weight_reg = tf_util.collection_losses()
+    weight_reg = tf_util.collection_losses(extra=[classify_loss])
     return classify_loss + weight_reg + uniform_weight * uniform_loss + regularization_loss

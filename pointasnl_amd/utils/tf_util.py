@@ -51,8 +51,44 @@ class VariableStore:
         h = hashlib.sha256(f"{self.seed}:{full}".encode()).digest()
         return np.random.Generator(np.random.PCG64(int.from_bytes(h[:8], "little")))
 
+    def load(self, variables, strict=True):
+        """Take variable VALUES from a mapping keyed by the reference's TF variable names -- a trained checkpoint
+        exported to npz, or any {name: array}:
+
+            reader = tf.train.load_checkpoint(ckpt)          # on a machine that has TF 1.x
+            np.savez("pointasnl.npz", **{n: reader.get_tensor(n) for n in reader.get_variable_to_shape_map()})
+            store.load(np.load("pointasnl.npz"))
+
+        Names are the graph's own ('layer1/layer1/conv_kv/weights', '.../bn/moving_variance', ...; a ':0' suffix and
+        optimizer slots are ignored).  Conv kernels [kh,kw,cin,cout] / [k,cin,cout] are flattened to [kh*kw*cin, cout]
+        (row-major: the [1,W] VALID kernels become one GEMM over the (W,C) window).  Shapes are validated when a layer
+        asks for its variables.  strict: a layer that asks for a variable the mapping does not hold raises instead of
+        drawing a seeded one.  Every cached BN-folded / concatenated weight is dropped."""
+        for name in getattr(variables, "files", None) or variables.keys():
+            leaf = name.split(":")[0].split("/")[-1]
+            if leaf not in ("weights", "biases", "beta", "gamma", "moving_mean", "moving_variance"):
+                continue  # Adam slots, global_step, batch counters
+            a = np.asarray(variables[name], dtype=np.float32)
+            if leaf == "weights" and a.ndim > 2:
+                a = a.reshape(-1, a.shape[-1])
+            self.vars[name.split(":")[0]] = torch.tensor(a, dtype=torch.float32, device=self.device)
+        self.strict = bool(strict)
+        self._folded.clear()
+        return self
+
+    def assign(self, full_name, value):
+        """Overwrite one variable (2-D weights / 1-D vectors, as stored) and invalidate the folded caches."""
+        self.vars[full_name] = torch.as_tensor(value, dtype=torch.float32).to(self.device).contiguous()
+        self._folded.clear()
+
+    strict = False
+
     def get(self, name, shape, kind):
         full = self.path(name)
+        if full in self.vars and tuple(self.vars[full].shape) != tuple(shape):
+            raise ValueError(f"variable {full}: stored shape {tuple(self.vars[full].shape)} but the layer needs {tuple(shape)}")
+        if full not in self.vars and self.strict:
+            raise KeyError(f"variable {full} {tuple(shape)} is not in the loaded checkpoint (VariableStore.load(strict=True))")
         if full not in self.vars:
             rng = self._rng(full)
             if kind == "xavier":  # tf.contrib.layers.xavier_initializer (uniform): limit = sqrt(6/(fan_in+fan_out))
@@ -209,10 +245,12 @@ def regularization_loss(weights_decay):
     return weights_decay * sum(l2_loss(v) for name, v in st.vars.items() if 'weights' in name)
 
 
-def collection_losses():
-    """tf.add_n(tf.get_collection('losses')): the wd * l2_loss(weights) terms of the layers built with a weight_decay.
-    Like tf.add_n it refuses an empty collection (a graph built with weight_decay=None)."""
+def collection_losses(extra=()):
+    """tf.add_n(tf.get_collection('losses')): the wd * l2_loss(weights) terms of the layers built with a weight_decay
+    (tf_util.py:46-48) plus whatever else the graph added to that collection -- `extra`: tf.losses.* functions add their
+    result to tf.GraphKeys.LOSSES, which IS the string 'losses'.  Like tf.add_n it refuses an empty collection."""
     st = store()
-    if not st.decays:
+    terms = [wd * l2_loss(st.vars[name]) for name, wd in st.decays.items()] + list(extra)
+    if not terms:
         raise ValueError("the 'losses' collection is empty: build the model with a weight_decay")
-    return sum(wd * l2_loss(st.vars[name]) for name, wd in st.decays.items())
+    return sum(terms)

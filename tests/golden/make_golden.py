@@ -7,7 +7,17 @@
                                                copied into tests/golden/ afterwards)
       ref_tfops_hip.npz             <- the reference .cu kernels compiled unchanged by hipcc -ffp-contract=off
 
-Inputs are regenerated from seeds by tests/conftest.clouds, so the files hold only seeds + outputs.
+  python tests/golden/make_golden.py cells    (this container: imports and RUNS the reference's own Python --
+  python tests/golden/make_golden.py models    utils/pointasnl_util.py, utils/pointnet_util.py, utils/tf_util.py,
+  python tests/golden/make_golden.py losses    tf_ops/*/tf_*.py, models/pointasnl_*.py -- under oracle/tf_shim, a numpy
+                                               stand-in for the TF symbols they use; custom ops = oracle/_ref + C oracle)
+      ref_cells.npz                 <- SampleWeights/AdaptiveSampling, PointNonLocalCell, PointASNLSetAbstraction,
+                                       PointASNLDecodingLayer, pointnet_fp_module, pointnet_sa_module, get_repulsion_loss
+      ref_models.npz                <- get_model of the three models, small sizes and BASELINE.json configs[1..4]
+      ref_losses.npz                <- get_loss of the three models
+
+Inputs are regenerated from seeds (tests/conftest.clouds, tests/golden/ref_cases.py, bench.synth_*) and weights from
+(seed, variable name, shape) by oracle/weights.py, so the files hold only outputs + the variable name/shape lists.
 """
 import os
 import sys
@@ -100,5 +110,144 @@ def make_gpu():
     print("wrote gpurun_out/ref_tfops_hip.npz")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# cells / models / losses: the reference's Python, executed
+
+def _ref_call_cell(tfs, case, x):
+    """Call the reference function of `case` on shim tensors -> dict of outputs.  All keyword names are the reference's."""
+    import pointasnl_util as U   # /root/reference/utils/pointasnl_util.py
+    import pointnet_util as PU   # /root/reference/utils/pointnet_util.py
+
+    T = lambda a: None if a is None else tfs.constant(a)  # noqa: E731
+    fn = case["fn"]
+    common = dict(is_training=tfs.constant(False), bn_decay=None)
+    if fn == "AdaptiveSampling":
+        nx, nf = U.AdaptiveSampling(T(x["group_xyz"]), T(x["group_feature"]), case["as_"], weight_decay=None, scope="layer1",
+                                    bn=True, **common)
+        return dict(new_xyz=nx, new_feature=nf)
+    if fn == "PointNonLocalCell":
+        c = case["c"]
+        out = U.PointNonLocalCell(T(x["feature"]), T(x["new_point"]), [max(32, c // 2), case["out"]], weight_decay=None,
+                                  scope="layerX", bn=True, **common)
+        return dict(out=out)
+    if fn == "PointASNLSetAbstraction":
+        nx, npts = U.PointASNLSetAbstraction(T(x["xyz"]), T(x["feature"]), npoint=case["npoint"], nsample=case["nsample"],
+                                             mlp=case["mlp"], weight_decay=None, scope="layerS", as_neighbor=case["as_"],
+                                             NL=case["NL"], **common)
+        return dict(new_xyz=nx, new_points=npts)
+    if fn == "PointASNLDecodingLayer":
+        out = U.PointASNLDecodingLayer(T(x["xyz1"]), T(x["xyz2"]), T(x["points1"]), T(x["points2"]), case["nsample"], case["mlp"],
+                                       weight_decay=None, scope="fa", **common)
+        return dict(out=out)
+    if fn == "pointnet_fp_module":
+        out = PU.pointnet_fp_module(T(x["xyz1"]), T(x["xyz2"]), T(x["points1"]), T(x["points2"]), case["mlp"], scope="fp", bn=True,
+                                    **common)
+        return dict(out=out)
+    if fn == "pointnet_sa_module":
+        _, out, _ = PU.pointnet_sa_module(T(x["xyz"]), T(x["points"]), npoint=None, radius=None, nsample=None, mlp=case["mlp"],
+                                          mlp2=None, group_all=True, scope="sa_all", **common)
+        return dict(out=out)
+    if fn == "get_repulsion_loss":
+        return dict(loss=U.get_repulsion_loss(T(x["pred"]), nsample=case["nsample"], radius=case["radius"]))
+    raise KeyError(fn)
+
+
+def _vars_json(tfs):
+    import json
+
+    return json.dumps([[k, list(v.shape)] for k, v in tfs.variables.items()])
+
+
+def make_cells():
+    from golden import ref_cases as R
+    from oracle import tf_shim
+
+    out = {}
+    for case in R.CELL_CASES:
+        x = R.cell_inputs(case)
+        for dt, tag in ((np.float64, "f64"),):  # the fp32 evaluation is kept for the model graphs only (ref_models.npz)
+            xs = {k: (None if v is None else v.astype(dt)) for k, v in x.items()}
+            with tf_shim.session(seed=R.cell_seed(case), dtype=dt) as tfs:
+                res = _ref_call_cell(tfs, case, xs)
+                out[f"{case['name']}/vars"] = np.array(_vars_json(tfs))
+            for k, v in res.items():
+                out[f"{case['name']}/{k}_{tag}"] = np.asarray(v)
+        if case.get("dup"):
+            # clouds with exactly equidistant neighbours: nanoflann's order among them is traversal order, the product's is
+            # ascending index (DESIGN.md 3).  Keep the reference's own neighbour lists so that the tests can (a) show that the
+            # deviation is confined to runs of equal distance and (b) check everything downstream on the reference's lists.
+            from oracle import ops, ref
+            fps = ops.farthest_point_sample(case["npoint"], x["xyz"])
+            q = np.take_along_axis(x["xyz"], fps[..., None].astype(np.int64), 1)
+            out[f"{case['name']}/knn_idx"] = ref.knn_batch(x["xyz"], q, case["nsample"], omp=True).astype(np.int32)
+        print(case["name"], {k: np.asarray(v).shape for k, v in res.items()})
+    np.savez_compressed(os.path.join(HERE, "ref_cells.npz"), **out)
+    print("wrote ref_cells.npz", os.path.getsize(os.path.join(HERE, "ref_cells.npz")))
+
+
+def _ref_model(name):
+    import importlib
+
+    return importlib.import_module({"cls": "pointasnl_cls", "sem_seg": "pointasnl_sem_seg", "sem_seg_res": "pointasnl_sem_seg_res"}[name])
+
+
+def make_models(only=None):
+    """get_model of the reference, one cloud at a time for the big ones (every op is per cloud at inference)."""
+    import time
+
+    from golden import ref_cases as R
+    from oracle import tf_shim
+
+    path = os.path.join(HERE, "ref_models.npz")
+    out = dict(np.load(path)) if os.path.exists(path) and only else {}
+    for case in R.MODEL_CASES:
+        if only and case["name"] not in only:
+            continue
+        pc = R.model_input(case)
+        stride = case.get("stride", 1)
+        t0 = time.time()
+        for dt, tag in ((np.float64, "f64"), (np.float32, "f32")):
+            logits, l1 = [], []
+            chunk = 8 if case["model"] == "cls" else 1
+            for s in range(0, case["b"], chunk):
+                with tf_shim.session(seed=R.model_seed(case), dtype=dt) as tfs:
+                    M = _ref_model(case["model"])
+                    net, ep = M.get_model(tfs.constant(pc[s:s + chunk].astype(dt)), tfs.constant(False), **case["kw"])
+                    out[f"{case['name']}/vars"] = np.array(_vars_json(tfs))
+                logits.append(np.asarray(net))
+                l1.append(np.asarray(ep["l1_xyz"]))
+            logits, l1 = np.concatenate(logits), np.concatenate(l1)
+            out[f"{case['name']}/logits_{tag}"] = logits if case["model"] == "cls" else logits[:, ::stride]
+            if tag == "f64":
+                out[f"{case['name']}/l1_xyz_{tag}"] = l1[:, ::max(1, l1.shape[1] // 64)].astype(np.float32)
+        print(case["name"], logits.shape, f"{time.time() - t0:.1f}s", flush=True)
+    np.savez_compressed(path, **out)
+    print("wrote ref_models.npz", os.path.getsize(path))
+
+
+def make_losses():
+    from golden import ref_cases as R
+    from oracle import tf_shim
+
+    out = {}
+    for case in R.LOSS_CASES:
+        x = R.loss_inputs(case)
+        with tf_shim.session(seed=R.loss_seed(case), dtype=np.float64) as tfs:
+            M = _ref_model(case["model"])
+            net, ep = M.get_model(tfs.constant(x["pc"].astype(np.float64)), tfs.constant(False), **case["kw"])
+            args = [net, tfs.constant(x["label"]), ep]
+            kw = dict(case["loss_kw"])
+            if "smpw" in x:
+                kw["smpw"] = tfs.constant(x["smpw"].astype(np.float64))
+            loss = M.get_loss(*args, **kw)
+            out[f"{case['name']}/vars"] = np.array(_vars_json(tfs))
+        out[f"{case['name']}/loss_f64"] = np.asarray(loss)
+        out[f"{case['name']}/logits_f64"] = np.asarray(net) if case["model"] == "cls" else np.asarray(net)[:, ::8]
+        print(case["name"], float(loss))
+    np.savez_compressed(os.path.join(HERE, "ref_losses.npz"), **out)
+
+
 if __name__ == "__main__":
-    (make_cpu if sys.argv[1:] == ["cpu"] else make_gpu)()
+    mode = sys.argv[1]
+    {"cpu": make_cpu, "gpu": make_gpu, "cells": make_cells, "losses": make_losses,
+     "models": lambda: make_models(sys.argv[2:] or None)}[mode]()
