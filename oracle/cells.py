@@ -19,6 +19,22 @@ from . import ops
 
 BN_EPS = 1e-3
 
+TRACE = None  # set to a list: every layer-level call below appends (function, scope, inputs, outputs) -- the tests use it to
+              # feed the product's layers the oracle's own intermediate tensors (layer-wise comparison without the
+              # amplification of an fp32-ulp difference by a later FPS / kNN decision)
+
+
+def _traced(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        out = fn(*args, **kw)
+        if TRACE is not None:
+            TRACE.append((fn.__name__, args, kw, out))
+        return out
+    return wrapper
+
 
 def _layer(x, p, act):
     """tf_util.conv2d / conv1d / fully_connected with a 1x1 kernel: matmul, bias, [BN], [activation]."""
@@ -113,6 +129,7 @@ def knn_query(k, support, query):
     return ops.knn_batch(support, query, k, omp=True).astype(np.int32)
 
 
+@_traced
 def set_abstraction(xyz, feature, npoint, nsample, mlp, params, scope, as_neighbor=8, NL=True, knn_idx=None):
     """PointASNLSetAbstraction, pointasnl_util.py:221-292 (use_knn=True, bn=True).  knn_idx: neighbour lists to use instead
     of the oracle's kNN (tests on clouds with equidistant neighbours pass the reference nanoflann's own lists)."""
@@ -164,6 +181,7 @@ def _three_interpolate(points, idx, w):
     return (g[:, :, 0] * w[:, :, 0:1] + g[:, :, 1] * w[:, :, 1:2]) + g[:, :, 2] * w[:, :, 2:3]
 
 
+@_traced
 def decoding_layer(xyz1, xyz2, points1, points2, nsample, mlp, params, scope):
     """PointASNLDecodingLayer, pointasnl_util.py:294-351 (NL=False, use_xyz=True, use_knn=True)."""
     dist, idx = ops.three_nn(xyz1.astype(np.float32), xyz2.astype(np.float32))  # :307
@@ -184,6 +202,7 @@ def decoding_layer(xyz1, xyz2, points1, points2, nsample, mlp, params, scope):
     return new_points
 
 
+@_traced
 def fp_module(xyz1, xyz2, points1, points2, mlp, params, scope):
     """pointnet_fp_module, utils/pointnet_util.py:199-229."""
     dist, idx = ops.three_nn(xyz1.astype(np.float32), xyz2.astype(np.float32))
@@ -249,6 +268,7 @@ def sem_seg_res_forward(point_cloud, params, num_class, dtype=np.float32, featur
     return (net, l1_xyz) if return_l1 else net
 
 
+@_traced
 def sa_group_all(xyz, points, mlp, params, scope):
     """pointnet_sa_module(group_all=True), utils/pointnet_util.py:59-84,109-125: concat xyz, MLP, max."""
     x = np.concatenate([xyz, points], axis=2)
