@@ -140,7 +140,9 @@ int pasnl_three_weights(int rows, const float* dist, float* weight, pasnl_stream
  *   out[b,i,:] = softmax_j( q[b,i,:] . k[b,j,:] / sqrt(cb) ) . v[b,j,:]
  * q (b,p,cb); kv (b,n,2*cb) with K = kv[...,:cb], V = kv[...,cb:] exactly as conv_kv produces them
  * (:193-194); out (b,p,cb).  The (b,p,n) attention map is never materialised.
- * variant: 0 = auto, 1 = vector-FMA kernel, 2 = fp32 MFMA kernel.  cb must be a multiple of 32, <= 128. */
+ * variant: 0 = auto, 1 = vector-FMA kernel (cb <= 64), 2 = fp32 MFMA kernel, 3 = fp32 MFMA kernel with LDS-staged K/V
+ * (the only MFMA form for cb = 128; kept selectable for A/B).  cb in {32, 64, 128} and kv / out 16-byte aligned;
+ * anything else: PASNL_EUNSUPPORTED (the Python mirror then takes the op-by-op path on the vendor BLAS). */
 int pasnl_nl_attention(int b, int p, int n, int cb, const float* q, const float* kv, float* out, int variant,
                        pasnl_stream_t stream);
 

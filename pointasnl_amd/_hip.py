@@ -28,6 +28,11 @@ class PasnlError(RuntimeError):
     pass
 
 
+class PasnlUnsupported(PasnlError):
+    """PASNL_EUNSUPPORTED: a valid request outside what the fused kernel covers (include/pasnl.h documents the limits).
+    The cells catch it and take their op-by-op path (still HIP kernels + vendor GEMMs, never a CPU path)."""
+
+
 _lib = None
 
 
@@ -58,7 +63,14 @@ def stream_ptr():
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    """Device pointer of a tensor for a launch on torch's CURRENT stream: the tensor has to live on the current device
+    (launching on cuda:0's stream with cuda:1's memory would fault or silently use the wrong GPU)."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    if t.device.index != torch.cuda.current_device():
+        raise PasnlError(f"tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: wrap the call in "
+                         "`with torch.cuda.device(tensor.device):` (launches go to the current device's stream)")
+    return ctypes.c_void_p(t.data_ptr())
 
 
 # Optional per-launch timing for bench.py: when PROFILE is a list, every C-ABI launch is bracketed by two
@@ -99,6 +111,8 @@ def check(code, what):
         msg = lib().pasnl_strerror(code).decode()
         if code == -1:
             raise ValueError(f"{what}: {msg}")
+        if code == -5:
+            raise PasnlUnsupported(f"{what}: {msg} (code {code})")
         raise PasnlError(f"{what}: {msg} (code {code})")
 
 

@@ -1338,9 +1338,10 @@ __global__ __launch_bounds__(256) void decode_cell_kernel(long points, int n, in
 using namespace pasnl;
 
 template <int CB, int SPLIT>
-static int nl_mfma_launch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, hipStream_t st) {
+static int nl_mfma_launch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, bool staged,
+                          hipStream_t st) {
   if constexpr (CB <= 64) {
-    if (!getenv("PASNL_NL_LDS")) {  // (the LDS-staged kernel stays selectable for A/B measurements)
+    if (!staged) {  // (the LDS-staged kernel stays selectable -- variant 3 -- for A/B measurements)
       const size_t lds = (size_t)SPLIT * (CB / 2 + 2) * 64 * sizeof(float);
       hipLaunchKernelGGL((nl_attention_direct_kernel<CB, SPLIT>), dim3((p + 31) / 32, b), dim3(SPLIT * 64), lds, st, p, n, qscale,
                          q, kv, out);
@@ -1359,7 +1360,8 @@ static int nl_mfma_launch(int b, int p, int n, float qscale, const float* q, con
 }
 
 template <int CB>
-static int nl_mfma_dispatch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, hipStream_t st) {
+static int nl_mfma_dispatch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, bool staged,
+                            hipStream_t st) {
   // split the keys over enough waves to put ~4 on every SIMD (4096 waves; measured best on all reference shapes:
   // cls layer1 140 -> 82 us, cls layer2 128 -> 37 us, ScanNet layer1 1030 -> 279 us with the LDS-staged kernel), but
   // keep >= 4 key blocks per wave (cls layer2, 16 blocks: 19 us at 4 waves, 23 us at 8: the merge is not free) and
@@ -1368,13 +1370,13 @@ static int nl_mfma_dispatch(int b, int p, int n, float qscale, const float* q, c
   long blocks = (n + NL_KB - 1) / NL_KB;
   int want = 1;
   while (want < 8 && tiles * want < 4096 && want * 2 * 4 <= blocks) want *= 2;
-  const char* force = getenv("PASNL_NL_SPLIT");  // tuning only
+  const char* force = tune_env("PASNL_NL_SPLIT");  // tuning only
   if (force && *force) want = atoi(force);
   if (CB == 128 && want > 4) want = 4;
-  if (want >= 8) return nl_mfma_launch<CB, 8>(b, p, n, qscale, q, kv, out, st);
-  if (want >= 4) return nl_mfma_launch<CB, 4>(b, p, n, qscale, q, kv, out, st);
-  if (want >= 2) return nl_mfma_launch<CB, 2>(b, p, n, qscale, q, kv, out, st);
-  return nl_mfma_launch<CB, 1>(b, p, n, qscale, q, kv, out, st);
+  if (want >= 8) return nl_mfma_launch<CB, 8>(b, p, n, qscale, q, kv, out, staged, st);
+  if (want >= 4) return nl_mfma_launch<CB, 4>(b, p, n, qscale, q, kv, out, staged, st);
+  if (want >= 2) return nl_mfma_launch<CB, 2>(b, p, n, qscale, q, kv, out, staged, st);
+  return nl_mfma_launch<CB, 1>(b, p, n, qscale, q, kv, out, staged, st);
 }
 
 template <int CB>
@@ -1386,12 +1388,12 @@ static int nl_valu_launch(int b, int p, int n, float qscale, const float* q, con
 extern "C" int pasnl_nl_attention(int b, int p, int n, int cb, const float* q, const float* kv, float* out, int variant,
                                   pasnl_stream_t stream) {
   PASNL_REQUIRE(b >= 0 && p >= 0 && n > 0 && cb > 0, PASNL_EINVAL);
-  PASNL_REQUIRE(variant >= 0 && variant <= 2, PASNL_EINVAL);
+  PASNL_REQUIRE(variant >= 0 && variant <= 3, PASNL_EINVAL);
   PASNL_REQUIRE(cb == 32 || cb == 64 || cb == 128, PASNL_EUNSUPPORTED);
   if (b == 0 || p == 0) return PASNL_OK;
   PASNL_REQUIRE(q && kv && out, PASNL_ENULL);
   PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
-  PASNL_REQUIRE(((reinterpret_cast<uintptr_t>(kv) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, PASNL_EINVAL);
+  PASNL_REQUIRE(((reinterpret_cast<uintptr_t>(kv) | reinterpret_cast<uintptr_t>(out)) & 15) == 0, PASNL_EUNSUPPORTED);
   hipStream_t st = pasnl_hip_stream(stream);
   // scores are kept in the log2 domain: exp(x/sqrt(cb) - m) == exp2((x*log2e/sqrt(cb)) - m')
   const float qscale = LOG2E / sqrtf((float)cb);
@@ -1400,9 +1402,9 @@ extern "C" int pasnl_nl_attention(int b, int p, int n, int cb, const float* q, c
     if (cb == 64) return nl_valu_launch<64>(b, p, n, qscale, q, kv, out, st);
     return PASNL_EUNSUPPORTED;  // cb=128 does not fit the one-query-per-lane register budget
   }
-  if (cb == 32) return nl_mfma_dispatch<32>(b, p, n, qscale, q, kv, out, st);
-  if (cb == 64) return nl_mfma_dispatch<64>(b, p, n, qscale, q, kv, out, st);
-  return nl_mfma_dispatch<128>(b, p, n, qscale, q, kv, out, st);
+  if (cb == 32) return nl_mfma_dispatch<32>(b, p, n, qscale, q, kv, out, variant == 3, st);
+  if (cb == 64) return nl_mfma_dispatch<64>(b, p, n, qscale, q, kv, out, variant == 3, st);
+  return nl_mfma_dispatch<128>(b, p, n, qscale, q, kv, out, variant == 3, st);
 }
 
 namespace pasnl {
@@ -1817,7 +1819,7 @@ extern "C" int pasnl_as_cell_wide(int g, int as, int cb, int w, int ch, const fl
   const float qscale = LOG2E / sqrtf((float)cb);
   const long wgs = ((long)g + 3) / 4;
   long cap = 768;  // persistent workgroups: a wave's weights (registers) and the workgroup's Wb (LDS) are loaded once
-  if (const char* e = getenv("PASNL_AS_GRID")) cap = atol(e) > 0 ? atol(e) : cap;  // tuning only
+  if (const char* e = tune_env("PASNL_AS_GRID")) cap = atol(e) > 0 ? atol(e) : cap;  // tuning only
   const dim3 grid((unsigned)(wgs < cap ? wgs : cap)), block(256);
   hipStream_t st = pasnl_hip_stream(stream);
 #define PASNL_AS_GO(CBLK)                                                                                                  \

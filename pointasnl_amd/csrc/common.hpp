@@ -95,4 +95,13 @@ __device__ __forceinline__ void dist2_multi(const float (&qx)[QW], const float (
   }
 }
 
+// Tuning / A-B switches read from the environment exist ONLY in the diagnostic build (make tuning ->
+// libpasnl_hip_tuning.so, never loaded by the package): the product library reads no environment variable and
+// keeps no global state (include/pasnl.h), so a launch is a pure function of its arguments.
+#ifdef PASNL_TUNING
+inline const char* tune_env(const char* name) { return getenv(name); }
+#else
+constexpr const char* tune_env(const char*) { return nullptr; }
+#endif
+
 }  // namespace pasnl

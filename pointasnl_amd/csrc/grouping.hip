@@ -1069,7 +1069,7 @@ extern "C" int pasnl_query_ball_point(int b, int n, int m, float radius, int nsa
   float thr2 = (radius > 1e-20f) ? ball_threshold(radius) : 0.f;
   // Grid-pruned kernel for LDS-sized clouds (every in-model use and the north-star shape); PASNL_BALL_BRUTE=1 forces
   // the brute-force kernel (A/B measurements), which also serves larger clouds.
-  if (n <= BQG_NMAX && nsample <= 1024 && !getenv("PASNL_BALL_BRUTE")) {
+  if (n <= BQG_NMAX && nsample <= 1024 && !tune_env("PASNL_BALL_BRUTE")) {
     // words per query row: the n-bit mask, later the nsample 16-bit hits; a power of two (XOR-swizzled, unpadded)
     int mwt = n <= 256 ? 8 : (n <= 512 ? 16 : (n <= 1024 ? 32 : 64));
     int rw = mwt;
@@ -1080,7 +1080,7 @@ extern "C" int pasnl_query_ball_point(int b, int n, int m, float radius, int nsa
       const float rpad = radius * 1.001f;
       // diagnostics: PASNL_BALL_PROBE=<device pointer to 8 int64, hex> makes workgroup 0 record its phase clocks
       long long* dbg = nullptr;
-      if (const char* pe = getenv("PASNL_BALL_PROBE")) dbg = reinterpret_cast<long long*>(strtoull(pe, nullptr, 16));
+      if (const char* pe = tune_env("PASNL_BALL_PROBE")) dbg = reinterpret_cast<long long*>(strtoull(pe, nullptr, 16));
       // e / d for e < 2^16 as umulhi(e, magic); d = list entries (or 16-byte groups of entries) per query
       const unsigned div = (nsample & 3) == 0 ? (unsigned)nsample / 4 : (unsigned)nsample;
       const uint32_t ns_magic = div == 1 ? 0u : (uint32_t)((0x100000000ull / div) + 1ull);  // 0: divisor 1
@@ -1148,7 +1148,7 @@ extern "C" int pasnl_knn_batch(int b, int n, int m, int k, const float* support,
   // Two-pass selection wins wherever selection dominates (measured: 2.6x at N=1024,K=32; 3.7x at N=512,K=64); for
   // small K over large clouds both kernels are bound by the distance loop and the single pass is ahead
   // (N=8192,K=16: 795 vs 982 us).  PASNL_KNN_INSERTION=1 forces the insertion kernel (A/B measurements).
-  if (k <= 64 && (!(k <= 16 && n > 2048) || getenv("PASNL_KNN_TWO_PASS")) && !getenv("PASNL_KNN_INSERTION")) {
+  if (k <= 64 && (!(k <= 16 && n > 2048) || tune_env("PASNL_KNN_TWO_PASS")) && !tune_env("PASNL_KNN_INSERTION")) {
     constexpr int QW = 4;
     dim3 grid((m + SEARCH_WAVES * QW - 1) / (SEARCH_WAVES * QW), b), block(SEARCH_WAVES * 64);
 #define PASNL_KNN2(RR, T) hipLaunchKernelGGL((knn2_kernel<RR, QW, T>), grid, block, 0, st, n, m, k, support, queries, static_cast<T*>(idx), dist2)

@@ -325,7 +325,7 @@ extern "C" int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz
   PASNL_REQUIRE(xyz && idx, PASNL_ENULL);
   hipStream_t st = pasnl_hip_stream(stream);
   // lanes x points-per-lane must cover n.  PASNL_FPS_CFG="waves,ppl" overrides the table (tuning only).
-  const char* cfg = getenv("PASNL_FPS_CFG");
+  const char* cfg = tune_env("PASNL_FPS_CFG");
   if (cfg) {
     int w = 0, p = 0;
     if (sscanf(cfg, "%d,%d", &w, &p) == 2 && (long)w * 64 * p >= n) {

@@ -88,10 +88,9 @@ LOCAL_CELL_FUSED = True  # False = the reference's op-by-op chain on the vendor 
 
 
 def _local_cell_supported(w, mlp, nsample):
-    if not LOCAL_CELL_FUSED or len(mlp) != 3 or mlp[0] != mlp[1] or mlp[0] not in (32, 64, 128) or nsample % 32:
-        return False
-    wp = (w + 31) // 32 * 32
-    return (wp * mlp[0] + mlp[0] * mlp[1] + 128 + mlp[0]) * 4 <= 160 * 1024  # weights must fit the LDS
+    """Cheap pre-filter only: the kernel launchers own the exact limits (LDS bytes: cells.hip pasnl_sa_cell) and answer
+    PASNL_EUNSUPPORTED beyond them, which PointASNLSetAbstraction catches and answers with the next path down."""
+    return LOCAL_CELL_FUSED and len(mlp) == 3 and mlp[0] == mlp[1] and mlp[0] in (32, 64, 128) and nsample % 32 == 0
 
 
 def sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn):
@@ -327,7 +326,15 @@ def PointNonLocalCell(feature, new_point, mlp, is_training, bn_decay, weight_dec
                                                bn=bn, is_training=is_training, scope='conv_query', bn_decay=bn_decay,
                                                weight_decay=weight_decay, activation_fn=None)
         transformed_new_point = transformed_new_point.reshape(batch_size, npoint * nsample, bottleneck_channel)
-        new_nonlocal_point = nl_attention(transformed_new_point, transformed_feature.squeeze(2))
+        try:
+            new_nonlocal_point = nl_attention(transformed_new_point, transformed_feature.squeeze(2))
+        except _hip.PasnlUnsupported:
+            # bottleneck widths outside {32, 64, 128} (any C with max(32, C//2) not in that set) or operand views that are
+            # not 16-byte aligned: the reference's op-by-op chain (pointasnl_util.py:196-212) on the vendor BLAS
+            kv = transformed_feature.squeeze(2)
+            attention_map = torch.matmul(transformed_new_point, kv[..., :bottleneck_channel].transpose(1, 2))
+            attention_map = torch.softmax(attention_map / (float(bottleneck_channel) ** 0.5), dim=-1)
+            new_nonlocal_point = torch.matmul(attention_map, kv[..., bottleneck_channel:])
         new_nonlocal_point = tf_util.conv2d(
             new_nonlocal_point.reshape(batch_size, npoint, nsample, bottleneck_channel), mlp[-1], [1, 1],
             padding='VALID', stride=[1, 1], bn=bn, is_training=is_training, scope='conv_back_project',
@@ -392,18 +399,25 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
             new_xyz, new_feature = AdaptiveSampling(g_xyz, g_pts, as_neighbor, is_training, bn_decay, weight_decay,
                                                     scope, bn)
         fused = _local_cell_supported(6 + num_channel, mlp, nsample)
+        new_point = None
         if fused and SA_CELL_GATHER:
             # grouping + skip max + local cell: one MFMA kernel reading the tables in place
             tf_util._require_inference(is_training)
-            new_point, skip_spatial = sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay, bn)
-        else:
+            try:
+                new_point, skip_spatial = sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay, bn)
+            except _hip.PasnlUnsupported:  # e.g. a row too wide for the LDS-resident weights: two-kernel / op-by-op path
+                new_point = None
+        if new_point is None:
             # gather + translation normalisation + both concats + the skip connection's reduce_max: one kernel
             new_point, skip_spatial = sa_group(xyz, feature, idx, new_xyz)
             grouped_xyz = new_point[..., 0:3]
             if fused:
                 tf_util._require_inference(is_training)
-                new_point = sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn)
-            else:
+                try:
+                    new_point = sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn)
+                except _hip.PasnlUnsupported:
+                    fused = False
+            if not fused:
                 for i, num_out_channel in enumerate(mlp):
                     if i != len(mlp) - 1:
                         new_point = tf_util.conv2d(new_point, num_out_channel, [1, 1], padding='VALID', stride=[1, 1],

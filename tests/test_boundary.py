@@ -124,3 +124,18 @@ def test_variable_store_is_seeded_and_folds_bn():
     x = np.random.default_rng(0).random((4, 7), dtype=np.float32)
     want = ((x @ p["w"] + p["b"]) - p["mean"]) / np.sqrt(p["var"] + 1e-3) * p["gamma"] + p["beta"]
     np.testing.assert_allclose(x @ wa.numpy() + ba.numpy(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_product_library_reads_no_environment_variable():
+    """include/pasnl.h promises "no global state": the A/B and probe switches of the kernels (PASNL_NL_SPLIT, PASNL_BALL_PROBE
+    ...) exist only in the tuning build (-DPASNL_TUNING -> libpasnl_hip_tuning.so, which the package never loads)."""
+    import re
+
+    csrc = os.path.join(ROOT, "pointasnl_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith((".hip", ".hpp")):
+            continue
+        text = open(os.path.join(csrc, name)).read()
+        text = re.sub(r"#ifdef PASNL_TUNING.*?#else", "", text, flags=re.S)
+        assert "getenv(" not in text, name
+    assert "libpasnl_hip_tuning" not in open(os.path.join(ROOT, "pointasnl_amd", "_hip.py")).read()

@@ -41,17 +41,16 @@ def test_nl_attention(b, p, n, cb, variant):
 
 
 @pytest.mark.parametrize("b,p,n,cb", [(2, 128, 512, 64), (2, 45, 77, 32)])
-def test_nl_attention_lds_staged_kernel_still_agrees(b, p, n, cb, monkeypatch):
+def test_nl_attention_lds_staged_kernel_still_agrees(b, p, n, cb):
     """cb <= 64 runs the kernel that takes its operands straight from global memory; the LDS-staged one (the only one
-    for cb = 128) stays selectable (PASNL_NL_LDS) and must give the same answer."""
+    for cb = 128) stays selectable (variant 3) and must give the same answer."""
     from pointasnl_amd.utils import pointasnl_util as U
 
     rng = np.random.default_rng(n)
     q = rng.standard_normal((b, p, cb)).astype(np.float32)
     kv = rng.standard_normal((b, n, 2 * cb)).astype(np.float32)
     want = cells.nl_attention_core(q.astype(np.float64), kv.astype(np.float64), cb)
-    monkeypatch.setenv("PASNL_NL_LDS", "1")
-    got = U.nl_attention(dev(q), dev(kv), variant=2).cpu().numpy()
+    got = U.nl_attention(dev(q), dev(kv), variant=3).cpu().numpy()
     np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)
 
 
@@ -410,3 +409,72 @@ def test_get_loss_sem_seg():
     # (pinned against the reference's Python in tests/test_gpu_reference_fixtures.py::test_get_loss_matches_reference_python)
     want = classify + (coll + classify) + 0.01 * uni + reg
     assert abs(got - want) < 1e-5 * max(1.0, abs(want))
+
+
+@pytest.mark.parametrize("n,c,p", [(200, 80, 50), (96, 512, 24), (64, 20, 16)])
+def test_point_nonlocal_cell_any_bottleneck_width(n, c, p):
+    """Bottleneck widths the fused kernel does not cover (max(32, C//2) = 40, 256) take the op-by-op chain
+    (pointasnl_util.py:196-212 on the vendor BLAS) instead of raising; 32 stays on the kernel."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    st = _store(n + c)
+    rng = np.random.default_rng(c)
+    feat = rng.standard_normal((2, n, c)).astype(np.float32)
+    newf = rng.standard_normal((2, p, 3 + c)).astype(np.float32)
+    mlp = [max(32, c // 2), 64]
+    got = U.PointNonLocalCell(dev(feat), dev(newf).unsqueeze(1), mlp, False, None, None, "layerX", True)
+    want = cells.point_nonlocal_cell(feat.astype(np.float64), newf.astype(np.float64), mlp, st.export_numpy(), "layerX")
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("c,as_", [(100, 12), (122, 8), (200, 12), (256, 6), (280, 4)])
+def test_adaptive_sampling_fused_wide_bottlenecks(c, as_):
+    """as_cell_wide instantiations beyond the models' own (cb = (3+c)//2 = 51, 62, 101, 129, 141: CBLK 4, 7, 9) and, for
+    c = 280 (cb = 141 <= 144 still fused; 1 + channel = 284 columns), the gate into the few-kernel chain."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    b, n, m, k = 2, 150, 40, 16
+    st = _store(c + as_)
+    rng = np.random.default_rng(c)
+    xyz = clouds(13, b, n)
+    feat = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, k)).astype(np.int32)
+    with st.scope("layerA"):
+        new_xyz, new_feat = U.adaptive_sampling_fused(dev(xyz), dev(feat), dev(idx), as_, "layerA", True)
+    bi = np.arange(b)[:, None, None]
+    gx = xyz[bi, idx].astype(np.float64)
+    gf = np.concatenate([gx, feat[bi, idx].astype(np.float64)], axis=-1)
+    want_xyz, want_feat = cells.adaptive_sampling(gx, gf, as_, st.export_numpy(), "layerA", outer="layerA")
+    np.testing.assert_allclose(new_xyz.cpu().numpy(), want_xyz, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(new_feat.cpu().numpy(), want_feat, rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("c,mlp", [(153, [128, 128, 256]), (154, [128, 128, 256]), (300, [64, 64, 128])])
+def test_set_abstraction_rows_too_wide_for_the_fused_cell_fall_back(c, mlp):
+    """Rows whose conv0 weights do not fit the LDS next to W1 (C = 153, 154 with c1 = 128: the Python gate of round 1 said
+    'fused', the launcher said PASNL_EUNSUPPORTED and the layer raised) now take the next path down and stay correct."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    b, n, npoint, ns = 1, 96, 24, 32
+    st = _store(c)
+    rng = np.random.default_rng(c)
+    xyz = clouds(14, b, n)
+    feat = rng.standard_normal((b, n, c)).astype(np.float32)
+    with torch.no_grad():
+        nx, npts = U.PointASNLSetAbstraction(dev(xyz), dev(feat), npoint, ns, mlp, False, None, None, "layerW", as_neighbor=0, NL=False)
+    wx, wpts = cells.set_abstraction(xyz.astype(np.float64), feat.astype(np.float64), npoint, ns, mlp, st.export_numpy(), "layerW",
+                                     as_neighbor=0, NL=False)
+    np.testing.assert_array_equal(nx.cpu().numpy(), wx.astype(np.float32))
+    scale = np.abs(wpts).max()
+    assert np.abs(npts.cpu().numpy() - wpts).max() / scale < 1e-4
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+def test_launch_refuses_tensors_of_another_device():
+    from pointasnl_amd import _hip, tf_sampling
+
+    x = torch.rand(1, 64, 3, device="cuda:1")
+    with torch.cuda.device(0), pytest.raises(_hip.PasnlError):
+        tf_sampling.farthest_point_sample(8, x)
+    with torch.cuda.device(1):
+        assert tf_sampling.farthest_point_sample(8, x).device.index == 1

@@ -1,9 +1,12 @@
-"""Diagnostics: phase clocks of workgroup 0 of the grid ball query (PASNL_BALL_PROBE)."""
+"""Diagnostics: phase clocks of workgroup 0 of the grid ball query (PASNL_BALL_PROBE; tuning build only:
+make -C pointasnl_amd/csrc tuning -> libpasnl_hip_tuning.so, loaded here instead of the product library)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench as B
 import pointasnl_amd as P
+from pointasnl_amd import _hip
+_hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libpasnl_hip_tuning.so")
 for b in (64, 4096):
     x = torch.from_numpy(B.synth_clouds(1, b, 1024)).cuda()
     q = x[:, :512].contiguous()
