@@ -111,7 +111,7 @@ def algorithmic(symbol, ints):
     """-> (bytes, flops, bound) for one launch"""
     if symbol == "pasnl_farthest_point_sample":
         b, n, m = ints
-        return 12 * b * n + 4 * b * m, 10 * b * n * m, "hbm"
+        return 12 * b * n + 4 * b * m, 10 * b * n * m, "latency"  # m dependent rounds per cloud: HBM fraction ~0 by construction
     if symbol == "pasnl_gather_point":
         b, n, m = ints
         return 28 * b * m, 0, "hbm"
@@ -184,27 +184,84 @@ def kernel_table(records):
     return rows
 
 
-def cpu_baseline(pc_all, params, adaptive, seconds_budget=25.0):
-    """The same forward on the host: C oracle ops (OpenMP over the batch) + numpy/BLAS dense layers, fp32."""
-    from oracle import cells, ops
+def cpu_baseline(pc_all, params, adaptive, seconds_budget=20.0):
+    """The same forward on the host cores, the way BASELINE.md 3 lays it out: the reference's OWN kNN (knn_.cxx + nanoflann,
+    OpenMP over the batch like knn_batch(omp=True); oracle/_ref/libref_knn.so) where that build travelled with the tree, C
+    ports of the ops the reference only has as CUDA kernels (FPS, gathers; OpenMP over the batch), and torch-CPU fp32 GEMMs
+    on all host threads for the dense layers and the attention (oracle/cells_torch.py).  A baseline, not a target."""
+    import torch
+
+    from oracle import cells_torch, ops, ref
 
     cores = os.cpu_count() or 1
     ops.set_threads(cores)
     bsz = 16  # BASELINE.json configs[0]: the reference's CPU-runnable case
     sample = pc_all[:bsz]
+    cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)  # warm-up (thread pools, BLAS)
     t0 = time.perf_counter()
-    cells.cls_forward(sample, params, adaptive_sample=adaptive)  # warm-up (also pages in BLAS)
+    cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)
     one = time.perf_counter() - t0
-    reps = max(1, min(5, int(seconds_budget / max(one, 1e-3)) - 1))
-    ts = []
+    reps = max(3, min(50, int(seconds_budget / max(one, 1e-3))))
+    ts, pieces = [], {}
     for _ in range(reps):
+        cells_torch.TIMES = {}
         t0 = time.perf_counter()
-        cells.cls_forward(sample, params, adaptive_sample=adaptive)
+        cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)
         ts.append(time.perf_counter() - t0)
+        for k, v in cells_torch.TIMES.items():
+            pieces.setdefault(k, []).append(v)
+    cells_torch.TIMES = None
     med = float(np.median(ts))
-    return {"value": round(bsz / med, 2), "unit": "point-clouds/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} forwards of B={bsz}x1024 (configs[0]) after 1 warm-up; C oracle ops with OpenMP over batch + "
-                      f"numpy fp32 dense layers; median {med:.3f} s/forward"}
+    # the reference's single-threaded CPU op of the decoder path, timed as a piece (tf_interpolate.cpp:60-103, 1 thread as in
+    # the TF op) next to the GPU kernel's line in `kernels`: ScanNet fa_layer3 shape, 16 x (1024 unknown, 256 known)
+    nn = None
+    if ref.available("libref_interp.so"):
+        a, b_ = synth_clouds(7, 16, 1024), synth_clouds(8, 16, 256)
+        t0 = time.perf_counter()
+        ref.three_nn(a, b_)
+        nn = {"shape": [16, 1024, 256], "seconds": round(time.perf_counter() - t0, 4), "threads": 1, "kind": "reference"}
+    return {"value": round(bsz / med, 2), "unit": "point-clouds/s", "cores": int(torch.get_num_threads()),
+            "kind": "reference" if ref.available("libref_knn.so") else "port",
+            "sample": f"{reps} forwards of B={bsz}x1024 (configs[0]) after 2 warm-ups, median {med * 1e3:.1f} ms/forward; "
+                      f"kNN = the reference's knn_.cxx + nanoflann with OpenMP over the batch"
+                      f"{'' if ref.available('libref_knn.so') else ' (C PORT: oracle/_ref absent)'}, FPS/gathers = C port (the "
+                      f"reference has no CPU kernel), dense + attention = torch CPU fp32 on {torch.get_num_threads()} threads "
+                      f"({cores} logical cores)",
+            "pieces_ms": {k: round(float(np.median(v)) * 1e3, 3) for k, v in pieces.items()},
+            "three_nn_reference_1thread": nn}
+
+
+def _sha256(path):
+    import hashlib
+
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()
+
+
+def csrc_digests():
+    d = os.path.join(ROOT, "pointasnl_amd", "csrc")
+    return {f: _sha256(os.path.join(d, f)) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".hpp"))}
+
+
+def measured_traffic(symbol, dims):
+    """HBM bytes per launch of (symbol, dims) from the committed PMC pass (profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, profiles/collect_traffic.sh + pmc_to_traffic.py) -> (bytes or None, provenance).  The file
+    records the digests of the kernel sources it was collected on; if the file that defines `symbol` (or common.hpp) has
+    changed since, the number is NOT reported (a stale traffic figure reads as a measurement when it is not one)."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tfile):
+        return None, "profiles/traffic.json absent"
+    data = json.load(open(tfile))
+    key = symbol + ":" + ",".join(map(str, dims))
+    src = data.get("_source") or {}
+    if key not in data:
+        return None, f"{key} not in profiles/traffic.json (collected at {src.get('commit', '?')})"
+    now, then = csrc_digests(), src.get("csrc_sha256", {})
+    owner = next((f for f in now if f.endswith(".hip") and f'extern "C" int {symbol}(' in
+                  open(os.path.join(ROOT, "pointasnl_amd", "csrc", f)).read()), None)
+    changed = [f for f in (owner, "common.hpp") if f and now.get(f) != then.get(f)]
+    if changed:
+        return None, f"stale: {', '.join(changed)} changed since profiles/traffic.json was collected at {src.get('commit', '?')}"
+    return data[key], f"profiles/traffic.json@{src.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; {owner} unchanged since)"
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -225,57 +282,163 @@ def beat(phase, extra=0.0):
         os.write(int(fd), f"{phase} {(ALLOWANCE[phase] + extra) * scale:.3f}\n".encode())
 
 
-def watch(cmd, env, first_allowance=ALLOWANCE["start"]):
-    """Run `cmd` with a heartbeat pipe; returns (returncode, None) or (None, stalled_phase) after killing a stalled child."""
-    r, w = os.pipe()
-    env = dict(env)
-    env[HEARTBEAT_ENV] = str(w)
-    proc = subprocess.Popen(cmd, env=env, pass_fds=(w,))
-    os.close(w)
+def watch_many(jobs, first_allowance=ALLOWANCE["start"]):
+    """Run every (cmd, env) of `jobs` with its own heartbeat pipe.  Returns (returncode, None) when all workers have exited
+    (the first non-zero code wins, and the other workers are killed as soon as one fails), or (None, stalled_phase) after
+    killing every worker because one of them made no progress within the allowance of the phase it last announced."""
+    procs, pipes = [], {}
+    for cmd, env in jobs:
+        r, w = os.pipe()
+        env = dict(env)
+        env[HEARTBEAT_ENV] = str(w)
+        proc = subprocess.Popen(cmd, env=env, pass_fds=(w,))
+        os.close(w)
+        procs.append(proc)
+        pipes[r] = {"proc": proc, "phase": "start", "deadline": time.monotonic() + first_allowance, "buf": b""}
 
-    def forward_signal(signum, _frame):  # the driver stops the supervisor: take the worker along
-        proc.kill()
-        proc.wait()
+    def kill_all():
+        for p in procs:  # exactly the processes started above
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+
+    def forward_signal(signum, _frame):  # the driver stops the supervisor: take the workers along
+        kill_all()
         sys.exit(128 + signum)
 
     old = {sig: signal.signal(sig, forward_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
-    phase, allowance, buf = "start", first_allowance, b""
+    rc = 0
     try:
-        while True:
-            ready, _, _ = select.select([r], [], [], allowance)
-            if not ready:
-                proc.kill()  # exactly the process started above
-                proc.wait()
-                return None, phase
-            data = os.read(r, 4096)
-            if not data:  # every write end closed: the worker has exited
-                return proc.wait(), None
-            buf += data
-            lines = buf.split(b"\n")
-            buf = lines.pop()
-            if lines:
-                name, secs = lines[-1].decode().split()
-                phase, allowance = name, float(secs)
+        while pipes:
+            now = time.monotonic()
+            late = [st for st in pipes.values() if st["deadline"] <= now]
+            if late:
+                kill_all()
+                return None, late[0]["phase"]
+            ready, _, _ = select.select(list(pipes), [], [], max(0.0, min(st["deadline"] for st in pipes.values()) - now))
+            for r in ready:
+                st = pipes[r]
+                data = os.read(r, 4096)
+                if not data:  # every write end closed: this worker has exited
+                    code = st["proc"].wait()
+                    os.close(r)
+                    del pipes[r]
+                    if code != 0 and rc == 0:
+                        rc = code
+                        kill_all()  # a rank that failed leaves the others waiting in a collective
+                    continue
+                st["buf"] += data
+                lines = st["buf"].split(b"\n")
+                st["buf"] = lines.pop()
+                if lines:
+                    name, secs = lines[-1].decode().split()
+                    st["phase"], st["deadline"] = name, time.monotonic() + float(secs)
+        return rc, None
     finally:
-        os.close(r)
+        for r in pipes:
+            os.close(r)
         for sig, h in old.items():
             signal.signal(sig, h)
 
 
+def watch(cmd, env, first_allowance=ALLOWANCE["start"]):
+    """One worker: (returncode, None), or (None, stalled_phase) after killing it."""
+    return watch_many([(cmd, env)], first_allowance)
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _flag(argv, name, default):
+    for i, a in enumerate(argv):
+        if a == name and i + 1 < len(argv):
+            return argv[i + 1]
+        if a.startswith(name + "="):
+            return a.split("=", 1)[1]
+    return default
+
+
 def supervise(argv):
-    """Supervisor side of every rank: worker with the given flags; on a stall one more worker with --pipeline serial."""
+    """Launcher + supervisor.  `python bench.py --gpus N` starts N ranks ITSELF (one process per GPU: RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT); under torch.distributed.run (WORLD_SIZE already set) it is one
+    rank of that job.  Every worker is watched through its heartbeat pipe; if one stalls, all are killed and the job is
+    re-run once with --pipeline serial."""
     base = [sys.executable, os.path.abspath(__file__), "--worker"]
     scale = float(os.environ.get("PASNL_BENCH_STALL_SCALE", "1"))
-    rc, stalled = watch(base + argv, os.environ, ALLOWANCE["start"] * scale)
+    n = int(_flag(argv, "--gpus", "1"))
+
+    def jobs(extra):
+        if "WORLD_SIZE" in os.environ or n == 1:
+            return [(base + argv + extra, os.environ)]
+        port = _free_port()
+        return [(base + argv + extra, dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))) for r in range(n)]
+
+    rc, stalled = watch_many(jobs([]), ALLOWANCE["start"] * scale)
     if stalled is None:
         return rc
-    print(f"bench.py: worker made no progress in phase '{stalled}' and was killed; retrying with --pipeline serial",
+    print(f"bench.py: a worker made no progress in phase '{stalled}'; all workers were killed, retrying with --pipeline serial",
           file=sys.stderr, flush=True)
-    rc, stalled2 = watch(base + argv + ["--pipeline", "serial", "--retry-of", stalled], os.environ, ALLOWANCE["start"] * scale)
+    rc, stalled2 = watch_many(jobs(["--pipeline", "serial", "--retry-of", stalled]), ALLOWANCE["start"] * scale)
     if stalled2 is None:
         return rc
     print(f"bench.py: the serial retry stalled in phase '{stalled2}' as well; giving up", file=sys.stderr, flush=True)
     return 3
+
+
+def protocol_only(args, rank, world):
+    """--model none: everything of a bench run except the model -- rendezvous, barriers, a per-step all-gather of (B,40)
+    stand-in logits, max-over-ranks timing, an all-reduce sanity value and the JSON line.  Runs on CPU with gloo."""
+    import torch
+    import torch.distributed as dist
+
+    from pointasnl_amd import sharding
+
+    dev = "cpu"
+    if args.backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dev = torch.device("cuda", torch.cuda.current_device())
+    multi = world > 1 or args.force_dist
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
+    B = args.batch
+    logits = torch.full((B, 40), float(rank + 1), device=dev)
+    gather = sharding.LogitsGather(world, B, 40, dev, force=multi)
+    beat("run", 0.25 * (args.warmup + args.steps))
+    for _ in range(args.warmup):
+        gather.all_gather(logits)
+    if multi:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = gather.all_gather(logits)
+    if multi:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    beat("post")
+    check, ranks = float(rank + 1), 1
+    if multi:
+        t = torch.tensor([elapsed, float(rank + 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        elapsed, check, ranks = float(t[0]), float(t[1]), dist.get_world_size()
+        assert torch.equal(out[:, 0].cpu(), torch.arange(1, world + 1, dtype=torch.float32).repeat_interleave(B))
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "protocol only (no model)", "value": round(world * B * args.steps / elapsed, 2),
+                          "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "none", "backend": args.backend, "rccl_ranks": ranks,
+                                     "allreduce_check": check, "global_batch": world * B}}), flush=True)
 
 
 def main():
@@ -292,20 +455,22 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="clouds per GPU (weak scaling)")
     ap.add_argument("--AS", action="store_true", help="configs[2]: adaptive sampling on, noisy clouds")
     ap.add_argument("--noise", type=int, default=10)
-    ap.add_argument("--model", default="cls", choices=["cls", "sem_seg", "sem_seg_res"],
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend: nccl = RCCL over xGMI (the product path); gloo only with --model none")
+    ap.add_argument("--model", default="cls", choices=["cls", "sem_seg", "sem_seg_res", "none"],
                     help="cls = the BASELINE metric (default).  sem_seg / sem_seg_res = configs[3] / configs[4] "
-                         "(ScanNet 8192 pts / SemanticKITTI 10240 pts); own measurements, not the driver's metric")
+                         "(ScanNet 8192 pts / SemanticKITTI 10240 pts); own measurements, not the driver's metric.  none = "
+                         "no model at all: only the launcher, the rendezvous, the per-step all-gather and the timing protocol "
+                         "(CPU tests drive it with --backend gloo)")
     ap.add_argument("--points", type=int, default=0, help="points per cloud (default: 1024 cls, 8192 sem_seg, 10240 sem_seg_res)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "lanes", "search", "serial", "1", "2"],
-                    help="how consecutive forwards overlap.  lanes = two graph instances of the whole forward replayed "
-                         "round-robin on two streams (the latency-bound kernels of one forward -- FPS: 512 dependent rounds on 64 "
-                         "CUs -- run under the MFMA/GEMM work of the other).  search = two-stage pipeline: only the search prefix "
-                         "of the first set-abstraction layer (FPS + gathers + kNN, no dense layer) of batch i+1 runs ahead on a "
-                         "second stream; the rest-graphs, which hold every vendor GEMM, stay serialised on one stream.  serial = "
-                         "one graph, one stream.  auto = lanes (stress-tested: 24k concurrent replays of the cls graph), except search for "
-                         "sem_seg, whose (4096 x 16480 x 256) hipBLASLt GEMM dead-locks the GPU when two instances of it run "
-                         "concurrently (tools/lanes_probe.py gemm_4096_16480_256; DESIGN.md 6).  1 / 2 = serial / auto")
+                    help="serial (= auto, the default) = ONE graph of the forward replayed on one stream; what can overlap overlaps "
+                         "inside the forward (fork/join in the models: the next layer's FPS + kNN and the non-local branch run on "
+                         "side streams of the same graph).  lanes = two graph instances of the whole forward round-robin on two "
+                         "streams (forward i+1's latency-bound FPS under forward i's MFMA work); search = only the search prefix of "
+                         "batch i+1 ahead on a second stream.  lanes / search are kept as measurements: two concurrent instances of "
+                         "a hipBLASLt Stream-K GEMM can dead-lock (DESIGN.md 6), which is why neither is the default.  1 = serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (RCCL init, per-step all-gather, barriers, max-over-ranks) even with "
@@ -335,10 +500,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        args.gpus = world
+    if world != args.gpus:  # never degrade silently: a line that says n_gpus=1 for a --gpus 8 request is a wrong measurement
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run", file=sys.stderr)
+        sys.exit(4)
+    if args.model == "none":
+        return protocol_only(args, rank, world)
+    if args.backend != "nccl":
+        print("bench.py: the product path runs on RCCL (--backend nccl); gloo is for --model none", file=sys.stderr)
+        sys.exit(4)
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: rank {rank} needs device {local_rank} but only {torch.cuda.device_count()} HIP device(s) are visible "
+              f"(--gpus {args.gpus}): refusing to run", file=sys.stderr)
+        sys.exit(4)
 
     from pointasnl_amd import _hip
     from pointasnl_amd.models import pointasnl_cls
@@ -358,6 +531,10 @@ def main():
             store = dist.PrefixStore("pasnl_retry/", base_store)
         dist.init_process_group("nccl", store=store, rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
+        t = torch.tensor([float(rank + 1)], device="cuda")
+        dist.all_reduce(t)  # sanity: every rank took part in one RCCL all-reduce
+        allreduce_check = float(t.item())
+        assert allreduce_check == world * (world + 1) / 2, allreduce_check
 
     import importlib
 
@@ -403,9 +580,9 @@ def main():
         torch.cuda.synchronize()
         graph = None
         lanes = []  # one entry per buffer set: dict(P=search graph or None, R=graph, out=logits, stream, ...)
-        mode = {"1": "serial", "2": "auto"}.get(args.pipeline, args.pipeline)
+        mode = {"1": "serial", "2": "lanes"}.get(args.pipeline, args.pipeline)
         if mode == "auto":
-            mode = "search" if args.model == "sem_seg" else "lanes"
+            mode = "serial"  # one graph per forward; the overlap lives INSIDE the forward (fork/join in the models)
         if args.no_graph:
             mode = "eager"
         sp, sr = torch.cuda.Stream(), torch.cuda.Stream()  # search-prefix stream, rest-of-forward stream
@@ -511,17 +688,17 @@ def main():
     # dominant hand-written kernel = largest total time per step
     roofline = None
     if rows:
-        dom = max(rows, key=lambda r: r["avg_us"])
+        dom = max((r for r in rows if r["bound"] in ("mfma", "hbm")), key=lambda r: r["avg_us"] * r["launches"])
         if dom["bound"] == "mfma":
             ach, peak, unit = dom["TFLOP/s"], F32_MFMA_PEAK_TF, "TFLOP/s"
         else:
             ach, peak, unit = dom["GB/s"], HBM_PEAK_GBS, "GB/s"
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(dom["kernel"] + ":" + ",".join(map(str, dom["dims"])))
+        traffic, traffic_source = measured_traffic(dom["kernel"], dom["dims"])
+        if traffic is None:
+            print(f"bench.py: roofline.traffic not reported: {traffic_source}", file=sys.stderr)
         roofline = {"kernel": dom["kernel"], "dims": dom["dims"], "bound": dom["bound"], "achieved": ach, "peak": peak,
-                    "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic, "avg_us": dom["avg_us"],
+                    "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic, "traffic_source": traffic_source,
+                    "avg_us": dom["avg_us"],
                     "alg_bytes": dom["alg_bytes"], "alg_flops": dom["alg_flops"]}
 
     cpu = None
@@ -547,6 +724,7 @@ def main():
                                  "configs[1]: ModelNet40 pointasnl_cls, 1024 pts") if args.model == "cls" else
                                 f"configs[{cfg_index}]: pointasnl_{args.model}, {N} pts") + f", batch={B}/GPU, seeded random weights",
                    "global_batch": world * B, "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
+                   "rccl_ranks": dist.get_world_size() if multi else 1,
                    "hip_graph": graph is not None, "pipeline": mode, "outputs_agree": lanes_agree,
                    "retry_of_stalled_phase": args.retry_of},
         "roofline": roofline,

@@ -69,7 +69,16 @@ def main(root, out):
         traffic[key] = int((2 * f + w) * 1024)
         detail[key] = {"kernel": kern[key], "launches_per_forward": len(v), "fetch_KiB_raw": round(f, 1),
                        "write_KiB": round(w, 1), "hbm_bytes_corrected": traffic[key]}
+    # provenance: the commit and the digests of the kernel sources the counters were collected on; bench.py refuses to
+    # report a figure whose kernel source has changed since (bench.measured_traffic)
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, here)
+    import bench
+    commit = subprocess.run(["git", "-C", here, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
+    traffic["_source"] = {"commit": commit, "csrc_sha256": bench.csrc_digests()}
     json.dump(traffic, open(out, "w"), indent=1, sort_keys=True)
+    del traffic["_source"]
     json.dump(detail, open(out.replace(".json", "_detail.json"), "w"), indent=1, sort_keys=True)
     for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]):
         print(f"{k:60s} {v/1e6:10.2f} MB   {kern[k][:60]}")

@@ -60,6 +60,46 @@ def test_bench_fails_loudly_without_a_gpu():
     assert p.returncode != 0 and not p.stdout.strip(), "no GPU: no JSON line, non-zero exit"
 
 
+def _bench(*flags, env=None, timeout=300):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=timeout,
+                          env=dict(os.environ, **(env or {})))
+
+
+def test_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` (no torchrun): the launcher forks two ranks with RANK / WORLD_SIZE / MASTER_* set, they
+    rendezvous (gloo here, RCCL on the GPU box), all-gather every step, and rank 0 prints ONE line that says n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--model", "none",
+                        "--steps", "3", "--warmup", "1", "--batch", "8"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2 and line["config"]["allreduce_check"] == 3.0
+    assert line["config"]["global_batch"] == 16 and line["steps"] == 3 and line["warmup"] == 1
+
+
+def test_same_worker_under_torch_distributed_run():
+    """The driver's launch form: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ..."""
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--backend", "gloo", "--model", "none", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_refuses_instead_of_degrading():
+    import torch
+
+    p = _bench("--gpus", "2", "--steps", "1", "--warmup", "0", env={"WORLD_SIZE": "1", "RANK": "0"})
+    assert p.returncode != 0 and "refusing" in p.stderr and not p.stdout.strip()  # --gpus 2 inside a 1-rank job
+    if torch.cuda.device_count() < 2:
+        p = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+        assert p.returncode != 0 and "refusing" in p.stderr and not p.stdout.strip()  # more ranks than visible devices
+
+
 @pytest.mark.gpu
 def test_stalled_pipelined_run_falls_back_to_serial():
     """The first worker hangs in the watched region (test hook); the supervisor kills it and the serial retry delivers
