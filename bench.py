@@ -194,13 +194,23 @@ def cpu_baseline(pc_all, params, adaptive, seconds_budget=20.0):
     from oracle import cells_torch, ops, ref
 
     cores = os.cpu_count() or 1
-    ops.set_threads(cores)
     bsz = 16  # BASELINE.json configs[0]: the reference's CPU-runnable case
+    ops.set_threads(min(cores, bsz))  # OpenMP over the batch: more threads than clouds only spin
     sample = pc_all[:bsz]
     cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)  # warm-up (thread pools, BLAS)
-    t0 = time.perf_counter()
-    cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)
-    one = time.perf_counter() - t0
+    # give the CPU its best configuration: the intra-op thread count that runs this forward fastest (all logical cores
+    # is NOT it on a 2-socket host with (B*P*K, C<=134) GEMMs)
+    best = (None, 1e30)
+    for t in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)}):
+        torch.set_num_threads(t)
+        cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)
+        t0 = time.perf_counter()
+        cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)
+        dt = time.perf_counter() - t0
+        if dt < best[1]:
+            best = (t, dt)
+    torch.set_num_threads(best[0])
+    one = best[1]
     reps = max(3, min(50, int(seconds_budget / max(one, 1e-3))))
     ts, pieces = [], {}
     for _ in range(reps):

@@ -186,6 +186,183 @@ __global__ __launch_bounds__(WAVES * 64) void fps_kernel(int n, int m, const flo
   for (int j = tid; j < m; j += T) out[j] = picks[j];
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Small clouds (n <= 4096, WAVES <= 4): the same algorithm with a shorter dependent chain per round.
+// What a round of fps_kernel spends after the in-lane tournament is synchronisation, not arithmetic:
+// wave max -> ballot -> readlane -> LDS slot -> barrier -> LDS read -> row DPP max -> ballot -> readlane ->
+// LDS read of the pick's coordinates.  Here the tournament carries the candidate's COORDINATES along with (d, k)
+// (a few more v_cndmask per level, off the critical path), the lane that holds the wave maximum writes
+// {d, tie key, x, y, z} to its wave's slot itself (exec-masked store: no ballot/readlane on the common path), and
+// after the ONE barrier every lane reads the WAVES slots (broadcast reads, one wait) and reduces them in registers
+// with 64-bit compares on (d bits << 32 | ~tie key): largest distance, then smallest tie key = the reference rule.
+// The winner's coordinates arrive with it: no second LDS round trip.
+// ---------------------------------------------------------------------------------------------
+template <int T, int PPL, int LO, int N>
+__device__ __forceinline__ void fps_tournament_xyz(const int (&td)[PPL], const f32x2 (&px)[PPL / 2], const f32x2 (&py)[PPL / 2],
+                                                   const f32x2 (&pz)[PPL / 2], int tid, int& d, int& k, float& x, float& y,
+                                                   float& z) {
+  if constexpr (N == 1) {
+    constexpr FpsOrder<T, PPL> ORDER{};
+    constexpr int I = ORDER.idx[LO];
+    d = td[I];
+    k = I * T + tid;
+    x = px[I / 2][I % 2];
+    y = py[I / 2][I % 2];
+    z = pz[I / 2][I % 2];
+  } else {
+    int dl, kl, dr, kr;
+    float xl, yl, zl, xr, yr, zr;
+    fps_tournament_xyz<T, PPL, LO, N / 2>(td, px, py, pz, tid, dl, kl, xl, yl, zl);
+    fps_tournament_xyz<T, PPL, LO + N / 2, N - N / 2>(td, px, py, pz, tid, dr, kr, xr, yr, zr);
+    const bool right = dr > dl;
+    d = right ? dr : dl;
+    k = right ? kr : kl;
+    x = right ? xr : xl;
+    y = right ? yr : yl;
+    z = right ? zr : zl;
+  }
+}
+
+struct __attribute__((aligned(16))) FpsSlot {
+  uint32_t nkey;  // ~tie key  (low half of the 64-bit order key)
+  int d;          // distance bits (high half)
+  float x, y;
+  float z;
+  int pad[3];
+};
+
+// best of slots [LO, LO+N): 64-bit order key (d bits << 32 | ~tie key) and the candidate's coordinates
+template <int LO, int N>
+__device__ __forceinline__ void fps_reduce_slots(const FpsSlot* slot, unsigned long long& key, float& x, float& y, float& z) {
+  if constexpr (N == 1) {
+    const float4 a = *reinterpret_cast<const float4*>(&slot[LO]);
+    key = ((unsigned long long)__float_as_uint(a.y) << 32) | __float_as_uint(a.x);
+    x = a.z;
+    y = a.w;
+    z = slot[LO].z;
+  } else {
+    unsigned long long kl, kr;
+    float xl, yl, zl, xr, yr, zr;
+    fps_reduce_slots<LO, N / 2>(slot, kl, xl, yl, zl);
+    fps_reduce_slots<LO + N / 2, N - N / 2>(slot, kr, xr, yr, zr);
+    const bool r = kr > kl;
+    key = r ? kr : kl;
+    x = r ? xr : xl;
+    y = r ? yr : yl;
+    z = r ? zr : zl;
+  }
+}
+
+#ifdef PASNL_TUNING
+#define FPS_MARK(i) do { if (dbg) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                                    __builtin_amdgcn_sched_barrier(0); acc[i] += t_ - tprev; tprev = t_; } } while (0)
+#define FPS_DBG_PARAM , long long* dbg
+#define FPS_DBG_ARG , dbg
+#else
+#define FPS_MARK(i)
+#define FPS_DBG_PARAM
+#define FPS_DBG_ARG
+#endif
+
+template <int WAVES, int PPL, int ABL = 0>  // ABL (tuning build, timing only): 1 = no cross-wave exchange, 2 = no wave reduction either
+__global__ __launch_bounds__(WAVES * 64) void fps_small_kernel(int n, int m, const float* __restrict__ xyz,
+                                                              int* __restrict__ idx FPS_DBG_PARAM) {
+  static_assert(PPL % 2 == 0 && WAVES <= 4, "");
+#ifdef PASNL_TUNING
+  unsigned long long acc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#endif
+  constexpr int T = WAVES * 64;
+  constexpr int NP = PPL / 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  FpsSlot* slots = reinterpret_cast<FpsSlot*>(smem);                      // [2][WAVES]
+  int* picks = reinterpret_cast<int*>(smem + 2 * WAVES * sizeof(FpsSlot));  // [m]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* cloud = xyz + (size_t)blockIdx.x * n * 3;
+
+  f32x2 px[NP], py[NP], pz[NP];
+  int td[PPL];
+#pragma unroll
+  for (int q = 0; q < NP; ++q)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int k = (2 * q + e) * T + tid;
+      const bool ok = k < n;
+      px[q][e] = ok ? cloud[k * 3] : 0.f;
+      py[q][e] = ok ? cloud[k * 3 + 1] : 0.f;
+      pz[q][e] = ok ? cloud[k * 3 + 2] : 0.f;
+      td[2 * q + e] = ok ? __float_as_int(1e38f) : __float_as_int(-(float)(tid + 1));
+    }
+  float x1 = cloud[0], y1 = cloud[1], z1 = cloud[2];
+  if (tid == 0) picks[0] = 0;
+
+  for (int j = 1; j < m; ++j) {
+    FPS_MARK(0);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      f32x2 dx = px[q] - x1, dy = py[q] - y1, dz = pz[q] - z1;
+      f32x2 d = (dx * dx + dy * dy) + dz * dz;
+      td[2 * q] = min(td[2 * q], __float_as_int(d[0]));
+      td[2 * q + 1] = min(td[2 * q + 1], __float_as_int(d[1]));
+    }
+    int bd, bk;
+    float bx, by, bz;
+    fps_tournament_xyz<T, PPL, 0, PPL>(td, px, py, pz, tid, bd, bk, bx, by, bz);
+    FPS_MARK(1);
+    if constexpr (ABL == 2) {
+      x1 = bx; y1 = by; z1 = bz;
+      if (tid == 0) picks[j] = bk;
+      continue;
+    }
+    const int wmaxi = __builtin_amdgcn_readlane(wave_max_i32_to_lane63(bd), 63);
+    FpsSlot* slot = slots + (j & 1) * WAVES;
+    const bool mine = bd == wmaxi;
+    unsigned long long tie = __ballot(mine);
+    bool writer = mine;
+    if (__builtin_popcountll(tie) > 1) writer = lane == fps_break_tie(tie, bk);  // rare, wave-uniform branch
+    if (writer) {
+      *reinterpret_cast<float4*>(&slot[wave]) =
+          make_float4(__uint_as_float(~fps_tiekey(bk)), __int_as_float(bd), bx, by);
+      slot[wave].z = bz;
+    }
+    FPS_MARK(2);
+    if constexpr (ABL == 1) {
+      x1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bx)));
+      y1 = by; z1 = bz;
+      if (tid == 0) picks[j] = bk;
+      continue;
+    }
+    if constexpr (WAVES > 1) __syncthreads();
+    else __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wave's own store
+    FPS_MARK(3);
+    // every lane reduces the WAVES candidates in registers (compile-time recursion: see fps_tournament)
+    unsigned long long wkey;
+    fps_reduce_slots<0, WAVES>(slot, wkey, x1, y1, z1);
+    if (tid == 0) picks[j] = (int)(~(uint32_t)wkey & 0x3fffffu);
+    FPS_MARK(4);
+  }
+#ifdef PASNL_TUNING
+  if (dbg && blockIdx.x == 0 && tid == 0)
+    for (int i = 0; i < 5; ++i) dbg[i] = (long long)acc[i];
+#endif
+  __syncthreads();
+  int* out = idx + (size_t)blockIdx.x * m;
+  for (int j = tid; j < m; j += T) out[j] = picks[j];
+}
+
+template <int WAVES, int PPL, int ABL = 0>
+static int fps_small_launch(int b, int n, int m, const float* xyz, int* idx, hipStream_t st) {
+  size_t lds = (size_t)2 * WAVES * sizeof(FpsSlot) + (size_t)m * 4;
+  if (lds > 64 * 1024) return PASNL_EUNSUPPORTED;
+#ifdef PASNL_TUNING
+  long long* dbg = nullptr;  // PASNL_FPS_PROBE=<device pointer to 8 int64, hex>: phase cycles of workgroup 0, wave 0
+  if (const char* pe = tune_env("PASNL_FPS_PROBE")) dbg = reinterpret_cast<long long*>(strtoull(pe, nullptr, 16));
+#endif
+  hipLaunchKernelGGL((fps_small_kernel<WAVES, PPL, ABL>), dim3(b), dim3(WAVES * 64), lds, st, n, m, xyz, idx FPS_DBG_ARG);
+  return pasnl_launch_status();
+}
+
 template <int WAVES, int PPL>
 static int fps_launch(int b, int n, int m, const float* xyz, int* idx, hipStream_t st) {
   size_t lds = (size_t)2 * 16 * 8 + (size_t)n * 16 + (size_t)m * 4;
@@ -337,6 +514,19 @@ extern "C" int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz
 #undef PASNL_FPS_TRY
     }
   }
+#ifdef PASNL_TUNING
+  if (cfg && cfg[0] == 'a') return fps_small_launch<4, 4, 1>(b, n, m, xyz, idx, st);
+  if (cfg && cfg[0] == 'b') return fps_small_launch<4, 4, 2>(b, n, m, xyz, idx, st);
+  if (cfg && cfg[0] == 's') {  // "s<waves>,<ppl>": the small-cloud kernel with an explicit shape
+    int w = 0, p = 0;
+    if (sscanf(cfg + 1, "%d,%d", &w, &p) == 2 && (long)w * 64 * p >= n && m <= 8192) {
+#define PASNL_FPS_TRY(W, P) if (w == W && p == P) return fps_small_launch<W, P>(b, n, m, xyz, idx, st);
+      PASNL_FPS_TRY(1, 2) PASNL_FPS_TRY(1, 4) PASNL_FPS_TRY(1, 8) PASNL_FPS_TRY(1, 16) PASNL_FPS_TRY(2, 2) PASNL_FPS_TRY(2, 4)
+      PASNL_FPS_TRY(2, 8) PASNL_FPS_TRY(2, 16) PASNL_FPS_TRY(4, 2) PASNL_FPS_TRY(4, 4) PASNL_FPS_TRY(4, 8) PASNL_FPS_TRY(4, 16)
+#undef PASNL_FPS_TRY
+    }
+  }
+#endif
   if (n <= 128) return fps_launch<1, 2>(b, n, m, xyz, idx, st);
   if (n <= 256) return fps_launch<1, 4>(b, n, m, xyz, idx, st);
   if (n <= 512) return fps_launch<1, 8>(b, n, m, xyz, idx, st);

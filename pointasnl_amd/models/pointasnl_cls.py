@@ -6,7 +6,7 @@ import torch
 
 from pointasnl_amd.utils import tf_util
 from pointasnl_amd.utils.pointnet_util import pointnet_sa_module
-from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction, get_repulsion_loss
+from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction, get_repulsion_loss, sa_search, Forked
 
 
 def first_layer(num_point=None):
@@ -28,14 +28,18 @@ def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, w
     end_points['l0_xyz'] = l0_xyz
     as_neighbor = [12, 12] if adaptive_sample else [0, 0]
 
-    # Set abstraction layers
+    # Set abstraction layers.  Layer 2's search (FPS + kNN) reads layer 1's sampled coordinates only, so it is forked onto
+    # a side stream the moment those are final and runs beside layer 1's MFMA / GEMM work (pointasnl_util.Forked)
+    search2 = []
     l1_xyz, l1_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=512, nsample=32, mlp=[64, 64, 128],
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
-                                                scope='layer1', as_neighbor=as_neighbor[0], search=search)
+                                                scope='layer1', as_neighbor=as_neighbor[0], search=search,
+                                                after_sampling=lambda xyz1: search2.append(
+                                                    Forked(lambda: sa_search(xyz1, None, 128, 64))))
     end_points['l1_xyz'] = l1_xyz
     l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=128, nsample=64, mlp=[128, 128, 256],
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
-                                                scope='layer2', as_neighbor=as_neighbor[1])
+                                                scope='layer2', as_neighbor=as_neighbor[1], search=search2[0])
     end_points['l2_xyz'] = l1_xyz  # sic: the reference stores l1_xyz here (pointasnl_cls.py:38)
     _, l3_points_res, _ = pointnet_sa_module(l1_xyz, l1_points, npoint=None, radius=None, nsample=None,
                                              mlp=[128, 256, 512], mlp2=None, group_all=True, is_training=is_training,

@@ -3,7 +3,9 @@
 (three_nn / three_interpolate + self-kNN local cell).  Same get_model signature; torch device tensors."""
 import torch
 from pointasnl_amd.utils import tf_util
-from pointasnl_amd.utils.pointasnl_util import PointASNLSetAbstraction, PointASNLDecodingLayer, get_repulsion_loss
+from pointasnl_amd.utils.pointasnl_util import (PointASNLSetAbstraction, PointASNLDecodingLayer, get_repulsion_loss, Forked,
+                                                sa_search, knn_query, neighbor0_xyz)
+from pointasnl_amd.tf_interpolate import three_nn
 
 
 def first_layer(num_point):
@@ -24,25 +26,57 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
     end_points['l0_xyz'] = l0_xyz
     num_points = [num_point // 8, num_point // 32, num_point // 128, num_point // 256]
     kw = dict(is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay)
+    # ---- searches.  Every FPS / kNN / three_nn of the graph reads coordinates only, and the coordinates of level k are
+    # final right after layer k's AdaptiveSampling -- long before its features are.  So each level's searches are forked
+    # onto side streams at that moment (pointasnl_util.Forked: hand-written kernels only) and run beside the MFMA / GEMM work:
+    #   * ONE self-kNN (K = 32) per level serves the encoder layer that samples from the level (its neighbour lists are the
+    #     rows of the sampled points) AND the decoder layer of the level (K = 16: the first 16 columns);
+    #   * level 0's self-kNN runs beside layer1's FPS (num_point/8 dependent rounds on one CU per cloud);
+    #   * three_nn of decoder k starts as soon as both of its levels exist; levels 3 and 4 (as_neighbor = 0: the sampled
+    #     coordinates are neighbour 0's) are searched ahead of layer2's dense part.
+    knn, nn, srch = {}, {}, {}
+    knn[0] = Forked(lambda: knn_query(32, l0_xyz, l0_xyz), slot=1)
+    srch[1] = search if search is not None else sa_search(l0_xyz, None, num_points[0], 32, knn_all=knn[0])
+
+    def level1(xyz1):  # l1_xyz final
+        knn[1] = Forked(lambda: knn_query(32, xyz1, xyz1), slot=1)
+        nn[4] = Forked(lambda: three_nn(l0_xyz, xyz1), slot=2)
+        srch[2] = Forked(lambda: sa_search(xyz1, None, num_points[1], 32, knn_all=knn[1]), slot=0)
+
+    def level2(xyz2):  # l2_xyz final: everything below it depends on coordinates only
+        def chain():
+            k2 = knn_query(32, xyz2, xyz2)
+            s3 = sa_search(xyz2, None, num_points[2], 32, knn_all=k2)
+            xyz3 = neighbor0_xyz(xyz2, s3[2])
+            k3 = knn_query(32, xyz3, xyz3)
+            s4 = sa_search(xyz3, None, num_points[3], 32, knn_all=k3)
+            xyz4 = neighbor0_xyz(xyz3, s4[2])
+            return dict(k2=k2, s3=s3, k3=k3, s4=s4, n1=three_nn(xyz3, xyz4), n2=three_nn(xyz2, xyz3))
+        srch["deep"] = Forked(chain, slot=0)
+        nn[3] = Forked(lambda: three_nn(l1_xyz_box[0], xyz2), slot=2)
+
+    l1_xyz_box = []
     # Feature encoding layers
     l1_xyz, l1_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=num_points[0], nsample=32, mlp=[32, 32, 64],
-                                                scope='layer1', as_neighbor=8, search=search, **kw)
+                                                scope='layer1', as_neighbor=8, search=srch[1],
+                                                after_sampling=lambda x: (l1_xyz_box.append(x), level1(x)), **kw)
     l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=num_points[1], nsample=32, mlp=[64, 64, 128],
-                                                scope='layer2', as_neighbor=4, **kw)
+                                                scope='layer2', as_neighbor=4, search=srch[2], after_sampling=level2, **kw)
+    deep = srch["deep"].get()
     l3_xyz, l3_points = PointASNLSetAbstraction(l2_xyz, l2_points, npoint=num_points[2], nsample=32, mlp=[128, 128, 256],
-                                                scope='layer3', as_neighbor=0, **kw)
+                                                scope='layer3', as_neighbor=0, search=deep["s3"], **kw)
     l4_xyz, l4_points = PointASNLSetAbstraction(l3_xyz, l3_points, npoint=num_points[3], nsample=32, mlp=[256, 256, 512],
-                                                scope='layer4', as_neighbor=0, **kw)
+                                                scope='layer4', as_neighbor=0, search=deep["s4"], **kw)
     end_points['l1_xyz'] = l1_xyz
     # Feature decoding layers
     l3_points = PointASNLDecodingLayer(l3_xyz, l4_xyz, l3_points, l4_points, 16, [512, 512], is_training, bn_decay,
-                                       weight_decay, scope='fa_layer1')
+                                       weight_decay, scope='fa_layer1', nn=deep["n1"], knn_all=deep["k3"])
     l2_points = PointASNLDecodingLayer(l2_xyz, l3_xyz, l2_points, l3_points, 16, [256, 256], is_training, bn_decay,
-                                       weight_decay, scope='fa_layer2')
+                                       weight_decay, scope='fa_layer2', nn=deep["n2"], knn_all=deep["k2"])
     l1_points = PointASNLDecodingLayer(l1_xyz, l2_xyz, l1_points, l2_points, 16, [256, 128], is_training, bn_decay,
-                                       weight_decay, scope='fa_layer3')
+                                       weight_decay, scope='fa_layer3', nn=nn[3], knn_all=knn[1])
     l0_points = PointASNLDecodingLayer(l0_xyz, l1_xyz, l0_points, l1_points, 16, [128, 128, 128], is_training, bn_decay,
-                                       weight_decay, scope='fa_layer4')
+                                       weight_decay, scope='fa_layer4', nn=nn[4], knn_all=knn[0])
     # FC layers
     net = tf_util.conv1d(l0_points, 128, 1, padding='VALID', bn=True, is_training=is_training, scope='fc1',
                          bn_decay=bn_decay, weight_decay=weight_decay)

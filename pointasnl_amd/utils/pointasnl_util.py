@@ -343,24 +343,103 @@ def PointNonLocalCell(feature, new_point, mlp, is_training, bn_decay, weight_dec
         return new_nonlocal_point
 
 
-def sa_search(xyz, feature, npoint, nsample, use_knn=True, radius=None):
-    """The search prefix of a set-abstraction layer (pointasnl_util.py:236-242): farthest point sampling + gathers
-    (skipped when npoint == ndataset) and the neighbour search.  No dense layer is involved, so a serving loop can
-    run it for batch i+1 on a second stream while the rest of batch i computes (bench.py --pipeline 2).
-    -> (new_xyz (B,npoint,3), new_feature (B,npoint,C), idx (B,npoint,nsample))"""
-    if feature.shape[1] == npoint:
-        new_xyz, new_feature = xyz, feature
-    else:
-        new_xyz, new_feature = sampling(npoint, xyz, feature)
-    if use_knn:
+import os as _os
+OVERLAP = _os.environ.get("PASNL_OVERLAP", "1") != "0"  # False = every kernel of a forward on the caller's stream, in program order
+_SIDE_STREAMS = {}
+
+
+def _side_stream(slot=0):
+    key = (torch.cuda.current_device(), slot)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream()
+    return _SIDE_STREAMS[key]
+
+
+class Forked:
+    """Work enqueued on a side stream of the SAME forward (fork), joined by .get().
+
+    Only hand-written kernels are forked (searches: FPS, kNN, three_nn, gathers) -- never a vendor GEMM: two concurrent
+    hipBLASLt Stream-K GEMMs can dead-lock against each other.  The searches are latency-bound (FPS: one
+    workgroup per cloud for hundreds of dependent rounds) and depend on coordinates only, so they run beside the MFMA / GEMM
+    work of the layer before.  Works under HIP-graph capture (the side stream joins the capture through the fork event and
+    rejoins at .get()) and eagerly.  Allocator safety: every fork starts by waiting for the caller's stream, so a block a
+    side-stream tensor gave back is never rewritten before its last consumer, which was enqueued earlier, has run."""
+
+    def __init__(self, fn, slot=0):
+        self.stream = None
+        if not OVERLAP:
+            self.value = fn()
+            return
+        main = torch.cuda.current_stream()
+        side = _side_stream(slot)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.value = fn()
+        self.stream = side
+
+    def get(self):
+        # every consumer stream joins (a result may be consumed by the caller's stream AND by another fork)
+        if self.stream is not None and torch.cuda.current_stream() != self.stream:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        return self.value
+
+
+def _resolved(x):
+    return x.get() if isinstance(x, Forked) else x
+
+
+def neighbor0_xyz(xyz, idx):
+    """new_xyz of a layer WITHOUT adaptive sampling (as_neighbor == 0): the coordinates of neighbour 0 of every group
+    (pointasnl_util.py:161-163) -- a function of coordinates and neighbour lists only, so the next level's searches can be
+    started from it before the layer's features exist (PointASNLSetAbstraction computes the same values again, with the
+    features, in pasnl_take_neighbor0)."""
+    return _gather_rows(xyz, idx[:, :, 0].contiguous())
+
+
+def _gather_index_rows(table, idx):
+    """rows of an int32 table (B,N,K) at idx (B,M) -> (B,M,K): the row gather on the bit pattern"""
+    return _gather_rows(table.view(torch.float32), idx).view(torch.int32)
+
+
+def sa_search(xyz, feature, npoint, nsample, use_knn=True, radius=None, knn_all=None):
+    """The search prefix of a set-abstraction layer (pointasnl_util.py:236-242): farthest point sampling + the gather of the
+    sampled coordinates (skipped when npoint == ndataset) and the neighbour search.  It reads coordinates only -- the
+    features sampling() also gathers are dead in the reference graph: AdaptiveSampling overwrites them whenever sampling
+    happened (:246-247) -- so a caller can run it ahead of / beside the dense layers.
+    knn_all: the self-kNN of xyz, (B,N,K>=nsample) int32 (tensor or Forked), when the caller already has it (the seg models
+    share one self-kNN per level between the encoder layer and the decoder layer of that level): the neighbour lists of
+    the sampled points are then ROWS of it -- the queries are support points, distances and the (distance, index) order do
+    not depend on which other queries run.  When more than half of the points are sampled the self-kNN is started here, on
+    a side stream, so that it runs beside the latency-bound FPS instead of after it.
+    -> (new_xyz (B,npoint,3), None, idx (B,npoint,nsample))"""
+    num_points = xyz.shape[1]
+    if num_points == npoint:
+        if knn_all is not None:
+            k_all = _resolved(knn_all)
+            idx = k_all if k_all.shape[2] == nsample else k_all[:, :, :nsample].contiguous()
+        elif use_knn:
+            idx = knn_query(nsample, xyz, xyz)
+        else:
+            idx, _ = tf_grouping.query_ball_point(radius, nsample, xyz, xyz)
+        return xyz, None, idx
+    if use_knn and knn_all is None and OVERLAP and 2 * npoint >= num_points:
+        knn_all = Forked(lambda: knn_query(nsample, xyz, xyz), slot=1)
+    fps_idx = tf_sampling.farthest_point_sample(npoint, xyz)
+    new_xyz = _gather_rows(xyz, fps_idx)
+    if use_knn and knn_all is not None:
+        k_all = _resolved(knn_all)
+        idx = _gather_index_rows(k_all, fps_idx)
+        if k_all.shape[2] != nsample:
+            idx = idx[:, :, :nsample].contiguous()
+    elif use_knn:
         idx = knn_query(nsample, xyz, new_xyz)
     else:
         idx, _ = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
-    return new_xyz, new_feature, idx
+    return new_xyz, None, idx
 
 
 def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_decay, weight_decay, scope, bn=True,
-                            use_knn=True, radius=None, as_neighbor=8, NL=True, search=None):
+                            use_knn=True, radius=None, as_neighbor=8, NL=True, search=None, after_sampling=None):
     ''' Input:
             xyz: (batch_size, ndataset, 3) tensor
             feature: (batch_size, ndataset, channel) tensor
@@ -374,8 +453,9 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
     with tf_util.variable_scope(scope):
         batch_size, num_points, num_channel = feature.shape
         # Farthest point sampling + neighbour search (the reference's sampling() / grouping(): pointasnl_util.py:236-242);
-        # `search` = the result of sa_search() on the same inputs, computed ahead by the caller
-        new_xyz, new_feature, idx = search if search is not None else sa_search(xyz, feature, npoint, nsample, use_knn, radius)
+        # `search` = the result of sa_search() on the same coordinates, computed ahead / on a side stream by the caller
+        new_xyz, _, idx = _resolved(search) if search is not None else sa_search(xyz, feature, npoint, nsample, use_knn, radius)
+        new_feature = feature  # npoint == ndataset (:237-239); otherwise AdaptiveSampling defines it below (:246-247)
         nl_channel = mlp[-1]
 
         '''Adaptive Sampling'''
@@ -398,6 +478,8 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
             g_pts = torch.cat([g_xyz, tf_grouping.group_point(feature, idx_as)], dim=-1)
             new_xyz, new_feature = AdaptiveSampling(g_xyz, g_pts, as_neighbor, is_training, bn_decay, weight_decay,
                                                     scope, bn)
+        if after_sampling is not None:
+            after_sampling(new_xyz)  # the sampled (and shifted) coordinates are final: the caller may start the next search
         fused = _local_cell_supported(6 + num_channel, mlp, nsample)
         new_point = None
         if fused and SA_CELL_GATHER:
@@ -471,7 +553,8 @@ def decode_cell(xyz, feature, idx, weight_decay=None):
 
 
 def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_training, bn_decay, weight_decay, scope,
-                           bn=True, use_xyz=True, use_knn=True, radius=None, dilate_rate=1, mode='concat', NL=False):
+                           bn=True, use_xyz=True, use_knn=True, radius=None, dilate_rate=1, mode='concat', NL=False,
+                           nn=None, knn_all=None):
     ''' Input:
             xyz1: (batch_size, ndataset1, 3) tensor
             xyz2: (batch_size, ndataset2, 3) tensor, sparser than xyz1
@@ -485,7 +568,9 @@ def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_traini
     if NL:
         raise NotImplementedError("NL=True in the decoder selects mode='concat', never used by the models (SURVEY a11)")
     with tf_util.variable_scope(scope):
-        dist, idx = three_nn(xyz1, xyz2)
+        # nn = three_nn(xyz1, xyz2), knn_all = the self-kNN of xyz1 (B,N1,K>=nsample): both read coordinates only and may
+        # have been computed ahead by the caller (tuple / tensor / Forked); the encoder layer of this level shares knn_all
+        dist, idx = three_nn(xyz1, xyz2) if nn is None else _resolved(nn)
         weight = three_weights(dist)  # pointasnl_util.py:308-311 as one kernel
         interpolated_points = three_interpolate(points2, idx, weight)
 
@@ -493,7 +578,12 @@ def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_traini
         if DECODE_CELL_FUSED and use_xyz and use_knn and nsample in (16, 32):
             # self-kNN, both gathers, the centring, the weight net and F^T.G in one kernel (no grouped tensors)
             tf_util._require_inference(is_training)
-            new_points = decode_cell(xyz1, interpolated_points, knn_query(nsample, xyz1, xyz1), weight_decay)
+            if knn_all is None:
+                kidx = knn_query(nsample, xyz1, xyz1)
+            else:  # ascending (distance, index): the first nsample columns of a wider self-kNN ARE the nsample-NN
+                kidx = _resolved(knn_all)
+                kidx = kidx if kidx.shape[2] == nsample else kidx[:, :, :nsample].contiguous()
+            new_points = decode_cell(xyz1, interpolated_points, kidx, weight_decay)
         else:
             grouped_xyz, grouped_feature, idx = grouping(interpolated_points, nsample, xyz1, xyz1, use_xyz=use_xyz,
                                                          use_knn=use_knn, radius=radius)

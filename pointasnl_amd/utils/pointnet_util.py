@@ -101,16 +101,17 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         return new_xyz, new_points, idx
 
 
-def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True):
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True, nn=None):
     ''' PointNet Feature Propogation (FP) Module (pointnet_util.py:199-229)
         Input:
             xyz1: (batch_size, ndataset1, 3), xyz2: (batch_size, ndataset2, 3) sparser than xyz1
             points1: (batch_size, ndataset1, nchannel1), points2: (batch_size, ndataset2, nchannel2)
         Return:
             new_points: (batch_size, ndataset1, mlp[-1])
+        nn: three_nn(xyz1, xyz2) computed ahead by the caller (tuple or pointasnl_util.Forked): it reads coordinates only
     '''
     with tf_util.variable_scope(scope):
-        dist, idx = three_nn(xyz1, xyz2)
+        dist, idx = three_nn(xyz1, xyz2) if nn is None else (nn.get() if hasattr(nn, "get") else nn)
         weight = three_weights(dist)  # pointnet_util.py:212-215 as one kernel
         interpolated_points = three_interpolate(points2, idx, weight)
         if points1 is not None:
