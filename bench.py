@@ -118,7 +118,7 @@ def algorithmic(symbol, ints):
     if symbol == "pasnl_group_point":
         b, n, c, m, ns = ints
         return 4 * b * (n * c + m * ns + m * ns * c), 0, "hbm"
-    if symbol == "pasnl_knn_batch":
+    if symbol in ("pasnl_knn_batch", "pasnl_knn_batch_ws"):
         b, n, m, k = ints[:4]
         return 12 * b * (n + m) + 4 * b * m * k, 8 * b * n * m, "hbm"
     if symbol == "pasnl_query_ball_point":

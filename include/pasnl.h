@@ -111,6 +111,17 @@ int pasnl_select_top_k(int b, int n, int m, int k, const float* dist, int* outi,
 int pasnl_knn_batch(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
                     int idx_is_i64, float* dist2, pasnl_stream_t stream);
 
+/* The same search with a caller-provided workspace.  Clouds of PASNL_KNN_GRID_MIN_N <= n <= 16384 points and k <= 64 are
+ * searched through a uniform grid built in the workspace (csrc/knn_grid.hip: counting sort by cell, expanding rings of
+ * cells, acceptance only when no unexamined cell can hold a closer or tying point -> results bit-identical to
+ * pasnl_knn_batch for every input); everything else is forwarded to pasnl_knn_batch.  pasnl_knn_workspace_bytes returns
+ * the bytes the pair (b, n) needs (0: the grid is not used and workspace may be NULL).  The workspace is scratch: nothing
+ * is kept between calls. */
+#define PASNL_KNN_GRID_MIN_N 4096
+size_t pasnl_knn_workspace_bytes(int b, int n);
+int pasnl_knn_batch_ws(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
+                       float* dist2, void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
+
 /* ------------------------------------------------------- interpolation (tf_ops/3d_interpolation) */
 
 /* Three nearest known points, squared distances ascending, lowest index first on ties.

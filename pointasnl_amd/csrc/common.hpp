@@ -95,6 +95,52 @@ __device__ __forceinline__ void dist2_multi(const float (&qx)[QW], const float (
   }
 }
 
+// ---- wave-wide bitonic sort (used by the kNN kernels)
+template <typename T>
+__device__ __forceinline__ T shfl_xor_any(T v, int j);
+template <>
+__device__ __forceinline__ uint32_t shfl_xor_any<uint32_t>(uint32_t v, int j) { return (uint32_t)__shfl_xor((int)v, j); }
+template <>
+__device__ __forceinline__ unsigned long long shfl_xor_any<unsigned long long>(unsigned long long v, int j) {
+  uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, j), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), j);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// ascending bitonic sort of 64*NREG keys; element e lives in register e/64 of lane e%64
+template <int NREG, typename KeyT>
+__device__ __forceinline__ void wave_bitonic_sort(KeyT (&v)[NREG], int lane) {
+#pragma unroll
+  for (int k = 2; k <= 64 * NREG; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      if (j >= 64) {
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          const int pr = r ^ (j >> 6);
+          if (pr > r) {
+            const bool up = ((r * 64) & k) == 0;
+            KeyT a = v[r], b = v[pr];
+            KeyT lo = a < b ? a : b, hi = a < b ? b : a;
+            v[r] = up ? lo : hi;
+            v[pr] = up ? hi : lo;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < NREG; ++r) {
+          KeyT mine = v[r];
+          KeyT other = shfl_xor_any<KeyT>(mine, j);
+          const bool up = (((r * 64 + lane) & k) == 0);
+          const bool lower = (lane & j) == 0;
+          const bool take_min = up == lower;
+          KeyT lo = mine < other ? mine : other, hi = mine < other ? other : mine;
+          v[r] = take_min ? lo : hi;
+        }
+      }
+    }
+  }
+}
+
 // Tuning / A-B switches read from the environment exist ONLY in the diagnostic build (make tuning ->
 // libpasnl_hip_tuning.so, never loaded by the package): the product library reads no environment variable and
 // keeps no global state (include/pasnl.h), so a launch is a pure function of its arguments.

@@ -12,7 +12,11 @@ tensors out (no copies), which is what utils/pointasnl_util.py uses.
 import numpy as np
 import torch
 
+import ctypes
+
 from pointasnl_amd import _hip
+
+GRID = True  # False: brute-force kernels for every size (A/B, and the reference point of the grid kernel's parity test)
 
 
 def _knn_dev(pts, queries, K, i64):
@@ -23,6 +27,12 @@ def _knn_dev(pts, queries, K, i64):
     b, n, _ = pts.shape
     m = queries.shape[1]
     out = torch.empty((b, m, int(K)), dtype=torch.int64 if i64 else torch.int32, device=pts.device)
+    nbytes = int(_hip.lib().pasnl_knn_workspace_bytes(b, n)) if GRID and K <= 64 else 0
+    if nbytes:  # large clouds: grid-pruned search in a scratch workspace (bit-identical results, csrc/knn_grid.hip)
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=pts.device)
+        _hip.launch("pasnl_knn_batch_ws", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
+                    _hip.ptr(None), _hip.ptr(ws), ctypes.c_size_t(nbytes))
+        return out
     _hip.launch("pasnl_knn_batch", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
                                           _hip.ptr(None))
     return out

@@ -1,0 +1,96 @@
+"""GPU: the grid-pruned kNN (csrc/knn_grid.hip, clouds of >= 4096 points) returns exactly what the brute-force kernels
+return -- same indices in the same (distance, index) order, same distance bits -- and both equal the C oracle, which is
+pinned to the reference's nanoflann (tests/test_oracle_golden.py).  Inputs aim at the acceptance test of the ring search:
+density gradients, flat clouds (2-D grid), duplicates and lattices (ties beyond the sort network), queries far outside the
+support's bounding box, more neighbours than a ring holds."""
+import numpy as np
+import pytest
+import torch
+
+import bench as B
+from conftest import clouds
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def both(sup, qry, k, dist=False):
+    import pointasnl_amd as P
+    from pointasnl_amd.utils.nearest_neighbors.lib.python import nearest_neighbors as NN
+
+    s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    NN.GRID = True
+    g = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32).cpu().numpy()
+    NN.GRID = False
+    try:
+        bf = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32).cpu().numpy()
+    finally:
+        NN.GRID = True
+    return g, bf
+
+
+def _cases():
+    rng = np.random.default_rng(1)
+    out = {}
+    out["ball_8192_self"] = (B.synth_clouds(1, 3, 8192), None, 32)
+    out["ball_8192_k16"] = (B.synth_clouds(2, 2, 8192), None, 16)
+    out["scannet_8192"] = (B.synth_scannet(3, 2, 8192)[..., :3].copy(), None, 32)
+    out["kitti_10240"] = (B.synth_kitti(4, 2, 10240), None, 32)
+    flat = B.synth_clouds(5, 2, 6000)
+    flat[..., 2] = 0.0
+    out["flat_plane"] = (flat, None, 32)
+    line = np.zeros((1, 4500, 3), np.float32)
+    line[0, :, 0] = rng.random(4500)
+    out["line"] = (line, None, 20)
+    out["lattice"] = (clouds(6, 2, 5000, "lattice"), None, 32)        # ~730 distinct positions: massive ties + duplicates
+    dup = B.synth_clouds(7, 2, 4096)
+    dup[:, 1::2] = dup[:, 0::2]
+    out["duplicates"] = (dup, None, 32)
+    same = np.ones((1, 4200, 3), np.float32)
+    out["all_identical"] = (same, None, 40)
+    clus = B.synth_clouds(8, 2, 9000) * 0.01
+    clus[:, :100] = B.synth_clouds(9, 2, 100) * 50.0                   # a dense blob inside a huge, nearly empty box
+    out["density_gradient"] = (clus, None, 32)
+    sup = B.synth_clouds(10, 2, 8192)
+    out["queries_outside"] = (sup, (B.synth_clouds(11, 2, 777) * 3.0 + 2.0).astype(np.float32), 32)
+    out["k64"] = (B.synth_clouds(12, 2, 4100), None, 64)
+    out["k1"] = (B.synth_clouds(13, 2, 4096), B.synth_clouds(14, 2, 333), 1)
+    out["n16384"] = (B.synth_clouds(15, 1, 16384), B.synth_clouds(15, 1, 16384)[:, :2000].copy(), 32)
+    return out
+
+
+CASES = _cases()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_grid_knn_is_bit_identical_to_brute_force_and_oracle(name):
+    sup, qry, k = CASES[name]
+    qry = sup if qry is None else qry
+    g, bf = both(sup, qry, k)
+    np.testing.assert_array_equal(g, bf)
+    sub = slice(0, min(qry.shape[1], 600))
+    want = O.knn_batch(sup[:1], qry[:1, sub], k).astype(np.int32)
+    np.testing.assert_array_equal(g[:1, sub], want)
+
+
+def test_grid_knn_distances_and_int64():
+    from pointasnl_amd import _hip
+    import ctypes
+
+    sup = B.synth_clouds(21, 2, 8192)
+    s = torch.from_numpy(sup).cuda()
+    b, n, k = 2, 8192, 32
+    nbytes = int(_hip.lib().pasnl_knn_workspace_bytes(b, n))
+    assert nbytes > 0 and int(_hip.lib().pasnl_knn_workspace_bytes(b, 2048)) == 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    idx = torch.empty((b, n, k), dtype=torch.int64, device="cuda")
+    d = torch.empty((b, n, k), dtype=torch.float32, device="cuda")
+    _hip.launch("pasnl_knn_batch_ws", "knn", b, n, n, k, _hip.ptr(s), _hip.ptr(s), _hip.ptr(idx), 1, _hip.ptr(d), _hip.ptr(ws),
+                ctypes.c_size_t(nbytes))
+    i2 = torch.empty((b, n, k), dtype=torch.int64, device="cuda")
+    d2 = torch.empty((b, n, k), dtype=torch.float32, device="cuda")
+    _hip.launch("pasnl_knn_batch", "knn", b, n, n, k, _hip.ptr(s), _hip.ptr(s), _hip.ptr(i2), 1, _hip.ptr(d2))
+    assert torch.equal(idx, i2) and torch.equal(d, d2)
+    with pytest.raises(_hip.PasnlError):  # a workspace that is too small is refused before anything is launched
+        _hip.launch("pasnl_knn_batch_ws", "knn", b, n, n, k, _hip.ptr(s), _hip.ptr(s), _hip.ptr(idx), 1, _hip.ptr(d), _hip.ptr(ws),
+                    ctypes.c_size_t(nbytes - 1))
