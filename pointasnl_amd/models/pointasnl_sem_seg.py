@@ -40,7 +40,6 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
 
     def level1(xyz1):  # l1_xyz final
         knn[1] = Forked(lambda: knn_query(32, xyz1, xyz1), slot=1)
-        nn[4] = Forked(lambda: three_nn(l0_xyz, xyz1), slot=2)
         srch[2] = Forked(lambda: sa_search(xyz1, None, num_points[1], 32, knn_all=knn[1]), slot=0)
 
     def level2(xyz2):  # l2_xyz final: everything below it depends on coordinates only
@@ -53,7 +52,9 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
             xyz4 = neighbor0_xyz(xyz3, s4[2])
             return dict(k2=k2, s3=s3, k3=k3, s4=s4, n1=three_nn(xyz3, xyz4), n2=three_nn(xyz2, xyz3))
         srch["deep"] = Forked(chain, slot=0)
-        nn[3] = Forked(lambda: three_nn(l1_xyz_box[0], xyz2), slot=2)
+        # needed by the decoders at the very end: queued BEHIND the urgent searches (side streams share hardware queues)
+        nn[3] = Forked(lambda: three_nn(l1_xyz_box[0], xyz2), slot=0)
+        nn[4] = Forked(lambda: three_nn(l0_xyz, l1_xyz_box[0]), slot=0)
 
     l1_xyz_box = []
     # Feature encoding layers

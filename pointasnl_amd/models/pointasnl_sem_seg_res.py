@@ -37,7 +37,6 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
     srch[0] = search if search is not None else sa_search(l0_xyz, None, num_point, 32, knn_all=knn0)
 
     def level1(xyz1):  # l1_xyz final (layer1_1's AdaptiveSampling)
-        nn[4] = Forked(lambda: three_nn(l0_xyz, xyz1), slot=2)
         srch[2] = Forked(lambda: sa_search(xyz1, None, num_points[1], 32), slot=0)
 
     def level2(xyz2):  # l2_xyz final: levels 3 and 4 have as_neighbor = 0 -> their coordinates follow from coordinates
@@ -52,7 +51,9 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
             return dict(s22=(xyz2, None, k2), s31=s31, s32=(xyz3, None, k3), s41=s41, s42=(xyz4, None, k4),
                         n1=three_nn(xyz3, xyz4), n2=three_nn(xyz2, xyz3))
         srch["deep"] = Forked(chain, slot=0)
-        nn[3] = Forked(lambda: three_nn(l1_xyz_box[0], xyz2), slot=2)
+        # needed by the decoders at the very end: queued BEHIND the urgent searches (side streams share hardware queues)
+        nn[3] = Forked(lambda: three_nn(l1_xyz_box[0], xyz2), slot=0)
+        nn[4] = Forked(lambda: three_nn(l0_xyz, l1_xyz_box[0]), slot=0)
 
     l1_xyz_box = []
     _, l0_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=num_point, nsample=32, mlp=[16, 16, 32],

@@ -90,7 +90,11 @@ LOCAL_CELL_FUSED = True  # False = the reference's op-by-op chain on the vendor 
 def _local_cell_supported(w, mlp, nsample):
     """Cheap pre-filter only: the kernel launchers own the exact limits (LDS bytes: cells.hip pasnl_sa_cell) and answer
     PASNL_EUNSUPPORTED beyond them, which PointASNLSetAbstraction catches and answers with the next path down."""
-    return LOCAL_CELL_FUSED and len(mlp) == 3 and mlp[0] == mlp[1] and mlp[0] in (32, 64, 128) and nsample % 32 == 0
+    if not LOCAL_CELL_FUSED or nsample % 32:
+        return False
+    if len(mlp) == 3:  # conv0 -> conv1 -> (weight net, matmul) -> after_conv
+        return mlp[0] == mlp[1] and mlp[0] in (16, 32, 64, 128)
+    return len(mlp) == 2 and mlp[0] in (32, 64, 128)  # one convolution only (the *_2 layers of pointasnl_sem_seg_res.py)
 
 
 def sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn):
@@ -113,28 +117,55 @@ def sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn):
     return out
 
 
+def _sa_cell_weights(w_in, mlp, bn, weight_decay):
+    """(w0, b0, w1, b1, ww, bw, c_kernel) for pasnl_sa_cell, whose two convolutions are c x c with c in {32, 64, 128}:
+      * mlp = [c, c, out]: the layer's own conv0 / conv1;
+      * mlp = [16, 16, out] (pointasnl_sem_seg_res.py layer0): both zero-padded to 32 channels -- the padded channels are
+        relu(0 + 0) = 0 and feed zero rows, so channels 0..15 are bit-identical to the unpadded arithmetic;
+      * mlp = [c, out] (the *_2 residual layers: ONE convolution, pointasnl_util.py:264-269 with len(mlp) == 2): conv1 = the
+        identity with zero bias -- relu(h * 1 + 0) = h exactly for h = relu(.) >= 0.
+    The folded / padded tensors are cached in the store like every other folded weight."""
+    st = tf_util.store()
+    key = st.path("sa_cell_weights")
+    if key not in st._folded:
+        c1 = mlp[0]
+        with tf_util.variable_scope('conv0'):
+            w0, b0 = st.layer(w_in, c1, bn, weight_decay)
+        if len(mlp) == 3:
+            with tf_util.variable_scope('conv1'):
+                w1, b1 = st.layer(c1, mlp[1], bn, weight_decay)
+        else:
+            w1, b1 = torch.eye(c1, dtype=torch.float32, device=w0.device), torch.zeros(c1, dtype=torch.float32, device=w0.device)
+        with tf_util.variable_scope('weight_net'), tf_util.variable_scope('wconv0'):
+            ww, bw = st.layer(3, 32, True, weight_decay)
+        ck = max(c1, 32)
+        if ck != c1:
+            pad = ck - c1
+            w0 = torch.nn.functional.pad(w0, (0, pad))
+            b0 = torch.nn.functional.pad(b0, (0, pad))
+            w1 = torch.nn.functional.pad(w1, (0, pad, 0, pad))
+            b1 = torch.nn.functional.pad(b1, (0, pad))
+        st._folded[key] = tuple(t.contiguous() for t in (w0, b0, w1, b1, ww, bw)) + (ck,)
+    return st._folded[key]
+
+
 def sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay, bn):
     """Grouping + local cell in ONE kernel (pointasnl_util.py:63-74,248-249,258,264-274): the (B,P,K,6+C) grouped
     tensor is never materialised -- rows are gathered from the L2-resident per-cloud tables inside the MFMA
     kernel, which also takes the skip connection's max over the K neighbours.
-    -> (B,P,mlp[1],32) = the input of after_conv,  skip (B,P,6+C)"""
+    -> (B,P,c,32) = the input of after_conv (c = the width of the last convolution; a view of the kernel's 32-channel
+       output when c = 16),  skip (B,P,6+C)"""
     b, n, c = feature.shape
     _, p, k = idx.shape
-    c1, c2 = mlp[0], mlp[1]
-    st = tf_util.store()
-    with tf_util.variable_scope('conv0'):
-        w0, b0 = st.layer(6 + c, c1, bn, weight_decay)
-    with tf_util.variable_scope('conv1'):
-        w1, b1 = st.layer(c1, c2, bn, weight_decay)
-    with tf_util.variable_scope('weight_net'), tf_util.variable_scope('wconv0'):
-        ww, bw = st.layer(3, 32, True, weight_decay)
+    w0, b0, w1, b1, ww, bw, ck = _sa_cell_weights(6 + c, mlp, bn, weight_decay)
     xyz, feature, idx, new_xyz = xyz.contiguous(), feature.contiguous(), idx.contiguous(), new_xyz.contiguous()
-    out = torch.empty((b, p, c2, 32), dtype=torch.float32, device=xyz.device)
+    out = torch.empty((b, p, ck, 32), dtype=torch.float32, device=xyz.device)
     skip = torch.empty((b, p, 6 + c), dtype=torch.float32, device=xyz.device)
-    _hip.launch("pasnl_sa_cell", "sa_cell", b, n, c, p, k, c1, c2, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx),
+    _hip.launch("pasnl_sa_cell", "sa_cell", b, n, c, p, k, ck, ck, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx),
                 _hip.ptr(new_xyz), _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(w1), _hip.ptr(b1), _hip.ptr(ww), _hip.ptr(bw),
                 _hip.ptr(out), _hip.ptr(skip))
-    return out, skip
+    c_out = mlp[0] if len(mlp) == 2 else mlp[1]
+    return (out if c_out == ck else out[:, :, :c_out, :]), skip
 
 
 def weight_net_hidden(xyz, hidden_units, scope, is_training, bn_decay=None, weight_decay=None, activation_fn="relu"):
@@ -493,6 +524,8 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
             # gather + translation normalisation + both concats + the skip connection's reduce_max: one kernel
             new_point, skip_spatial = sa_group(xyz, feature, idx, new_xyz)
             grouped_xyz = new_point[..., 0:3]
+            if fused and not (len(mlp) == 3 and mlp[0] >= 32):
+                fused = False  # the two-kernel form exists for the plain [c, c, out] shape only
             if fused:
                 tf_util._require_inference(is_training)
                 try:

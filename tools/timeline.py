@@ -4,11 +4,14 @@
 import csv, glob, os, sys
 root = sys.argv[1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+marker = sys.argv[3] if len(sys.argv) > 3 else None  # substring of the kernel a forward starts with
 f = glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = sorted(({"s": int(r["Start_Timestamp"]), "e": int(r["End_Timestamp"]), "q": r.get("Queue_Id", "?"), "n": r["Kernel_Name"]}
                for r in csv.DictReader(open(f))), key=lambda r: r["s"])
 # a forward starts with the first FPS kernel of n=1024 (fps_kernel<4, 4...) -- split on it
-starts = [i for i, r in enumerate(rows) if "fps_kernel<4, 4" in r["n"] or "fps_kernel<16" in r["n"]]
+starts = [i for i, r in enumerate(rows) if (marker in r["n"] if marker else ("fps_kernel<4, 4" in r["n"] or "fps_kernel<16" in r["n"]))]
+if marker:  # several launches of the marker kernel per forward: keep the first of each burst (> 1 ms apart)
+    starts = [i for n_, i in enumerate(starts) if n_ == 0 or rows[i]["s"] - rows[starts[n_ - 1]]["s"] > 1_000_000]
 if len(starts) < back + 1:
     starts = [0, len(rows)]
 a, b = starts[-back - 1], starts[-back]
