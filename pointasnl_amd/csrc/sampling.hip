@@ -382,6 +382,221 @@ static int fps_launch(int b, int n, int m, const float* xyz, int* idx, hipStream
 }
 
 // ---------------------------------------------------------------------------------------------
+// Large clouds (2048 < n <= 10240): the same sampling with the round's arithmetic PRUNED.
+// fps_kernel updates every running distance in every round: n x npoint updates (8192 x 1024 x 16 clouds), one compute unit
+// per cloud, ~0.9 us per round of pure vector work.  But a new pick p changes min(td[x], |x-p|^2) only for points closer
+// to p than sqrt(td[x]) -- after a few hundred picks a small neighbourhood.  So:
+//   * once, at the start: the points are sorted along a Morton curve (16^3 cells over the bounding box, counting sort in
+//     LDS) and dealt out so that a wave owns 64*NB consecutive points = a compact blob, a lane NB consecutive ones; each
+//     wave keeps its blob's centre c and radius R (wave-uniform);
+//   * every round a wave first tests  |p - c| >= R + sqrt(M)  (M = its current largest running distance; margins of 1e-5
+//     dwarf the rounding of the test and of the fp32 distances): then NO point of the wave can change, its cached candidate
+//     (largest distance, tie key) is still exact, and the wave skips the update, the tournament and the wave reduction;
+//   * every wave -- active or not -- folds its candidate into one LDS word with ds_max_u64 on
+//     (distance bits << 32 | ~tie key): largest distance, then lowest k mod 512, then lowest k: the reference rule
+//     (tf_sampling_g.cu:142-164) as an unsigned 64-bit order.  One barrier; every lane reads the winner and its coordinates.
+// Exactly the reference's picks for every input (tests: lattice clouds, duplicates, metre-scale KITTI coordinates).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fps_spread3(uint32_t v) {  // 4 bits -> every third bit
+  return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
+}
+
+template <int WAVES, int NB>
+__global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, const float* __restrict__ xyz, int* __restrict__ idx) {
+  constexpr int T = WAVES * 64;
+  constexpr int NCELL = 4096;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* spt = reinterpret_cast<float*>(smem);                                   // [n][3], ORIGINAL order: pick coordinates
+  unsigned short* order = reinterpret_cast<unsigned short*>(spt + (size_t)n * 3);  // [n]: sorted position -> original index
+  int* hist = reinterpret_cast<int*>(order + ((n + 1) & ~1));                     // [4096] during the sort ...
+  unsigned long long* best = reinterpret_cast<unsigned long long*>(hist);         // ... then [2][16] {distance, key} slots
+  int* picks = hist + 64;                                                         // ... and [m] picks
+  __shared__ float red[6][WAVES];
+  __shared__ int wsum[WAVES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* cloud = xyz + (size_t)blockIdx.x * n * 3;
+
+  // ---- stage the cloud, bounding box
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int f = tid; f < n * 3; f += T) spt[f] = cloud[f];  // coalesced flat copy
+  __syncthreads();
+  for (int k = tid; k < n; k += T) {
+    const float x = spt[k * 3], y = spt[k * 3 + 1], z = spt[k * 3 + 2];
+    mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+    mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+    mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      mn[a] = fminf(mn[a], __shfl_xor(mn[a], sft));
+      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], sft));
+    }
+    if (lane == 0) { red[a][wave] = mn[a]; red[3 + a][wave] = mx[a]; }
+  }
+  for (int c = tid; c < NCELL; c += T) hist[c] = 0;
+  __syncthreads();
+  float lo[3], sc[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float l = red[a][0], u = red[3 + a][0];
+    for (int w = 1; w < WAVES; ++w) { l = fminf(l, red[a][w]); u = fmaxf(u, red[3 + a][w]); }
+    lo[a] = l;
+    sc[a] = u > l ? 15.999f / (u - l) : 0.f;
+  }
+  // ---- Morton counting sort: histogram, scan, scatter of the original indices
+  auto code_of = [&](int k) {
+    const uint32_t cx = (uint32_t)min(15, max(0, (int)((spt[k * 3] - lo[0]) * sc[0])));
+    const uint32_t cy = (uint32_t)min(15, max(0, (int)((spt[k * 3 + 1] - lo[1]) * sc[1])));
+    const uint32_t cz = (uint32_t)min(15, max(0, (int)((spt[k * 3 + 2] - lo[2]) * sc[2])));
+    return (int)(fps_spread3(cx) | (fps_spread3(cy) << 1) | (fps_spread3(cz) << 2));
+  };
+  for (int k = tid; k < n; k += T) atomicAdd(&hist[code_of(k)], 1);
+  __syncthreads();
+  {
+    constexpr int PER = NCELL / T;  // cells per thread (T divides 4096)
+    int v[PER], tsum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { v[i] = hist[tid * PER + i]; tsum += v[i]; }
+    int incl = tsum;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      const int o = __shfl_up(incl, sft);
+      if (lane >= sft) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int run = incl - tsum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { hist[tid * PER + i] = run; run += v[i]; }
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += T) order[atomicAdd(&hist[code_of(k)], 1)] = (unsigned short)k;
+  __syncthreads();
+
+  // ---- this lane's NB consecutive points of the sorted order
+  f32x2 px[NB / 2], py[NB / 2], pz[NB / 2];
+  uint32_t td[NB], nkey[NB];  // running distance bits; ~tie key (0 = padding: loses every comparison)
+  float bmn[3] = {INFINITY, INFINITY, INFINITY}, bmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int pos = (wave * 64 + lane) * NB + i;
+    const bool ok = pos < n;
+    const int k = ok ? (int)order[pos] : 0;
+    const float x = ok ? spt[k * 3] : 0.f, y = ok ? spt[k * 3 + 1] : 0.f, z = ok ? spt[k * 3 + 2] : 0.f;
+    px[i / 2][i % 2] = x; py[i / 2][i % 2] = y; pz[i / 2][i % 2] = z;
+    td[i] = ok ? __float_as_uint(1e38f) : 0u;
+    nkey[i] = ok ? ~fps_tiekey(k) : 0u;
+    if (ok) {
+      bmn[0] = fminf(bmn[0], x); bmx[0] = fmaxf(bmx[0], x);
+      bmn[1] = fminf(bmn[1], y); bmx[1] = fmaxf(bmx[1], y);
+      bmn[2] = fminf(bmn[2], z); bmx[2] = fmaxf(bmx[2], z);
+    }
+  }
+  __syncthreads();  // everybody has read hist-as-fill-pointers / order: the region becomes best[] + picks[]
+  // the wave's bounding box, inflated by 1e-5 of its size (rounding of the test below)
+  float blo[3], bhi[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+      bmn[a] = fminf(bmn[a], __shfl_xor(bmn[a], sft));
+      bmx[a] = fmaxf(bmx[a], __shfl_xor(bmx[a], sft));
+    }
+    const float pad = 1e-5f * fmaxf(fabsf(bmn[a]), fabsf(bmx[a])) + 1e-30f;
+    blo[a] = bmn[a] - pad;
+    bhi[a] = bmx[a] + pad;
+  }
+  const bool empty_wave = !(bmn[0] <= bmx[0]);
+  float2* slots = reinterpret_cast<float2*>(best);  // [2][16] {distance bits, ~tie key}
+  if (tid == 0) picks[0] = 0;
+  float x1 = spt[0], y1 = spt[1], z1 = spt[2];
+  float thr = empty_wave ? -1.f : INFINITY;  // the wave is active while dist^2(p, box) < thr  (= its largest running distance, inflated)
+  uint32_t cand_d = 0u, cand_k = 0u;         // the wave's candidate: largest running distance (bits), ~tie key
+  __syncthreads();
+
+  for (int j = 1; j < m; ++j) {
+    const float ex = fmaxf(fmaxf(blo[0] - x1, x1 - bhi[0]), 0.f), ey = fmaxf(fmaxf(blo[1] - y1, y1 - bhi[1]), 0.f),
+                ez = fmaxf(fmaxf(blo[2] - z1, z1 - bhi[2]), 0.f);
+    const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+    if (lb < thr) {  // wave-uniform
+#pragma unroll
+      for (int q = 0; q < NB / 2; ++q) {
+        const f32x2 dx = px[q] - x1, dy = py[q] - y1, dz = pz[q] - z1;
+        const f32x2 d = (dx * dx + dy * dy) + dz * dz;
+        td[2 * q] = min(td[2 * q], __float_as_uint(d[0]));
+        td[2 * q + 1] = min(td[2 * q + 1], __float_as_uint(d[1]));
+      }
+      unsigned long long bk = ((unsigned long long)td[0] << 32) | nkey[0];
+#pragma unroll
+      for (int i = 1; i < NB; ++i) {
+        const unsigned long long o = ((unsigned long long)td[i] << 32) | nkey[i];
+        bk = o > bk ? o : bk;
+      }
+      const uint32_t bd = (uint32_t)(bk >> 32);
+      const int wmaxi = __builtin_amdgcn_readlane(wave_max_i32_to_lane63((int)bd), 63);  // distances >= 0: signed order is fine
+      unsigned long long tie = __ballot(bd == (uint32_t)wmaxi);
+      uint32_t wkey = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bk, (int)__builtin_ctzll(tie));
+      if (__builtin_popcountll(tie) > 1) {
+        tie &= tie - 1;
+        while (tie) {
+          const int l = (int)__builtin_ctzll(tie);
+          tie &= tie - 1;
+          const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bk, l);
+          wkey = kk > wkey ? kk : wkey;
+        }
+      }
+      cand_d = (uint32_t)wmaxi;
+      cand_k = wkey;
+      // no point of this wave changes while dist^2(p, box) >= M (1 + 1e-5): every running distance is <= M
+      thr = __uint_as_float(cand_d) * 1.00001f;
+    }
+    float2* slot = slots + (j & 1) * 16;
+    if (lane == 0) slot[wave] = make_float2(__uint_as_float(cand_d), __uint_as_float(cand_k));
+    __syncthreads();
+    const float2 sv = lane < WAVES ? slot[lane] : make_float2(0.f, 0.f);
+    const int di = (int)__float_as_uint(sv.x);
+    const uint32_t ki = __float_as_uint(sv.y);
+    const int gmax = __builtin_amdgcn_readlane(row_max_i32_to_lane15(di), 15);
+    unsigned long long wt = __ballot(di == gmax && lane < WAVES) & 0xffffull;
+    uint32_t gkey = (uint32_t)__builtin_amdgcn_readlane((int)ki, (int)__builtin_ctzll(wt));
+    if (__builtin_popcountll(wt) > 1) {
+      wt &= wt - 1;
+      while (wt) {
+        const int l = (int)__builtin_ctzll(wt);
+        wt &= wt - 1;
+        const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)ki, l);
+        gkey = kk > gkey ? kk : gkey;
+      }
+    }
+    const int old = (int)(~gkey & 0x3fffffu);
+    x1 = spt[old * 3]; y1 = spt[old * 3 + 1]; z1 = spt[old * 3 + 2];
+    if (tid == 0) picks[j] = old;
+  }
+  __syncthreads();
+  int* out = idx + (size_t)blockIdx.x * m;
+  for (int j = tid; j < m; j += T) out[j] = picks[j];
+}
+
+template <int WAVES, int NB>
+static int fps_pruned_launch(int b, int n, int m, const float* xyz, int* idx, hipStream_t st) {
+  size_t lds = (size_t)n * 12 + (size_t)((n + 1) & ~1) * 2;
+  lds = (lds + 15) & ~(size_t)15;
+  const size_t tail = (size_t)4096 * 4 > (size_t)(64 + m) * 4 ? (size_t)4096 * 4 : (size_t)(64 + m) * 4;
+  lds += tail;
+  if (lds > 160 * 1024 - 1024 || n > 65535) return PASNL_EUNSUPPORTED;
+  auto kern = fps_pruned_kernel<WAVES, NB>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(b), dim3(WAVES * 64), lds, st, n, m, xyz, idx);
+  return pasnl_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // gather_point / grad
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_point_kernel(int n, int m, long total, const float* __restrict__ inp,
@@ -532,6 +747,14 @@ extern "C" int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz
   if (n <= 512) return fps_launch<1, 8>(b, n, m, xyz, idx, st);
   if (n <= 1024) return fps_launch<4, 4>(b, n, m, xyz, idx, st);   // measured: (4,4) 192 us vs (1,16) 241 us at B=64, m=512
   if (n <= 2048) return fps_launch<2, 16>(b, n, m, xyz, idx, st);
+  if (!tune_env("PASNL_FPS_NOPRUNE")) {
+    // pruned rounds (fps_pruned_kernel): the unpruned kernels below stay as the A/B reference
+    int rc = PASNL_EUNSUPPORTED;
+    if (n <= 4096) rc = fps_pruned_launch<16, 4>(b, n, m, xyz, idx, st);
+    else if (n <= 8192) rc = fps_pruned_launch<16, 8>(b, n, m, xyz, idx, st);
+    else if (n <= 10240) rc = fps_pruned_launch<16, 10>(b, n, m, xyz, idx, st);
+    if (rc != PASNL_EUNSUPPORTED) return rc;
+  }
   if (n <= 4096) return fps_launch<4, 16>(b, n, m, xyz, idx, st);
   if (n <= 8192) return fps_launch<16, 8>(b, n, m, xyz, idx, st);
   if (n <= 10240) return fps_launch<16, 10>(b, n, m, xyz, idx, st);
