@@ -131,7 +131,7 @@ constexpr int BQG_U = 4;          // candidates examined per lane and step (inde
 // them into hit lists and copies them out itself, so there is no workgroup barrier in the query phase.
 template <int MWT>  // mask words per query row held in registers during the bit-row -> list step: n <= 32*MWT
 __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int m, float rpad, float thr2, int nsample,
-                                                                     int rw, uint32_t ns_magic,
+                                                                     int rw, uint32_t ns_magic, int qchunk,
                                                                      const float* __restrict__ xyz1,
                                                                      const float* __restrict__ xyz2, int* __restrict__ idx,
                                                                      int* __restrict__ pts_cnt, long long* __restrict__ dbg) {
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int
   const int swmask = (min(rw >> 2, 8) - 1) << 2;
   const int swz = (lane << 2) & swmask;
   uint32_t* row = rows + (size_t)tid * rw;
-  const int qbase = blockIdx.x * BQG_QCHUNK;
-  const int qend = min(m, qbase + BQG_QCHUNK);
+  const int qbase = blockIdx.x * qchunk;  // qchunk: a multiple of 64 (a wave owns whole rounds of 64 queries)
+  const int qend = min(m, qbase + qchunk);
   const int last = n > 0 ? n - 1 : 0;
   const bool vec4 = (nsample & 3) == 0;
   for (int q0 = qbase + wave * 64; q0 < qend; q0 += BQG_THREADS) {
@@ -1031,7 +1031,12 @@ extern "C" int pasnl_query_ball_point(int b, int n, int m, float radius, int nsa
     while (rw < nsample) rw *= 2;
     size_t glds = (size_t)n * 16 + (size_t)BQG_THREADS * rw * 4 + (size_t)((BQG_NC + 2 + 1) & ~1) * 2 + 32 * 4;
     if (glds <= 160 * 1024 && (size_t)BQG_THREADS * rw >= (size_t)BQG_NC) {
-      dim3 grid((m + BQG_QCHUNK - 1) / BQG_QCHUNK, b);
+      // queries per workgroup: 512 (two rounds per lane) amortises the grid build when the launch fills the GPU anyway; a
+      // small batch is latency-bound (one round = ~20 us of dependent LDS work per wave), so its queries are spread over
+      // more workgroups -- each rebuilds the cloud's grid (1.6 us) -- down to one round of 64 queries per workgroup
+      int qchunk = BQG_QCHUNK;
+      while (qchunk > 64 && (long)b * ((m + qchunk - 1) / qchunk) < 1024) qchunk >>= 1;
+      dim3 grid((m + qchunk - 1) / qchunk, b);
       const float rpad = radius * 1.001f;
       // diagnostics: PASNL_BALL_PROBE=<device pointer to 8 int64, hex> makes workgroup 0 record its phase clocks
       long long* dbg = nullptr;
@@ -1046,7 +1051,7 @@ extern "C" int pasnl_query_ball_point(int b, int n, int m, float radius, int nsa
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds) != hipSuccess)   \
       return PASNL_ELAUNCH;                                                                                             \
     hipLaunchKernelGGL(gk, grid, dim3(BQG_THREADS), glds, pasnl_hip_stream(stream), n, m, rpad, thr2, nsample, rw,      \
-                       ns_magic, xyz1, xyz2, idx, pts_cnt, dbg);                                                        \
+                       ns_magic, qchunk, xyz1, xyz2, idx, pts_cnt, dbg);                                                        \
   }
       if (mwt == 8) PASNL_BQG(8)
       else if (mwt == 16) PASNL_BQG(16)

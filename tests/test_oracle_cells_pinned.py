@@ -154,3 +154,16 @@ def test_loss_restatement_equals_reference_python(gold_losses, case):
                              decayed=decayed, **case["loss_kw"])
     want = float(gold_losses[f"{case['name']}/loss_f64"])
     assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), (got, want)
+
+
+@pytest.mark.parametrize("name", ["cls_small", "cls_small_AS"])
+def test_torch_cpu_baseline_forward_equals_reference_python(gold_models, name):
+    """oracle/cells_torch.py (bench.py's cpu_baseline leg: reference kNN + C ports + torch-CPU dense) computes the same
+    logits as the reference graph."""
+    from oracle import cells_torch
+
+    case = next(c for c in R.MODEL_CASES if c["name"] == name)
+    params = _params(gold_models, name, R.model_seed(case))
+    got = cells_torch.cls_forward(R.model_input(case), params, **case["kw"])
+    want = gold_models[f"{name}/logits_f64"]
+    assert np.abs(got - want).max() <= 2e-5 * max(1.0, np.abs(want).max())
