@@ -213,6 +213,17 @@ int pasnl_group_point_grad_det(int b, int n, int c, int m, int nsample, const fl
 int pasnl_three_interpolate_grad_det(int b, int n, int c, int m, const float* grad_out, const int* idx, const float* weight,
                                      float* grad_points, void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
 
+/* Tail of a set-abstraction layer, fused (pointasnl_util.py:258-261 skip connection, :213-216 back-projection of the
+ * non-local cell, :282-290 the two adds and the aggregation layer):
+ *   out = relu( ( after + relu(skip_max ws + bs) + relu(att wb + bb) ) wagg + bagg )
+ * after (rows,c) = the after_conv output; skip_max (rows,w) = pasnl_sa_cell's skip maxima; att (rows,cb) = pasnl_nl_attention's
+ * output (cb == 0 and att/wb/bb NULL for a layer without non-local cell); ws (w,c), wb (cb,c), wagg (c,c) and the biases are
+ * the BN-folded `skip`, `conv_back_project`, `aggregation` layers.  c % 32 == 0 and c <= 512, else PASNL_EUNSUPPORTED (the
+ * Python mirror then runs the three GEMMs and two adds). */
+int pasnl_sa_tail(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att, const float* ws,
+                  const float* bs, const float* wb, const float* bb, const float* wagg, const float* bagg, float* out,
+                  pasnl_stream_t stream);
+
 /* Decoder local cell (PointASNLDecodingLayer, pointasnl_util.py:323-331): per point p of the dense level with its k
  * nearest neighbours i_s = idx[b,p,s] (self-kNN on xyz):
  *   F = [xyz[i_s] | feature[i_s]] (k,3+c);  G = relu((xyz[i_s]-xyz[p]) Ww + bw) (k,32);  out[b,p] = F^T G  (3+c,32)

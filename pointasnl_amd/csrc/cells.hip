@@ -2049,6 +2049,163 @@ extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, 
   return PASNL_EUNSUPPORTED;
 }
 
+namespace pasnl {
+// =============================================================================================
+// Tail of a set-abstraction layer (pointasnl_util.py:258-261, 213-216, 282-290), fused:
+//     out = relu( ( A + relu(S Ws + bs) + relu(N Wb + bb) ) Wagg + bagg )
+//   A (rows, C)  the after_conv output (already ReLU'd by its GEMM epilogue),   S (rows, w)  the skip maxima of the groups,
+//   N (rows, cb) the non-local attention output (absent when the layer has no non-local cell),
+//   Ws / Wb / Wagg  the BN-folded weights of the `skip`, `conv_back_project` and `aggregation` layers.
+// In the reference these are three 1x1 convolutions, two adds; on the vendor BLAS three GEMMs of 7-20 us each (launch- and
+// latency-bound: 0.1-0.5 GFLOP) plus two element-wise passes -- 67 + 50 us per classification forward.  Here a workgroup
+// owns a tile of 32 rows and chains v_mfma_f32_32x32x2_f32 the way sa_cell does: the products are formed TRANSPOSED
+// (T^T = Ws^T S^T), so that a D tile holds, per lane, channels kappa(i, h) of the lane's row -- exactly the B operand of the
+// next product O^T = Wagg^T V^T.  V = A + relu(T) + relu(U) passes through LDS once (channel-major, stride 33: conflict-free
+// both ways) because the four waves of the workgroup split the channel blocks of both stages; A enters and O leaves through
+// the same LDS tile so that global memory only sees coalesced 128-byte rows.  Weights stream from L2 (coalesced rows).
+// =============================================================================================
+// A-operand stream of one 32-channel output block: weight rows k (lanes 0-31) / k+1 (lanes 32-63), 16 k-steps per chunk,
+// the next chunk requested while the current one feeds the MFMAs.
+constexpr int TAIL_KS = 8;  // k-steps (pairs of input channels) per operand chunk
+struct TailW {
+  const float* __restrict__ base;  // W + cbase + l32
+  int C, kdim, h;
+  __device__ __forceinline__ void load(int k0, float (&a)[TAIL_KS]) const {
+#pragma unroll
+    for (int t = 0; t < TAIL_KS; ++t) {
+      const int kk = k0 + 2 * t + h;
+      a[t] = kk < kdim ? base[(size_t)kk * C] : 0.f;
+    }
+  }
+};
+
+// acc += W[:, block]^T . X^T for X rows held in LDS as xs[k * 33 + row] (k-major, zero-padded to a multiple of 2 TAIL_KS
+// channels).  Chunks of TAIL_KS unconditional MFMAs (zero operands beyond kdim), the next chunk's weights in flight.
+__device__ __forceinline__ f32x16 tail_product(const TailW& W, const float* __restrict__ xs, int l32, f32x16 acc) {
+  float a0[TAIL_KS], a1[TAIL_KS];
+  W.load(0, a0);
+  for (int k0 = 0; k0 < W.kdim; k0 += 4 * TAIL_KS) {
+    W.load(k0 + 2 * TAIL_KS, a1);  // (all zero beyond kdim: no memory access)
+#pragma unroll
+    for (int t = 0; t < TAIL_KS; ++t)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], xs[(k0 + 2 * t + W.h) * 33 + l32], acc, 0, 0, 0);
+    if (k0 + 2 * TAIL_KS >= W.kdim) break;
+    W.load(k0 + 4 * TAIL_KS, a0);
+#pragma unroll
+    for (int t = 0; t < TAIL_KS; ++t)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], xs[(k0 + 2 * TAIL_KS + 2 * t + W.h) * 33 + l32], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+template <int NW>  // waves per workgroup = 32-channel output blocks in flight (one per wave): C <= 32 NW
+__global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int cb, int C, const float* __restrict__ A,
+                                                         const float* __restrict__ S, const float* __restrict__ N,
+                                                         const float* __restrict__ Ws, const float* __restrict__ bs,
+                                                         const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                         const float* __restrict__ Wagg, const float* __restrict__ bagg,
+                                                         float* __restrict__ out) {
+  constexpr int RPW = 32 / NW;  // tile rows a wave stages / writes back
+  extern __shared__ float lds[];
+  float* vt = lds;                         // [C][33]      V^T, then O^T
+  const int wp = (w + 2 * TAIL_KS - 1) & ~(2 * TAIL_KS - 1), cbp = (cb + 2 * TAIL_KS - 1) & ~(2 * TAIL_KS - 1);
+  float* st = vt + (size_t)C * 33;         // [wp][33]     S^T tile
+  float* nt_ = st + (size_t)wp * 33;       // [cbp][33]    N^T tile
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
+  const long row0 = (long)blockIdx.x * 32;
+  const int nblk = C >> 5;
+  // ---- tiles into LDS, transposed (coalesced rows in, stride-33 columns out: conflict-free)
+  auto stage = [&](const float* __restrict__ src, int width, int padded, float* dst) {
+    for (int c0 = 0; c0 < padded; c0 += 64) {  // a wave owns RPW rows: RPW row segments in flight
+      const int c = c0 + lane;
+      float v[RPW];
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const long row = row0 + wave * RPW + i;
+        v[i] = (row < rows && c < width) ? src[row * width + c] : 0.f;
+      }
+      if (c < padded) {
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) dst[c * 33 + wave * RPW + i] = v[i];
+      }
+    }
+  };
+  stage(A, C, C, vt);
+  stage(S, w, wp, st);
+  if (N) stage(N, cb, cbp, nt_);
+  __syncthreads();
+  // ---- stage 1: V^T += relu(Ws^T S^T + bs) + relu(Wb^T N^T + bb); wave = channel block
+  const int cbase = wave * 32;
+  const bool mine = wave < nblk;
+  if (mine) {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = bs[cbase + kappa(i, h)];
+    acc = tail_product(TailW{Ws + cbase + l32, C, w, h}, st, l32, acc);
+    f32x16 v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
+    if (N) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = bb[cbase + kappa(i, h)];
+      acc = tail_product(TailW{Wb + cbase + l32, C, cb, h}, nt_, l32, acc);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] += fmaxf(acc[i], 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float* cell = vt + (cbase + kappa(i, h)) * 33 + l32;
+      *cell = *cell + v[i];
+    }
+  }
+  __syncthreads();
+  // ---- stage 2: O^T = relu(Wagg^T V^T + bagg); k-step t contracts channels 2t (lanes 0-31) and 2t+1 (lanes 32-63)
+  f32x16 o;
+  if (mine) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[i] = bagg[cbase + kappa(i, h)];
+    o = tail_product(TailW{Wagg + cbase + l32, C, C, h}, vt, l32, o);
+  }
+  __syncthreads();  // every wave has read V^T: the tile becomes O^T
+  if (mine) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) vt[(cbase + kappa(i, h)) * 33 + l32] = fmaxf(o[i], 0.f);
+  }
+  __syncthreads();
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    float v[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) v[i] = c < C ? vt[c * 33 + wave * RPW + i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const long row = row0 + wave * RPW + i;
+      if (row < rows && c < C) out[row * C + c] = v[i];
+    }
+  }
+}
+}  // namespace pasnl
+
+extern "C" int pasnl_sa_tail(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
+                             const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
+                             const float* bagg, float* out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(rows >= 0 && w > 0 && cb >= 0 && c > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(c % 32 == 0 && c <= 512, PASNL_EUNSUPPORTED);
+  if (rows == 0) return PASNL_OK;
+  PASNL_REQUIRE(after && skip_max && ws && bs && wagg && bagg && out, PASNL_ENULL);
+  PASNL_REQUIRE(cb == 0 || (att && wb && bb), PASNL_ENULL);
+  const size_t lds = ((size_t)c + ((w + 15) & ~15) + ((cb + 15) & ~15)) * 33 * sizeof(float);
+  PASNL_REQUIRE(lds <= 160 * 1024, PASNL_EUNSUPPORTED);
+  const int nw = c <= 128 ? 4 : (c <= 256 ? 8 : 16);  // one wave per 32-channel block (>= 4 waves stage the tiles)
+  auto kern = nw == 4 ? pasnl::sa_tail_kernel<4> : (nw == 8 ? pasnl::sa_tail_kernel<8> : pasnl::sa_tail_kernel<16>);
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 31) / 32)), dim3(nw * 64), lds, pasnl_hip_stream(stream), (long)rows, w, cb, c,
+                     after, skip_max, cb ? att : nullptr, ws, bs, wb, bb, wagg, bagg, out);
+  return pasnl_launch_status();
+}
+
 extern "C" int pasnl_decode_cell(int b, int n, int c, int k, const float* xyz, const float* feature, const int* idx,
                                  const float* ww, const float* bw, float* out, pasnl_stream_t stream) {
   PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && k > 0, PASNL_EINVAL);

@@ -83,6 +83,7 @@ def sa_group(xyz, feature, idx, new_xyz):
     return new_point, skip
 
 
+SA_TAIL_FUSED = True     # skip conv + back-projection + adds + aggregation in one kernel (pasnl_sa_tail); False = op by op
 SA_CELL_GATHER = True    # grouping fused into the local cell (pasnl_sa_cell); False = pasnl_sa_group + pasnl_sa_local_cell
 LOCAL_CELL_FUSED = True  # False = the reference's op-by-op chain on the vendor BLAS (kept for A/B and as fallback)
 
@@ -337,7 +338,7 @@ def nl_attention(q, kv, variant=None):
 
 
 def PointNonLocalCell(feature, new_point, mlp, is_training, bn_decay, weight_decay, scope, bn=True, scaled=True,
-                      mode='dot'):
+                      mode='dot', project=True):
     """Input
         feature: (batch_size, ndataset, channel) tensor
         new_point: (batch_size, npoint, nsample, channel)
@@ -366,6 +367,8 @@ def PointNonLocalCell(feature, new_point, mlp, is_training, bn_decay, weight_dec
             attention_map = torch.matmul(transformed_new_point, kv[..., :bottleneck_channel].transpose(1, 2))
             attention_map = torch.softmax(attention_map / (float(bottleneck_channel) ** 0.5), dim=-1)
             new_nonlocal_point = torch.matmul(attention_map, kv[..., bottleneck_channel:])
+        if not project:  # the caller fuses conv_back_project into the layer's tail (pasnl_sa_tail)
+            return new_nonlocal_point
         new_nonlocal_point = tf_util.conv2d(
             new_nonlocal_point.reshape(batch_size, npoint, nsample, bottleneck_channel), mlp[-1], [1, 1],
             padding='VALID', stride=[1, 1], bn=bn, is_training=is_training, scope='conv_back_project',
@@ -542,6 +545,35 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                                            bn_decay=bn_decay, weight_decay=weight_decay)
                 new_point = new_point.transpose(2, 3)
                 new_point = torch.matmul(new_point, weight)
+
+        c_out = mlp[-1]
+        if SA_TAIL_FUSED and c_out % 32 == 0 and c_out <= 512:
+            # skip convolution + back-projection of the non-local cell + both adds + aggregation: ONE kernel behind the
+            # after_conv GEMM (pasnl_sa_tail) instead of three small GEMMs and two element-wise passes
+            tf_util._require_inference(is_training)
+            cb = max(32, num_channel // 2)
+            att = None
+            if NL:
+                att = PointNonLocalCell(feature, new_feature.unsqueeze(1), [cb, nl_channel], is_training, bn_decay,
+                                        weight_decay, scope, bn, project=False)  # (B, P, cb)
+            after = tf_util.conv2d(new_point, c_out, [1, new_point.shape[2]], padding='VALID', stride=[1, 1], bn=bn,
+                                   is_training=is_training, scope='after_conv', bn_decay=bn_decay, weight_decay=weight_decay)
+            st = tf_util.store()
+            w_in = skip_spatial.shape[-1]
+            with tf_util.variable_scope('skip'):
+                ws, bs = st.layer(w_in, c_out, bn, weight_decay)
+            if NL:
+                with tf_util.variable_scope(scope), tf_util.variable_scope('conv_back_project'):
+                    wb, bb = st.layer(cb, c_out, bn, weight_decay)
+            with tf_util.variable_scope('aggregation'):
+                wagg, bagg = st.layer(c_out, c_out, bn, weight_decay)
+            rows = batch_size * npoint
+            after, skip_spatial = after.contiguous(), skip_spatial.contiguous()
+            out = torch.empty((batch_size, npoint, c_out), dtype=torch.float32, device=xyz.device)
+            _hip.launch("pasnl_sa_tail", "sa_tail", rows, int(w_in), int(cb if NL else 0), int(c_out), _hip.ptr(after),
+                        _hip.ptr(skip_spatial), _hip.ptr(att.contiguous() if NL else None), _hip.ptr(ws), _hip.ptr(bs),
+                        _hip.ptr(wb if NL else None), _hip.ptr(bb if NL else None), _hip.ptr(wagg), _hip.ptr(bagg), _hip.ptr(out))
+            return new_xyz, out
 
         '''Point NonLocal Cell'''
         if NL:
