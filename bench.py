@@ -152,6 +152,9 @@ def algorithmic(symbol, ints):
         # reads the tables, the indices and the centres once; writes (c2 x 32) per group + the skip maxima
         return (4 * (b * n * (3 + c) + g * k + 3 * g + g * c2 * 32 + g * w + w * c1 + c1 * c2),
                 g * (2 * k * (w * c1 + c1 * c2 + 3 * 32) + 2 * c2 * k * 32), "mfma")
+    if symbol == "pasnl_sa_tail":
+        rows, w, cb, c = ints
+        return 4 * (rows * (2 * c + w + cb) + c * (w + cb + c)), 2 * rows * c * (w + cb + c), "mfma"
     if symbol == "pasnl_decode_cell":
         b, n, c, k = ints
         return 4 * b * n * (3 + c + k + (3 + c) * 32), 2 * b * n * k * ((3 + c) * 32 + 3 * 32), "hbm"

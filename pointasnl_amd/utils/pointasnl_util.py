@@ -83,6 +83,7 @@ def sa_group(xyz, feature, idx, new_xyz):
     return new_point, skip
 
 
+SA_TAIL_MIN_ROWS = 2048
 SA_TAIL_FUSED = True     # skip conv + back-projection + adds + aggregation in one kernel (pasnl_sa_tail); False = op by op
 SA_CELL_GATHER = True    # grouping fused into the local cell (pasnl_sa_cell); False = pasnl_sa_group + pasnl_sa_local_cell
 LOCAL_CELL_FUSED = True  # False = the reference's op-by-op chain on the vendor BLAS (kept for A/B and as fallback)
@@ -547,7 +548,9 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                 new_point = torch.matmul(new_point, weight)
 
         c_out = mlp[-1]
-        if SA_TAIL_FUSED and c_out % 32 == 0 and c_out <= 512:
+        # (layers with few groups -- the deep, wide ones: 512 rows x 512 channels -- are 16 workgroups of dependent MFMA
+        # chains fed from L2; there the three small vendor GEMMs are faster: measured 101 vs ~45 us)
+        if SA_TAIL_FUSED and c_out % 32 == 0 and c_out <= 512 and batch_size * npoint >= SA_TAIL_MIN_ROWS:
             # skip convolution + back-projection of the non-local cell + both adds + aggregation: ONE kernel behind the
             # after_conv GEMM (pasnl_sa_tail) instead of three small GEMMs and two element-wise passes
             tf_util._require_inference(is_training)
