@@ -4,8 +4,13 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``b
 package; nothing under ``pointasnl_amd/`` does (tests/test_boundary.py greps for it).
 
 ``oracle.ops``   numpy front-ends of oracle/pasnl_oracle.c (index/byte-exact ops)
-``oracle.cells`` numpy fp32/fp64 restatement of the AS / NL cells (utils/pointasnl_util.py:112-219)
-``oracle.ref``   the reference's own sources compiled into oracle/_ref (when built)
+``oracle.cells`` numpy fp32/fp64 restatement of the cells, layers, model graphs and losses (pinned to the reference's own
+                 Python: tests/test_oracle_cells_pinned.py)
+``oracle.cells_torch`` the classification forward with torch-CPU dense layers (bench.py's cpu_baseline leg)
+``oracle.ref``   the reference's own C++ sources compiled into oracle/_ref (when built)
+``oracle.tf_shim`` numpy stand-in for the TensorFlow symbols the reference imports: runs the reference's own Python
+                 (tests/golden/make_golden.py cells|models|losses; needs /root/reference)
+``oracle.weights`` seeded values for the reference's TF variables, regenerated on both sides of a fixture
 """
 import ctypes
 import os
