@@ -401,6 +401,13 @@ __device__ __forceinline__ uint32_t fps_spread3(uint32_t v) {  // 4 bits -> ever
   return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4) | ((v & 8u) << 6);
 }
 
+#ifdef PASNL_TUNING
+__device__ unsigned long long fps_dbg[4];  // [active wave-rounds, wave-rounds]
+#endif
+
+#ifndef PASNL_FPS_ABL
+#define PASNL_FPS_ABL 0  // tuning builds only: 1 = no wave is ever active (exchange cost alone), 2 = every wave always active
+#endif
 template <int WAVES, int NB>
 __global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, const float* __restrict__ xyz, int* __restrict__ idx) {
   constexpr int T = WAVES * 64;
@@ -515,14 +522,17 @@ __global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, co
   if (tid == 0) picks[0] = 0;
   float x1 = spt[0], y1 = spt[1], z1 = spt[2];
   float thr = empty_wave ? -1.f : INFINITY;  // the wave is active while dist^2(p, box) < thr  (= its largest running distance, inflated)
-  uint32_t cand_d = 0u, cand_k = 0u;         // the wave's candidate: largest running distance (bits), ~tie key
+  uint32_t cand_d = PASNL_FPS_ABL == 1 ? (uint32_t)(wave + 1) : 0u, cand_k = 0u;  // the wave's candidate: largest running distance (bits), ~tie key
   __syncthreads();
 
   for (int j = 1; j < m; ++j) {
     const float ex = fmaxf(fmaxf(blo[0] - x1, x1 - bhi[0]), 0.f), ey = fmaxf(fmaxf(blo[1] - y1, y1 - bhi[1]), 0.f),
                 ez = fmaxf(fmaxf(blo[2] - z1, z1 - bhi[2]), 0.f);
     const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-    if (lb < thr) {  // wave-uniform
+#if defined(PASNL_TUNING) && PASNL_FPS_ABL == 0
+    if (lane == 0 && (blockIdx.x & 3) == 0) { atomicAdd(&fps_dbg[1], 1ull); if (lb < thr) atomicAdd(&fps_dbg[0], 1ull); }
+#endif
+    if ((PASNL_FPS_ABL == 2 || lb < thr) && PASNL_FPS_ABL != 1) {  // wave-uniform
 #pragma unroll
       for (int q = 0; q < NB / 2; ++q) {
         const f32x2 dx = px[q] - x1, dy = py[q] - y1, dz = pz[q] - z1;
@@ -530,22 +540,33 @@ __global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, co
         td[2 * q] = min(td[2 * q], __float_as_uint(d[0]));
         td[2 * q + 1] = min(td[2 * q + 1], __float_as_uint(d[1]));
       }
-      unsigned long long bk = ((unsigned long long)td[0] << 32) | nkey[0];
+      // in-lane maximum of (td, ~tie key): the distance by a max tree, then the largest key among the slots that hold it
+      // (short dependent chains: a linear scan of 64-bit compares was the longest piece of an active round)
+      uint32_t t2[NB];
 #pragma unroll
-      for (int i = 1; i < NB; ++i) {
-        const unsigned long long o = ((unsigned long long)td[i] << 32) | nkey[i];
-        bk = o > bk ? o : bk;
-      }
-      const uint32_t bd = (uint32_t)(bk >> 32);
+      for (int i = 0; i < NB; ++i) t2[i] = td[i];
+#pragma unroll
+      for (int stp = 1; stp < NB; stp *= 2)
+#pragma unroll
+        for (int i = 0; i + stp < NB; i += 2 * stp) t2[i] = max(t2[i], t2[i + stp]);
+      const uint32_t bd = t2[0];
+      uint32_t k2[NB];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) k2[i] = td[i] == bd ? nkey[i] : 0u;
+#pragma unroll
+      for (int stp = 1; stp < NB; stp *= 2)
+#pragma unroll
+        for (int i = 0; i + stp < NB; i += 2 * stp) k2[i] = max(k2[i], k2[i + stp]);
+      const uint32_t bkey = k2[0];
       const int wmaxi = __builtin_amdgcn_readlane(wave_max_i32_to_lane63((int)bd), 63);  // distances >= 0: signed order is fine
       unsigned long long tie = __ballot(bd == (uint32_t)wmaxi);
-      uint32_t wkey = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bk, (int)__builtin_ctzll(tie));
+      uint32_t wkey = (uint32_t)__builtin_amdgcn_readlane((int)bkey, (int)__builtin_ctzll(tie));
       if (__builtin_popcountll(tie) > 1) {
         tie &= tie - 1;
         while (tie) {
           const int l = (int)__builtin_ctzll(tie);
           tie &= tie - 1;
-          const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bk, l);
+          const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)bkey, l);
           wkey = kk > wkey ? kk : wkey;
         }
       }
@@ -708,6 +729,14 @@ __global__ __launch_bounds__(256) void binary_search_kernel(int n, int m, const 
 }  // namespace pasnl
 
 using namespace pasnl;
+
+#ifdef PASNL_TUNING
+extern "C" int pasnl_fps_dbg_read(unsigned long long* host4) {
+  if (hipMemcpyFromSymbol(host4, HIP_SYMBOL(pasnl::fps_dbg), sizeof(pasnl::fps_dbg)) != hipSuccess) return -1;
+  unsigned long long zero[4] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(pasnl::fps_dbg), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz, int* idx, pasnl_stream_t stream) {
   PASNL_REQUIRE(m > 0, PASNL_EINVAL);  // "FarthestPointSample expects positive npoint"
