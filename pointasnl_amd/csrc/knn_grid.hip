@@ -50,8 +50,8 @@ __device__ __forceinline__ int kg_cell1(float v, float v0, float inv_h, int g) {
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(KG_BUILD_T) void knn_grid_build_kernel(int n, float rho, const float* __restrict__ support, char* ws_all,
-                                                                  size_t stride) {
+__global__ __launch_bounds__(KG_BUILD_T) void knn_grid_build_kernel(int n, float rho, int refine, const float* __restrict__ support,
+                                                                  char* ws_all, size_t stride) {
   __shared__ int cnt[KG_CMAX];
   __shared__ float red[6][KG_BUILD_T / 64];
   __shared__ int wsum[KG_BUILD_T / 64];
@@ -81,48 +81,79 @@ __global__ __launch_bounds__(KG_BUILD_T) void knn_grid_build_kernel(int n, float
     }
     if (lane == 0) { red[a][wave] = mn[a]; red[3 + a][wave] = mx[a]; }
   }
-  for (int c = tid; c < KG_CMAX; c += KG_BUILD_T) cnt[c] = 0;
-  __syncthreads();
-  if (tid == 0) {
-    float lo[3], e[3];
-    for (int a = 0; a < 3; ++a) {
-      float l = red[a][0], u = red[3 + a][0];
-      for (int w = 1; w < KG_BUILD_T / 64; ++w) { l = fminf(l, red[a][w]); u = fmaxf(u, red[3 + a][w]); }
-      lo[a] = l;
-      e[a] = u - l;
-    }
-    const float emax = fmaxf(e[0], fmaxf(e[1], e[2]));
-    float h = 1.f;
-    if (emax > 0.f) {
-      const float cells = fmaxf(1.f, (float)n / rho);
-      h = emax;
-      for (int it = 0; it < 8; ++it)  // h^3 * cells = prod max(e_i, h): flat axes drop out of the volume
-        h = cbrtf(fmaxf(e[0], h) * fmaxf(e[1], h) * fmaxf(e[2], h) / cells);
-      h = fmaxf(h, emax * (1.f / 1024.f));
-    }
-    int gx, gy, gz;
-    for (;;) {
-      gx = (int)(e[0] / h) + 1; gy = (int)(e[1] / h) + 1; gz = (int)(e[2] / h) + 1;
-      if ((long)gx * gy * gz <= KG_CMAX) break;
-      h *= 1.1f;
-    }
-    P.x0 = lo[0]; P.y0 = lo[1]; P.z0 = lo[2]; P.h = h; P.inv_h = 1.f / h;
-    P.gx = gx; P.gy = gy; P.gz = gz;
-    *reinterpret_cast<KgParams*>(ws) = P;
-  }
-  __syncthreads();
-  const KgParams p = P;
-  const int ncell = p.gx * p.gy * p.gz;
+  __shared__ float occ2[KG_BUILD_T / 64];
+  __shared__ float hscale;
   int cell[KG_PPT];
-#pragma unroll
-  for (int i = 0; i < KG_PPT; ++i) {
-    if (i * KG_BUILD_T + tid < n) {
-      cell[i] = (kg_cell1(pz[i], p.z0, p.inv_h, p.gz) * p.gy + kg_cell1(py[i], p.y0, p.inv_h, p.gy)) * p.gx +
-                kg_cell1(px[i], p.x0, p.inv_h, p.gx);
-      atomicAdd(&cnt[cell[i]], 1);
+  KgParams p;
+  int ncell = 1;
+  // Two passes: the cell edge from the bounding-box volume assumes the points fill the box; the occupancy a point
+  // actually sees (sum c^2 / n over the cells) then corrects it once (a ball fills 52 % of its box, a scan far less).
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int c = tid; c < KG_CMAX; c += KG_BUILD_T) cnt[c] = 0;
+    __syncthreads();
+    if (tid == 0) {
+      float lo[3], e[3];
+      for (int a = 0; a < 3; ++a) {
+        float l = red[a][0], u = red[3 + a][0];
+        for (int w = 1; w < KG_BUILD_T / 64; ++w) { l = fminf(l, red[a][w]); u = fmaxf(u, red[3 + a][w]); }
+        lo[a] = l;
+        e[a] = u - l;
+      }
+      const float emax = fmaxf(e[0], fmaxf(e[1], e[2]));
+      float h = 1.f;
+      if (pass == 1) {
+        h = P.h * hscale;
+      } else if (emax > 0.f) {
+        const float cells = fmaxf(1.f, (float)n / rho);
+        h = emax;
+        for (int it = 0; it < 8; ++it)  // h^3 * cells = prod max(e_i, h): flat axes drop out of the volume
+          h = cbrtf(fmaxf(e[0], h) * fmaxf(e[1], h) * fmaxf(e[2], h) / cells);
+      }
+      h = fmaxf(h, emax * (1.f / 1024.f));
+      if (!(h > 0.f)) h = 1.f;
+      int gx, gy, gz;
+      for (;;) {
+        gx = (int)(e[0] / h) + 1; gy = (int)(e[1] / h) + 1; gz = (int)(e[2] / h) + 1;
+        if ((long)gx * gy * gz <= KG_CMAX) break;
+        h *= 1.1f;
+      }
+      P.x0 = lo[0]; P.y0 = lo[1]; P.z0 = lo[2]; P.h = h; P.inv_h = 1.f / h;
+      P.gx = gx; P.gy = gy; P.gz = gz;
+      *reinterpret_cast<KgParams*>(ws) = P;
     }
+    __syncthreads();
+    p = P;
+    ncell = p.gx * p.gy * p.gz;
+#pragma unroll
+    for (int i = 0; i < KG_PPT; ++i) {
+      if (i * KG_BUILD_T + tid < n) {
+        cell[i] = (kg_cell1(pz[i], p.z0, p.inv_h, p.gz) * p.gy + kg_cell1(py[i], p.y0, p.inv_h, p.gy)) * p.gx +
+                  kg_cell1(px[i], p.x0, p.inv_h, p.gx);
+        atomicAdd(&cnt[cell[i]], 1);
+      }
+    }
+    __syncthreads();
+    if (pass == 1) break;
+    // occupancy seen by a point: sum over cells of c^2 / n
+    float s2 = 0.f;
+    for (int c = tid; c < ncell; c += KG_BUILD_T) { const float cc = (float)cnt[c]; s2 += cc * cc; }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) s2 += __shfl_xor(s2, sft);
+    if (lane == 0) occ2[wave] = s2;
+    __syncthreads();
+    if (tid == 0) {
+      float tot = 0.f;
+      for (int w = 0; w < KG_BUILD_T / 64; ++w) tot += occ2[w];
+      const float seen = tot / (float)n;  // >= 1
+      // dimension the cloud fills at this scale: flat axes (one cell thick) do not rescale the count
+      const int dims = (p.gx > 1) + (p.gy > 1) + (p.gz > 1);
+      const float ratio = rho / fmaxf(seen, 1e-3f);
+      // refine: 0 = keep the box estimate, 1 = correct fully, 2 = half way (in log scale: robust against density gradients)
+      hscale = (dims == 0 || refine == 0) ? 1.f : powf(ratio, (refine == 2 ? 0.5f : 1.f) / (float)dims);
+      if (hscale > 0.93f && hscale < 1.07f) hscale = 1.f;  // close enough: keep the grid (the second pass repeats it)
+    }
+    __syncthreads();
   }
-  __syncthreads();
   // exclusive scan of cnt[0 .. KG_CMAX): 4 consecutive entries per thread
   int v[KG_CMAX / KG_BUILD_T], tsum = 0;
 #pragma unroll
@@ -169,7 +200,67 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   return v;
 }
 
-template <int R, typename IdxT>
+// Selection over the candidates `scan` enumerates for this lane (scan(f) calls f(distance bits, key) once per candidate;
+// it may be called several times and must enumerate the same candidates each time).  Returns the wave's K nearest as keys
+// (distance bits << 32 | index), ascending, lane t < k holding the t-th.
+template <int R, typename Scan>
+__device__ __forceinline__ unsigned long long kg_select(Scan&& scan, int k, int lane, unsigned long long* cb) {
+  constexpr uint32_t INF_BITS = 0x7f800000u;
+  // ---- pass 1: per-lane smallest distance(s) -> U = the K-th smallest of the lane minima bounds the K-th neighbour
+  uint32_t m1 = INF_BITS, m2 = INF_BITS;
+  scan([&](uint32_t di, unsigned long long) {
+    if (R == 2) m2 = min(m2, max(m1, di));
+    m1 = min(m1, di);
+  });
+  uint32_t mv[R];
+  mv[0] = m1;
+  if (R == 2) mv[1] = m2;
+  wave_bitonic_sort<R, uint32_t>(mv, lane);
+  uint32_t U = 0;
+#pragma unroll
+  for (int rr = 0; rr < R; ++rr)
+    if (rr == ((k - 1) >> 6)) U = (uint32_t)__builtin_amdgcn_readlane((int)mv[rr], (k - 1) & 63);
+  // ---- pass 2: candidates with d <= U  (U = +inf when fewer than K lanes saw one: everything is collected)
+  int cnt = 0;
+  scan([&](uint32_t di, unsigned long long key) {
+    const bool c = di <= U;
+    const unsigned long long mask = __ballot(c);
+    if (mask) {
+      const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+      const int slot = cnt + rank;
+      if (c && slot < KG_CAP) cb[slot] = key;
+      cnt += (int)__builtin_popcountll(mask);
+    }
+  });
+  // ---- order them
+  if (cnt <= 64) {
+    unsigned long long key[1];
+    key[0] = lane < cnt ? cb[lane] : ~0ull;
+    wave_bitonic_sort<1, unsigned long long>(key, lane);
+    return key[0];
+  }
+  if (cnt <= KG_CAP) {
+    unsigned long long key[2];
+    key[0] = cb[lane];
+    key[1] = 64 + lane < cnt ? cb[64 + lane] : ~0ull;
+    wave_bitonic_sort<2, unsigned long long>(key, lane);
+    return key[0];
+  }
+  // heavy ties: K rounds of "smallest key not below `lower`"
+  unsigned long long mykey = ~0ull, lower = 0;
+  for (int t = 0; t < k; ++t) {
+    unsigned long long best = ~0ull;
+    scan([&](uint32_t di, unsigned long long key) {
+      if (di != 0xffffffffu && key >= lower && key < best) best = key;
+    });
+    best = wave_min_u64(best);
+    if (lane == t) mykey = best;
+    lower = best + 1;
+  }
+  return mykey;
+}
+
+template <int R, bool WIDE, typename IdxT>  // WIDE: two slots per run in the ring-1 fast path (runs up to 128 records)
 __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, int m, int k, const float* __restrict__ queries,
                                                                      const char* __restrict__ ws_all, size_t stride,
                                                                      IdxT* __restrict__ idx, float* __restrict__ dist_out) {
@@ -185,122 +276,110 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, in
   const float* qp = queries + ((size_t)bi * m + j) * 3;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
   const int cx = kg_cell1(qx, P.x0, P.inv_h, P.gx), cy = kg_cell1(qy, P.y0, P.inv_h, P.gy), cz = kg_cell1(qz, P.z0, P.inv_h, P.gz);
-  constexpr uint32_t INF_BITS = 0x7f800000u;
   unsigned long long* cb = cand[wave];
 
+  // squared distance below which nothing outside the block [xl..xh] x [yl..yh] x [zl..zh] of cells can lie (see the header)
+  auto bound_of = [&](int xl, int xh, int yl, int yh, int zl, int zh) {
+    float b = INFINITY;
+    if (xl > 0) b = fminf(b, qx - (P.x0 + (float)xl * P.h));
+    if (xh < P.gx - 1) b = fminf(b, (P.x0 + (float)(xh + 1) * P.h) - qx);
+    if (yl > 0) b = fminf(b, qy - (P.y0 + (float)yl * P.h));
+    if (yh < P.gy - 1) b = fminf(b, (P.y0 + (float)(yh + 1) * P.h) - qy);
+    if (zl > 0) b = fminf(b, qz - (P.z0 + (float)zl * P.h));
+    if (zh < P.gz - 1) b = fminf(b, (P.z0 + (float)(zh + 1) * P.h) - qz);
+    if (b == INFINITY) return INFINITY;  // the block is the whole grid
+    b = fmaxf(b - 1e-3f * P.h, 0.f);
+    return b * b * (1.f - 9.5367431640625e-07f);
+  };
+
   unsigned long long mykey = ~0ull;  // lane t < k ends up with the t-th neighbour's key
-  for (int r = 1;; ++r) {
+  bool done = false;
+  int r = 1;
+  // ---- ring 1, the common case: the nine runs' bounds, then their records, are requested together (ONE memory latency
+  // instead of one per run and pass), and both selection passes work from registers
+  {
+    const int xl = max(cx - 1, 0), xh = min(cx + 1, P.gx - 1);
+    int rs[9], rl[9], total = 0, longest = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+      const int y = cy + q % 3 - 1, z = cz + q / 3 - 1;
+      const bool ok = y >= 0 && y < P.gy && z >= 0 && z < P.gz;
+      const int base = ok ? (z * P.gy + y) * P.gx : 0;
+      const int s0 = cells[base + xl], e0 = cells[base + xh + 1];
+      rs[q] = s0;
+      rl[q] = ok ? e0 - s0 : 0;
+      total += rl[q];
+      longest = max(longest, rl[q]);
+    }
+    constexpr int NS = WIDE ? 18 : 9;  // lanes-wide slots: one or two per run
+    if (total >= k && longest <= 64 * (NS / 9)) {
+      uint32_t dq[NS];
+      unsigned long long kq[NS];
+      const bool wide = longest > 64;  // wave-uniform: the second slot of every run is dead (and not even loaded) otherwise
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        dq[q] = 0xffffffffu;
+        kq[q] = ~0ull;
+        const int run_q = WIDE ? q >> 1 : q, half = WIDE ? (q & 1) : 0;
+        if (!half || wide) {
+          const int off = lane + 64 * half;
+          const float4 c = rec[min(rs[run_q] + off, n - 1)];
+          const uint32_t di = __float_as_uint(dist2(qx, qy, qz, c.x, c.y, c.z));
+          const bool live = off < rl[run_q];
+          dq[q] = live ? di : 0xffffffffu;  // (above every real distance and above +inf: never selected, never collected)
+          kq[q] = ((unsigned long long)di << 32) | (uint32_t)__float_as_int(c.w);
+        }
+      }
+      auto scan = [&](auto&& f) {
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+          if (!(WIDE && (q & 1)) || wide) f(dq[q], kq[q]);
+      };
+      // (dead slots carry 0xffffffff: kg_select's pass 1 sees them as > INF, pass 2 never collects them unless U is
+      // 0xffffffff itself, which cannot happen: U is a lane minimum <= INF_BITS or INF_BITS)
+      mykey = kg_select<R>(scan, k, lane, cb);
+      const uint32_t dk = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mykey >> 32), k - 1);
+      const float bnd = bound_of(xl, xh, max(cy - 1, 0), min(cy + 1, P.gy - 1), max(cz - 1, 0), min(cz + 1, P.gz - 1));
+      done = __uint_as_float(dk) < bnd || bnd == INFINITY;
+    }
+    r = done ? 1 : (total >= k && longest <= 64 * (NS / 9) ? 2 : 1);  // an overlong run: ring 1 again, through the generic path
+  }
+  for (; !done; ++r) {
     const bool whole_req = r > KG_RMAX;
     const int xl = whole_req ? 0 : max(cx - r, 0), xh = whole_req ? P.gx - 1 : min(cx + r, P.gx - 1);
     const int yl = whole_req ? 0 : max(cy - r, 0), yh = whole_req ? P.gy - 1 : min(cy + r, P.gy - 1);
     const int zl = whole_req ? 0 : max(cz - r, 0), zh = whole_req ? P.gz - 1 : min(cz + r, P.gz - 1);
-    const bool whole = xl == 0 && yl == 0 && zl == 0 && xh == P.gx - 1 && yh == P.gy - 1 && zh == P.gz - 1;
-    // squared distance below which nothing outside the block can lie (see the header)
-    float bnd = INFINITY;
-    if (!whole) {
-      float b = INFINITY;
-      if (xl > 0) b = fminf(b, qx - (P.x0 + (float)xl * P.h));
-      if (xh < P.gx - 1) b = fminf(b, (P.x0 + (float)(xh + 1) * P.h) - qx);
-      if (yl > 0) b = fminf(b, qy - (P.y0 + (float)yl * P.h));
-      if (yh < P.gy - 1) b = fminf(b, (P.y0 + (float)(yh + 1) * P.h) - qy);
-      if (zl > 0) b = fminf(b, qz - (P.z0 + (float)zl * P.h));
-      if (zh < P.gz - 1) b = fminf(b, (P.z0 + (float)(zh + 1) * P.h) - qz);
-      b = fmaxf(b - 1e-3f * P.h, 0.f);
-      bnd = b * b * (1.f - 9.5367431640625e-07f);
-    }
-    const int nrows = (yh - yl + 1) * (zh - zl + 1), ny = yh - yl + 1;
+    const float bnd = bound_of(xl, xh, yl, yh, zl, zh);
+    const bool whole = bnd == INFINITY;
     // a block that is the whole grid is ONE run; otherwise one run per (y, z) row
-    auto run_of = [&](int row, int& s, int& e) {
-      if (whole) { s = 0; e = n; return; }
-      const int base = ((zl + row / ny) * P.gy + (yl + row % ny)) * P.gx;
-      s = cells[base + xl];
-      e = cells[base + xh + 1];
-    };
-    const int runs = whole ? 1 : nrows;
     if (!whole) {
       int total = 0;
-      for (int row = 0; row < runs; ++row) { int s, e; run_of(row, s, e); total += e - s; }
+      for (int z = zl; z <= zh; ++z)
+        for (int y = yl; y <= yh; ++y) {
+          const int base = (z * P.gy + y) * P.gx;
+          total += cells[base + xh + 1] - cells[base + xl];
+        }
       if (total < k) continue;  // not even K records in the block: grow the ring
     }
-    // ---- pass 1: per-lane smallest distance(s)
-    uint32_t m1 = INF_BITS, m2 = INF_BITS;
-    for (int row = 0; row < runs; ++row) {
-      int s, e;
-      run_of(row, s, e);
-      for (int p = s + lane; p < e; p += 64) {
-        const float4 c = rec[p];
-        const uint32_t di = __float_as_uint(dist2(qx, qy, qz, c.x, c.y, c.z));
-        if (R == 2) m2 = min(m2, max(m1, di));
-        m1 = min(m1, di);
-      }
-    }
-    uint32_t mv[R];
-    mv[0] = m1;
-    if (R == 2) mv[1] = m2;
-    wave_bitonic_sort<R, uint32_t>(mv, lane);
-    uint32_t U = 0;
-#pragma unroll
-    for (int rr = 0; rr < R; ++rr)
-      if (rr == ((k - 1) >> 6)) U = (uint32_t)__builtin_amdgcn_readlane((int)mv[rr], (k - 1) & 63);
-    // ---- pass 2: records with d <= U  (U = +inf when fewer than K lanes saw a record: everything is collected)
-    int cnt = 0;
-    for (int row = 0; row < runs; ++row) {
-      int s, e;
-      run_of(row, s, e);
-      for (int p0 = s; p0 < e; p0 += 64) {
-        const int p = p0 + lane;
-        bool c = false;
-        unsigned long long key = 0;
-        if (p < e) {
-          const float4 cr = rec[p];
-          const uint32_t di = __float_as_uint(dist2(qx, qy, qz, cr.x, cr.y, cr.z));
-          c = di <= U;
-          key = ((unsigned long long)di << 32) | (uint32_t)__float_as_int(cr.w);
+    auto scan = [&](auto&& f) {
+      auto run = [&](int s0, int e0) {
+        for (int p0 = s0; p0 < e0; p0 += 64) {
+          const int p = p0 + lane;
+          const float4 c = rec[min(p, n - 1)];
+          const uint32_t di = __float_as_uint(dist2(qx, qy, qz, c.x, c.y, c.z));
+          f(p < e0 ? di : 0xffffffffu, ((unsigned long long)di << 32) | (uint32_t)__float_as_int(c.w));
         }
-        const unsigned long long mask = __ballot(c);
-        if (mask) {
-          const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-          const int slot = cnt + rank;
-          if (c && slot < KG_CAP) cb[slot] = key;
-          cnt += (int)__builtin_popcountll(mask);
+      };
+      if (whole) { run(0, n); return; }
+      for (int z = zl; z <= zh; ++z)
+        for (int y = yl; y <= yh; ++y) {
+          const int base = (z * P.gy + y) * P.gx;
+          run(cells[base + xl], cells[base + xh + 1]);
         }
-      }
-    }
-    // ---- order them
-    if (cnt <= 64) {
-      unsigned long long key[1];
-      key[0] = lane < cnt ? cb[lane] : ~0ull;
-      wave_bitonic_sort<1, unsigned long long>(key, lane);
-      mykey = key[0];
-    } else if (cnt <= KG_CAP) {
-      unsigned long long key[2];
-      key[0] = cb[lane];
-      key[1] = 64 + lane < cnt ? cb[64 + lane] : ~0ull;
-      wave_bitonic_sort<2, unsigned long long>(key, lane);
-      mykey = key[0];
-    } else {
-      // heavy ties: K rounds of "smallest key not below `lower`" over the same runs
-      unsigned long long lower = 0;
-      for (int t = 0; t < k; ++t) {
-        unsigned long long best = ~0ull;
-        for (int row = 0; row < runs; ++row) {
-          int s, e;
-          run_of(row, s, e);
-          for (int p = s + lane; p < e; p += 64) {
-            const float4 cr = rec[p];
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(dist2(qx, qy, qz, cr.x, cr.y, cr.z)) << 32) | (uint32_t)__float_as_int(cr.w);
-            if (key >= lower && key < best) best = key;
-          }
-        }
-        best = wave_min_u64(best);
-        if (lane == t) mykey = best;
-        lower = best + 1;
-      }
-    }
-    // ---- accept iff the K-th distance is below what the unexamined cells can hold
+    };
+    mykey = kg_select<R>(scan, k, lane, cb);
     const uint32_t dk = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mykey >> 32), k - 1);
-    if (whole || __uint_as_float(dk) < bnd) break;
+    done = whole || __uint_as_float(dk) < bnd;
   }
   const size_t o = ((size_t)bi * m + j) * k;
   if (lane < k) {
@@ -334,13 +413,19 @@ extern "C" int pasnl_knn_batch_ws(int b, int n, int m, int k, const float* suppo
   hipStream_t st = pasnl_hip_stream(stream);
   const size_t stride = kg_stride(n);
   // ~0.4 K records per cell: the sphere of radius h around a query (what ring 1 certifies) then holds ~1.7 K of them
-  const float rho = fmaxf(4.f, 0.4f * (float)k);
-  hipLaunchKernelGGL(knn_grid_build_kernel, dim3(b), dim3(KG_BUILD_T), 0, st, n, rho, support, static_cast<char*>(workspace), stride);
+  // target: ~0.7 K records in the cell of a point (measured optimum on uniform-box, ball and lidar-like clouds, K = 16 / 32)
+  float rho = fmaxf(4.f, 0.7f * (float)k);
+  if (const char* e = tune_env("PASNL_KNN_RHO")) rho = (float)atof(e) * (float)k;  // tuning build only
+  int refine = 2;
+  if (const char* e = tune_env("PASNL_KNN_REFINE")) refine = atoi(e);  // tuning build only
+  hipLaunchKernelGGL(knn_grid_build_kernel, dim3(b), dim3(KG_BUILD_T), 0, st, n, rho, refine, support, static_cast<char*>(workspace),
+                     stride);
   dim3 grid((m + KG_WAVES - 1) / KG_WAVES, b), block(KG_WAVES * 64);
-#define PASNL_KG(RR, T) hipLaunchKernelGGL((knn_grid_query_kernel<RR, T>), grid, block, 0, st, n, m, k, queries, \
-                                           static_cast<const char*>(workspace), stride, static_cast<T*>(idx), dist2)
-  if (k <= 32) { if (idx_is_i64) PASNL_KG(1, long long); else PASNL_KG(1, int); }
-  else { if (idx_is_i64) PASNL_KG(2, long long); else PASNL_KG(2, int); }
+#define PASNL_KG(RR, WW, T) hipLaunchKernelGGL((knn_grid_query_kernel<RR, WW, T>), grid, block, 0, st, n, m, k, queries, \
+                                               static_cast<const char*>(workspace), stride, static_cast<T*>(idx), dist2)
+  if (k <= 16) { if (idx_is_i64) PASNL_KG(1, false, long long); else PASNL_KG(1, false, int); }
+  else if (k <= 32) { if (idx_is_i64) PASNL_KG(1, true, long long); else PASNL_KG(1, true, int); }
+  else { if (idx_is_i64) PASNL_KG(2, true, long long); else PASNL_KG(2, true, int); }
 #undef PASNL_KG
   return pasnl_launch_status();
 }
