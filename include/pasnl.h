@@ -111,6 +111,16 @@ int pasnl_select_top_k(int b, int n, int m, int k, const float* dist, int* outi,
 int pasnl_knn_batch(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
                     int idx_is_i64, float* dist2, pasnl_stream_t stream);
 
+/* Coverage-driven query selection + kNN.  replaces cpp_knn_batch_distance_pick(_omp)  knn_.cxx:136-266 (binding
+ * knn.pyx:111-148): per cloud, nq times, among the points used least often so far take number (rnd % how many) in ascending
+ * index order, output its k nearest neighbours (ascending (squared distance, index)) and its coordinates, raise the use
+ * count of the neighbours by 1 and of the pick by 100.  pts (b,n,3) -> idx (b,nq,k) int64, queries (b,nq,3).  rnd (b,nq)
+ * uint32 = the outputs of the caller's generator: the reference seeds one std::mt19937 with time(0) and walks the clouds in
+ * order, so cloud i consumes outputs [i nq, (i+1) nq) (the Python mirror draws them with the same generator from an
+ * explicit seed).  n <= 16384. */
+int pasnl_knn_distance_pick(int b, int n, int nq, int k, const float* pts, const unsigned int* rnd, long long* idx,
+                            float* queries, pasnl_stream_t stream);
+
 /* The same search with a caller-provided workspace.  Clouds of PASNL_KNN_GRID_MIN_N <= n <= 16384 points and k <= 64 are
  * searched through a uniform grid built in the workspace (csrc/knn_grid.hip: counting sort by cell, expanding rings of
  * cells, acceptance only when no unexamined cell can hold a closer or tying point -> results bit-identical to

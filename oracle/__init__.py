@@ -165,6 +165,24 @@ class ops:
         return (idx, d) if return_dist else idx
 
     @staticmethod
+    def mt19937(seed, count):
+        """`count` successive outputs of std::mt19937(seed) (numpy's MT19937 with legacy seeding is the same generator)"""
+        bg = np.random.MT19937()
+        bg._legacy_seeding(int(seed))
+        return bg.random_raw(int(count)).astype(np.uint32)
+
+    @staticmethod
+    def knn_batch_distance_pick(pts, nqueries, K, seed):
+        """knn_.cxx:136-200 with an explicit seed -> (indices (B,nq,K) int64, queries (B,nq,3) float32)"""
+        pts = _f32(pts)
+        b, n, _ = pts.shape
+        rnd = np.ascontiguousarray(ops.mt19937(seed, b * nqueries))
+        idx = np.zeros((b, nqueries, K), np.int64)
+        q = np.zeros((b, nqueries, 3), np.float32)
+        lib().oracle_knn_distance_pick(b, n, int(nqueries), int(K), _p(pts), _p(rnd), _p(idx), _p(q))
+        return idx, q
+
+    @staticmethod
     def three_nn(xyz1, xyz2):
         xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
         b, n, _ = xyz1.shape

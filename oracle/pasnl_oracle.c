@@ -384,3 +384,44 @@ API int oracle_grid_subsample(long n, int fdim, int ldim, const float* pts, cons
   free(pr);
   return m;
 }
+
+
+/* knn_batch_distance_pick: coverage-driven query selection + kNN (utils/nearest_neighbors/knn_.cxx:136-200, binding
+ * knn.pyx:111-148).  Per cloud, nq times: among the points whose use count equals `current` (raised to the minimum count
+ * when none is left) pick number (random % how many), in ascending index order; its K nearest neighbours get their
+ * count raised by one, the pick itself by 100.  The reference draws from ONE std::mt19937 seeded with time(0) and walks
+ * the clouds in order, i.e. cloud b consumes outputs [b*nq, (b+1)*nq) of the stream: `rnd` holds those outputs (the
+ * caller generates them: numpy's MT19937 with legacy seeding == std::mt19937(seed)).  Neighbour order = ascending
+ * (distance, index) like oracle_knn (nanoflann's order among equal distances is traversal order). */
+API void oracle_knn_distance_pick(int b, int n, int nq, int k, const float* pts, const uint32_t* rnd, int64_t* idx, float* queries) {
+  int* used = (int*)malloc(sizeof(int) * (size_t)n);
+  int64_t* ids = (int64_t*)malloc(sizeof(int64_t) * (size_t)k);
+  float* d2 = (float*)malloc(sizeof(float) * (size_t)k);
+  for (int bi = 0; bi < b; ++bi) {
+    const float* cloud = pts + (size_t)bi * n * 3;
+    for (int i = 0; i < n; ++i) used[i] = 0;
+    int current = 0;
+    for (int it = 0; it < nq; ++it) {
+      int count = 0;
+      for (;;) {
+        count = 0;
+        for (int i = 0; i < n; ++i) count += used[i] == current;
+        if (count) break;
+        current = used[0];
+        for (int i = 1; i < n; ++i) current = used[i] < current ? used[i] : current;
+      }
+      int r = (int)(rnd[(size_t)bi * nq + it] % (uint32_t)count), index = 0;
+      for (int i = 0; i < n; ++i)
+        if (used[i] == current && r-- == 0) { index = i; break; }
+      const float* q = cloud + (size_t)index * 3;
+      oracle_knn(1, n, 1, k, cloud, q, ids, d2);
+      for (int t = 0; t < k; ++t) {
+        used[ids[t]] += 1;
+        idx[((size_t)bi * nq + it) * k + t] = ids[t];
+      }
+      used[index] += 100;
+      for (int c = 0; c < 3; ++c) queries[((size_t)bi * nq + it) * 3 + c] = q[c];
+    }
+  }
+  free(used); free(ids); free(d2);
+}

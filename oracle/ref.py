@@ -49,6 +49,21 @@ def knn_batch(pts, queries, K, omp=False):
     return out
 
 
+def knn_batch_distance_pick(pts, nqueries, K, seed):
+    """reference cpp_knn_batch_distance_pick (knn_.cxx:136-200) with its time(0) seed pinned to `seed` (the shim overrides
+    time() inside libref_knn.so) -> (indices (B,nq,K) int64, queries (B,nq,3))"""
+    global _knn
+    if _knn is None:
+        _knn = _load("libref_knn.so")
+    pts = _f32(pts)
+    b, n, dim = pts.shape
+    out = np.zeros((b, nqueries, K), np.int64)
+    q = np.zeros((b, nqueries, dim), np.float32)
+    sz = ctypes.c_size_t
+    _knn.ref_knn_batch_distance_pick(ctypes.c_long(int(seed)), _p(pts), sz(b), sz(n), sz(dim), _p(q), sz(nqueries), sz(K), _p(out))
+    return out, q
+
+
 def three_nn(xyz1, xyz2):
     """reference threenn_cpu (tf_interpolate.cpp:60-103)"""
     global _interp

@@ -1373,7 +1373,9 @@ static int nl_mfma_dispatch(int b, int p, int n, float qscale, const float* q, c
   const char* force = tune_env("PASNL_NL_SPLIT");  // tuning only
   if (force && *force) want = atoi(force);
   if (CB == 128 && want > 4) want = 4;
-  if (want >= 8) return nl_mfma_launch<CB, 8>(b, p, n, qscale, q, kv, out, staged, st);
+  if constexpr (CB < 128) {  // (cb = 128: 4 wave regions fill the LDS; the 8-wave form would also spill)
+    if (want >= 8) return nl_mfma_launch<CB, 8>(b, p, n, qscale, q, kv, out, staged, st);
+  }
   if (want >= 4) return nl_mfma_launch<CB, 4>(b, p, n, qscale, q, kv, out, staged, st);
   if (want >= 2) return nl_mfma_launch<CB, 2>(b, p, n, qscale, q, kv, out, staged, st);
   return nl_mfma_launch<CB, 1>(b, p, n, qscale, q, kv, out, staged, st);

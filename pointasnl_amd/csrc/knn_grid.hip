@@ -93,8 +93,10 @@ __global__ __launch_bounds__(KG_BUILD_T) void knn_grid_build_kernel(int n, float
     __syncthreads();
     if (tid == 0) {
       float lo[3], e[3];
+#pragma unroll
       for (int a = 0; a < 3; ++a) {
         float l = red[a][0], u = red[3 + a][0];
+#pragma unroll
         for (int w = 1; w < KG_BUILD_T / 64; ++w) { l = fminf(l, red[a][w]); u = fmaxf(u, red[3 + a][w]); }
         lo[a] = l;
         e[a] = u - l;
@@ -388,6 +390,130 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// knn_batch_distance_pick (utils/nearest_neighbors/knn_.cxx:136-200, binding knn.pyx:111-148): coverage-driven query
+// selection.  Per cloud, nq times: among the points whose use count equals `current` (raised to the minimum count when none
+// is left) take number (random % how many) in ascending index order; its K nearest neighbours (ascending (distance, index))
+// get their count raised by one, the pick itself by 100.  Inherently sequential per cloud: one workgroup per cloud walks the
+// nq iterations; a thread owns KD_PPT consecutive points (coordinates and keys in registers), the counts live in LDS, the K
+// nearest are extracted by K rounds of "smallest key above the previous one".  The random stream is the caller's (the
+// reference seeds ONE std::mt19937 with time(0) and walks the clouds in order: cloud b consumes outputs [b nq, (b+1) nq)).
+// ---------------------------------------------------------------------------------------------
+constexpr int KD_T = 1024, KD_PPT = 16;  // n <= 16384
+
+__device__ __forceinline__ unsigned long long kd_block_min_u64(unsigned long long v, unsigned long long* red, int lane, int wave) {
+  v = wave_min_u64(v);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  unsigned long long r = lane < KD_T / 64 ? red[lane] : ~0ull;
+  r = wave_min_u64(r);
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(KD_T) void knn_distance_pick_kernel(int n, int nq, int k, const float* __restrict__ pts,
+                                                                const uint32_t* __restrict__ rnd, long long* __restrict__ idx,
+                                                                float* __restrict__ queries) {
+  extern __shared__ int used[];  // [n]
+  __shared__ unsigned long long red[KD_T / 64];
+  __shared__ int wsum[KD_T / 64];
+  __shared__ int pick_s, cur_s, total_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bi = blockIdx.x;
+  const float* cloud = pts + (size_t)bi * n * 3;
+  const int c = (n + KD_T - 1) / KD_T;  // points per thread, consecutive: [tid*c, tid*c + c)
+  float px[KD_PPT], py[KD_PPT], pz[KD_PPT];
+#pragma unroll
+  for (int j = 0; j < KD_PPT; ++j) {
+    const int i = tid * c + j;
+    const bool ok = j < c && i < n;
+    px[j] = ok ? cloud[i * 3] : 0.f; py[j] = ok ? cloud[i * 3 + 1] : 0.f; pz[j] = ok ? cloud[i * 3 + 2] : 0.f;
+  }
+  for (int i = tid; i < n; i += KD_T) used[i] = 0;
+  if (tid == 0) cur_s = 0;
+  __syncthreads();
+  for (int it = 0; it < nq; ++it) {
+    // ---- how many points have the current count, and where
+    int mine, incl;
+    for (;;) {
+      const int cur = cur_s;
+      mine = 0;
+#pragma unroll
+      for (int j = 0; j < KD_PPT; ++j) {
+        const int i = tid * c + j;
+        if (j < c && i < n) mine += used[i] == cur;
+      }
+      incl = mine;
+#pragma unroll
+      for (int sft = 1; sft < 64; sft <<= 1) {
+        const int o = __shfl_up(incl, sft);
+        if (lane >= sft) incl += o;
+      }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      int base = 0, tot = 0;
+      for (int w = 0; w < KD_T / 64; ++w) { if (w < wave) base += wsum[w]; tot += wsum[w]; }
+      incl += base;
+      if (tid == 0) total_s = tot;
+      __syncthreads();
+      if (total_s > 0) break;
+      // none left: raise `current` to the minimum count
+      unsigned long long mn = ~0ull;
+#pragma unroll
+      for (int j = 0; j < KD_PPT; ++j) {
+        const int i = tid * c + j;
+        if (j < c && i < n) mn = min(mn, (unsigned long long)(unsigned)used[i]);
+      }
+      mn = kd_block_min_u64(mn, red, lane, wave);
+      if (tid == 0) cur_s = (int)mn;
+      __syncthreads();
+    }
+    // ---- the r-th of them in ascending index order
+    const int r = (int)(rnd[(size_t)bi * nq + it] % (uint32_t)total_s);
+    const int before = incl - mine;
+    if (r >= before && r < incl) {
+      int want = r - before;
+      const int cur = cur_s;
+#pragma unroll
+      for (int j = 0; j < KD_PPT; ++j) {
+        const int i = tid * c + j;
+        if (j < c && i < n && used[i] == cur && want-- == 0) pick_s = i;
+      }
+    }
+    __syncthreads();
+    const int index = pick_s;
+    const float qx = cloud[index * 3], qy = cloud[index * 3 + 1], qz = cloud[index * 3 + 2];
+    // ---- its K nearest: keys (distance bits << 32 | index) in registers, K rounds of block-wide minimum
+    unsigned long long key[KD_PPT];
+#pragma unroll
+    for (int j = 0; j < KD_PPT; ++j) {
+      const int i = tid * c + j;
+      key[j] = (j < c && i < n) ? ((unsigned long long)__float_as_uint(dist2(qx, qy, qz, px[j], py[j], pz[j])) << 32) | (unsigned)i : ~0ull;
+    }
+    unsigned long long lower = 0;
+    long long* o = idx + ((size_t)bi * nq + it) * k;
+    for (int t = 0; t < k; ++t) {
+      unsigned long long best = ~0ull;
+#pragma unroll
+      for (int j = 0; j < KD_PPT; ++j)
+        if (key[j] >= lower && key[j] < best) best = key[j];
+      best = kd_block_min_u64(best, red, lane, wave);
+      if (tid == 0) {
+        const int nb = (int)(unsigned)best;
+        o[t] = nb;
+        used[nb] += 1;
+      }
+      lower = best + 1;
+    }
+    if (tid == 0) {
+      used[index] += 100;
+      float* qo = queries + ((size_t)bi * nq + it) * 3;
+      qo[0] = qx; qo[1] = qy; qo[2] = qz;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace pasnl
 
 using namespace pasnl;
@@ -427,5 +553,20 @@ extern "C" int pasnl_knn_batch_ws(int b, int n, int m, int k, const float* suppo
   else if (k <= 32) { if (idx_is_i64) PASNL_KG(1, true, long long); else PASNL_KG(1, true, int); }
   else { if (idx_is_i64) PASNL_KG(2, true, long long); else PASNL_KG(2, true, int); }
 #undef PASNL_KG
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_knn_distance_pick(int b, int n, int nq, int k, const float* pts, const unsigned int* rnd, long long* idx,
+                                       float* queries, pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && nq >= 0 && k > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(k <= n, PASNL_EINVAL);
+  PASNL_REQUIRE(n <= KD_T * KD_PPT, PASNL_EUNSUPPORTED);
+  if (b == 0 || nq == 0) return PASNL_OK;
+  PASNL_REQUIRE(pts && rnd && idx && queries, PASNL_ENULL);
+  const size_t lds = (size_t)n * sizeof(int);
+  if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_distance_pick_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  hipLaunchKernelGGL(knn_distance_pick_kernel, dim3(b), dim3(KD_T), lds, pasnl_hip_stream(stream), n, nq, k, pts, rnd, idx, queries);
   return pasnl_launch_status();
 }

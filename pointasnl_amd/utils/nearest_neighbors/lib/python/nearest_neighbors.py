@@ -56,3 +56,27 @@ def knn(pts, queries, K, omp=False):
     q = _hip.as_dev(queries, torch.float32)[None]
     out = _knn_dev(p, q, K, True)[0]
     return out.cpu().numpy() if host else out
+
+
+def knn_batch_distance_pick(pts, nqueries, K, omp=False, seed=None):
+    """(B,N,3) -> (indices (B,nqueries,K) int64, queries (B,nqueries,3) float32)   (knn.pyx:111-148 -> knn_.cxx:136-266)
+    Coverage-driven selection of `nqueries` query points per cloud (always among the points used least often so far) with
+    their K nearest neighbours.  The reference seeds a std::mt19937 with time(0); `seed` makes the draw reproducible
+    (None = the reference's behaviour: seconds since the epoch).  The same generator (numpy's MT19937 with legacy seeding ==
+    std::mt19937(seed)) produces the stream on the host, the selection itself runs on the GPU.  `omp` is accepted and
+    ignored (the reference's OpenMP variant shares one generator between threads without synchronisation)."""
+    import time
+
+    host = not isinstance(pts, torch.Tensor)
+    p = _hip.as_dev(pts, torch.float32)
+    if p.dim() != 3 or p.shape[2] != 3:
+        raise ValueError("knn_batch_distance_pick expects (B,N,3) pts")
+    b, n, _ = p.shape
+    bg = np.random.MT19937()
+    bg._legacy_seeding(int(time.time()) if seed is None else int(seed))
+    rnd = torch.from_numpy(bg.random_raw(b * int(nqueries)).astype(np.uint32).view(np.int32)).to(p.device)
+    idx = torch.empty((b, int(nqueries), int(K)), dtype=torch.int64, device=p.device)
+    q = torch.empty((b, int(nqueries), 3), dtype=torch.float32, device=p.device)
+    _hip.launch("pasnl_knn_distance_pick", "knn_batch_distance_pick", b, n, int(nqueries), int(K), _hip.ptr(p), _hip.ptr(rnd),
+                _hip.ptr(idx), _hip.ptr(q))
+    return (idx.cpu().numpy(), q.cpu().numpy()) if host else (idx, q)

@@ -33,6 +33,7 @@ KNN_CASES = [  # (seed, b, n, m, k, kind)
     (301, 4, 1024, 512, 32, "ball"), (302, 4, 512, 128, 64, "ball"), (303, 2, 2048, 256, 16, "cube"),
     (304, 2, 40, 40, 32, "ball"), (305, 2, 300, 64, 8, "cube"),
 ]
+PICK_CASES = [(311, 3, 700, 90, 16, "ball"), (312, 2, 1500, 400, 8, "cube"), (313, 1, 64, 200, 5, "ball")]  # nq > n: counts wrap
 NN_CASES = [(401, 4, 512, 128, "cube"), (402, 2, 2048, 256, "ball"), (403, 2, 320, 80, "lattice"), (404, 2, 10, 2, "cube")]
 FPS_CASES = [(501, 4, 1024, 512, "ball"), (502, 3, 1024, 512, "lattice"), (503, 2, 2500, 300, "lattice"), (504, 6, 512, 128, "cube")]
 GRIDSUB_CASES = [(701, 6000, 0.1, 3, 1), (702, 2500, 0.03, 0, 0), (703, 1500, 0.4, 5, 2)]  # seed, n, sampleDl, fdim, ldim
@@ -56,6 +57,9 @@ def make_cpu():
     for seed, b, n, m, k, kind in KNN_CASES:
         sup = clouds(seed, b, n, kind)
         out[f"knn_{seed}"] = ref.knn_batch(sup, sup[:, :m].copy(), k, omp=False).astype(np.int32)
+    for seed, b, n, nq, k, kind in PICK_CASES:  # cpp_knn_batch_distance_pick with its time(0) seed pinned to `seed`
+        i, q = ref.knn_batch_distance_pick(clouds(seed, b, n, kind), nq, k, seed)
+        out[f"pick_idx_{seed}"], out[f"pick_q_{seed}"] = i.astype(np.int32), q
     np.savez_compressed(os.path.join(HERE, "ref_knn.npz"), **out)
     out = {}
     for seed, b, n, m, kind in NN_CASES:

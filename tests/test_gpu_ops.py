@@ -336,3 +336,22 @@ def test_grid_subsampling(P, n, dl, fdim, ldim, kind):
     assert len(got) == len(want)
     for g, w in zip(got, want):
         np.testing.assert_array_equal(g, w)
+
+
+@pytest.mark.parametrize("b,n,nq,k,kind", [(3, 700, 90, 16, "ball"), (2, 1500, 400, 8, "cube"), (1, 64, 200, 5, "ball"),
+                                          (2, 5000, 64, 32, "ball"), (1, 300, 50, 12, "lattice")])
+def test_knn_batch_distance_pick(b, n, nq, k, kind):
+    """nearest_neighbors.knn_batch_distance_pick (knn.pyx:111-148): picks and neighbour lists equal the oracle's (itself
+    equal to the reference's cpp_knn_batch_distance_pick with the seed pinned: tests/test_oracle_golden.py); numpy in ->
+    numpy out like the reference binding; a fixed seed reproduces, another seed differs."""
+    import pointasnl_amd as P
+
+    x = clouds(900 + n, b, n, kind)
+    want_i, want_q = O.knn_batch_distance_pick(x, nq, k, seed=77)
+    got_i, got_q = P.nearest_neighbors.knn_batch_distance_pick(torch.from_numpy(x).cuda(), nq, k, seed=77)
+    np.testing.assert_array_equal(got_i.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(got_q.cpu().numpy(), want_q)
+    hi, hq = P.nearest_neighbors.knn_batch_distance_pick(x, nq, k, omp=True, seed=77)
+    assert isinstance(hi, np.ndarray) and hi.dtype == np.int64 and (hi == want_i).all() and (hq == want_q).all()
+    other, _ = P.nearest_neighbors.knn_batch_distance_pick(x, nq, k, seed=78)
+    assert (other != want_i).any()

@@ -36,6 +36,17 @@ def test_knn_matches_reference_nanoflann(knn_gold, case):
     np.testing.assert_array_equal(got.astype(np.int32), knn_gold[f"knn_{seed}"])  # tie-free clouds: identical
 
 
+@pytest.mark.parametrize("case", G.PICK_CASES)
+def test_knn_distance_pick_matches_reference(knn_gold, case):
+    """oracle_knn_distance_pick == the reference's cpp_knn_batch_distance_pick (knn_.cxx:136-200) run with its time(0) seed
+    pinned (oracle/shims/ref_knn_shim.cpp overrides time() inside libref_knn.so); the random stream is numpy's MT19937 with
+    legacy seeding == std::mt19937(seed)."""
+    seed, b, n, nq, k, kind = case
+    idx, q = O.knn_batch_distance_pick(clouds(seed, b, n, kind), nq, k, seed)
+    np.testing.assert_array_equal(idx.astype(np.int32), knn_gold[f"pick_idx_{seed}"])
+    np.testing.assert_array_equal(q, knn_gold[f"pick_q_{seed}"])
+
+
 @pytest.mark.parametrize("case", G.NN_CASES)
 def test_three_nn_interpolate_match_reference(interp_gold, case):
     seed, b, n, m, kind = case

@@ -25,7 +25,7 @@ def run(cfg, x, m, iters=20):
         ts.append(e0.elapsed_time(e1) * 1e3)
     return out.cpu().numpy(), float(np.median(ts))
 
-for (b, n, m, cfgs) in [(64, 1024, 512, ["", "s4,4", "a", "b"]), (64, 512, 128, ["", "1,8", "s1,8", "s2,4", "s4,2", "s4,4"]),
+for (b, n, m, cfgs) in [(64, 1024, 512, ["", "4,4", "8,2", "16,2", "2,8", "8,4"]), (64, 512, 128, ["", "1,8", "s1,8", "s2,4", "s4,2", "s4,4"]),
                         (256, 1024, 512, ["", "s4,4", "s2,8"]), (16, 2048, 256, ["", "s4,8", "s2,16"]), (16, 4096, 512, ["", "s4,16"])]:
     for kind in ("ball", "lattice"):
         x_np = B.synth_clouds(3, b, n) if kind == "ball" else clouds(7, b, n, "lattice")
