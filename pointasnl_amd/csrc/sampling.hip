@@ -504,24 +504,21 @@ __global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, co
     }
   }
   __syncthreads();  // everybody has read hist-as-fill-pointers / order: the region becomes best[] + picks[]
-  // the wave's bounding box, inflated by 1e-5 of its size (rounding of the test below)
+  // this LANE's bounding box (its NB consecutive points of the Morton order: a tight cluster), inflated by 1e-5 of its size
+  // (rounding of the test below).  The wave skips a round iff NO lane's box is closer to the pick than that lane's largest
+  // running distance -- tighter than one box per wave, at the same cost (the test is one value per lane either way).
   float blo[3], bhi[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-      bmn[a] = fminf(bmn[a], __shfl_xor(bmn[a], sft));
-      bmx[a] = fmaxf(bmx[a], __shfl_xor(bmx[a], sft));
-    }
     const float pad = 1e-5f * fmaxf(fabsf(bmn[a]), fabsf(bmx[a])) + 1e-30f;
     blo[a] = bmn[a] - pad;
     bhi[a] = bmx[a] + pad;
   }
-  const bool empty_wave = !(bmn[0] <= bmx[0]);
+  const bool empty_lane = !(bmn[0] <= bmx[0]);
   float2* slots = reinterpret_cast<float2*>(best);  // [2][16] {distance bits, ~tie key}
   if (tid == 0) picks[0] = 0;
   float x1 = spt[0], y1 = spt[1], z1 = spt[2];
-  float thr = empty_wave ? -1.f : INFINITY;  // the wave is active while dist^2(p, box) < thr  (= its largest running distance, inflated)
+  float thr = empty_lane ? -1.f : INFINITY;  // the lane is active while dist^2(p, its box) < thr  (= its largest running distance, inflated)
   uint32_t cand_d = PASNL_FPS_ABL == 1 ? (uint32_t)(wave + 1) : 0u, cand_k = 0u;  // the wave's candidate: largest running distance (bits), ~tie key
   __syncthreads();
 
@@ -530,9 +527,9 @@ __global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, co
                 ez = fmaxf(fmaxf(blo[2] - z1, z1 - bhi[2]), 0.f);
     const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
 #if defined(PASNL_TUNING) && PASNL_FPS_ABL == 0
-    if (lane == 0 && (blockIdx.x & 3) == 0) { atomicAdd(&fps_dbg[1], 1ull); if (lb < thr) atomicAdd(&fps_dbg[0], 1ull); }
+    if (lane == 0 && (blockIdx.x & 3) == 0) { atomicAdd(&fps_dbg[1], 1ull); if (__ballot(lb < thr) != 0ull) atomicAdd(&fps_dbg[0], 1ull); }
 #endif
-    if ((PASNL_FPS_ABL == 2 || lb < thr) && PASNL_FPS_ABL != 1) {  // wave-uniform
+    if ((PASNL_FPS_ABL == 2 || __ballot(lb < thr) != 0ull) && PASNL_FPS_ABL != 1) {  // wave-uniform
 #pragma unroll
       for (int q = 0; q < NB / 2; ++q) {
         const f32x2 dx = px[q] - x1, dy = py[q] - y1, dz = pz[q] - z1;
@@ -572,8 +569,8 @@ __global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, co
       }
       cand_d = (uint32_t)wmaxi;
       cand_k = wkey;
-      // no point of this wave changes while dist^2(p, box) >= M (1 + 1e-5): every running distance is <= M
-      thr = __uint_as_float(cand_d) * 1.00001f;
+      // no point of this lane changes while dist^2(p, its box) >= (its largest running distance) (1 + 1e-5)
+      thr = empty_lane ? -1.f : __uint_as_float(bd) * 1.00001f;
     }
     float2* slot = slots + (j & 1) * 16;
     if (lane == 0) slot[wave] = make_float2(__uint_as_float(cand_d), __uint_as_float(cand_k));
