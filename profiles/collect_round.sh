@@ -20,7 +20,8 @@ for cfg in "cls_b64:" "cls_AS_b64:--AS" "sem_seg_b16:--model sem_seg" "sem_seg_r
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$name -o p -f csv -- python bench.py --worker --steps 20 --warmup 5 --no-cpu-baseline $flags > /dev/null 2>&1
   cp $O/prof_$name/p_kernel_stats.csv $O/${TAG}_${name}_kernel_stats.csv 2>/dev/null
 done
-bash profiles/collect_traffic.sh > /dev/null 2>&1
+# (HBM traffic: `bash profiles/collect_traffic.sh` in its OWN gpurun call BEFORE this one, then profiles/pmc_to_traffic.py here
+# and a commit, so that the bench lines below find a traffic.json whose provenance matches the kernels they run)
 bash profiles/collect_mfma_util.sh > $O/${TAG}_mfma_util.log 2>&1; cp $O/mfma_util.json $O/${TAG}_mfma_util.json
 python bench_ops.py --sweep --out $O/${TAG}_bench_ops_sweep.json > $O/${TAG}_bench_ops.log 2>&1
 ls $O | grep ${TAG} | head -30
