@@ -9,14 +9,8 @@ from pointasnl_amd import _hip
 
 
 def three_nn(xyz1, xyz2):
-    '''
-    Input:
-        xyz1: (b,n,3) float32 array, unknown points
-        xyz2: (b,m,3) float32 array, known points
-    Output:
-        dist: (b,n,3) float32 array, distances to known points
-        idx: (b,n,3) int32 array, indices to known points
-    '''
+    '''ThreeNN (tf_interpolate.py:8-18).  For every row of xyz1 (b,n,3) its three nearest rows of xyz2 (b,m,3)
+    -> dist (b,n,3) f32 (squared), idx (b,n,3) int32, nearest first.'''
     xyz1, xyz2 = _hip.as_dev(xyz1, torch.float32), _hip.as_dev(xyz2, torch.float32)
     if xyz1.dim() != 3 or xyz1.shape[2] != 3:
         raise ValueError("ThreeNN expects (b,n,3) xyz1 shape.")
@@ -59,14 +53,8 @@ class _ThreeInterpolate(torch.autograd.Function):
 
 
 def three_interpolate(points, idx, weight):
-    '''
-    Input:
-        points: (b,m,c) float32 array, known points
-        idx: (b,n,3) int32 array, indices to known points
-        weight: (b,n,3) float32 array, weights on known points
-    Output:
-        out: (b,n,c) float32 array, interpolated point values
-    '''
+    '''ThreeInterpolate (tf_interpolate.py:20-30).  out[b,i,:] = sum_j weight[b,i,j] * points[b, idx[b,i,j], :]
+    points (b,m,c), idx (b,n,3) int32, weight (b,n,3) -> (b,n,c).  Differentiable w.r.t. points (tf_interpolate.py:31-35).'''
     points = _hip.as_dev(points, torch.float32)
     idx = _hip.as_dev(idx, torch.int32)
     weight = _hip.as_dev(weight, torch.float32)

@@ -7,16 +7,9 @@ from pointasnl_amd import _hip
 
 
 def query_ball_point(radius, nsample, xyz1, xyz2):
-    '''
-    Input:
-        radius: float32, ball search radius
-        nsample: int32, number of points selected in each ball region
-        xyz1: (batch_size, ndataset, 3) float32 array, input points
-        xyz2: (batch_size, npoint, 3) float32 array, query points
-    Output:
-        idx: (batch_size, npoint, nsample) int32 array, indices to input points
-        pts_cnt: (batch_size, npoint) int32 array, number of unique points in each local region
-    '''
+    '''QueryBallPoint (tf_grouping.py:8-21).  For every query xyz2 (B,npoint,3): the first `nsample` indices (ascending) of
+    xyz1 (B,ndataset,3) closer than `radius`, padded with the first hit.
+    -> idx (B,npoint,nsample) int32, pts_cnt (B,npoint) int32 = hits found (capped at nsample).'''
     if not float(radius) > 0:
         raise ValueError("QueryBallPoint expects positive radius")
     if int(nsample) <= 0:
@@ -36,14 +29,9 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
 
 
 def select_top_k(k, dist):
-    '''
-    Input:
-        k: int32, number of k SMALLEST elements selected
-        dist: (b,m,n) float32 array, distance matrix, m query points, n dataset points
-    Output:
-        idx: (b,m,n) int32 array, first k in n are indices to the top k
-        dist_out: (b,m,n) float32 array, first k in n are the top k
-    '''
+    '''SelectionSort (tf_grouping.py:23-34).  dist (b,m,n) f32, one row of n distances per query -> (idx, dist_out), both
+    (b,m,n): the first k columns hold the k smallest distances, ascending, and where they came from; the rest of the row is
+    whatever the partial selection sort left there (reproduced bit for bit).'''
     if int(k) <= 0:
         raise ValueError("SelectionSort expects positive k")
     dist = _hip.as_dev(dist, torch.float32)
@@ -83,13 +71,8 @@ class _GroupPoint(torch.autograd.Function):
 
 
 def group_point(points, idx):
-    '''
-    Input:
-        points: (batch_size, ndataset, channel) float32 array, points to sample from
-        idx: (batch_size, npoint, nsample) int32 array, indices to points
-    Output:
-        out: (batch_size, npoint, nsample, channel) float32 array, values sampled from points
-    '''
+    '''GroupPoint (tf_grouping.py:36-45): rows idx (B,npoint,nsample) int32 of points (B,ndataset,C) f32
+    -> (B,npoint,nsample,C) f32.  Differentiable w.r.t. points (tf_grouping.py:46-50).'''
     points, idx = _hip.as_dev(points, torch.float32), _hip.as_dev(idx, torch.int32)
     if points.dim() != 3:
         raise ValueError("GroupPoint expects (batch_size, num_points, channel) points shape")
@@ -99,15 +82,8 @@ def group_point(points, idx):
 
 
 def knn_point(k, xyz1, xyz2):
-    '''
-    Input:
-        k: int32, number of k in k-nn search
-        xyz1: (batch_size, ndataset, c) float32 array, input points
-        xyz2: (batch_size, npoint, c) float32 array, query points
-    Output:
-        val: (batch_size, npoint, k) float32 array, L2 distances
-        idx: (batch_size, npoint, k) int32 array, indices to input points
-    '''
+    '''tf_grouping.py:52-73.  k nearest rows of xyz1 (B,ndataset,c) for every row of xyz2 (B,npoint,c)
+    -> val (B,npoint,k) f32 squared distances, idx (B,npoint,k) int32, nearest first.'''
     # Same composition as the reference (tf_grouping.py:58-71): broadcast squared distances, selection
     # sort, slice.  The (b,m,n) tensor is torch plumbing; the sort is the HIP kernel.
     xyz1, xyz2 = _hip.as_dev(xyz1, torch.float32), _hip.as_dev(xyz2, torch.float32)

@@ -10,13 +10,8 @@ from pointasnl_amd import _hip
 
 
 def prob_sample(inp, inpr):
-    '''
-input:
-    batch_size * ncategory float32
-    batch_size * npoints   float32
-returns:
-    batch_size * npoints   int32
-    '''
+    '''ProbSample (tf_sampling.py:13-22): inp (B,ncategory) f32 unnormalised weights, inpr (B,npoints) f32 draws in [0,1)
+    -> (B,npoints) int32, the category each draw falls into (inverse CDF).'''
     inp, inpr = _hip.as_dev(inp, torch.float32), _hip.as_dev(inpr, torch.float32)
     if inp.dim() != 2:
         raise ValueError("ProbSample expects (batch_size,num_choices) inp shape")
@@ -57,13 +52,8 @@ class _GatherPoint(torch.autograd.Function):
 
 
 def gather_point(inp, idx):
-    '''
-input:
-    batch_size * ndataset * 3   float32
-    batch_size * npoints        int32
-returns:
-    batch_size * npoints * 3    float32
-    '''
+    '''GatherPoint (tf_sampling.py:26-35): rows idx (B,npoints) int32 of inp (B,ndataset,3) f32 -> (B,npoints,3) f32.
+    Differentiable w.r.t. inp (scatter-add, tf_sampling.py:37-43).'''
     inp, idx = _hip.as_dev(inp, torch.float32), _hip.as_dev(idx, torch.int32)
     if inp.dim() != 3 or inp.shape[2] != 3:
         raise ValueError("GatherPoint expects (batch_size,num_points,3) inp shape")
@@ -73,13 +63,8 @@ returns:
 
 
 def farthest_point_sample(npoint, inp):
-    '''
-input:
-    int32
-    batch_size * ndataset * 3   float32
-returns:
-    batch_size * npoint         int32
-    '''
+    '''FarthestPointSample (tf_sampling.py:45-54): inp (B,ndataset,3) f32 -> (B,npoint) int32, starting at point 0 and
+    adding the point farthest from the chosen set each time (ties: lowest index).'''
     if int(npoint) <= 0:
         raise ValueError("FarthestPointSample expects positive npoint")
     inp = _hip.as_dev(inp, torch.float32)

@@ -21,12 +21,8 @@ NL_VARIANT = 0  # 0 auto / 1 vector-FMA / 2 MFMA  (pasnl_nl_attention); bench.py
 
 
 def knn_query(k, support_pts, query_pts):
-    """
-    :param support_pts: points you have, B*N1*3
-    :param query_pts: points you want to know the neighbour index, B*N2*3
-    :param k: Number of neighbours in knn search
-    :return: neighbor_idx: neighboring points indexes, B*N2*k   (int32, pointasnl_util.py:22-30)
-    """
+    """Mirror of pointasnl_util.py:22-30.  support_pts (B,N1,3), query_pts (B,N2,3) -> (B,N2,k) int32: for every query the
+    indices of its k nearest support points, nearest first.  No host round trip here: the search is a gfx950 kernel."""
     return nearest_neighbors.knn_batch(support_pts, query_pts, k, omp=True, dtype=torch.int32)
 
 
@@ -36,13 +32,8 @@ def _gather_rows(points, idx):
 
 
 def sampling(npoint, pts, feature=None):
-    '''
-    inputs:
-    npoint: scalar, number of points to sample
-    pointcloud: B * N * D, input point cloud
-    output:
-    sub_pts: B * npoint * D, sub-sampled point cloud
-    '''
+    '''Mirror of pointasnl_util.py:33-49.  Farthest point sampling of `npoint` rows of pts (B,N,D); returns the sampled rows
+    (B,npoint,D), and the same rows of `feature` when it is given.'''
     fps_idx = tf_sampling.farthest_point_sample(npoint, pts)
     if feature is None:
         return _gather_rows(pts, fps_idx)
@@ -50,11 +41,9 @@ def sampling(npoint, pts, feature=None):
 
 
 def grouping(feature, K, src_xyz, q_xyz, use_xyz=True, use_knn=True, radius=0.2):
-    '''
-    K: neighbor size
-    src_xyz: original point xyz (batch_size, ndataset, 3)
-    q_xyz: query point xyz (batch_size, npoint, 3)
-    '''
+    '''Mirror of pointasnl_util.py:51-76.  For every row of q_xyz (B,P,3) its K neighbours among src_xyz (B,N,3) -- kNN, or
+    a ball query of `radius` -- and the gathered coordinates / features (with the coordinates prepended when use_xyz).
+    -> (grouped_xyz (B,P,K,3), grouped_feature (B,P,K,[3+]C), indices (B,P,K))'''
     if use_knn:
         point_indices = knn_query(K, src_xyz, q_xyz)
     else:
@@ -193,13 +182,9 @@ def as_attention(q, kv):
 
 def SampleWeights(new_point, grouped_xyz, mlps, is_training, bn_decay, weight_decay, scope, bn=True, scaled=True,
                   return_logits=False):
-    """Input
-        grouped_feature: (batch_size, npoint, nsample, channel) tensor
-        grouped_xyz: (batch_size, npoint, nsample, 3)
-        new_point: (batch_size, npoint, nsample, channel)
-        Output
-        (batch_size, npoint, nsample, 1)
-    """
+    """Mirror of pointasnl_util.py:112-173.  new_point (B,P,S,C) and grouped_xyz (B,P,S,3) of every group -> the group's
+    re-weighting (B,P,S,mlps[-1]): self-attention among the S neighbours (scaled dot product), the mlps chain, then
+    a softmax over the S neighbours (the logits themselves with return_logits)."""
     if not scaled:
         raise NotImplementedError("scaled=False is never used by the reference models")
     with tf_util.variable_scope(scope):
@@ -340,12 +325,9 @@ def nl_attention(q, kv, variant=None):
 
 def PointNonLocalCell(feature, new_point, mlp, is_training, bn_decay, weight_decay, scope, bn=True, scaled=True,
                       mode='dot', project=True):
-    """Input
-        feature: (batch_size, ndataset, channel) tensor
-        new_point: (batch_size, npoint, nsample, channel)
-        Output
-        (batch_size, npoint, nsample, channel)
-    """
+    """Mirror of pointasnl_util.py:175-219.  Every one of the P sampled points (new_point (B,P,1,C)) attends to ALL N points
+    of the level (feature (B,N,C)) through a mlp[0]-wide bottleneck, and is projected back to mlp[-1] channels
+    -> (B,P,1,mlp[-1]).  project=False stops before the projection (the caller fuses it)."""
     if mode != 'dot' or not scaled:
         raise NotImplementedError("only mode='dot', scaled=True is reachable in the reference models (SURVEY a11)")
     with tf_util.variable_scope(scope):
@@ -475,16 +457,13 @@ def sa_search(xyz, feature, npoint, nsample, use_knn=True, radius=None, knn_all=
 
 def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_decay, weight_decay, scope, bn=True,
                             use_knn=True, radius=None, as_neighbor=8, NL=True, search=None, after_sampling=None):
-    ''' Input:
-            xyz: (batch_size, ndataset, 3) tensor
-            feature: (batch_size, ndataset, channel) tensor
-            point: int32 -- #points sampled in Euclidean space by farthest point sampling
-            nsample: int32 -- how many points in each local region
-            mlp: list of int32 -- output size for MLP on each point
-        Return:
-            new_xyz: (batch_size, npoint, 3) tensor
-            new_points: (batch_size, npoint, mlp[-1] or mlp2[-1]) tensor
-    '''
+    '''Mirror of pointasnl_util.py:221-292: one PointASNL set-abstraction layer.
+        xyz (B,N,3), feature (B,N,C)  ->  new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1])
+    npoint points are sampled (FPS) and moved by AdaptiveSampling over their first `as_neighbor` neighbours; each keeps
+    `nsample` neighbours, which feed the local cell (mlp[:-1], weight net, after_conv); skip connection, the optional
+    Point-NonLocal cell over the whole level, and the aggregation layer follow.
+    search: (new_xyz, None, idx) of sa_search() on the same coordinates (tuple or Forked), computed ahead by the caller;
+    after_sampling: callback(new_xyz) the moment the level's coordinates are final (the caller forks the next searches).'''
     with tf_util.variable_scope(scope):
         batch_size, num_points, num_channel = feature.shape
         # Farthest point sampling + neighbour search (the reference's sampling() / grouping(): pointasnl_util.py:236-242);
@@ -493,7 +472,7 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
         new_feature = feature  # npoint == ndataset (:237-239); otherwise AdaptiveSampling defines it below (:246-247)
         nl_channel = mlp[-1]
 
-        '''Adaptive Sampling'''
+        # ---- adaptive sampling (:244-247)
         if num_points != npoint and as_neighbor == 0:
             # AdaptiveSampling with num_neighbor == 0 takes neighbour 0 of every group (:161-164): one gather kernel
             xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
@@ -578,13 +557,13 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                         _hip.ptr(wb if NL else None), _hip.ptr(bb if NL else None), _hip.ptr(wagg), _hip.ptr(bagg), _hip.ptr(out))
             return new_xyz, out
 
-        '''Point NonLocal Cell'''
+        # ---- non-local cell (:251-255)
         if NL:
             new_nonlocal_point = PointNonLocalCell(feature, new_feature.unsqueeze(1),
                                                    [max(32, num_channel // 2), nl_channel], is_training, bn_decay,
                                                    weight_decay, scope, bn)
 
-        '''Skip Connection'''
+        # ---- skip connection (:257-261)
         skip_spatial = tf_util.conv1d(skip_spatial, mlp[-1], 1, padding='VALID', stride=1, bn=bn,
                                       is_training=is_training, scope='skip', bn_decay=bn_decay,
                                       weight_decay=weight_decay)
@@ -597,7 +576,7 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
         if NL:
             new_point = new_point + new_nonlocal_point
 
-        '''Feature Fushion'''
+        # ---- aggregation (:287-290)
         new_point = tf_util.conv1d(new_point, mlp[-1], 1, padding='VALID', stride=1, bn=bn, is_training=is_training,
                                    scope='aggregation', bn_decay=bn_decay, weight_decay=weight_decay)
         return new_xyz, new_point
@@ -623,16 +602,10 @@ def decode_cell(xyz, feature, idx, weight_decay=None):
 def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_training, bn_decay, weight_decay, scope,
                            bn=True, use_xyz=True, use_knn=True, radius=None, dilate_rate=1, mode='concat', NL=False,
                            nn=None, knn_all=None):
-    ''' Input:
-            xyz1: (batch_size, ndataset1, 3) tensor
-            xyz2: (batch_size, ndataset2, 3) tensor, sparser than xyz1
-            points1: (batch_size, ndataset1, nchannel1) tensor
-            points2: (batch_size, ndataset2, nchannel2) tensor
-            K: int32 -- how many points in each local region
-            mlp: list of int32 -- output size for MLP on each point
-        Return:
-            new_points: (batch_size, ndataset1, mlp[-1]) tensor
-    '''
+    '''Mirror of pointasnl_util.py:294-345: one PointASNL up-sampling layer.
+        dense level xyz1 (B,N1,3) / points1 (B,N1,C1), coarse level xyz2 (B,N2,3) / points2 (B,N2,C2) -> (B,N1,mlp[-1])
+    points2 is carried to the dense level by inverse-distance interpolation over 3 neighbours, the dense level's own
+    local cell over `nsample` neighbours is added, and the mlp chain runs on the sum joined with points1.'''
     if NL:
         raise NotImplementedError("NL=True in the decoder selects mode='concat', never used by the models (SURVEY a11)")
     with tf_util.variable_scope(scope):
@@ -642,7 +615,7 @@ def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_traini
         weight = three_weights(dist)  # pointasnl_util.py:308-311 as one kernel
         interpolated_points = three_interpolate(points2, idx, weight)
 
-        '''Point Local Cell'''
+        # ---- local cell (:322-331)
         if DECODE_CELL_FUSED and use_xyz and use_knn and nsample in (16, 32):
             # self-kNN, both gathers, the centring, the weight net and F^T.G in one kernel (no grouped tensors)
             tf_util._require_inference(is_training)

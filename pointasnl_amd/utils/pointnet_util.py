@@ -13,19 +13,9 @@ from pointasnl_amd import _hip
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
-    '''
-    Input:
-        npoint: int32
-        radius: float32
-        nsample: int32
-        xyz: (batch_size, ndataset, 3) tensor
-        points: (batch_size, ndataset, channel) tensor, if None will just use xyz as points
-        knn: bool, if True use kNN instead of radius search
-        use_xyz: bool, if True concat XYZ with local point features, otherwise just use point features
-    Output:
-        new_xyz: (batch_size, npoint, 3), new_points: (batch_size, npoint, nsample, 3+channel),
-        idx: (batch_size, npoint, nsample), grouped_xyz: (batch_size, npoint, nsample, 3) centred on new_xyz
-    '''
+    '''pointnet_util.py:20-57.  FPS of npoint rows of xyz (B,N,3), then nsample neighbours each (kNN if knn, else ball of
+    `radius`), coordinates made relative to the sampled row; `points` (B,N,C) rows are joined behind them when use_xyz.
+    -> new_xyz (B,npoint,3), new_points (B,npoint,nsample,3+C), idx (B,npoint,nsample), grouped_xyz (B,npoint,nsample,3)'''
     new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
     if knn:
         _, idx = knn_point(nsample, xyz, new_xyz)
