@@ -488,6 +488,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (RCCL init, per-step all-gather, barriers, max-over-ranks) even with "
                          "one rank: a 1-GPU box can then exercise everything but the wire")
+    ap.add_argument("--set", action="append", default=[], metavar="MODULE.FLAG=VALUE",
+                    help="A/B switch of the host mirror for measurements, e.g. --set tf_util.DENSE_ROWS=0 "
+                         "--set pointasnl_util.SA_TAIL_FUSED=0 (modules of pointasnl_amd.utils; the line records them)")
     ap.add_argument("--launch-order", action="store_true",
                     help="add the per-forward sequence of C-ABI launches to the JSON line (profiles/pmc_to_traffic.py uses "
                          "it to attribute rocprofv3 PMC rows to launches)")
@@ -529,6 +532,15 @@ def main():
     from pointasnl_amd import _hip
     from pointasnl_amd.models import pointasnl_cls
     from pointasnl_amd.utils import tf_util, pointasnl_util
+    for item in args.set:  # A/B switches (module-level flags of the host mirror)
+        import ast
+        import importlib
+        target, value = item.split("=", 1)
+        mod, flag = target.rsplit(".", 1)
+        m = importlib.import_module("pointasnl_amd.utils." + mod)
+        if not hasattr(m, flag):
+            raise SystemExit(f"--set {item}: pointasnl_amd.utils.{mod} has no {flag}")
+        setattr(m, flag, ast.literal_eval(value))
     from pointasnl_amd import sharding
 
     _hip.lib()
@@ -738,7 +750,7 @@ def main():
                                 f"configs[{cfg_index}]: pointasnl_{args.model}, {N} pts") + f", batch={B}/GPU, seeded random weights",
                    "global_batch": world * B, "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
                    "rccl_ranks": dist.get_world_size() if multi else 1,
-                   "hip_graph": graph is not None, "pipeline": mode, "outputs_agree": lanes_agree,
+                   "hip_graph": graph is not None, "pipeline": mode, "switches": args.set, "outputs_agree": lanes_agree,
                    "retry_of_stalled_phase": args.retry_of},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -56,6 +56,13 @@ int pasnl_device_count(void);
  * distances in registers, so no workspace is required (m <= 0 -> PASNL_EINVAL as tf_sampling.cpp:99). */
 int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz, int* idx, pasnl_stream_t stream);
 
+/* The same sampling, and the gather of the sampled coordinates in the same launch: new_xyz[b,j,:] = xyz[b, idx[b,j], :]
+ * (bit-equal to pasnl_gather_point on idx).  Replaces the pair farthest_point_sample + gather_point every caller of the
+ * reference runs back to back (pointasnl_util.py:33-49 sampling(), pointnet_util.py:44): the sampler has the picks in
+ * LDS when it ends, so the second launch -- on the critical path of every set-abstraction layer -- disappears. */
+int pasnl_farthest_point_sample_gather(int b, int n, int m, const float* xyz, int* idx, float* new_xyz,
+                                       pasnl_stream_t stream);
+
 /* out[b,j,:] = inp[b, idx[b,j], :] for 3-wide rows.
  * replaces gatherpointLauncher  tf_sampling_g.cu:206-208 (kernel :172-181) */
 int pasnl_gather_point(int b, int n, int m, const float* inp, const int* idx, float* out, pasnl_stream_t stream);
@@ -197,15 +204,51 @@ int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, const float* x
  * (L2-resident), so the (b,m,k,6+c) grouped tensor never exists in HBM.  Also returns the skip connection's
  * reduce_max over the k neighbours: skip_max (b,m,6+c) -- bit-equal to pasnl_sa_group's.
  * out (b*m, c2*32) as pasnl_sa_local_cell.  Replaces two tf.gather_nd, two concats, a subtraction, a reduce_max,
- * three conv2d, a transpose and a batched matmul of the reference graph.  Same shape limits as above. */
+ * three conv2d, a transpose and a batched matmul of the reference graph.  Same shape limits as above.
+ * new_xyz == NULL: the centre of group (b,j) is its own neighbour 0, xyz[b, idx[b,j,0]] -- AdaptiveSampling with
+ * as_neighbor == 0 (pointasnl_util.py:161-163), taken from the tile the kernel gathers anyway, so that the launch does not
+ * wait for pasnl_take_neighbor0 (needs m <= n, else PASNL_EUNSUPPORTED). */
 int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
                   const int* idx, const float* new_xyz, const float* w0, const float* b0, const float* w1,
                   const float* b1, const float* ww, const float* bw, float* out, float* skip_max,
                   pasnl_stream_t stream);
 
+/* pasnl_sa_cell with new_xyz = NULL that ALSO writes what pasnl_take_neighbor0 would have: new_xyz (b,m,3) = the centres and
+ * new_feature (b,m,3+c) = [centre | feature row of neighbour 0] (pointasnl_util.py:161-164) -- the wave that owns a group
+ * holds that row's address anyway.  A set-abstraction layer without adaptive sampling then needs no gather launch between
+ * its neighbour search and its cell.  c <= 128, else PASNL_EUNSUPPORTED. */
+int pasnl_sa_cell_centre0(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
+                          const int* idx, const float* w0, const float* b0, const float* w1, const float* b1,
+                          const float* ww, const float* bw, float* out, float* skip_max, float* new_xyz, float* new_feature,
+                          pasnl_stream_t stream);
+
 /* PointNet set-abstraction pooling (pointnet_util.py:137, tf.reduce_max(new_points, axis=[2], keep_dims=True)):
  * out[b,ch] = max over the n points of x (b,n,c).  The two group_all modules of pointasnl_cls pool 67 + 34 MB. */
 int pasnl_max_pool_rows(int b, int n, int c, const float* x, float* out, pasnl_stream_t stream);
+
+/* The same pooling into rows of a wider table: out[b * out_stride + ch], out_stride >= c -- the two pooled vectors of
+ * pointasnl_cls land side by side in the (B, 1536) input of fc1 (models/pointasnl_cls.py:43-45: the tf.concat is free). */
+int pasnl_max_pool_rows_strided(int b, int n, int c, const float* x, float* out, long out_stride, pasnl_stream_t stream);
+
+/* ------------------------------------------------------------------ dense layers with few rows (csrc/dense.hip) */
+
+/* out (rows,n) = act(x (rows,kdim) . w (kdim,n) + bias), rows <= 128, relu != 0 -> ReLU: the classifier head
+ * (tf_util.fully_connected, tf_util.py:327-365, called at models/pointasnl_cls.py:46-50 with one row per cloud; BN folded
+ * into w / bias by the caller).  A product this thin is cut along n AND along kdim over ~128 workgroups; the K slices meet in
+ * `workspace` and are summed in slice order (bit-reproducible).  kdim % 8 == 0 and x 16-byte aligned, else PASNL_EUNSUPPORTED.
+ * workspace: pasnl_dense_rows_workspace_bytes(rows, kdim, n) bytes of device memory, ZERO-FILLED once by the caller before
+ * its first use (the kernel leaves its counters at zero); one workspace serves one stream at a time. */
+size_t pasnl_dense_rows_workspace_bytes(int rows, int kdim, int n);
+int pasnl_dense_rows(int rows, int kdim, int n, const float* x, const float* w, const float* bias, int relu, float* out,
+                     void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
+
+/* Two projections of NARROW rows in one launch: out_i (rows_i, n_i) = x_i (rows_i, kdim_i) . w_i + bias_i, kdim_i <= 16,
+ * n_i in {32, 64, 128, 256}, no activation: conv_kv and conv_query of the first layer's non-local cell, whose inputs are
+ * coordinates (3 or 6 channels) -- pointasnl_util.py:186-193, two tf_util.conv2d with activation_fn=None.  rows_1 == 0
+ * runs the first job alone.  w_i / bias_i / out_i 16-byte aligned, else PASNL_EUNSUPPORTED. */
+int pasnl_narrow_project2(long rows0, int kdim0, int n0, const float* x0, const float* w0, const float* bias0, float* out0,
+                          long rows1, int kdim1, int n1, const float* x1, const float* w1, const float* bias1, float* out1,
+                          pasnl_stream_t stream);
 
 /* Deterministic backward of gather_point / group_point / three_interpolate: the gradient row of a source point is
  * the sum of its contributions in ascending order of the forward output element -- the order of the reference's

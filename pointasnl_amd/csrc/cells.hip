@@ -646,9 +646,12 @@ struct SaGatherSrc {
   const float* xyz;      // (b,n,3)
   const float* feature;  // (b,n,c), c = w - 6
   const int* idx;        // (b,m,k)
-  const float* new_xyz;  // (b,m,3)
+  const float* new_xyz;  // (b,m,3); with centre0: any readable (b,m,3) array (requested, never used)
   float* skip_max;       // (b,m,w)
   int n, m;
+  int centre0;           // 1: the centre of a group is its neighbour 0, xyz[b, idx[b,j,0]] (AdaptiveSampling with no neighbours)
+  float* new_xyz_out;    // centre0 only, optional: (b,m,3) the centres, and
+  float* new_feature_out;  //                          (b,m,3+c) [centre | feature row of neighbour 0]  (pasnl_take_neighbor0's outputs)
 };
 
 template <int C1, int C2>
@@ -907,6 +910,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   // only that chunk is masked.
   float xr[16];
   float px = 0.f, py = 0.f, pz = 0.f;   // the tile's neighbour coordinates (one row per lane pair)
+  float nf0 = 0.f, nf1 = 0.f;           // centre0 outputs: neighbour 0's feature row, in flight during a group's first tile
   const float* frow = src.feature;       // and its feature row
   // operands [u0, u1) of chunk ch (VEC: whole 16-byte groups); the loops unroll, u0 / u1 are constants at every call
   auto load_part = [&](int ch, int u0, int u1) {
@@ -975,7 +979,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
     // the group after this one (this one again when it is the last: a dummy request)
     const long bi_next = li + step < my_groups ? (xcd_map ? xcd + 8L * cl : (long)cl) : bi;
     const long g_next = li + step < my_groups ? bi_next * m + pj : g;
-    const float cx = cxn, cy = cyn, cz = czn;
+    float cx = cxn, cy = cyn, cz = czn;
     cxn = src.new_xyz[g_next * 3]; cyn = src.new_xyz[g_next * 3 + 1]; czn = src.new_xyz[g_next * 3 + 2];
     for (int c = lane; c < SA_SKIP_REP * sks; c += 64) skp[c] = -INFINITY;
     f32x16 M[C2 / 32];
@@ -1006,6 +1010,21 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) G[r] = 0.f;
 
+      if (src.centre0 && tile == 0) {
+        // the group's centre IS row 0 of its first tile (pointasnl_util.py:161-163): lane 0 holds it -- three readlanes
+        // instead of a (b,m,3) table somebody had to gather first
+        cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), 0));
+        cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), 0));
+        cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), 0));
+        if (src.new_feature_out) {  // neighbour 0's feature row: requested now, stored when the tile's matrix work has issued
+          const unsigned long long fp = reinterpret_cast<unsigned long long>(frow);
+          const float* f0 = reinterpret_cast<const float*>(
+              ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(fp >> 32), 0) << 32) |
+              (unsigned)__builtin_amdgcn_readlane((int)fp, 0));
+          nf0 = f0[min(lane, cf - 1)];
+          nf1 = f0[min(lane + 64, cf - 1)];
+        }
+      }
       const int nfull = wi >> 5;  // chunks whose 32 columns all exist
       if (nfull == 0) mask_chunk(0, xr);
       // internal columns 0..7 = [xyz - centre | xyz | 1 | 0]; the weight net (3 -> 32) rides on the same operands
@@ -1142,6 +1161,16 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
         for (int r = 0; r < 16; ++r) H2[r] = fmaxf(H2[r] + b1r[cb], 0.f);
 #pragma unroll
         for (int t = 0; t < 16; ++t) M[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(H2[t], G[t], M[cb], 0, 0, 0);
+      }
+      if (src.centre0 && tile == 0 && src.new_feature_out) {
+        float* nfo = src.new_feature_out + (size_t)g * (3 + cf);
+        if (lane < 3) {
+          const float v = lane == 0 ? cx : (lane == 1 ? cy : cz);
+          nfo[lane] = v;
+          src.new_xyz_out[(size_t)g * 3 + lane] = v;
+        }
+        if (lane < cf) nfo[3 + lane] = nf0;
+        if (lane + 64 < cf) nfo[3 + lane + 64] = nf1;
       }
       SA_MARK(pt3);
       SA_PROBE(a_conv1 += pt3 - pt2; a_tiles += 1;)
@@ -2027,17 +2056,21 @@ extern "C" int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, con
   return local_cell_dispatch(groups, k, w, c1, c2, x, w0, b0, w1, b1, ww, bw, out, pasnl_hip_stream(stream));
 }
 
-extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
-                             const int* idx, const float* new_xyz, const float* w0, const float* b0, const float* w1,
-                             const float* b1, const float* ww, const float* bw, float* out, float* skip_max,
-                             pasnl_stream_t stream) {
+static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
+                         const int* idx, const float* new_xyz, const float* w0, const float* b0, const float* w1,
+                         const float* b1, const float* ww, const float* bw, float* out, float* skip_max, float* new_xyz_out,
+                         float* new_feature_out, pasnl_stream_t stream) {
   PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && m >= 0 && k > 0 && c1 > 0 && c2 > 0, PASNL_EINVAL);
   PASNL_REQUIRE(k % 32 == 0, PASNL_EUNSUPPORTED);
   const long groups = (long)b * m;
   if (groups == 0) return PASNL_OK;
   PASNL_REQUIRE(groups < (1L << 31), PASNL_EUNSUPPORTED);
-  PASNL_REQUIRE(xyz && feature && idx && new_xyz && w0 && b0 && w1 && b1 && ww && bw && out && skip_max, PASNL_ENULL);
-  SaGatherSrc src{xyz, feature, idx, new_xyz, skip_max, n, m};
+  PASNL_REQUIRE(xyz && feature && idx && w0 && b0 && w1 && b1 && ww && bw && out && skip_max, PASNL_ENULL);
+  // new_xyz == NULL: the centre of a group is its neighbour 0.  The kernel's centre prefetch stays unconditional and is
+  // pointed at xyz, whose b*n*3 floats cover the b*m*3 it touches when m <= n
+  PASNL_REQUIRE(new_xyz || m <= n, PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE(!new_feature_out || c <= 128, PASNL_EUNSUPPORTED);  // two words per lane carry neighbour 0's row
+  SaGatherSrc src{xyz, feature, idx, new_xyz ? new_xyz : xyz, skip_max, n, m, new_xyz ? 0 : 1, new_xyz_out, new_feature_out};
   hipStream_t st = pasnl_hip_stream(stream);
   const int w = 6 + c;
   // 16-byte operand loads need 16-byte aligned feature rows
@@ -2049,6 +2082,23 @@ extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, 
   if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   if (c1 == 128 && c2 == 128) return sa_cell_cfg<128, 128>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   return PASNL_EUNSUPPORTED;
+}
+
+extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
+                             const int* idx, const float* new_xyz, const float* w0, const float* b0, const float* w1,
+                             const float* b1, const float* ww, const float* bw, float* out, float* skip_max,
+                             pasnl_stream_t stream) {
+  return sa_cell_entry(b, n, c, m, k, c1, c2, xyz, feature, idx, new_xyz, w0, b0, w1, b1, ww, bw, out, skip_max, nullptr,
+                       nullptr, stream);
+}
+
+extern "C" int pasnl_sa_cell_centre0(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
+                                     const int* idx, const float* w0, const float* b0, const float* w1, const float* b1,
+                                     const float* ww, const float* bw, float* out, float* skip_max, float* new_xyz,
+                                     float* new_feature, pasnl_stream_t stream) {
+  PASNL_REQUIRE((long)b * m == 0 || (new_xyz && new_feature), PASNL_ENULL);
+  return sa_cell_entry(b, n, c, m, k, c1, c2, xyz, feature, idx, nullptr, w0, b0, w1, b1, ww, bw, out, skip_max, new_xyz,
+                       new_feature, stream);
 }
 
 namespace pasnl {

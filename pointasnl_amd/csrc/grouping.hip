@@ -925,7 +925,8 @@ __global__ __launch_bounds__(256) void take_neighbor0_kernel(int n, int c, int m
 // region (pointnet_util.py:137, tf.reduce_max(new_points, axis=[2])).  One workgroup per (cloud, 64-channel
 // slab): lanes over channels (coalesced 256-byte rows), the 4 waves split the rows, partial maxima meet in LDS.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void max_pool_rows_kernel(int n, int c, const float* __restrict__ x, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void max_pool_rows_kernel(int n, int c, const float* __restrict__ x, float* __restrict__ out,
+                                                            long out_stride) {
   __shared__ float part[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
@@ -941,7 +942,7 @@ __global__ __launch_bounds__(256) void max_pool_rows_kernel(int n, int c, const 
   part[wave][lane] = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
   __syncthreads();
   if (wave == 0 && ok)
-    out[(size_t)blockIdx.y * c + col] = fmaxf(fmaxf(part[0][lane], part[1][lane]), fmaxf(part[2][lane], part[3][lane]));
+    out[(size_t)blockIdx.y * out_stride + col] = fmaxf(fmaxf(part[0][lane], part[1][lane]), fmaxf(part[2][lane], part[3][lane]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1242,13 +1243,19 @@ extern "C" int pasnl_take_neighbor0(int b, int n, int c, int m, int k, const flo
   return pasnl_launch_status();
 }
 
-extern "C" int pasnl_max_pool_rows(int b, int n, int c, const float* x, float* out, pasnl_stream_t stream) {
-  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0, PASNL_EINVAL);
+extern "C" int pasnl_max_pool_rows_strided(int b, int n, int c, const float* x, float* out, long out_stride,
+                                           pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && out_stride >= c, PASNL_EINVAL);
   if (b == 0) return PASNL_OK;
   PASNL_REQUIRE(x && out, PASNL_ENULL);
   PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
-  hipLaunchKernelGGL(max_pool_rows_kernel, dim3((c + 63) / 64, b), dim3(256), 0, pasnl_hip_stream(stream), n, c, x, out);
+  hipLaunchKernelGGL(max_pool_rows_kernel, dim3((c + 63) / 64, b), dim3(256), 0, pasnl_hip_stream(stream), n, c, x, out,
+                     out_stride);
   return pasnl_launch_status();
+}
+
+extern "C" int pasnl_max_pool_rows(int b, int n, int c, const float* x, float* out, pasnl_stream_t stream) {
+  return pasnl_max_pool_rows_strided(b, n, c, x, out, c, stream);
 }
 
 extern "C" int pasnl_select_top_k(int b, int n, int m, int k, const float* dist, int* outi, float* out,

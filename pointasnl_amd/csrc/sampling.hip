@@ -104,9 +104,20 @@ __device__ __forceinline__ void fps_tournament(const int (&td)[PPL], int tid, in
   }
 }
 
+// The sampled coordinates (gather_point of the picks) written by the sampler itself: (m,3) rows of the cloud, copied from
+// the (L2-resident) input so that the bits are the gather's.  picks = the LDS list of the workgroup, complete and visible.
+template <int T>
+__device__ __forceinline__ void fps_emit_xyz(const float* __restrict__ cloud, const int* picks, int m, float* __restrict__ o, int tid) {
+  if (!o) return;
+  for (int f = tid; f < m * 3; f += T) {
+    const int j = f / 3;
+    o[f] = cloud[(size_t)picks[j] * 3 + (f - 3 * j)];
+  }
+}
+
 template <int WAVES, int PPL, int STRIDE>  // STRIDE = floats per LDS point record (4: one b128 read; 3: 10240-point clouds)
 __global__ __launch_bounds__(WAVES * 64) void fps_kernel(int n, int m, const float* __restrict__ xyz,
-                                                        int* __restrict__ idx) {
+                                                        int* __restrict__ idx, float* __restrict__ out_xyz) {
   static_assert(PPL % 2 == 0, "points are processed in packed pairs");
   constexpr int T = WAVES * 64;
   constexpr int NP = PPL / 2;
@@ -184,6 +195,7 @@ __global__ __launch_bounds__(WAVES * 64) void fps_kernel(int n, int m, const flo
   __syncthreads();
   int* out = idx + (size_t)blockIdx.x * m;
   for (int j = tid; j < m; j += T) out[j] = picks[j];
+  fps_emit_xyz<T>(xyz + (size_t)blockIdx.x * n * 3, picks, m, out_xyz ? out_xyz + (size_t)blockIdx.x * m * 3 : nullptr, tid);
 }
 
 
@@ -364,7 +376,7 @@ static int fps_small_launch(int b, int n, int m, const float* xyz, int* idx, hip
 }
 
 template <int WAVES, int PPL>
-static int fps_launch(int b, int n, int m, const float* xyz, int* idx, hipStream_t st) {
+static int fps_launch(int b, int n, int m, const float* xyz, int* idx, hipStream_t st, float* oxyz = nullptr) {
   size_t lds = (size_t)2 * 16 * 8 + (size_t)n * 16 + (size_t)m * 4;
   auto kern = fps_kernel<WAVES, PPL, 4>;
   if (lds > 160 * 1024) {  // fall back to 12-byte records
@@ -377,7 +389,7 @@ static int fps_launch(int b, int n, int m, const float* xyz, int* idx, hipStream
         hipSuccess)
       return PASNL_ELAUNCH;
   }
-  hipLaunchKernelGGL(kern, dim3(b), dim3(WAVES * 64), lds, st, n, m, xyz, idx);
+  hipLaunchKernelGGL(kern, dim3(b), dim3(WAVES * 64), lds, st, n, m, xyz, idx, oxyz);
   return pasnl_launch_status();
 }
 
@@ -409,7 +421,8 @@ __device__ unsigned long long fps_dbg[4];  // [active wave-rounds, wave-rounds]
 #define PASNL_FPS_ABL 0  // tuning builds only: 1 = no wave is ever active (exchange cost alone), 2 = every wave always active
 #endif
 template <int WAVES, int NB>
-__global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, const float* __restrict__ xyz, int* __restrict__ idx) {
+__global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, const float* __restrict__ xyz, int* __restrict__ idx,
+                                                               float* __restrict__ out_xyz) {
   constexpr int T = WAVES * 64;
   constexpr int NCELL = 4096;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -597,10 +610,11 @@ __global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, co
   __syncthreads();
   int* out = idx + (size_t)blockIdx.x * m;
   for (int j = tid; j < m; j += T) out[j] = picks[j];
+  fps_emit_xyz<T>(xyz + (size_t)blockIdx.x * n * 3, picks, m, out_xyz ? out_xyz + (size_t)blockIdx.x * m * 3 : nullptr, tid);
 }
 
 template <int WAVES, int NB>
-static int fps_pruned_launch(int b, int n, int m, const float* xyz, int* idx, hipStream_t st) {
+static int fps_pruned_launch(int b, int n, int m, const float* xyz, int* idx, hipStream_t st, float* oxyz = nullptr) {
   size_t lds = (size_t)n * 12 + (size_t)((n + 1) & ~1) * 2;
   lds = (lds + 15) & ~(size_t)15;
   const size_t tail = (size_t)4096 * 4 > (size_t)(64 + m) * 4 ? (size_t)4096 * 4 : (size_t)(64 + m) * 4;
@@ -610,7 +624,7 @@ static int fps_pruned_launch(int b, int n, int m, const float* xyz, int* idx, hi
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3(b), dim3(WAVES * 64), lds, st, n, m, xyz, idx);
+  hipLaunchKernelGGL(kern, dim3(b), dim3(WAVES * 64), lds, st, n, m, xyz, idx, oxyz);
   return pasnl_launch_status();
 }
 
@@ -735,7 +749,7 @@ extern "C" int pasnl_fps_dbg_read(unsigned long long* host4) {
 }
 #endif
 
-extern "C" int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz, int* idx, pasnl_stream_t stream) {
+static int fps_dispatch(int b, int n, int m, const float* xyz, int* idx, float* oxyz, pasnl_stream_t stream) {
   PASNL_REQUIRE(m > 0, PASNL_EINVAL);  // "FarthestPointSample expects positive npoint"
   PASNL_REQUIRE(b >= 0 && n > 0, PASNL_EINVAL);
   PASNL_REQUIRE(n < (1 << 22), PASNL_EUNSUPPORTED);
@@ -747,7 +761,7 @@ extern "C" int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz
   if (cfg) {
     int w = 0, p = 0;
     if (sscanf(cfg, "%d,%d", &w, &p) == 2 && (long)w * 64 * p >= n) {
-#define PASNL_FPS_TRY(W, P) if (w == W && p == P) return fps_launch<W, P>(b, n, m, xyz, idx, st);
+#define PASNL_FPS_TRY(W, P) if (w == W && p == P) return fps_launch<W, P>(b, n, m, xyz, idx, st, oxyz);
       PASNL_FPS_TRY(1, 2) PASNL_FPS_TRY(1, 4) PASNL_FPS_TRY(1, 8) PASNL_FPS_TRY(1, 16) PASNL_FPS_TRY(2, 4) PASNL_FPS_TRY(2, 8)
       PASNL_FPS_TRY(2, 16) PASNL_FPS_TRY(4, 2) PASNL_FPS_TRY(4, 4) PASNL_FPS_TRY(4, 8) PASNL_FPS_TRY(4, 16) PASNL_FPS_TRY(8, 2)
       PASNL_FPS_TRY(8, 4) PASNL_FPS_TRY(8, 8) PASNL_FPS_TRY(8, 16) PASNL_FPS_TRY(16, 2) PASNL_FPS_TRY(16, 4) PASNL_FPS_TRY(16, 8)
@@ -768,24 +782,34 @@ extern "C" int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz
     }
   }
 #endif
-  if (n <= 128) return fps_launch<1, 2>(b, n, m, xyz, idx, st);
-  if (n <= 256) return fps_launch<1, 4>(b, n, m, xyz, idx, st);
-  if (n <= 512) return fps_launch<1, 8>(b, n, m, xyz, idx, st);
-  if (n <= 1024) return fps_launch<4, 4>(b, n, m, xyz, idx, st);   // measured: (4,4) 192 us vs (1,16) 241 us at B=64, m=512
-  if (n <= 2048) return fps_launch<2, 16>(b, n, m, xyz, idx, st);
+  if (n <= 128) return fps_launch<1, 2>(b, n, m, xyz, idx, st, oxyz);
+  if (n <= 256) return fps_launch<1, 4>(b, n, m, xyz, idx, st, oxyz);
+  if (n <= 512) return fps_launch<1, 8>(b, n, m, xyz, idx, st, oxyz);
+  if (n <= 1024) return fps_launch<4, 4>(b, n, m, xyz, idx, st, oxyz);   // measured: (4,4) 192 us vs (1,16) 241 us at B=64, m=512
+  if (n <= 2048) return fps_launch<2, 16>(b, n, m, xyz, idx, st, oxyz);
   if (!tune_env("PASNL_FPS_NOPRUNE")) {
     // pruned rounds (fps_pruned_kernel): the unpruned kernels below stay as the A/B reference
     int rc = PASNL_EUNSUPPORTED;
-    if (n <= 4096) rc = fps_pruned_launch<16, 4>(b, n, m, xyz, idx, st);
-    else if (n <= 8192) rc = fps_pruned_launch<16, 8>(b, n, m, xyz, idx, st);
-    else if (n <= 10240) rc = fps_pruned_launch<16, 10>(b, n, m, xyz, idx, st);
+    if (n <= 4096) rc = fps_pruned_launch<16, 4>(b, n, m, xyz, idx, st, oxyz);
+    else if (n <= 8192) rc = fps_pruned_launch<16, 8>(b, n, m, xyz, idx, st, oxyz);
+    else if (n <= 10240) rc = fps_pruned_launch<16, 10>(b, n, m, xyz, idx, st, oxyz);
     if (rc != PASNL_EUNSUPPORTED) return rc;
   }
-  if (n <= 4096) return fps_launch<4, 16>(b, n, m, xyz, idx, st);
-  if (n <= 8192) return fps_launch<16, 8>(b, n, m, xyz, idx, st);
-  if (n <= 10240) return fps_launch<16, 10>(b, n, m, xyz, idx, st);
+  if (n <= 4096) return fps_launch<4, 16>(b, n, m, xyz, idx, st, oxyz);
+  if (n <= 8192) return fps_launch<16, 8>(b, n, m, xyz, idx, st, oxyz);
+  if (n <= 10240) return fps_launch<16, 10>(b, n, m, xyz, idx, st, oxyz);
   return PASNL_EUNSUPPORTED;  // > 10240 points/cloud (or cloud + picks > 160 KiB LDS): LDS-resident design limit = the
                               // largest reference config (SemanticKITTI, 10240 points)
+}
+
+extern "C" int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz, int* idx, pasnl_stream_t stream) {
+  return fps_dispatch(b, n, m, xyz, idx, nullptr, stream);
+}
+
+extern "C" int pasnl_farthest_point_sample_gather(int b, int n, int m, const float* xyz, int* idx, float* new_xyz,
+                                                  pasnl_stream_t stream) {
+  PASNL_REQUIRE(b == 0 || new_xyz, PASNL_ENULL);
+  return fps_dispatch(b, n, m, xyz, idx, new_xyz, stream);
 }
 
 static int grid_for(long total) {

@@ -41,17 +41,16 @@ def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, w
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
                                                 scope='layer2', as_neighbor=as_neighbor[1], search=search2[0])
     end_points['l2_xyz'] = l1_xyz  # sic: the reference stores l1_xyz here (pointasnl_cls.py:38)
+    # the two pooled vectors are written side by side into fc1's input: tf.concat([l3_points, l3_points_res]) for free
+    net = torch.empty((batch_size, 1024 + 512), dtype=torch.float32, device=point_cloud.device)
     _, l3_points_res, _ = pointnet_sa_module(l1_xyz, l1_points, npoint=None, radius=None, nsample=None,
                                              mlp=[128, 256, 512], mlp2=None, group_all=True, is_training=is_training,
-                                             bn_decay=bn_decay, scope='layer3_1')
+                                             bn_decay=bn_decay, scope='layer3_1', pooled_out=net[:, 1024:])
     _, l3_points, _ = pointnet_sa_module(l2_xyz, l2_points, npoint=None, radius=None, nsample=None,
                                          mlp=[256, 512, 1024], mlp2=None, group_all=True, is_training=is_training,
-                                         bn_decay=bn_decay, scope='layer3_2')
+                                         bn_decay=bn_decay, scope='layer3_2', pooled_out=net[:, :1024])
 
     # Fully connected layers
-    l3_points = l3_points.reshape(batch_size, -1)
-    l3_points_res = l3_points_res.reshape(batch_size, -1)
-    net = torch.cat([l3_points, l3_points_res], dim=-1)
     net = tf_util.fully_connected(net, 512, bn=True, is_training=is_training, scope='fc1', bn_decay=bn_decay)
     net = tf_util.dropout(net, keep_prob=0.4, is_training=is_training, scope='dp1')
     net = tf_util.fully_connected(net, 256, bn=True, is_training=is_training, scope='fc2', bn_decay=bn_decay)

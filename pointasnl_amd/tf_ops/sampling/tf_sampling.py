@@ -74,3 +74,20 @@ def farthest_point_sample(npoint, inp):
     out = torch.empty((b, int(npoint)), dtype=torch.int32, device=inp.device)
     _hip.launch("pasnl_farthest_point_sample", "FarthestPointSample", b, n, int(npoint), _hip.ptr(inp), _hip.ptr(out))
     return out
+
+
+def farthest_point_sample_gather(npoint, inp):
+    '''farthest_point_sample + gather_point of its picks in ONE launch (not a symbol of the reference module: its callers run
+    the two back to back, pointasnl_util.py:33-49, pointnet_util.py:44).  inp (B,ndataset,3) f32
+    -> idx (B,npoint) int32, new_xyz (B,npoint,3) f32 == gather_point(inp, idx) bit for bit.  No gradient path.'''
+    if int(npoint) <= 0:
+        raise ValueError("FarthestPointSample expects positive npoint")
+    inp = _hip.as_dev(inp, torch.float32)
+    if inp.dim() != 3 or inp.shape[2] != 3:
+        raise ValueError("FarthestPointSample expects (batch_size,num_points,3) inp shape")
+    b, n, _ = inp.shape
+    out = torch.empty((b, int(npoint)), dtype=torch.int32, device=inp.device)
+    new_xyz = torch.empty((b, int(npoint), 3), dtype=torch.float32, device=inp.device)
+    _hip.launch("pasnl_farthest_point_sample_gather", "FarthestPointSample", b, n, int(npoint), _hip.ptr(inp), _hip.ptr(out),
+                _hip.ptr(new_xyz))
+    return out, new_xyz

@@ -10,6 +10,8 @@ What changes underneath (and nothing else):
   * 1x1 convolutions + inference BN are folded GEMMs on the vendor BLAS (tf_util.py here).
 """
 
+import ctypes
+
 import torch
 
 from pointasnl_amd import _hip
@@ -34,10 +36,14 @@ def _gather_rows(points, idx):
 def sampling(npoint, pts, feature=None):
     '''Mirror of pointasnl_util.py:33-49.  Farthest point sampling of `npoint` rows of pts (B,N,D); returns the sampled rows
     (B,npoint,D), and the same rows of `feature` when it is given.'''
-    fps_idx = tf_sampling.farthest_point_sample(npoint, pts)
+    if pts.shape[-1] == 3:
+        fps_idx, sub_pts = tf_sampling.farthest_point_sample_gather(npoint, pts)
+    else:
+        fps_idx = tf_sampling.farthest_point_sample(npoint, pts)
+        sub_pts = _gather_rows(pts, fps_idx)
     if feature is None:
-        return _gather_rows(pts, fps_idx)
-    return _gather_rows(pts, fps_idx), _gather_rows(feature, fps_idx)
+        return sub_pts
+    return sub_pts, _gather_rows(feature, fps_idx)
 
 
 def grouping(feature, K, src_xyz, q_xyz, use_xyz=True, use_knn=True, radius=0.2):
@@ -149,14 +155,25 @@ def sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay
     b, n, c = feature.shape
     _, p, k = idx.shape
     w0, b0, w1, b1, ww, bw, ck = _sa_cell_weights(6 + c, mlp, bn, weight_decay)
-    xyz, feature, idx, new_xyz = xyz.contiguous(), feature.contiguous(), idx.contiguous(), new_xyz.contiguous()
+    xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
     out = torch.empty((b, p, ck, 32), dtype=torch.float32, device=xyz.device)
     skip = torch.empty((b, p, 6 + c), dtype=torch.float32, device=xyz.device)
+    c_out = mlp[0] if len(mlp) == 2 else mlp[1]
+    view = out if c_out == ck else out[:, :, :c_out, :]
+    if new_xyz is None:
+        # the groups' centres are their neighbour 0 (as_neighbor == 0): the kernel takes them from its own tiles and also
+        # returns new_xyz (B,P,3) and new_feature (B,P,3+C) = [centre | neighbour 0's feature row]
+        cen = torch.empty((b, p, 3), dtype=torch.float32, device=xyz.device)
+        nf = torch.empty((b, p, 3 + c), dtype=torch.float32, device=xyz.device)
+        _hip.launch("pasnl_sa_cell_centre0", "sa_cell", b, n, c, p, k, ck, ck, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx),
+                    _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(w1), _hip.ptr(b1), _hip.ptr(ww), _hip.ptr(bw), _hip.ptr(out),
+                    _hip.ptr(skip), _hip.ptr(cen), _hip.ptr(nf))
+        return view, skip, cen, nf
+    new_xyz = new_xyz.contiguous()
     _hip.launch("pasnl_sa_cell", "sa_cell", b, n, c, p, k, ck, ck, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx),
                 _hip.ptr(new_xyz), _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(w1), _hip.ptr(b1), _hip.ptr(ww), _hip.ptr(bw),
                 _hip.ptr(out), _hip.ptr(skip))
-    c_out = mlp[0] if len(mlp) == 2 else mlp[1]
-    return (out if c_out == ck else out[:, :, :c_out, :]), skip
+    return view, skip
 
 
 def weight_net_hidden(xyz, hidden_units, scope, is_training, bn_decay=None, weight_decay=None, activation_fn="relu"):
@@ -323,6 +340,10 @@ def nl_attention(q, kv, variant=None):
     return out
 
 
+CENTRE0 = True  # as_neighbor == 0 layers: the fused cell reads its centres from its own tiles (pasnl_sa_cell, new_xyz = NULL)
+NL_NARROW_PROJECT = True  # False = conv_kv / conv_query of narrow inputs as two vendor GEMMs
+
+
 def PointNonLocalCell(feature, new_point, mlp, is_training, bn_decay, weight_decay, scope, bn=True, scaled=True,
                       mode='dot', project=True):
     """Mirror of pointasnl_util.py:175-219.  Every one of the P sampled points (new_point (B,P,1,C)) attends to ALL N points
@@ -333,6 +354,31 @@ def PointNonLocalCell(feature, new_point, mlp, is_training, bn_decay, weight_dec
     with tf_util.variable_scope(scope):
         bottleneck_channel = mlp[0]
         batch_size, npoint, nsample, channel = new_point.shape
+        if NL_NARROW_PROJECT and feature.shape[-1] <= 16 and channel <= 16 and bottleneck_channel in (32, 64, 128):
+            # coordinates in, keys|values and queries out: both projections as ONE streaming kernel (two GEMMs with K = 3 / 6
+            # are bound by their own start-up); the variables are the ones conv2d creates (scopes conv_kv, conv_query)
+            tf_util._require_inference(is_training)
+            st = tf_util.store()
+            with tf_util.variable_scope('conv_kv'):
+                wkv, bkv = st.layer(feature.shape[-1], 2 * bottleneck_channel, bn, weight_decay)
+            with tf_util.variable_scope('conv_query'):
+                wq, bq = st.layer(channel, bottleneck_channel, bn, weight_decay)
+            n_all = feature.shape[1]
+            feature, new_point = feature.contiguous(), new_point.contiguous()
+            kv = torch.empty((batch_size, n_all, 2 * bottleneck_channel), dtype=torch.float32, device=feature.device)
+            q = torch.empty((batch_size, npoint * nsample, bottleneck_channel), dtype=torch.float32, device=feature.device)
+            _hip.launch("pasnl_narrow_project2", "narrow_project", ctypes.c_long(batch_size * n_all), int(feature.shape[-1]),
+                        2 * bottleneck_channel, _hip.ptr(feature), _hip.ptr(wkv), _hip.ptr(bkv), _hip.ptr(kv),
+                        ctypes.c_long(batch_size * npoint * nsample), int(channel), bottleneck_channel, _hip.ptr(new_point), _hip.ptr(wq),
+                        _hip.ptr(bq), _hip.ptr(q))
+            new_nonlocal_point = nl_attention(q, kv)
+            if not project:
+                return new_nonlocal_point
+            new_nonlocal_point = tf_util.conv2d(
+                new_nonlocal_point.reshape(batch_size, npoint, nsample, bottleneck_channel), mlp[-1], [1, 1],
+                padding='VALID', stride=[1, 1], bn=bn, is_training=is_training, scope='conv_back_project',
+                bn_decay=bn_decay, weight_decay=weight_decay)
+            return new_nonlocal_point.squeeze(1)
         feature = feature.unsqueeze(2)  # (batch_size, ndataset, 1, channel)
         transformed_feature = tf_util.conv2d(feature, bottleneck_channel * 2, [1, 1], padding='VALID', stride=[1, 1],
                                              bn=bn, is_training=is_training, scope='conv_kv', bn_decay=bn_decay,
@@ -392,12 +438,16 @@ class Forked:
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self.value = fn()
+            # the join point is THIS work's end, not whatever else is queued on the side stream by the time .get() runs
+            # (a set-abstraction layer queues the next level's search behind its own small gather)
+            self.done = torch.cuda.Event()
+            self.done.record(side)
         self.stream = side
 
     def get(self):
         # every consumer stream joins (a result may be consumed by the caller's stream AND by another fork)
         if self.stream is not None and torch.cuda.current_stream() != self.stream:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            torch.cuda.current_stream().wait_event(self.done)
         return self.value
 
 
@@ -441,8 +491,7 @@ def sa_search(xyz, feature, npoint, nsample, use_knn=True, radius=None, knn_all=
         return xyz, None, idx
     if use_knn and knn_all is None and OVERLAP and 2 * npoint >= num_points:
         knn_all = Forked(lambda: knn_query(nsample, xyz, xyz), slot=1)
-    fps_idx = tf_sampling.farthest_point_sample(npoint, xyz)
-    new_xyz = _gather_rows(xyz, fps_idx)
+    fps_idx, new_xyz = tf_sampling.farthest_point_sample_gather(npoint, xyz)  # the sampler writes the sampled rows itself
     if use_knn and knn_all is not None:
         k_all = _resolved(knn_all)
         idx = _gather_index_rows(k_all, fps_idx)
@@ -473,13 +522,23 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
         nl_channel = mlp[-1]
 
         # ---- adaptive sampling (:244-247)
+        fused = _local_cell_supported(6 + num_channel, mlp, nsample)
+        centre0 = False  # True: the layer's centres are its groups' neighbour 0 and the fused cell produces them
         if num_points != npoint and as_neighbor == 0:
             # AdaptiveSampling with num_neighbor == 0 takes neighbour 0 of every group (:161-164): one gather kernel
             xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
-            new_xyz = torch.empty((batch_size, npoint, 3), dtype=torch.float32, device=xyz.device)
-            new_feature = torch.empty((batch_size, npoint, 3 + num_channel), dtype=torch.float32, device=xyz.device)
-            _hip.launch("pasnl_take_neighbor0", "take_neighbor0", batch_size, num_points, num_channel, npoint, nsample,
-                        _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx), _hip.ptr(new_xyz), _hip.ptr(new_feature))
+
+            def take0():
+                nx = torch.empty((batch_size, npoint, 3), dtype=torch.float32, device=xyz.device)
+                nf = torch.empty((batch_size, npoint, 3 + num_channel), dtype=torch.float32, device=xyz.device)
+                _hip.launch("pasnl_take_neighbor0", "take_neighbor0", batch_size, num_points, num_channel, npoint, nsample,
+                            _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx), _hip.ptr(nx), _hip.ptr(nf))
+                return nx, nf
+            # the fused cell finds its centres in its own tiles and writes new_xyz / new_feature itself: no gather launch
+            # between the search and the cell (pasnl_sa_cell_centre0)
+            centre0 = CENTRE0 and fused and SA_CELL_GATHER and npoint <= num_points and num_channel <= 128
+            if not centre0:
+                new_xyz, new_feature = take0()
         elif num_points != npoint and AS_FUSED and as_neighbor <= 16:
             tf_util._require_inference(is_training)
             new_xyz, new_feature = adaptive_sampling_fused(xyz, feature, idx, as_neighbor, scope, bn, weight_decay)
@@ -492,17 +551,25 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
             g_pts = torch.cat([g_xyz, tf_grouping.group_point(feature, idx_as)], dim=-1)
             new_xyz, new_feature = AdaptiveSampling(g_xyz, g_pts, as_neighbor, is_training, bn_decay, weight_decay,
                                                     scope, bn)
-        if after_sampling is not None:
+        if after_sampling is not None and not centre0:
             after_sampling(new_xyz)  # the sampled (and shifted) coordinates are final: the caller may start the next search
-        fused = _local_cell_supported(6 + num_channel, mlp, nsample)
         new_point = None
         if fused and SA_CELL_GATHER:
             # grouping + skip max + local cell: one MFMA kernel reading the tables in place
             tf_util._require_inference(is_training)
             try:
-                new_point, skip_spatial = sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay, bn)
+                if centre0:
+                    new_point, skip_spatial, new_xyz, new_feature = sa_cell(xyz, feature, idx, None, mlp, is_training,
+                                                                            bn_decay, weight_decay, bn)
+                else:
+                    new_point, skip_spatial = sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay, bn)
             except _hip.PasnlUnsupported:  # e.g. a row too wide for the LDS-resident weights: two-kernel / op-by-op path
                 new_point = None
+        if centre0:
+            if new_point is None:
+                new_xyz, new_feature = take0()
+            if after_sampling is not None:
+                after_sampling(new_xyz)
         if new_point is None:
             # gather + translation normalisation + both concats + the skip connection's reduce_max: one kernel
             new_point, skip_spatial = sa_group(xyz, feature, idx, new_xyz)

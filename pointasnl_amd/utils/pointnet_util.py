@@ -3,9 +3,11 @@ sample_and_group, sample_and_group_all, pointnet_sa_module (max pooling) and poi
 Inference only, torch device tensors; the native ops are the gfx950 kernels.  The MSG / pooling variants the
 three models never reach are out of scope.
 """
+import ctypes
+
 import torch
 
-from pointasnl_amd.tf_sampling import farthest_point_sample, gather_point
+from pointasnl_amd.tf_sampling import farthest_point_sample, farthest_point_sample_gather, gather_point
 from pointasnl_amd.tf_grouping import query_ball_point, group_point, knn_point
 from pointasnl_amd.tf_interpolate import three_nn, three_interpolate, three_weights
 from pointasnl_amd.utils import tf_util
@@ -16,7 +18,7 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
     '''pointnet_util.py:20-57.  FPS of npoint rows of xyz (B,N,3), then nsample neighbours each (kNN if knn, else ball of
     `radius`), coordinates made relative to the sampled row; `points` (B,N,C) rows are joined behind them when use_xyz.
     -> new_xyz (B,npoint,3), new_points (B,npoint,nsample,3+C), idx (B,npoint,nsample), grouped_xyz (B,npoint,nsample,3)'''
-    new_xyz = gather_point(xyz, farthest_point_sample(npoint, xyz))
+    _, new_xyz = farthest_point_sample_gather(npoint, xyz)
     if knn:
         _, idx = knn_point(nsample, xyz, new_xyz)
     else:
@@ -34,13 +36,21 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
 _GROUP_ALL_CONST = {}
 
 
-def max_pool_points(new_points):
-    """tf.reduce_max(new_points, axis=[2], keep_dims=True) for (B, npoint, nsample, C) (pointnet_util.py:137)."""
+def max_pool_points(new_points, out=None):
+    """tf.reduce_max(new_points, axis=[2], keep_dims=True) for (B, npoint, nsample, C) (pointnet_util.py:137).
+    out: optional (B*npoint, C) float32 view whose rows may be slices of a wider table (unit column stride): the maxima are
+    written there -- the caller's concat of several pooled vectors then costs nothing."""
     b, p, ns, c = new_points.shape
     new_points = new_points.contiguous()
-    out = torch.empty((b, p, 1, c), dtype=torch.float32, device=new_points.device)
-    _hip.launch("pasnl_max_pool_rows", "max_pool_rows", b * p, ns, c, _hip.ptr(new_points), _hip.ptr(out))
-    return out
+    if out is None:
+        out = torch.empty((b, p, 1, c), dtype=torch.float32, device=new_points.device)
+        _hip.launch("pasnl_max_pool_rows", "max_pool_rows", b * p, ns, c, _hip.ptr(new_points), _hip.ptr(out))
+        return out
+    if tuple(out.shape) != (b * p, c) or out.stride(1) != 1 or out.dtype != torch.float32:
+        raise ValueError("max_pool_points: out must be a (B*npoint, C) float32 view with unit column stride")
+    _hip.launch("pasnl_max_pool_rows_strided", "max_pool_rows", b * p, ns, c, _hip.ptr(new_points), _hip.ptr(out),
+                ctypes.c_long(out.stride(0) if b * p > 1 else c))
+    return out.unflatten(0, (b, p)).unsqueeze(2)
 
 
 def sample_and_group_all(xyz, points, use_xyz=True):
@@ -65,7 +75,7 @@ def sample_and_group_all(xyz, points, use_xyz=True):
 
 
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
-                       bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False):
+                       bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False, pooled_out=None):
     ''' PointNet Set Abstraction (SA) Module (pointnet_util.py:87-153), max pooling
         Return:
             new_xyz: (batch_size, npoint, 3), new_points: (batch_size, npoint, mlp[-1] or mlp2[-1]),
@@ -82,7 +92,7 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         for i, num_out_channel in enumerate(mlp):
             new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
                                         is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay)
-        new_points = max_pool_points(new_points)
+        new_points = max_pool_points(new_points, out=pooled_out)
         if mlp2 is not None:
             for i, num_out_channel in enumerate(mlp2):
                 new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,

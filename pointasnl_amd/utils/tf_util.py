@@ -18,6 +18,8 @@ import math
 import numpy as np
 import torch
 
+from pointasnl_amd import _hip
+
 BN_EPS = 1e-3
 FUSE_RELU_EPILOGUE = True
 
@@ -180,11 +182,49 @@ def _act(x, activation_fn):
     return activation_fn(x)
 
 
+DENSE_ROWS = True     # dense layers with <= DENSE_ROWS_MAX rows (the classifier head) on pasnl_dense_rows instead of a vendor GEMM
+DENSE_ROWS_MAX = 128
+_DENSE_WS = {}
+
+
+def _dense_rows_workspace(nbytes, device):
+    """Zero-filled scratch of pasnl_dense_rows, one per (device, stream): a workspace serves one stream at a time, and a
+    captured graph keeps using the buffer it was captured with (entries are never freed or replaced by smaller ones)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _DENSE_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _DENSE_WS[key] = ws
+    return ws
+
+
+def _dense_rows(x2d, w, b, relu):
+    """act(x2d . w + b) for a handful of rows: csrc/dense.hip (K slices over ~128 workgroups, fixed summation order)."""
+    import ctypes
+    rows, cin = x2d.shape
+    cout = w.shape[1]
+    x2d = x2d.contiguous()
+    nbytes = int(_hip.lib().pasnl_dense_rows_workspace_bytes(rows, cin, cout))
+    ws = _dense_rows_workspace(nbytes, x2d.device)
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x2d.device)
+    _hip.launch("pasnl_dense_rows", "dense_rows", rows, cin, cout, _hip.ptr(x2d), _hip.ptr(w), _hip.ptr(b), int(bool(relu)),
+                _hip.ptr(out), _hip.ptr(ws), ctypes.c_size_t(ws.numel()))
+    return out
+
+
 def _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay=None):
     cin = inputs.shape[-1]
     with variable_scope(scope):
         w, b = store().layer(cin, num_output_channels, bn, weight_decay)
     x2d = inputs.reshape(-1, cin)
+    is_relu = activation_fn in ("relu", torch.relu, torch.nn.functional.relu)
+    if (DENSE_ROWS and x2d.is_cuda and 0 < x2d.shape[0] <= DENSE_ROWS_MAX and cin % 8 == 0 and (is_relu or activation_fn is None)
+            and x2d.dtype == torch.float32):
+        try:
+            out = _dense_rows(x2d, w, b, is_relu)
+            return out.reshape(*inputs.shape[:-1], num_output_channels)
+        except _hip.PasnlUnsupported:
+            pass  # e.g. an unaligned view: the vendor GEMM below
     if activation_fn in ("relu", torch.relu, torch.nn.functional.relu) and FUSE_RELU_EPILOGUE:
         # bias + ReLU in the GEMM epilogue (hipBLASLt) instead of a second pass over the output
         out = torch._addmm_activation(b, x2d, w)

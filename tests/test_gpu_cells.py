@@ -478,3 +478,47 @@ def test_launch_refuses_tensors_of_another_device():
         tf_sampling.farthest_point_sample(8, x)
     with torch.cuda.device(1):
         assert tf_sampling.farthest_point_sample(8, x).device.index == 1
+
+
+@pytest.mark.parametrize("b,n,c,m,k,c1", [
+    (3, 300, 3, 70, 32, 64), (2, 256, 128, 40, 64, 128), (17, 128, 32, 50, 32, 32), (2, 200, 64, 200, 96, 64),
+])
+def test_sa_cell_takes_its_centres_from_neighbour_0(b, n, c, m, k, c1):
+    """pasnl_sa_cell with new_xyz = NULL (AdaptiveSampling with as_neighbor == 0, pointasnl_util.py:161-163): the centre of a
+    group is xyz[idx[b,j,0]], read from the kernel's own first tile -- bit-identical to handing it the gathered centres."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    st = _store(b * 13 + c)
+    rng = np.random.default_rng(n + c + 1)
+    xyz = clouds(8, b, n)
+    feat = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, k)).astype(np.int32)
+    centres = xyz[np.arange(b)[:, None], idx[:, :, 0]]
+    with st.scope("L"):
+        want, want_skip = U.sa_cell(dev(xyz), dev(feat), dev(idx), dev(centres), [c1, c1, 2 * c1], False, None, None, True)
+        got, got_skip, cen, nf = U.sa_cell(dev(xyz), dev(feat), dev(idx), None, [c1, c1, 2 * c1], False, None, None, True)
+    assert torch.equal(got, want) and torch.equal(got_skip, want_skip)
+    # ... and it hands back what pasnl_take_neighbor0 computes: the centres and [centre | feature row of neighbour 0]
+    np.testing.assert_array_equal(cen.cpu().numpy(), centres)
+    np.testing.assert_array_equal(nf.cpu().numpy(), np.concatenate([centres, feat[np.arange(b)[:, None], idx[:, :, 0]]], axis=-1))
+
+
+def test_set_abstraction_without_adaptive_sampling_is_the_same_with_and_without_centre0():
+    from pointasnl_amd.utils import pointasnl_util as U, tf_util
+
+    rng = np.random.default_rng(4)
+    xyz = dev(clouds(9, 3, 512))
+    feat = dev(rng.standard_normal((3, 512, 64)).astype(np.float32))
+    outs = []
+    for flag in (True, False):
+        tf_util.set_store(tf_util.VariableStore(seed=31, randomize_bn=True))
+        U.CENTRE0 = flag
+        try:
+            seen = []
+            outs.append(U.PointASNLSetAbstraction(xyz, feat, 128, 32, [64, 64, 128], False, None, None, 'layer', as_neighbor=0,
+                                                  after_sampling=lambda x: seen.append(x)) + (seen[0],))
+        finally:
+            U.CENTRE0 = True
+    torch.cuda.synchronize()
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
