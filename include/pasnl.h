@@ -277,6 +277,13 @@ int pasnl_sa_tail(int rows, int w, int cb, int c, const float* after, const floa
                   const float* bs, const float* wb, const float* bb, const float* wagg, const float* bagg, float* out,
                   pasnl_stream_t stream);
 
+/* pasnl_sa_tail that writes its rows a second time as out_cat (rows, c + 4) = [0 | new_xyz (rows,3) | out]: the
+ * tf.concat([xyz, points]) the next group_all module starts with (pointnet_util.py:77-80, sample_and_group_all), one
+ * zero column in front so that the rows stay 16-byte aligned (the consumer's weights get a zero row in front). */
+int pasnl_sa_tail_cat(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
+                      const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
+                      const float* bagg, float* out, const float* new_xyz, float* out_cat, pasnl_stream_t stream);
+
 /* Decoder local cell (PointASNLDecodingLayer, pointasnl_util.py:323-331): per point p of the dense level with its k
  * nearest neighbours i_s = idx[b,p,s] (self-kNN on xyz):
  *   F = [xyz[i_s] | feature[i_s]] (k,3+c);  G = relu((xyz[i_s]-xyz[p]) Ww + bw) (k,32);  out[b,p] = F^T G  (3+c,32)

@@ -2156,7 +2156,8 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
                                                          const float* __restrict__ Ws, const float* __restrict__ bs,
                                                          const float* __restrict__ Wb, const float* __restrict__ bb,
                                                          const float* __restrict__ Wagg, const float* __restrict__ bagg,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, const float* __restrict__ xyz3,
+                                                         float* __restrict__ out_cat) {
   constexpr int RPW = 32 / NW;  // tile rows a wave stages / writes back
   extern __shared__ float lds[];
   float* vt = lds;                         // [C][33]      V^T, then O^T
@@ -2234,13 +2235,21 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
       const long row = row0 + wave * RPW + i;
       if (row < rows && c < C) out[row * C + c] = v[i];
     }
+    if (out_cat) {  // the same rows again as [0 | xyz | O] (C + 4 wide, 16-byte aligned): the next module's concat for free
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const long row = row0 + wave * RPW + i;
+        if (row < rows && c < C) out_cat[row * (C + 4) + 4 + c] = v[i];
+        if (c0 == 0 && lane < 4 && row < rows) out_cat[row * (C + 4) + lane] = lane ? xyz3[row * 3 + lane - 1] : 0.f;
+      }
+    }
   }
 }
 }  // namespace pasnl
 
-extern "C" int pasnl_sa_tail(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
-                             const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
-                             const float* bagg, float* out, pasnl_stream_t stream) {
+static int sa_tail_entry(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
+                         const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
+                         const float* bagg, float* out, const float* xyz3, float* out_cat, pasnl_stream_t stream) {
   PASNL_REQUIRE(rows >= 0 && w > 0 && cb >= 0 && c > 0, PASNL_EINVAL);
   PASNL_REQUIRE(c % 32 == 0 && c <= 512, PASNL_EUNSUPPORTED);
   if (rows == 0) return PASNL_OK;
@@ -2254,8 +2263,21 @@ extern "C" int pasnl_sa_tail(int rows, int w, int cb, int c, const float* after,
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 31) / 32)), dim3(nw * 64), lds, pasnl_hip_stream(stream), (long)rows, w, cb, c,
-                     after, skip_max, cb ? att : nullptr, ws, bs, wb, bb, wagg, bagg, out);
+                     after, skip_max, cb ? att : nullptr, ws, bs, wb, bb, wagg, bagg, out, xyz3, out_cat);
   return pasnl_launch_status();
+}
+
+extern "C" int pasnl_sa_tail(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
+                             const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
+                             const float* bagg, float* out, pasnl_stream_t stream) {
+  return sa_tail_entry(rows, w, cb, c, after, skip_max, att, ws, bs, wb, bb, wagg, bagg, out, nullptr, nullptr, stream);
+}
+
+extern "C" int pasnl_sa_tail_cat(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
+                                 const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
+                                 const float* bagg, float* out, const float* new_xyz, float* out_cat, pasnl_stream_t stream) {
+  PASNL_REQUIRE(rows == 0 || (new_xyz && out_cat), PASNL_ENULL);
+  return sa_tail_entry(rows, w, cb, c, after, skip_max, att, ws, bs, wb, bb, wagg, bagg, out, new_xyz, out_cat, stream);
 }
 
 extern "C" int pasnl_decode_cell(int b, int n, int c, int k, const float* xyz, const float* feature, const int* idx,

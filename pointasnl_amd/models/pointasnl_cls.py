@@ -33,13 +33,13 @@ def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, w
     search2 = []
     l1_xyz, l1_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=512, nsample=32, mlp=[64, 64, 128],
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
-                                                scope='layer1', as_neighbor=as_neighbor[0], search=search,
+                                                scope='layer1', as_neighbor=as_neighbor[0], search=search, xyz_concat=True,
                                                 after_sampling=lambda xyz1: search2.append(
                                                     Forked(lambda: sa_search(xyz1, None, 128, 64))))
     end_points['l1_xyz'] = l1_xyz
     l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=128, nsample=64, mlp=[128, 128, 256],
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
-                                                scope='layer2', as_neighbor=as_neighbor[1], search=search2[0])
+                                                scope='layer2', as_neighbor=as_neighbor[1], search=search2[0], xyz_concat=True)
     end_points['l2_xyz'] = l1_xyz  # sic: the reference stores l1_xyz here (pointasnl_cls.py:38)
     # the two pooled vectors are written side by side into fc1's input: tf.concat([l3_points, l3_points_res]) for free
     net = torch.empty((batch_size, 1024 + 512), dtype=torch.float32, device=point_cloud.device)

@@ -340,6 +340,7 @@ def nl_attention(q, kv, variant=None):
     return out
 
 
+XYZ_CONCAT = True  # False = ignore xyz_concat requests (the group_all module concatenates itself)
 CENTRE0 = True  # as_neighbor == 0 layers: the fused cell reads its centres from its own tiles (pasnl_sa_cell, new_xyz = NULL)
 NL_NARROW_PROJECT = True  # False = conv_kv / conv_query of narrow inputs as two vendor GEMMs
 
@@ -505,14 +506,18 @@ def sa_search(xyz, feature, npoint, nsample, use_knn=True, radius=None, knn_all=
 
 
 def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_decay, weight_decay, scope, bn=True,
-                            use_knn=True, radius=None, as_neighbor=8, NL=True, search=None, after_sampling=None):
+                            use_knn=True, radius=None, as_neighbor=8, NL=True, search=None, after_sampling=None,
+                            xyz_concat=False):
     '''Mirror of pointasnl_util.py:221-292: one PointASNL set-abstraction layer.
         xyz (B,N,3), feature (B,N,C)  ->  new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1])
     npoint points are sampled (FPS) and moved by AdaptiveSampling over their first `as_neighbor` neighbours; each keeps
     `nsample` neighbours, which feed the local cell (mlp[:-1], weight net, after_conv); skip connection, the optional
     Point-NonLocal cell over the whole level, and the aggregation layer follow.
     search: (new_xyz, None, idx) of sa_search() on the same coordinates (tuple or Forked), computed ahead by the caller;
-    after_sampling: callback(new_xyz) the moment the level's coordinates are final (the caller forks the next searches).'''
+    after_sampling: callback(new_xyz) the moment the level's coordinates are final (the caller forks the next searches).
+    xyz_concat: the caller will feed tf.concat([new_xyz, new_points]) to a group_all module (pointasnl_cls layer3_x): the
+    layer's last kernel then writes those rows as well, and the returned new_points carries them as `.xyz_concat`
+    = (new_xyz, (B,npoint,4+C) table [0 | xyz | points]) for pointnet_util.sample_and_group_all to pick up.'''
     with tf_util.variable_scope(scope):
         batch_size, num_points, num_channel = feature.shape
         # Farthest point sampling + neighbour search (the reference's sampling() / grouping(): pointasnl_util.py:236-242);
@@ -619,9 +624,16 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
             rows = batch_size * npoint
             after, skip_spatial = after.contiguous(), skip_spatial.contiguous()
             out = torch.empty((batch_size, npoint, c_out), dtype=torch.float32, device=xyz.device)
-            _hip.launch("pasnl_sa_tail", "sa_tail", rows, int(w_in), int(cb if NL else 0), int(c_out), _hip.ptr(after),
-                        _hip.ptr(skip_spatial), _hip.ptr(att.contiguous() if NL else None), _hip.ptr(ws), _hip.ptr(bs),
-                        _hip.ptr(wb if NL else None), _hip.ptr(bb if NL else None), _hip.ptr(wagg), _hip.ptr(bagg), _hip.ptr(out))
+            args = (rows, int(w_in), int(cb if NL else 0), int(c_out), _hip.ptr(after), _hip.ptr(skip_spatial),
+                    _hip.ptr(att.contiguous() if NL else None), _hip.ptr(ws), _hip.ptr(bs), _hip.ptr(wb if NL else None),
+                    _hip.ptr(bb if NL else None), _hip.ptr(wagg), _hip.ptr(bagg), _hip.ptr(out))
+            if xyz_concat and XYZ_CONCAT:
+                new_xyz = new_xyz.contiguous()
+                cat = torch.empty((batch_size, npoint, 4 + c_out), dtype=torch.float32, device=xyz.device)
+                _hip.launch("pasnl_sa_tail_cat", "sa_tail", *args, _hip.ptr(new_xyz), _hip.ptr(cat))
+                out.xyz_concat = (new_xyz, cat)
+            else:
+                _hip.launch("pasnl_sa_tail", "sa_tail", *args)
             return new_xyz, out
 
         # ---- non-local cell (:251-255)

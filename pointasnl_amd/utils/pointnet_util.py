@@ -66,7 +66,13 @@ def sample_and_group_all(xyz, points, use_xyz=True):
         _GROUP_ALL_CONST[key] = (new_xyz, idx)
     new_xyz, idx = _GROUP_ALL_CONST[key]
     grouped_xyz = xyz.reshape(batch_size, 1, nsample, 3)
-    if points is not None:
+    pre = getattr(points, "xyz_concat", None) if (points is not None and use_xyz) else None
+    if pre is not None and pre[0] is xyz:
+        # the producer of `points` already wrote [0 | xyz | points] rows (PointASNLSetAbstraction(xyz_concat=True)): one zero
+        # column in front of the reference's concat -- pointnet_sa_module gives its first convolution a matching zero row
+        new_points = pre[1].unsqueeze(1)
+        new_points.input_pad = 1
+    elif points is not None:
         new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
         new_points = new_points.unsqueeze(1)
     else:
@@ -91,7 +97,8 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, knn, use_xyz)
         for i, num_out_channel in enumerate(mlp):
             new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
-                                        is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay)
+                                        is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay,
+                                        input_pad=getattr(new_points, "input_pad", 0) if i == 0 else 0)
         new_points = max_pool_points(new_points, out=pooled_out)
         if mlp2 is not None:
             for i, num_out_channel in enumerate(mlp2):

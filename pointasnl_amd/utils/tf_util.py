@@ -212,10 +212,16 @@ def _dense_rows(x2d, w, b, relu):
     return out
 
 
-def _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay=None):
-    cin = inputs.shape[-1]
+def _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay=None, input_pad=0):
+    cin = inputs.shape[-1] - input_pad
     with variable_scope(scope):
         w, b = store().layer(cin, num_output_channels, bn, weight_decay)
+        if input_pad:  # the first `input_pad` input channels are alignment padding the reference's tensor does not have
+            key = store().path("") + "@pad%d" % input_pad
+            if key not in store()._folded:
+                store()._folded[key] = (torch.cat([w.new_zeros((input_pad, w.shape[1])), w], dim=0).contiguous(), b)
+            w, b = store()._folded[key]
+            cin += input_pad
     x2d = inputs.reshape(-1, cin)
     is_relu = activation_fn in ("relu", torch.relu, torch.nn.functional.relu)
     if (DENSE_ROWS and x2d.is_cuda and 0 < x2d.shape[0] <= DENSE_ROWS_MAX and cin % 8 == 0 and (is_relu or activation_fn is None)
@@ -245,7 +251,7 @@ def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='S
 
 def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], padding='SAME', data_format='NHWC',
            use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn="relu", bn=False, bn_decay=None,
-           is_training=None):
+           is_training=None, input_pad=0):
     """tf_util.py:120-185.  [1,1] kernels, and the [1,W] VALID kernel that collapses the whole W axis
     (pointasnl_util.py:275, 337): inputs (B,H,W,C) -> (B,H,1,cout) == one GEMM over the flattened (W,C) window."""
     _require_inference(is_training)
@@ -253,7 +259,7 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], paddi
     if data_format != 'NHWC' or kh != 1:
         raise NotImplementedError("conv2d mirror supports NHWC, kernel height 1")
     if kw == 1:
-        return _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay)
+        return _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay, input_pad=input_pad)
     if padding != 'VALID' or kw != inputs.shape[2]:
         raise NotImplementedError("conv2d mirror supports [1,1] or the full-width VALID kernel")
     b, h, w, c = inputs.shape

@@ -522,3 +522,28 @@ def test_set_abstraction_without_adaptive_sampling_is_the_same_with_and_without_
     torch.cuda.synchronize()
     for a, b_ in zip(*outs):
         assert torch.equal(a, b_)
+
+
+def test_set_abstraction_can_write_the_next_modules_concat():
+    """xyz_concat=True: the layer's tail kernel also writes [0 | new_xyz | new_points] rows and the group_all module that
+    follows (pointasnl_cls layer3_x) consumes them instead of concatenating -- same numbers as the plain path."""
+    from pointasnl_amd.utils import pointasnl_util as U, pointnet_util as PU, tf_util
+
+    rng = np.random.default_rng(14)
+    xyz = dev(clouds(19, 40, 256))
+    feat = dev(rng.standard_normal((40, 256, 32)).astype(np.float32))
+    res = []
+    for flag in (True, False):
+        tf_util.set_store(tf_util.VariableStore(seed=77, randomize_bn=True))
+        new_xyz, pts = U.PointASNLSetAbstraction(xyz, feat, 64, 32, [32, 32, 64], False, None, None, 'layer1', as_neighbor=0,
+                                                 xyz_concat=flag)
+        assert hasattr(pts, "xyz_concat") == flag
+        if flag:
+            cat = pts.xyz_concat[1]
+            assert pts.xyz_concat[0] is new_xyz and cat.shape == (40, 64, 4 + 64)
+            want = torch.cat([torch.zeros_like(new_xyz[..., :1]), new_xyz, pts], dim=-1)
+            assert torch.equal(cat, want)
+        _, pooled, _ = PU.pointnet_sa_module(new_xyz, pts, None, None, None, [64, 128], None, True, False, None, 'layer3')
+        res.append((pts, pooled))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.allclose(res[0][1], res[1][1], rtol=1e-5, atol=1e-5)
