@@ -2150,6 +2150,13 @@ __device__ __forceinline__ f32x16 tail_product(const TailW& W, const float* __re
   return acc;
 }
 
+#ifdef PASNL_TUNING  // timing ablations of sa_tail (tools/tail_probe.py): bit 0 no tile loads, 1 no stage 1, 2 no stage 2, 3 no stores
+#define TAIL_ABL_PARAM , int abl
+#define TAIL_ABL(bit) (abl & (1 << (bit)))
+#else
+#define TAIL_ABL_PARAM
+#define TAIL_ABL(bit) 0
+#endif
 template <int NW>  // waves per workgroup = 32-channel output blocks in flight (one per wave): C <= 32 NW
 __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int cb, int C, const float* __restrict__ A,
                                                          const float* __restrict__ S, const float* __restrict__ N,
@@ -2157,7 +2164,7 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
                                                          const float* __restrict__ Wb, const float* __restrict__ bb,
                                                          const float* __restrict__ Wagg, const float* __restrict__ bagg,
                                                          float* __restrict__ out, const float* __restrict__ xyz3,
-                                                         float* __restrict__ out_cat) {
+                                                         float* __restrict__ out_cat TAIL_ABL_PARAM) {
   constexpr int RPW = 32 / NW;  // tile rows a wave stages / writes back
   extern __shared__ float lds[];
   float* vt = lds;                         // [C][33]      V^T, then O^T
@@ -2183,14 +2190,16 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
       }
     }
   };
-  stage(A, C, C, vt);
-  stage(S, w, wp, st);
-  if (N) stage(N, cb, cbp, nt_);
+  if (!TAIL_ABL(0)) {
+    stage(A, C, C, vt);
+    stage(S, w, wp, st);
+    if (N) stage(N, cb, cbp, nt_);
+  }
   __syncthreads();
   // ---- stage 1: V^T += relu(Ws^T S^T + bs) + relu(Wb^T N^T + bb); wave = channel block
   const int cbase = wave * 32;
   const bool mine = wave < nblk;
-  if (mine) {
+  if (mine && !TAIL_ABL(1)) {
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = bs[cbase + kappa(i, h)];
@@ -2217,7 +2226,7 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
   if (mine) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = bagg[cbase + kappa(i, h)];
-    o = tail_product(TailW{Wagg + cbase + l32, C, C, h}, vt, l32, o);
+    if (!TAIL_ABL(2)) o = tail_product(TailW{Wagg + cbase + l32, C, C, h}, vt, l32, o);
   }
   __syncthreads();  // every wave has read V^T: the tile becomes O^T
   if (mine) {
@@ -2233,7 +2242,7 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const long row = row0 + wave * RPW + i;
-      if (row < rows && c < C) out[row * C + c] = v[i];
+      if (row < rows && c < C && !(TAIL_ABL(3) && v[i] != 12345.f)) out[row * C + c] = v[i];
     }
     if (out_cat) {  // the same rows again as [0 | xyz | O] (C + 4 wide, 16-byte aligned): the next module's concat for free
 #pragma unroll
@@ -2247,6 +2256,11 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
 }
 }  // namespace pasnl
 
+#ifdef PASNL_TUNING
+#define TAIL_ABL_ARG , (tune_env("PASNL_TAIL_ABL") ? atoi(tune_env("PASNL_TAIL_ABL")) : 0)
+#else
+#define TAIL_ABL_ARG
+#endif
 static int sa_tail_entry(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
                          const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
                          const float* bagg, float* out, const float* xyz3, float* out_cat, pasnl_stream_t stream) {
@@ -2263,7 +2277,7 @@ static int sa_tail_entry(int rows, int w, int cb, int c, const float* after, con
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 31) / 32)), dim3(nw * 64), lds, pasnl_hip_stream(stream), (long)rows, w, cb, c,
-                     after, skip_max, cb ? att : nullptr, ws, bs, wb, bb, wagg, bagg, out, xyz3, out_cat);
+                     after, skip_max, cb ? att : nullptr, ws, bs, wb, bb, wagg, bagg, out, xyz3, out_cat TAIL_ABL_ARG);
   return pasnl_launch_status();
 }
 
