@@ -323,6 +323,13 @@ int pasnl_as_cell_narrow(int g, int as, int cb, int w, int ch, const float* x, c
  *   (any cb <= 144: the reference's widths are (3 + c) / 2 = 33, 65, ...), x (g,as,w) the gathered rows (for the re-weighted sums) -> new_xyz (g,3), new_feature (g,ch). */
 int pasnl_as_cell_wide(int g, int as, int cb, int w, int ch, const float* kvq, const float* x, const float* wa, const float* ba,
                        const float* wb, const float* bb, float* new_xyz, float* new_feature, pasnl_stream_t stream);
+
+/* pasnl_as_cell_wide on projection rows that are WIDER than 3 cb: kvq (g*as, ld), ld >= 3 cb, columns [K | V | Q | unused].
+ * The reference's bottleneck widths are (3 + c) / 2 = 33, 65, ...: a GEMM with N = 195 runs at 38 TF where N = 224 runs at
+ * 82 (measured, 98304 x 134 inputs), so the Python mirror pads the projection's weights with zero columns. */
+int pasnl_as_cell_wide_ld(int g, int as, int cb, int w, int ch, const float* kvq, int ld, const float* x, const float* wa,
+                          const float* ba, const float* wb, const float* bb, float* new_xyz, float* new_feature,
+                          pasnl_stream_t stream);
 int pasnl_as_reweight_x(int g, int as, int ch, const float* logits, const float* x, float* new_xyz, float* new_feature,
                         pasnl_stream_t stream);
 

@@ -1720,11 +1720,11 @@ namespace pasnl {
 // ---------------------------------------------------------------------------------------------
 template <int CBLK>  // cb <= 16 * CBLK (the reference's bottleneck widths are (3 + c) / 2: 33, 65, ... -- any cb works)
 __global__ __launch_bounds__(256) void as_cell_wide_kernel(long groups, int as, int cb, int w, int ch, float qscale,
-                                                          const float* __restrict__ kvq, const float* __restrict__ x,
+                                                          const float* __restrict__ kvq, int ld, const float* __restrict__ x,
                                                           const float* __restrict__ wa, const float* __restrict__ ba,
                                                           const float* __restrict__ wb, const float* __restrict__ bb,
                                                           float* __restrict__ new_xyz, float* __restrict__ new_feature) {
-  const int cb3 = 3 * cb;
+  const int cb3 = ld;  // row stride of kvq: 3 cb, or more when the projection GEMM was given a rounder width
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Wbs = reinterpret_cast<float*>(smem);  // [32][nout]
   const int nout = 1 + ch;
@@ -1838,10 +1838,10 @@ __global__ __launch_bounds__(256) void as_cell_wide_kernel(long groups, int as, 
 }
 }  // namespace pasnl
 
-extern "C" int pasnl_as_cell_wide(int g, int as, int cb, int w, int ch, const float* kvq, const float* x, const float* wa,
-                                  const float* ba, const float* wb, const float* bb, float* new_xyz, float* new_feature,
-                                  pasnl_stream_t stream) {
-  PASNL_REQUIRE(g >= 0 && as > 0 && cb > 0 && w > 0 && ch > 0, PASNL_EINVAL);
+extern "C" int pasnl_as_cell_wide_ld(int g, int as, int cb, int w, int ch, const float* kvq, int ld, const float* x,
+                                     const float* wa, const float* ba, const float* wb, const float* bb, float* new_xyz,
+                                     float* new_feature, pasnl_stream_t stream) {
+  PASNL_REQUIRE(g >= 0 && as > 0 && cb > 0 && w > 0 && ch > 0 && ld >= 3 * cb, PASNL_EINVAL);
   PASNL_REQUIRE(as <= 16 && cb <= 144 && w == 3 + ch, PASNL_EUNSUPPORTED);
   if (g == 0) return PASNL_OK;
   PASNL_REQUIRE(kvq && x && wa && ba && wb && bb && new_xyz && new_feature, PASNL_ENULL);
@@ -1859,7 +1859,7 @@ extern "C" int pasnl_as_cell_wide(int g, int as, int cb, int w, int ch, const fl
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                (int)lds) != hipSuccess)                                                    \
       return PASNL_ELAUNCH;                                                                                                \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, (long)g, as, cb, w, ch, qscale, kvq, x, wa, ba, wb, bb, new_xyz,        \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, (long)g, as, cb, w, ch, qscale, kvq, ld, x, wa, ba, wb, bb, new_xyz,    \
                        new_feature);                                                                                       \
   } while (0)
   const int cblk = (cb + 15) / 16;
@@ -1867,6 +1867,12 @@ extern "C" int pasnl_as_cell_wide(int g, int as, int cb, int w, int ch, const fl
   else if (cblk == 5) PASNL_AS_GO(5); else if (cblk <= 7) PASNL_AS_GO(7); else PASNL_AS_GO(9);
 #undef PASNL_AS_GO
   return pasnl_launch_status();
+}
+
+extern "C" int pasnl_as_cell_wide(int g, int as, int cb, int w, int ch, const float* kvq, const float* x, const float* wa,
+                                  const float* ba, const float* wb, const float* bb, float* new_xyz, float* new_feature,
+                                  pasnl_stream_t stream) {
+  return pasnl_as_cell_wide_ld(g, as, cb, w, ch, kvq, 3 * cb, x, wa, ba, wb, bb, new_xyz, new_feature, stream);
 }
 
 extern "C" int pasnl_as_cell_narrow(int g, int as, int cb, int w, int ch, const float* x, const float* wkvq, const float* bkvq,

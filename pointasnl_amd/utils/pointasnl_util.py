@@ -303,11 +303,20 @@ def adaptive_sampling_fused(xyz, feature, idx, num_neighbor, scope, bn, weight_d
                 wa, ba = st.layer(cb, 32, bn, weight_decay)
             with tf_util.variable_scope('mlp2_1'):
                 wb, bb = st.layer(32, 1 + channel, bn, weight_decay)
-            kvq = torch.addmm(bkvq, x.reshape(-1, 6 + c), wkvq)  # (B*P*as, 3cb) = [K | V | Q]
+            # the projection's width 3 cb is odd-sized (cb = (3 + c) // 2: 195 columns at cls layer2) and the vendor GEMM
+            # falls off a cliff there (135 us at N = 195, 74 us at N = 224): zero columns round it up to a multiple of 32
+            ld = (3 * cb + 31) // 32 * 32 if AS_PAD_PROJECTION else 3 * cb
+            if ld != 3 * cb:
+                pkey = key + "@ld%d" % ld
+                if pkey not in st._folded:
+                    st._folded[pkey] = (torch.cat([wkvq, wkvq.new_zeros((6 + c, ld - 3 * cb))], dim=1).contiguous(),
+                                        torch.cat([bkvq, bkvq.new_zeros(ld - 3 * cb)]).contiguous())
+                wkvq, bkvq = st._folded[pkey]
+            kvq = torch.addmm(bkvq, x.reshape(-1, 6 + c), wkvq)  # (B*P*as, ld) = [K | V | Q | -]
             new_xyz = torch.empty((b, p, 3), dtype=torch.float32, device=xyz.device)
             new_feature = torch.empty((b, p, channel), dtype=torch.float32, device=xyz.device)
-            _hip.launch("pasnl_as_cell_wide", "as_cell", b * p, as_, cb, 6 + c, channel, _hip.ptr(kvq), _hip.ptr(x), _hip.ptr(wa),
-                        _hip.ptr(ba), _hip.ptr(wb), _hip.ptr(bb), _hip.ptr(new_xyz), _hip.ptr(new_feature))
+            _hip.launch("pasnl_as_cell_wide_ld", "as_cell", b * p, as_, cb, 6 + c, channel, _hip.ptr(kvq), int(ld), _hip.ptr(x),
+                        _hip.ptr(wa), _hip.ptr(ba), _hip.ptr(wb), _hip.ptr(bb), _hip.ptr(new_xyz), _hip.ptr(new_feature))
             return new_xyz, new_feature
         att = torch.empty((b, p, as_, cb), dtype=torch.float32, device=xyz.device)
         if AS_PROJ_FUSED and 6 + c <= 15 and cb in (32, 64):
@@ -340,6 +349,7 @@ def nl_attention(q, kv, variant=None):
     return out
 
 
+AS_PAD_PROJECTION = True  # AdaptiveSampling, wide layers: [K | V | Q] projection padded to a multiple of 32 columns
 XYZ_CONCAT = True  # False = ignore xyz_concat requests (the group_all module concatenates itself)
 CENTRE0 = True  # as_neighbor == 0 layers: the fused cell reads its centres from its own tiles (pasnl_sa_cell, new_xyz = NULL)
 NL_NARROW_PROJECT = True  # False = conv_kv / conv_query of narrow inputs as two vendor GEMMs
