@@ -109,9 +109,10 @@ def synth_kitti(seed, b, n):
 # ---- algorithmic work per launch, SURVEY.md 8(d).  ints = the integer arguments of the C-ABI call.
 def algorithmic(symbol, ints):
     """-> (bytes, flops, bound) for one launch"""
-    if symbol == "pasnl_farthest_point_sample":
+    if symbol in ("pasnl_farthest_point_sample", "pasnl_farthest_point_sample_gather"):
         b, n, m = ints
-        return 12 * b * n + 4 * b * m, 10 * b * n * m, "latency"  # m dependent rounds per cloud: HBM fraction ~0 by construction
+        out = 4 * b * m + (12 * b * m if symbol.endswith("_gather") else 0)
+        return 12 * b * n + out, 10 * b * n * m, "latency"  # m dependent rounds per cloud: HBM fraction ~0 by construction
     if symbol == "pasnl_gather_point":
         b, n, m = ints
         return 28 * b * m, 0, "hbm"
@@ -146,20 +147,29 @@ def algorithmic(symbol, ints):
         g, k, w, c1, c2 = ints
         # reads the grouped points once, writes (c2 x 32) per group; weights are LDS-resident
         return 4 * (g * k * w + g * c2 * 32 + w * c1 + c1 * c2), g * (2 * k * (w * c1 + c1 * c2 + 3 * 32) + 2 * c2 * k * 32), "mfma"
-    if symbol == "pasnl_sa_cell":
+    if symbol in ("pasnl_sa_cell", "pasnl_sa_cell_centre0"):
         b, n, c, m, k, c1, c2 = ints
         g, w = b * m, 6 + c
         # reads the tables, the indices and the centres once; writes (c2 x 32) per group + the skip maxima
-        return (4 * (b * n * (3 + c) + g * k + 3 * g + g * c2 * 32 + g * w + w * c1 + c1 * c2),
+        # (centre0: no centre table to read; the centres and neighbour 0's feature rows are written instead)
+        centres = 3 * g if symbol == "pasnl_sa_cell" else 3 * g + (3 + c) * g
+        return (4 * (b * n * (3 + c) + g * k + centres + g * c2 * 32 + g * w + w * c1 + c1 * c2),
                 g * (2 * k * (w * c1 + c1 * c2 + 3 * 32) + 2 * c2 * k * 32), "mfma")
-    if symbol == "pasnl_sa_tail":
+    if symbol in ("pasnl_sa_tail", "pasnl_sa_tail_cat"):
         rows, w, cb, c = ints
-        return 4 * (rows * (2 * c + w + cb) + c * (w + cb + c)), 2 * rows * c * (w + cb + c), "mfma"
+        extra = rows * (c + 4 + 3) if symbol.endswith("_cat") else 0
+        return 4 * (rows * (2 * c + w + cb) + c * (w + cb + c) + extra), 2 * rows * c * (w + cb + c), "mfma"
+    if symbol == "pasnl_dense_rows":
+        rows, k, n, _relu = ints
+        return 4 * (rows * k + k * n + n + rows * n), 2 * rows * k * n, "latency"  # ~0.1 GFLOP: bound by its own start-up
+    if symbol == "pasnl_narrow_project2":
+        r0, k0, n0, r1, k1, n1 = ints
+        return 4 * (r0 * (k0 + n0) + r1 * (k1 + n1)), 2 * (r0 * k0 * n0 + r1 * k1 * n1), "hbm"
     if symbol == "pasnl_decode_cell":
         b, n, c, k = ints
         return 4 * b * n * (3 + c + k + (3 + c) * 32), 2 * b * n * k * ((3 + c) * 32 + 3 * 32), "hbm"
-    if symbol == "pasnl_max_pool_rows":
-        b, n, c = ints
+    if symbol in ("pasnl_max_pool_rows", "pasnl_max_pool_rows_strided"):
+        b, n, c = ints[:3]
         return 4 * b * c * (n + 1), 0, "hbm"
     if symbol == "pasnl_as_reweight":
         g, as_, ns, ch = ints
@@ -490,7 +500,8 @@ def main():
                          "one rank: a 1-GPU box can then exercise everything but the wire")
     ap.add_argument("--set", action="append", default=[], metavar="MODULE.FLAG=VALUE",
                     help="A/B switch of the host mirror for measurements, e.g. --set tf_util.DENSE_ROWS=0 "
-                         "--set pointasnl_util.SA_TAIL_FUSED=0 (modules of pointasnl_amd.utils; the line records them)")
+                         "--set pointasnl_util.SA_TAIL_FUSED=0 (modules of pointasnl_amd.utils, or _hip.LIB_PATH='<another build>'; "
+                         "the line records them)")
     ap.add_argument("--launch-order", action="store_true",
                     help="add the per-forward sequence of C-ABI launches to the JSON line (profiles/pmc_to_traffic.py uses "
                          "it to attribute rocprofv3 PMC rows to launches)")
@@ -537,9 +548,9 @@ def main():
         import importlib
         target, value = item.split("=", 1)
         mod, flag = target.rsplit(".", 1)
-        m = importlib.import_module("pointasnl_amd.utils." + mod)
+        m = importlib.import_module("pointasnl_amd." + mod if mod == "_hip" else "pointasnl_amd.utils." + mod)
         if not hasattr(m, flag):
-            raise SystemExit(f"--set {item}: pointasnl_amd.utils.{mod} has no {flag}")
+            raise SystemExit(f"--set {item}: {m.__name__} has no {flag}")
         setattr(m, flag, ast.literal_eval(value))
     from pointasnl_amd import sharding
 

@@ -105,7 +105,7 @@ def launch(symbol, what, *args):
     code = fn(*args, stream_ptr())
     e1.record()
     check(code, what)
-    PROFILE.append((symbol, tuple(a for a in args if isinstance(a, int)), e0, e1))
+    PROFILE.append((symbol, tuple(a if isinstance(a, int) else a.value for a in args if isinstance(a, (int, ctypes.c_long))), e0, e1))
 
 
 def check(code, what):
