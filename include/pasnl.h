@@ -293,6 +293,18 @@ int pasnl_sa_tail_cat(int rows, int w, int cb, int c, const float* after, const 
 int pasnl_decode_cell(int b, int n, int c, int k, const float* xyz, const float* feature, const int* idx, const float* ww,
                       const float* bw, float* out, pasnl_stream_t stream);
 
+/* The same cell with its (3+c)*32 output values per point in a TILED order, for a consumer that contracts all of them (the
+ * `decode_after_conv` GEMM with its weight rows permuted to match): 4 full-width 1-KiB stores per 32-channel tile instead
+ * of 16 256-byte ones and, for c % 128 == 0, one 16-byte feature load per neighbour and 128 features instead of four 4-byte
+ * ones -- the plain kernel is bound by the vector-memory instructions it issues, not by bytes.  Position q of a point holds
+ *     q < 96:                                        channel q / 32 (a coordinate), j = q % 32          (reference order)
+ *     q = 96 + T*1024 + (2g+h)*128 + 4m + i:         channel 3 + 32 V (T / V) + V m + T % V,   j = 8g + 4h + i
+ * with V = pasnl_decode_cell_tiled_v4(c, feature) ? 4 : 1, g < 4, h < 2, m < 32, i < 4.  k == 16 and c % 32 == 0, else
+ * PASNL_EUNSUPPORTED. */
+int pasnl_decode_cell_tiled(int b, int n, int c, int k, const float* xyz, const float* feature, const int* idx,
+                            const float* ww, const float* bw, float* out, pasnl_stream_t stream);
+int pasnl_decode_cell_tiled_v4(int c, const float* feature);
+
 /* AdaptiveSampling with as_neighbor == 0 (pointasnl_util.py:161-164): new_xyz (b,m,3) = xyz[idx[b,j,0]] and
  * new_feature (b,m,3+c) = [xyz | feature][idx[b,j,0]], idx (b,m,k) the neighbour indices of the layer. */
 int pasnl_take_neighbor0(int b, int n, int c, int m, int k, const float* xyz, const float* feature, const int* idx,

@@ -69,6 +69,12 @@ __device__ unsigned long long nl_probe[16];
 #define SA_WAIT_VM()
 #define SA_PROBE(...)
 #endif
+// streaming (non-temporal) stores of the cell's (C2 x 32)-per-group output: written once, read by the next kernel from HBM
+// anyway, and without the hint 67-268 MB per launch wash through every XCD's L2 (cls step 1.497 -> 1.483 ms; the cell itself
+// takes the same time)
+#ifndef PASNL_SA_NT
+#define PASNL_SA_NT 1
+#endif
 #ifndef PASNL_SA_ABLATE
 #define PASNL_SA_ABLATE 0
 #endif
@@ -763,7 +769,13 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
 #pragma unroll
     for (int cb = 0; cb < C2 / 32; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[(size_t)(cb * 32 + kappa(r, h)) * 32 + ql] = M[cb][r];
+      for (int r = 0; r < 16; ++r) {
+#if PASNL_SA_NT
+        __builtin_nontemporal_store(M[cb][r], &o[(size_t)(cb * 32 + kappa(r, h)) * 32 + ql]);
+#else
+        o[(size_t)(cb * 32 + kappa(r, h)) * 32 + ql] = M[cb][r];
+#endif
+      }
   }
 }
 
@@ -1182,7 +1194,13 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 #pragma unroll
     for (int cb = 0; cb < C2 / 32; ++cb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[(size_t)(cb * 32 + kappa(r, h)) * 32 + ql] = M[cb][r];
+      for (int r = 0; r < 16; ++r) {
+#if PASNL_SA_NT
+        __builtin_nontemporal_store(M[cb][r], &o[(size_t)(cb * 32 + kappa(r, h)) * 32 + ql]);
+#else
+        o[(size_t)(cb * 32 + kappa(r, h)) * 32 + ql] = M[cb][r];
+#endif
+      }
     // the wave's LDS operations execute in order; the fences only keep the compiler from moving the reads up
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -2298,6 +2316,144 @@ extern "C" int pasnl_sa_tail_cat(int rows, int w, int cb, int c, const float* af
                                  const float* bagg, float* out, const float* new_xyz, float* out_cat, pasnl_stream_t stream) {
   PASNL_REQUIRE(rows == 0 || (new_xyz && out_cat), PASNL_ENULL);
   return sa_tail_entry(rows, w, cb, c, after, skip_max, att, ws, bs, wb, bb, wagg, bagg, out, new_xyz, out_cat, stream);
+}
+
+namespace pasnl {
+// ---------------------------------------------------------------------------------------------
+// The decoder cell again, with the output in a TILED order of the (3+c)*32 values of a point (pasnl_decode_cell_tiled).
+// decode_cell_kernel is bound by how many vector-memory INSTRUCTIONS a compute unit can issue (152 per point: 72 loads,
+// 80 stores of 256 bytes each -- 3.0-3.5 TB/s of the ~7.9 TB/s a plain fill reaches), not by bytes.  The only consumer of
+// its output is the `decode_after_conv` GEMM, which contracts ALL (3+c)*32 values of a point: any fixed permutation of them
+// is as good as the reference's (channel, j) order once the GEMM's weight rows are permuted the same way.  So:
+//   * the product is formed transposed (the same two operand registers, swapped): a lane holds, for ONE channel, j = 8g + 4h
+//     + (0..3), g = 0..3 -- four float4;
+//   * a tile of 32 channels x 32 j is stored as  [g][h][channel-in-tile][4]  (1024 floats): store g of a wave is 64 lanes x 16
+//     bytes = 1 KiB CONTIGUOUS -- 4 stores per tile instead of 16;
+//   * with c % 128 == 0 a lane reads FOUR consecutive features of a neighbour (one 16-byte load) and spends them on four
+//     tiles: tile e of a 128-feature group holds features 4 m + e, m = 0..31 -- 8 loads per group instead of 32.
+// Layout of a point's (3+c)*32 floats (the Python mirror builds the matching row permutation of the weights):
+//   [0, 96)                                   the three coordinate channels, (channel, j) order as before
+//   96 + T*1024 + (2g+h)*128 + 4m + i         tile T = Gq*V + e (V = 4 or 1):  channel 3 + 32 V Gq + V m + e,  j = 8g + 4h + i
+// ---------------------------------------------------------------------------------------------
+template <int K, int V, bool NT>  // NT: streaming (non-temporal) output stores
+__global__ __launch_bounds__(256) void decode_cell_tiled_kernel(long points, int n, int c, const float* __restrict__ xyz,
+                                                               const float* __restrict__ feature, const int* __restrict__ idx,
+                                                               const float* __restrict__ ww, const float* __restrict__ bw,
+                                                               float* __restrict__ out) {
+  constexpr int T = K / 2;  // MFMA steps: step t contracts neighbours 2t (lanes 0..31) and 2t+1 (lanes 32..63)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, ql = lane & 31;
+  const int w = 3 + c, ngroup = c / (32 * V);
+  const float w0 = ww[ql], w1 = ww[32 + ql], w2 = ww[64 + ql], bj = bw[ql];
+  const int nclouds = (int)(points / n);
+  const bool xcd_map = (gridDim.x % 8 == 0) && nclouds >= 8;
+  const int xcd = blockIdx.x & 7;
+  const long mine = xcd_map ? (long)((nclouds - xcd + 7) >> 3) * n : points;
+  const long first = xcd_map ? (long)(blockIdx.x >> 3) * 4 + wave : (long)blockIdx.x * 4 + wave;
+  const long step = xcd_map ? (long)(gridDim.x >> 3) * 4 : (long)gridDim.x * 4;
+  typedef float fvec __attribute__((ext_vector_type(V)));
+  for (long li = first; li < mine; li += step) {
+    long p = li, bi;
+    if (xcd_map) {
+      const int cl = (int)(li / n);
+      bi = xcd + 8 * cl;
+      p = bi * n + (li - (long)cl * n);
+    } else {
+      bi = p / n;
+    }
+    const float cx = xyz[p * 3], cy = xyz[p * 3 + 1], cz = xyz[p * 3 + 2];
+    float G[T], qc[T];
+    const float* frow[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int is = idx[p * K + 2 * t + h];
+      const float* q = xyz + ((size_t)bi * n + is) * 3;
+      const float qx = q[0], qy = q[1], qz = q[2];
+      G[t] = fmaxf(__builtin_fmaf(qz - cz, w2, __builtin_fmaf(qy - cy, w1, (qx - cx) * w0)) + bj, 0.f);
+      qc[t] = ql == 0 ? qx : (ql == 1 ? qy : (ql == 2 ? qz : 0.f));
+      frow[t] = feature + ((size_t)bi * n + is) * (size_t)c + V * ql;  // this lane's V features of a group
+    }
+    float* o = out + (size_t)p * w * 32;
+    fvec a[T], an[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) a[t] = *reinterpret_cast<const fvec*>(frow[t]);
+    {  // coordinate channels (rows 0..2 of an MFMA tile), the reference's order
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[t], G[t], acc, 0, 0, 0);
+      if (h == 0) {  // kappa(r, 0) = r for r < 3
+        o[ql] = acc[0];
+        o[32 + ql] = acc[1];
+        o[64 + ql] = acc[2];
+      }
+    }
+    for (int gq = 0; gq < ngroup; ++gq) {
+      const int gn = min(gq + 1, ngroup - 1) * 32 * V;  // next group's features in flight during this group's tiles
+#pragma unroll
+      for (int t = 0; t < T; ++t) an[t] = *reinterpret_cast<const fvec*>(frow[t] + gn);
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          float fv;
+          fv = a[t][e];
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(G[t], fv, acc, 0, 0, 0);  // rows = j, columns = this tile's 32 channels
+        }
+        float* ot = o + 96 + (size_t)(gq * V + e) * 1024 + h * 128 + ql * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+        {
+          // NT = streaming stores: the output is written once and read by the next kernel from HBM anyway; without the hint
+          // it washes the neighbours' feature table (4 MiB per cloud at ScanNet fa_layer4 = the whole L2 of an XCD) out of
+          // L2 (650 -> 490 us there; tables that fit beside the output stream anyway lose a little, so the launcher decides)
+          typedef float f4 __attribute__((ext_vector_type(4)));
+          f4 v4 = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+          if constexpr (NT) __builtin_nontemporal_store(v4, reinterpret_cast<f4*>(ot + g * 256));
+          else *reinterpret_cast<f4*>(ot + g * 256) = v4;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T; ++t) a[t] = an[t];
+    }
+  }
+}
+}  // namespace pasnl
+
+extern "C" int pasnl_decode_cell_tiled(int b, int n, int c, int k, const float* xyz, const float* feature, const int* idx,
+                                       const float* ww, const float* bw, float* out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && k > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(k == 16 && c % 32 == 0, PASNL_EUNSUPPORTED);
+  const long points = (long)b * n;
+  if (points == 0) return PASNL_OK;
+  PASNL_REQUIRE(xyz && feature && idx && ww && bw && out, PASNL_ENULL);
+  PASNL_REQUIRE(points * k < (1L << 40), PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE(reinterpret_cast<uintptr_t>(out) % 16 == 0, PASNL_EUNSUPPORTED);
+  const bool v4 = c % 128 == 0 && reinterpret_cast<uintptr_t>(feature) % 16 == 0;
+  hipStream_t st = pasnl_hip_stream(stream);
+  const bool nt = (size_t)n * c * sizeof(float) >= (1u << 20);  // a cloud's feature table is worth protecting in L2
+  const void* kern = nullptr;
+#define PASNL_DT(V, NT) reinterpret_cast<const void*>(pasnl::decode_cell_tiled_kernel<16, V, NT>)
+  kern = v4 ? (nt ? PASNL_DT(4, true) : PASNL_DT(4, false)) : (nt ? PASNL_DT(1, true) : PASNL_DT(1, false));
+#undef PASNL_DT
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+  long wgs = (points + 3) / 4;
+  const long cap = 256L * per_cu;
+  unsigned grid = (unsigned)(wgs < cap ? wgs : cap);
+  void* args[] = {(void*)&points, (void*)&n, (void*)&c, (void*)&xyz, (void*)&feature, (void*)&idx, (void*)&ww, (void*)&bw, (void*)&out};
+  if (hipLaunchKernel(kern, dim3(grid), dim3(256), args, 0, st) != hipSuccess) return PASNL_ELAUNCH;
+  return pasnl_launch_status();
+}
+
+/* 1 when pasnl_decode_cell_tiled spends one 16-byte load on four tiles for this width and feature pointer (V = 4), else 0
+ * (V = 1): the tiled order depends on it. */
+extern "C" int pasnl_decode_cell_tiled_v4(int c, const float* feature) {
+  return (c % 128 == 0 && reinterpret_cast<uintptr_t>(feature) % 16 == 0) ? 1 : 0;
 }
 
 extern "C" int pasnl_decode_cell(int b, int n, int c, int k, const float* xyz, const float* feature, const int* idx,

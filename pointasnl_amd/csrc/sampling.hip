@@ -786,7 +786,7 @@ static int fps_dispatch(int b, int n, int m, const float* xyz, int* idx, float* 
   if (n <= 256) return fps_launch<1, 4>(b, n, m, xyz, idx, st, oxyz);
   if (n <= 512) return fps_launch<1, 8>(b, n, m, xyz, idx, st, oxyz);
   if (n <= 1024) return fps_launch<4, 4>(b, n, m, xyz, idx, st, oxyz);   // measured: (4,4) 192 us vs (1,16) 241 us at B=64, m=512
-  if (n <= 2048) return fps_launch<2, 16>(b, n, m, xyz, idx, st, oxyz);
+  if (n <= 2048) return fps_launch<4, 8>(b, n, m, xyz, idx, st, oxyz);   // measured (tools/fps_cfg_sweep.py): 146 vs 207 us for (2,16) at 8x1280->320, 231 vs 329 us at 16x2048->512
   if (!tune_env("PASNL_FPS_NOPRUNE")) {
     // pruned rounds (fps_pruned_kernel): the unpruned kernels below stay as the A/B reference
     int rc = PASNL_EUNSUPPORTED;

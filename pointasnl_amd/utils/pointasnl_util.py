@@ -674,6 +674,28 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
 DECODE_CELL_FUSED = True  # False = the reference's op-by-op chain (gathers, concat, conv2d, transpose, batched matmul)
 
 
+DECODE_CELL_TILED = True  # the decoder cell writes its output in the tiled order (pasnl_decode_cell_tiled) when it can
+_DECODE_PERM = {}
+
+
+def decode_tiled_order(c, v4, device):
+    """(3+c)*32 int64: entry q = the reference position ch*32 + j of what pasnl_decode_cell_tiled stores at position q of a
+    point (include/pasnl.h); cached per (c, v4, device).  decode_after_conv's weight rows are gathered with it."""
+    key = (c, bool(v4), str(device))
+    if key not in _DECODE_PERM:
+        V = 4 if v4 else 1
+        T = torch.arange(c // 32).view(-1, 1, 1, 1, 1)
+        g = torch.arange(4).view(1, -1, 1, 1, 1)
+        h = torch.arange(2).view(1, 1, -1, 1, 1)
+        m = torch.arange(32).view(1, 1, 1, -1, 1)
+        i = torch.arange(4).view(1, 1, 1, 1, -1)
+        ch = 3 + 32 * V * (T // V) + V * m + T % V
+        j = 8 * g + 4 * h + i
+        tiles = (ch * 32 + j).reshape(-1)  # order (T, g, h, m, i) == 96 + T*1024 + (2g+h)*128 + 4m + i
+        _DECODE_PERM[key] = torch.cat([torch.arange(96), tiles]).to(device)
+    return _DECODE_PERM[key]
+
+
 def decode_cell(xyz, feature, idx, weight_decay=None):
     """Decoder local cell (pointasnl_util.py:323-331) fused: (B,N,3), (B,N,C), (B,N,K) -> (B,N,3+C,32).
     The variables are the ones the op-by-op chain creates (scope decode_weight_net/wconv0)."""
@@ -683,6 +705,14 @@ def decode_cell(xyz, feature, idx, weight_decay=None):
         ww, bw = tf_util.store().layer(3, 32, True, weight_decay)
     xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
     out = torch.empty((b, n, 3 + c, 32), dtype=torch.float32, device=xyz.device)
+    if DECODE_CELL_TILED and k == 16 and c % 32 == 0:
+        # the same values in an order that is cheap to write (4 x 1 KiB per tile) -- its only consumer, decode_after_conv,
+        # contracts all of them and gets its weight rows in the same order (`row_order` rides on the tensor)
+        v4 = int(_hip.lib().pasnl_decode_cell_tiled_v4(c, _hip.ptr(feature)))
+        _hip.launch("pasnl_decode_cell_tiled", "decode_cell", b, n, c, k, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx),
+                    _hip.ptr(ww), _hip.ptr(bw), _hip.ptr(out))
+        out.row_order = ("decode_tiled_c%d_v%d" % (c, v4), decode_tiled_order(c, v4, xyz.device))
+        return out
     _hip.launch("pasnl_decode_cell", "decode_cell", b, n, c, k, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx), _hip.ptr(ww),
                 _hip.ptr(bw), _hip.ptr(out))
     return out
@@ -724,7 +754,7 @@ def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_traini
             new_points = torch.matmul(new_points, weight)
         new_points = tf_util.conv2d(new_points, mlp[0], [1, new_points.shape[2]], padding='VALID', stride=[1, 1], bn=bn,
                                     is_training=is_training, scope='decode_after_conv', bn_decay=bn_decay,
-                                    weight_decay=weight_decay)
+                                    weight_decay=weight_decay, row_order=getattr(new_points, "row_order", None))
         if points1 is not None:
             new_points1 = torch.cat([new_points, points1.unsqueeze(2)], dim=-1)
         else:

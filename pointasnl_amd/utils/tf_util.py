@@ -212,10 +212,15 @@ def _dense_rows(x2d, w, b, relu):
     return out
 
 
-def _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay=None, input_pad=0):
+def _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay=None, input_pad=0, row_order=None):
     cin = inputs.shape[-1] - input_pad
     with variable_scope(scope):
         w, b = store().layer(cin, num_output_channels, bn, weight_decay)
+        if row_order is not None:  # (name, index): the producer wrote the cin values of a row in another fixed order
+            key = store().path("") + "@" + row_order[0]
+            if key not in store()._folded:
+                store()._folded[key] = (w[row_order[1]].contiguous(), b)
+            w, b = store()._folded[key]
         if input_pad:  # the first `input_pad` input channels are alignment padding the reference's tensor does not have
             key = store().path("") + "@pad%d" % input_pad
             if key not in store()._folded:
@@ -251,7 +256,7 @@ def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='S
 
 def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], padding='SAME', data_format='NHWC',
            use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn="relu", bn=False, bn_decay=None,
-           is_training=None, input_pad=0):
+           is_training=None, input_pad=0, row_order=None):
     """tf_util.py:120-185.  [1,1] kernels, and the [1,W] VALID kernel that collapses the whole W axis
     (pointasnl_util.py:275, 337): inputs (B,H,W,C) -> (B,H,1,cout) == one GEMM over the flattened (W,C) window."""
     _require_inference(is_training)
@@ -263,7 +268,7 @@ def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], paddi
     if padding != 'VALID' or kw != inputs.shape[2]:
         raise NotImplementedError("conv2d mirror supports [1,1] or the full-width VALID kernel")
     b, h, w, c = inputs.shape
-    out = _dense(inputs.reshape(b, h, w * c), num_output_channels, scope, bn, activation_fn, weight_decay)
+    out = _dense(inputs.reshape(b, h, w * c), num_output_channels, scope, bn, activation_fn, weight_decay, row_order=row_order)
     return out.reshape(b, h, 1, num_output_channels)
 
 

@@ -284,7 +284,12 @@ def test_decode_cell(b, n, c, k):
     feat = rng.standard_normal((b, n, c)).astype(np.float32)
     idx = rng.integers(0, n, (b, n, k)).astype(np.int32)
     with st.scope("D"):
-        got = U.decode_cell(dev(xyz), dev(feat), dev(idx)).cpu().numpy()
+        out = U.decode_cell(dev(xyz), dev(feat), dev(idx))
+    if hasattr(out, "row_order"):  # the tiled order (c % 32 == 0, k = 16): back to the reference's (channel, j) order
+        flat = torch.empty_like(out).reshape(b, n, -1)
+        flat[:, :, out.row_order[1]] = out.reshape(b, n, -1)
+        out = flat.reshape(out.shape)
+    got = out.cpu().numpy()
     p = st.export_numpy()
     bi = np.arange(b)[:, None, None]
     gx = xyz[bi, idx].astype(np.float64)
@@ -568,3 +573,45 @@ def test_adaptive_sampling_padded_projection_is_the_same_function():
             U.AS_PAD_PROJECTION = True
     for a, b_ in zip(*outs):
         assert torch.allclose(a, b_, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("b,n,c", [(2, 300, 128), (3, 100, 32), (1, 257, 256), (2, 64, 512), (2, 200, 96)])
+def test_decode_cell_tiled_is_the_plain_cell_reordered(b, n, c):
+    """pasnl_decode_cell_tiled: the same (3+c)*32 values per point, bit for bit, at the positions include/pasnl.h documents
+    (the order decode_after_conv's weight rows are gathered in)."""
+    from pointasnl_amd.utils import pointasnl_util as U, tf_util
+
+    rng = np.random.default_rng(c + n)
+    xyz, feat = dev(clouds(3, b, n)), dev(rng.standard_normal((b, n, c)).astype(np.float32))
+    idx = dev(rng.integers(0, n, (b, n, 16)).astype(np.int32))
+    outs = []
+    for flag in (False, True):
+        tf_util.set_store(tf_util.VariableStore(seed=8, randomize_bn=True))
+        U.DECODE_CELL_TILED = flag
+        try:
+            outs.append(U.decode_cell(xyz, feat, idx))
+        finally:
+            U.DECODE_CELL_TILED = True
+    plain, tiled = outs
+    assert not hasattr(plain, "row_order") and hasattr(tiled, "row_order")
+    order = tiled.row_order[1]
+    assert torch.equal(tiled.reshape(b, n, -1), plain.reshape(b, n, -1)[:, :, order])
+    assert torch.equal(torch.sort(order).values, torch.arange((3 + c) * 32, device=order.device))
+
+
+def test_decoding_layer_tiled_matches_plain():
+    from pointasnl_amd.utils import pointasnl_util as U, tf_util
+
+    rng = np.random.default_rng(5)
+    xyz1, xyz2 = dev(clouds(4, 2, 512)), dev(clouds(5, 2, 128))
+    p1 = dev(rng.standard_normal((2, 512, 64)).astype(np.float32))
+    p2 = dev(rng.standard_normal((2, 128, 128)).astype(np.float32))
+    outs = []
+    for flag in (False, True):
+        tf_util.set_store(tf_util.VariableStore(seed=9, randomize_bn=True))
+        U.DECODE_CELL_TILED = flag
+        try:
+            outs.append(U.PointASNLDecodingLayer(xyz1, xyz2, p1, p2, 16, [128, 64], False, None, None, 'fa'))
+        finally:
+            U.DECODE_CELL_TILED = True
+    assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-5)
