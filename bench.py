@@ -165,7 +165,7 @@ def algorithmic(symbol, ints):
     if symbol == "pasnl_narrow_project2":
         r0, k0, n0, r1, k1, n1 = ints
         return 4 * (r0 * (k0 + n0) + r1 * (k1 + n1)), 2 * (r0 * k0 * n0 + r1 * k1 * n1), "hbm"
-    if symbol == "pasnl_decode_cell":
+    if symbol in ("pasnl_decode_cell", "pasnl_decode_cell_tiled"):
         b, n, c, k = ints
         return 4 * b * n * (3 + c + k + (3 + c) * 32), 2 * b * n * k * ((3 + c) * 32 + 3 * 32), "hbm"
     if symbol in ("pasnl_max_pool_rows", "pasnl_max_pool_rows_strided"):
