@@ -56,3 +56,40 @@ def test_updates_invalidate_the_folded_cache():
     with st.scope("fc"):
         w_loaded, _ = st.layer(4, 2, bn=True)
     np.testing.assert_allclose(w_loaded.numpy(), 3.0 / np.sqrt(st.vars["fc/bn/moving_variance"].numpy() + 1e-3) * np.ones((4, 1)), rtol=1e-6)
+
+
+def test_dense_layer_with_padded_or_reordered_inputs_is_the_same_function():
+    """tf_util.conv2d(input_pad=..., row_order=...): producers may hand a dense layer rows with alignment padding in front
+    (PointASNLSetAbstraction(xyz_concat=True)) or with their values in another fixed order (the tiled decoder cell); the layer
+    pads / gathers its weight rows once and caches them with the other folded weights -- and load() drops that cache."""
+    st = tf_util.VariableStore(seed=3, device="cpu", randomize_bn=True)
+    tf_util.set_store(st)
+    x = torch.randn(4, 7, 1, 12)
+    ref = tf_util.conv2d(x, 5, [1, 1], scope="L", bn=True, is_training=False)
+    padded = torch.cat([torch.full((4, 7, 1, 2), 123.0), x], dim=-1)  # whatever sits in the padding meets zero weight rows
+    got = tf_util.conv2d(padded, 5, [1, 1], scope="L", bn=True, is_training=False, input_pad=2)
+    torch.testing.assert_close(got, ref)
+    order = torch.randperm(12)
+    wide = torch.randn(2, 3, 4, 3)  # (B, H, W, C): the [1, W] VALID kernel contracts the flattened (W, C) window
+    ref2 = tf_util.conv2d(wide, 6, [1, 4], scope="M", padding="VALID", bn=False, is_training=False)
+    shuffled = wide.reshape(2, 3, 12)[:, :, order].reshape(2, 3, 4, 3)
+    got2 = tf_util.conv2d(shuffled, 6, [1, 4], scope="M", padding="VALID", bn=False, is_training=False, row_order=("perm", order))
+    torch.testing.assert_close(got2, ref2)
+    assert any("@pad2" in k for k in st._folded) and any("@perm" in k for k in st._folded)
+    st.assign("L/weights", torch.zeros(12, 5))
+    assert not st._folded  # every derived weight is rebuilt after an update
+
+
+def test_decode_tiled_order_is_a_permutation_with_the_documented_layout():
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    for c, v4 in [(128, True), (128, False), (32, False), (512, True), (96, False)]:
+        order = U.decode_tiled_order(c, v4, torch.device("cpu"))
+        assert order.shape == ((3 + c) * 32,)
+        assert torch.equal(torch.sort(order).values, torch.arange((3 + c) * 32))
+        assert torch.equal(order[:96], torch.arange(96))
+        V = 4 if v4 else 1
+        for T, g, h, m, i in [(0, 0, 0, 0, 0), (c // 32 - 1, 3, 1, 31, 3), (min(2, c // 32 - 1), 1, 0, 7, 2)]:
+            q = 96 + T * 1024 + (2 * g + h) * 128 + 4 * m + i
+            ch, j = 3 + 32 * V * (T // V) + V * m + T % V, 8 * g + 4 * h + i
+            assert int(order[q]) == ch * 32 + j
