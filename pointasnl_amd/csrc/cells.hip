@@ -817,7 +817,7 @@ __device__ __forceinline__ float vmaxf(float a, float b) {
 
 constexpr int SA_SKIP_REP = 4;
 
-template <int C1, int C2, int NW, bool VEC, bool TAIL8>
+template <int C1, int C2, int NW, bool VEC, bool TAIL8, bool XYZ3 = false>  // XYZ3: the feature rows are 3 wide (xyz-only first layers)
 __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, int w, SaGatherSrc src,
                                                          const float* __restrict__ w0, const float* __restrict__ b0,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
@@ -923,6 +923,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   float xr[16];
   float px = 0.f, py = 0.f, pz = 0.f;   // the tile's neighbour coordinates (one row per lane pair)
   float nf0 = 0.f, nf1 = 0.f;           // centre0 outputs: neighbour 0's feature row, in flight during a group's first tile
+  float f3x = 0.f, f3y = 0.f, f3z = 0.f;  // XYZ3: the tile row's three features (one 12-byte load instead of clamped dword loads)
   const float* frow = src.feature;       // and its feature row
   // operands [u0, u1) of chunk ch (VEC: whole 16-byte groups); the loops unroll, u0 / u1 are constants at every call
   auto load_part = [&](int ch, int u0, int u1) {
@@ -968,8 +969,12 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
     const float* pp = src.xyz + ((size_t)bc * src.n + i) * 3;
     px = pp[0]; py = pp[1]; pz = pp[2];
     frow = src.feature + ((size_t)bc * src.n + i) * (size_t)cf;
-    if (TAIL8 && wi < 32) load_part(0, 0, 8);  // a one-chunk row: only 8 steps exist
-    else load_part(0, 0, 16);
+    if constexpr (XYZ3) {
+      f3x = frow[0]; f3y = frow[1]; f3z = frow[2];
+    } else {
+      if (TAIL8 && wi < 32) load_part(0, 0, 8);  // a one-chunk row: only 8 steps exist
+      else load_part(0, 0, 16);
+    }
   };
   // Software pipeline over tiles: the neighbour indices of tile t+1 are requested when tile t starts, its rows when
   // tile t has finished conv0; the centre of the next group when a group starts.  Only a wave's first tile waits
@@ -1016,8 +1021,12 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       for (int ob = 0; ob < C1 / 32; ++ob)
 #pragma unroll
         for (int r = 0; r < 16; ++r) H1T[ob][r] = 0.f;
+      // (pinned in AccVGPRs where registers are scarce; the narrow first-layer variant has room, and without the pin the
+      // compiler folds the zeros into the first MFMA's accumulator operand instead of writing 16 registers per block)
+      if constexpr (!XYZ3) {
 #pragma unroll
-      for (int ob = 0; ob < C1 / 32; ++ob) asm volatile("" : "+a"(H1T[ob]));
+        for (int ob = 0; ob < C1 / 32; ++ob) asm volatile("" : "+a"(H1T[ob]));
+      }
       f32x16 G;
 #pragma unroll
       for (int r = 0; r < 16; ++r) G[r] = 0.f;
@@ -1038,7 +1047,15 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
         }
       }
       const int nfull = wi >> 5;  // chunks whose 32 columns all exist
-      if (nfull == 0) mask_chunk(0, xr);
+      if constexpr (XYZ3) {
+        // internal columns 8..10 = the three features, 11..15 padding; step t holds columns 2t (h = 0) and 2t + 1 (h = 1)
+        xr[4] = h ? f3y : f3x;
+        xr[5] = h ? 0.f : f3z;
+        xr[6] = 0.f;
+        xr[7] = 0.f;
+      } else if (nfull == 0) {
+        mask_chunk(0, xr);
+      }
       // internal columns 0..7 = [xyz - centre | xyz | 1 | 0]; the weight net (3 -> 32) rides on the same operands
       if constexpr (VEC) {
         if (h == 0) {
@@ -1075,13 +1092,16 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
           lds_float* srow = (lds_float*)(skl + ch * 32);
           asm volatile("" : "+v"(srow));
 #pragma unroll
-          for (int t = 0; t < NS; ++t)
+          for (int t = 0; t < NS; ++t) {
+            // XYZ3: steps 3 (the constant-1 / zero columns) and 6, 7 (padding) hold no column the skip connection reads
+            if (XYZ3 && (t == 3 || t >= 6)) continue;
             __hip_atomic_fetch_max(srow + RS * t, xr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
         }
 #ifdef PASNL_SA_BT
         constexpr int BT = PASNL_SA_BT;
 #else
-        constexpr int BT = C1 >= 128 ? 1 : 128 / C1;  // MFMA steps per batch
+        constexpr int BT = XYZ3 ? 2 : (C1 >= 128 ? 1 : 128 / C1);  // MFMA steps per batch (XYZ3: 6 steps = 3 batches of 2)
 #endif
         constexpr int NB = NS / BT;
         const float* wbase = VEC ? W0s + (size_t)(ch * 32 + 16 * h) * C1 + ql : W0s + (size_t)(ch * 32 + h) * C1 + ql;
@@ -1124,7 +1144,9 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       }
       // ---- the last chunk of a row whose width is not a multiple of 32: 8 or 16 steps (rows of W0 past the width and
       // the masked operands are zero, so steps past the last live column add nothing)
-      if constexpr (TAIL8) {
+      if constexpr (XYZ3) {
+        chunk_steps(0, std::integral_constant<int, 6>{}, std::false_type{});  // steps 6, 7 would multiply padding: skipped
+      } else if constexpr (TAIL8) {
         if (nfull > 0) mask_chunk(nfull, xr);
         chunk_steps(nfull, std::integral_constant<int, 8>{}, std::false_type{});
       } else if (nfull < nchunk) {
@@ -2032,13 +2054,13 @@ static int local_cell_dispatch(long groups, int k, int w, int c1, int c2, const 
   return PASNL_EUNSUPPORTED;
 }
 
-template <int C1, int C2, int NW, bool VEC, bool TAIL8>
+template <int C1, int C2, int NW, bool VEC, bool TAIL8, bool XYZ3 = false>
 static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0, const float* w1,
                           const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
   const int wp = (8 + (w - 6) + 31) & ~31;  // internal width: [xyz-c | xyz | 1 | 0 | feature], padded to 32-chunks
   size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 6 * 32 + (size_t)NW * SA_SKIP_REP * (wp + 4)) * sizeof(float);
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
-  auto kern = sa_cell_kernel<C1, C2, NW, VEC, TAIL8>;
+  auto kern = sa_cell_kernel<C1, C2, NW, VEC, TAIL8, XYZ3>;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
@@ -2066,6 +2088,10 @@ static int sa_cell_cfg(bool vec, bool tail8, long groups, int k, int w, SaGather
   constexpr int NW = C1 >= 128 ? 4 : 8;
   if (vec) return tail8 ? sa_cell_launch<C1, C2, NW, true, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
                         : sa_cell_launch<C1, C2, NW, true, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  if constexpr (C1 <= 64) {
+    if (w == 9 && tail8)  // the xyz-only first layer of every model: rows [xyz - c | xyz | xyz-as-feature]
+      return sa_cell_launch<C1, C2, NW, false, true, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  }
   return tail8 ? sa_cell_launch<C1, C2, NW, false, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
                : sa_cell_launch<C1, C2, NW, false, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
 }
