@@ -998,7 +998,13 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
     const long g_next = li + step < my_groups ? bi_next * m + pj : g;
     float cx = cxn, cy = cyn, cz = czn;
     cxn = src.new_xyz[g_next * 3]; cyn = src.new_xyz[g_next * 3 + 1]; czn = src.new_xyz[g_next * 3 + 2];
-    for (int c = lane; c < SA_SKIP_REP * sks; c += 64) skp[c] = -INFINITY;
+    if constexpr (XYZ3) {  // sks = 36: 144 words, known at compile time
+      skp[lane] = -INFINITY;
+      skp[lane + 64] = -INFINITY;
+      if (lane < SA_SKIP_REP * 36 - 128) skp[lane + 128] = -INFINITY;
+    } else {
+      for (int c = lane; c < SA_SKIP_REP * sks; c += 64) skp[c] = -INFINITY;
+    }
     f32x16 M[C2 / 32];
 #pragma unroll
     for (int cb = 0; cb < C2 / 32; ++cb)
@@ -1228,9 +1234,16 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // reference column c of the skip maxima = internal column c (c < 6) or c + 2 (features)
-    for (int c = lane; c < w; c += 64) {
-      const float* sc = skp + (c < 6 ? c : c + 2);
-      src.skip_max[(size_t)g * w + c] = fmaxf(fmaxf(sc[0], sc[sks]), fmaxf(sc[2 * sks], sc[3 * sks]));
+    if constexpr (XYZ3) {  // nine columns: one masked step instead of a general loop
+      if (lane < 9) {
+        const float* sc = skp + (lane < 6 ? lane : lane + 2);
+        src.skip_max[(size_t)g * 9 + lane] = fmaxf(fmaxf(sc[0], sc[sks]), fmaxf(sc[2 * sks], sc[3 * sks]));
+      }
+    } else {
+      for (int c = lane; c < w; c += 64) {
+        const float* sc = skp + (c < 6 ? c : c + 2);
+        src.skip_max[(size_t)g * w + c] = fmaxf(fmaxf(sc[0], sc[sks]), fmaxf(sc[2 * sks], sc[3 * sks]));
+      }
     }
     __builtin_amdgcn_wave_barrier();
     SA_MARK(pt0);
