@@ -22,6 +22,7 @@ from pointasnl_amd import _hip
 
 BN_EPS = 1e-3
 FUSE_RELU_EPILOGUE = True
+WEIGHTS_TRANSPOSED_MIN_K = 2048  # dense layers contracting at least this many inputs keep their weights transposed (see _dense)
 
 
 class VariableStore:
@@ -236,6 +237,15 @@ def _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay=N
             return out.reshape(*inputs.shape[:-1], num_output_channels)
         except _hip.PasnlUnsupported:
             pass  # e.g. an unaligned view: the vendor GEMM below
+    if w.shape[0] >= WEIGHTS_TRANSPOSED_MIN_K and x2d.is_cuda:
+        # long contractions (the [1,C] after_conv / decode_after_conv windows: K = 2048 ... 16480): the vendor library picks
+        # a better kernel when the weights are stored (N,K) and handed over as a transposed view (tools/gemm_layout_probe.py:
+        # (320,16384,512) 98 -> 68 us, (8192,4096,256) 138 -> 131 us; short contractions do not care)
+        key = "@T%x" % w.data_ptr()
+        st = store()
+        if key not in st._folded:
+            st._folded[key] = (w.t().contiguous(), w)  # (keeps `w` alive: the pointer in the key stays unique)
+        w = st._folded[key][0].t()
     if activation_fn in ("relu", torch.relu, torch.nn.functional.relu) and FUSE_RELU_EPILOGUE:
         # bias + ReLU in the GEMM epilogue (hipBLASLt) instead of a second pass over the output
         out = torch._addmm_activation(b, x2d, w)
