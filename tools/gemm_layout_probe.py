@@ -22,6 +22,8 @@ def timed(fn, n=40):
     return e0.elapsed_time(e1) * 1e3 / (n // 5 * 5)
 
 
+if __name__ != "__main__":
+    raise SystemExit
 for M, K, N in [(32768, 2048, 128), (8192, 4096, 256), (32768, 256, 512), (8192, 512, 1024), (32768, 128, 256), (131072, 4192, 128),
                 (16384, 8288, 256), (2560, 4096, 128), (320, 16384, 512)]:
     x = torch.randn(M, K, device="cuda"); w = torch.randn(K, N, device="cuda"); b = torch.randn(N, device="cuda")
