@@ -1011,13 +1011,18 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 #pragma unroll
       for (int r = 0; r < 16; ++r) M[cb][r] = 0.f;
 
-    for (int tile = 0; tile < k; tile += 32) {
+    // (XYZ3 is dispatched for k == 32 only: one tile per group, known at compile time -- the accumulators' zeros fold into
+    // their first MFMA and nothing has to be pinned)
+    const int ktile = XYZ3 ? 32 : k;
+    for (int tile = 0; tile < ktile; tile += 32) {
+      if constexpr (!XYZ3) {
 #pragma unroll
-      for (int cb = 0; cb < C2 / 32; ++cb) asm volatile("" : "+a"(M[cb]));  // M lives in AccVGPRs: no VALU ever reads it
+        for (int cb = 0; cb < C2 / 32; ++cb) asm volatile("" : "+a"(M[cb]));  // M lives in AccVGPRs: no VALU ever reads it
+      }
       SA_MARK(pt0);
       SA_PROBE(if (tile == 0) a_pro += pt0 - pg0;)
       // (this tile's rows were requested during the previous tile; now the indices of the following tile)
-      inext = src.idx[(tile + 32 < k ? (size_t)g * k + tile + 32 : (size_t)g_next * k) + ql];
+      inext = src.idx[(tile + 32 < ktile ? (size_t)g * k + tile + 32 : (size_t)g_next * k) + ql];
       SA_WAIT_VM();
       SA_MARK(pt1);
       SA_PROBE(a_start += pt1 - pt0;)
@@ -1164,7 +1169,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
         else chunk_steps(ch, std::integral_constant<int, 16>{}, std::false_type{});
       }
       // rows of the following tile (same group, or the first tile of the next one): they arrive during conv1
-      request_rows(tile + 32 < k ? bi : bi_next, inext);
+      request_rows(tile + 32 < ktile ? bi : bi_next, inext);
       SA_MARK(pt2);
       SA_PROBE(a_conv0 += pt2 - pt1;)
       // ReLU (the bias came with the MFMA); G: bias + ReLU
@@ -2102,7 +2107,7 @@ static int sa_cell_cfg(bool vec, bool tail8, long groups, int k, int w, SaGather
   if (vec) return tail8 ? sa_cell_launch<C1, C2, NW, true, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
                         : sa_cell_launch<C1, C2, NW, true, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   if constexpr (C1 <= 64) {
-    if (w == 9 && tail8)  // the xyz-only first layer of every model: rows [xyz - c | xyz | xyz-as-feature]
+    if (w == 9 && tail8 && k == 32)  // the xyz-only first layer of every model: rows [xyz - c | xyz | xyz-as-feature]
       return sa_cell_launch<C1, C2, NW, false, true, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   }
   return tail8 ? sa_cell_launch<C1, C2, NW, false, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
