@@ -1096,19 +1096,11 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       auto chunk_steps = [&](int ch, auto ns_c, auto stream_c) {
         constexpr int NS = decltype(ns_c)::value;
         constexpr bool STREAM = decltype(stream_c)::value;
-        if constexpr (!(PASNL_SA_ABLATE & 1)) {
-          // an opaque LDS address: one address register + immediate offsets instead of one address add per ds_max
-          // (the row lies past the 64 KiB an immediate offset could reach from the start of the LDS)
-          typedef __attribute__((address_space(3))) float lds_float;
-          lds_float* srow = (lds_float*)(skl + ch * 32);
-          asm volatile("" : "+v"(srow));
-#pragma unroll
-          for (int t = 0; t < NS; ++t) {
-            // XYZ3: steps 3 (the constant-1 / zero columns) and 6, 7 (padding) hold no column the skip connection reads
-            if (XYZ3 && (t == 3 || t >= 6)) continue;
-            __hip_atomic_fetch_max(srow + RS * t, xr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          }
-        }
+        // an opaque LDS address: one address register + immediate offsets instead of one address add per ds_max
+        // (the row lies past the 64 KiB an immediate offset could reach from the start of the LDS)
+        typedef __attribute__((address_space(3))) float lds_float;
+        lds_float* srow = (lds_float*)(skl + ch * 32);
+        asm volatile("" : "+v"(srow));
 #ifdef PASNL_SA_BT
         constexpr int BT = PASNL_SA_BT;
 #else
@@ -1131,6 +1123,18 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
                 wa[(j + 1) & 1][u][ob] = wbase[(size_t)(RS * ((j + 1) * BT + u)) * C1 + ob * 32];
           }
           __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!(PASNL_SA_ABLATE & 1)) {
+            // the skip maxima of THIS batch's operands, next to the MFMAs that consume the same registers: folded in one go at
+            // the top of the chunk they made the wave wait for the operand refills the previous chunk had only just requested
+            // (3.4 k of a 49.7-k-cycle tile: what the "no skip maxima" ablation gains); here they wait for what the MFMAs wait for
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+              const int t = j * BT + u;
+              // XYZ3: steps 3 (the constant-1 / zero columns) and 6, 7 (padding) hold no column the skip connection reads
+              if (XYZ3 && (t == 3 || t >= 6)) continue;
+              __hip_atomic_fetch_max(srow + RS * t, xr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+          }
 #pragma unroll
           for (int u = 0; u < BT; ++u)
 #pragma unroll
