@@ -1142,8 +1142,15 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
               H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j & 1][u][ob], xr[j * BT + u], H1T[ob], 0, 0, 0);
           if constexpr (STREAM) {
             constexpr int GR = VEC ? 4 : 1;  // operands per load
-            // the load groups whose last step this batch finished: [floor(j*BT / GR), floor((j+1)*BT / GR)) * GR
-            load_part(min(ch + 1, nchunk - 1), j * BT / GR * GR, (j + 1) * BT / GR * GR);
+            // the load groups whose last step the PREVIOUS batch finished: [floor((j-1)*BT / GR), floor(j*BT / GR)) * GR.
+            // One batch late on purpose: across the chunk loop's back edge the compiler waits for EVERY outstanding load
+            // (vmcnt(0)) before the first use of a refilled register; with the refill of a group issued right behind its last
+            // step, that wait sat three instructions after a load had been issued -- a full memory round trip per chunk.
+            // The LAST group's refill cannot be issued behind the last batch for the same reason (the next iteration's first
+            // wait would follow it immediately): it is deferred to the first batch of the chunk that owns the data -- 12 batches
+            // before its first use.  (Chunk 0's operands all come from request_rows.)
+            if (j >= 1) load_part(min(ch + 1, nchunk - 1), (j - 1) * BT / GR * GR, j * BT / GR * GR);
+            else if (ch > 0) load_part(ch, (NB - 1) * BT / GR * GR, NS);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -1166,7 +1173,12 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
         chunk_steps(nfull, std::integral_constant<int, 8>{}, std::false_type{});
       } else if (nfull < nchunk) {
         const int ch = nfull;
-        if (nfull > 0) mask_chunk(ch, xr);
+        if (nfull > 0) {
+          // (the group the last full chunk left to its successor: see chunk_steps)
+          constexpr int BTF = C1 >= 128 ? 1 : 128 / C1, GRF = VEC ? 4 : 1;
+          load_part(ch, (16 / BTF - 1) * BTF / GRF * GRF, 16);
+          mask_chunk(ch, xr);
+        }
         const int rem = wi - ch * 32;
         const int live = VEC ? min(16, rem) : min(16, (rem + 1) >> 1);  // MFMA steps that touch a column < wi
         if (live <= 8) chunk_steps(ch, std::integral_constant<int, 8>{}, std::false_type{});
