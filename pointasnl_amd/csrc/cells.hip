@@ -2450,9 +2450,13 @@ __global__ __launch_bounds__(256) void decode_cell_tiled_kernel(long points, int
       }
     }
     for (int gq = 0; gq < ngroup; ++gq) {
-      const int gn = min(gq + 1, ngroup - 1) * 32 * V;  // next group's features in flight during this group's tiles
+      // next group's features in flight during this group's tiles (none behind the last group: a dummy request there
+      // would be 8 wasted loads per point -- and the wait for this group's operands would wait for them too)
+      if (gq + 1 < ngroup) {
+        const int gn = (gq + 1) * 32 * V;
 #pragma unroll
-      for (int t = 0; t < T; ++t) an[t] = *reinterpret_cast<const fvec*>(frow[t] + gn);
+        for (int t = 0; t < T; ++t) an[t] = *reinterpret_cast<const fvec*>(frow[t] + gn);
+      }
 #pragma unroll
       for (int e = 0; e < V; ++e) {
         f32x16 acc;
