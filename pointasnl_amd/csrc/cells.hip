@@ -346,9 +346,14 @@ __global__ __launch_bounds__(SPLIT * 64) void nl_attention_direct_kernel(int p, 
   };
   const int first = wave * NL_KB;
   if (first < n) {
+    // K strictly BEFORE V, as in the loop: loads return in order, and the wait in front of the first K.Q step is the
+    // weaker of "entered from here" and "came round the back edge".  With V first (the compiler's choice for SPLIT = 8) it
+    // became vmcnt(0) -- every round drained the V refill it had just issued
     load_k(first);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < CB / 32; ++c) load_v(first, c);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   for (int base = first; base < n; base += SPLIT * NL_KB) {
@@ -2202,34 +2207,43 @@ namespace pasnl {
 // =============================================================================================
 // A-operand stream of one 32-channel output block: weight rows k (lanes 0-31) / k+1 (lanes 32-63), 16 k-steps per chunk,
 // the next chunk requested while the current one feeds the MFMAs.
-constexpr int TAIL_KS = 8;  // k-steps (pairs of input channels) per operand chunk
+constexpr int TAIL_KS = 16;  // k-steps (pairs of input channels) per operand chunk
 struct TailW {
   const float* __restrict__ base;  // W + cbase + l32
   int C, kdim, h;
   __device__ __forceinline__ void load(int k0, float (&a)[TAIL_KS]) const {
 #pragma unroll
     for (int t = 0; t < TAIL_KS; ++t) {
-      const int kk = k0 + 2 * t + h;
-      a[t] = kk < kdim ? base[(size_t)kk * C] : 0.f;
+      // rows past kdim are CLAMPED, not skipped: the X tile is zero there, so any finite weight contributes nothing, and
+      // unconditional loads need no branch each and let the waits count (a skipped load costs an exec test per load and
+      // the waits in front of the products all became vmcnt(0))
+      const int kk = min(k0 + 2 * t + h, kdim - 1);
+      a[t] = base[(size_t)kk * C];
     }
   }
 };
 
 // acc += W[:, block]^T . X^T for X rows held in LDS as xs[k * 33 + row] (k-major, zero-padded to a multiple of 2 TAIL_KS
-// channels).  Chunks of TAIL_KS unconditional MFMAs (zero operands beyond kdim), the next chunk's weights in flight.
+// channels).  Chunks of TAIL_KS unconditional MFMAs (zero X beyond kdim), the next chunk's weights in flight.
 __device__ __forceinline__ f32x16 tail_product(const TailW& W, const float* __restrict__ xs, int l32, f32x16 acc) {
-  float a0[TAIL_KS], a1[TAIL_KS];
-  W.load(0, a0);
-  for (int k0 = 0; k0 < W.kdim; k0 += 4 * TAIL_KS) {
-    W.load(k0 + 2 * TAIL_KS, a1);  // (all zero beyond kdim: no memory access)
+  // `a` feeds the products while `b` (the next chunk) is in flight, covered by TAIL_KS products (~1000 cycles: an L2 round
+  // trip).  One loop body without an early exit -- an exit between a load and its use lets the compiler sink the load behind
+  // the exit, right in front of its use -- and the rotation as register copies after the products: by then `b` has arrived.
+  float a[TAIL_KS], b[TAIL_KS];
+  W.load(0, a);
+  for (int k0 = 0; k0 < W.kdim; k0 += 2 * TAIL_KS) {
+    W.load(k0 + 2 * TAIL_KS, b);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < TAIL_KS; ++t)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], xs[(k0 + 2 * t + W.h) * 33 + l32], acc, 0, 0, 0);
-    if (k0 + 2 * TAIL_KS >= W.kdim) break;
-    W.load(k0 + 4 * TAIL_KS, a0);
+    for (int g = 0; g < TAIL_KS / 4; ++g)
+      if (k0 + 8 * g < W.kdim) {  // uniform: a narrow product (9 skip columns) does not pay for a whole chunk
 #pragma unroll
-    for (int t = 0; t < TAIL_KS; ++t)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], xs[(k0 + 2 * TAIL_KS + 2 * t + W.h) * 33 + l32], acc, 0, 0, 0);
+        for (int t = 4 * g; t < 4 * g + 4; ++t)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], xs[(k0 + 2 * t + W.h) * 33 + l32], acc, 0, 0, 0);
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < TAIL_KS; ++t) a[t] = b[t];
   }
   return acc;
 }
@@ -2258,26 +2272,48 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l32 = lane & 31;
   const long row0 = (long)blockIdx.x * 32;
   const int nblk = C >> 5;
-  // ---- tiles into LDS, transposed (coalesced rows in, stride-33 columns out: conflict-free)
-  auto stage = [&](const float* __restrict__ src, int width, int padded, float* dst) {
-    for (int c0 = 0; c0 < padded; c0 += 64) {  // a wave owns RPW rows: RPW row segments in flight
-      const int c = c0 + lane;
-      float v[RPW];
+  // ---- tiles into LDS, transposed (coalesced rows in, stride-33 columns out: conflict-free).  The three tiles are one list
+  // of 64-column segments, STAGE_DEPTH of them requested before the first is written: a workgroup's segments are one memory
+  // round trip, not one each (the grid is a single wave of workgroups -- its time IS a workgroup's chain of round trips).
+  // Everything unconditional, so that the loads cannot be sunk in front of their use: rows, columns and the segment index are
+  // clamped (a clamped lane / segment re-writes the value its twin writes), padding columns are zeroed by a select.
+  float cat_xyz[RPW];  // lanes 0..3 of a wave: [0 | xyz] of its rows for out_cat, requested now, stored at the very end
+  if (out_cat) {
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const long row = row0 + wave * RPW + i;
-        v[i] = (row < rows && c < width) ? src[row * width + c] : 0.f;
-      }
-      if (c < padded) {
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) dst[c * 33 + wave * RPW + i] = v[i];
-      }
+    for (int i = 0; i < RPW; ++i) {
+      const long row = min(row0 + wave * RPW + i, rows - 1);
+      cat_xyz[i] = xyz3[row * 3 + max(min(lane, 3) - 1, 0)];
     }
-  };
+  }
   if (!TAIL_ABL(0)) {
-    stage(A, C, C, vt);
-    stage(S, w, wp, st);
-    if (N) stage(N, cb, cbp, nt_);
+    constexpr int STAGE_DEPTH = 4;
+    const int nA = (C + 63) >> 6, nS = (wp + 63) >> 6, nN = N ? (cbp + 63) >> 6 : 0, total = nA + nS + nN;
+    for (int it0 = 0; it0 < total; it0 += STAGE_DEPTH) {
+      float v[STAGE_DEPTH][RPW];
+      int cl[STAGE_DEPTH], width[STAGE_DEPTH];
+      float* dst[STAGE_DEPTH];
+#pragma unroll
+      for (int d = 0; d < STAGE_DEPTH; ++d) {
+        const int it = min(it0 + d, total - 1);
+        const bool isA = it < nA, isS = !isA && it < nA + nS;
+        const float* __restrict__ src = isA ? A : (isS ? S : N);
+        const int padded = isA ? C : (isS ? wp : cbp), c0 = (isA ? it : (isS ? it - nA : it - nA - nS)) * 64;
+        width[d] = isA ? C : (isS ? w : cb);
+        dst[d] = isA ? vt : (isS ? st : nt_);
+        cl[d] = min(c0 + lane, padded - 1);
+        const int cc = min(cl[d], width[d] - 1);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const long row = min(row0 + wave * RPW + i, rows - 1);
+          v[d][i] = src[row * width[d] + cc];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int d = 0; d < STAGE_DEPTH; ++d)
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) dst[d][cl[d] * 33 + wave * RPW + i] = cl[d] < width[d] ? v[d][i] : 0.f;
+    }
   }
   __syncthreads();
   // ---- stage 1: V^T += relu(Ws^T S^T + bs) + relu(Wb^T N^T + bb); wave = channel block
@@ -2333,7 +2369,7 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
       for (int i = 0; i < RPW; ++i) {
         const long row = row0 + wave * RPW + i;
         if (row < rows && c < C) out_cat[row * (C + 4) + 4 + c] = v[i];
-        if (c0 == 0 && lane < 4 && row < rows) out_cat[row * (C + 4) + lane] = lane ? xyz3[row * 3 + lane - 1] : 0.f;
+        if (c0 == 0 && lane < 4 && row < rows) out_cat[row * (C + 4) + lane] = lane ? cat_xyz[i] : 0.f;
       }
     }
   }
@@ -2353,7 +2389,7 @@ static int sa_tail_entry(int rows, int w, int cb, int c, const float* after, con
   if (rows == 0) return PASNL_OK;
   PASNL_REQUIRE(after && skip_max && ws && bs && wagg && bagg && out, PASNL_ENULL);
   PASNL_REQUIRE(cb == 0 || (att && wb && bb), PASNL_ENULL);
-  const size_t lds = ((size_t)c + ((w + 15) & ~15) + ((cb + 15) & ~15)) * 33 * sizeof(float);
+  const size_t lds = ((size_t)c + ((w + 31) & ~31) + ((cb + 31) & ~31)) * 33 * sizeof(float);  // tiles padded to 2 TAIL_KS rows
   PASNL_REQUIRE(lds <= 160 * 1024, PASNL_EUNSUPPORTED);
   const int nw = c <= 128 ? 4 : (c <= 256 ? 8 : 16);  // one wave per 32-channel block (>= 4 waves stage the tiles)
   auto kern = nw == 4 ? pasnl::sa_tail_kernel<4> : (nw == 8 ? pasnl::sa_tail_kernel<8> : pasnl::sa_tail_kernel<16>);

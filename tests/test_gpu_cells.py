@@ -615,3 +615,47 @@ def test_decoding_layer_tiled_matches_plain():
         finally:
             U.DECODE_CELL_TILED = True
     assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,w,cb,c,cat", [
+    (32768, 9, 32, 128, True),    # cls layer1 (narrow skip product: 9 columns), with the [0 | xyz | out] rows
+    (8192, 134, 64, 256, False),  # cls layer2
+    (100, 9, 32, 128, False),     # ragged last tile
+    (77, 134, 64, 256, True),
+    (33, 70, 0, 32, False),       # no back-projection (NL=False layers): att = NULL
+    (64, 16, 16, 512, False),     # 16 waves per workgroup
+    (1, 1, 1, 32, True),
+    (2049, 257, 33, 96, False),   # nothing a multiple of a chunk
+])
+def test_sa_tail_matches_fp64(rows, w, cb, c, cat):
+    """pasnl_sa_tail / pasnl_sa_tail_cat through the C ABI: out = relu((A + relu(S Ws + bs) + relu(N Wb + bb)) Wagg + bagg)
+    (pointasnl_util.py:138-151 of the reference: skip convolution, back-projection, both adds, aggregation) against the
+    fp64 product; operand chunks, tiles and row tiles that do not divide (clamped loads, zero-padded tiles)."""
+    from pointasnl_amd import _hip
+    rng = np.random.default_rng(rows + w + c)
+    f = lambda *sh: rng.standard_normal(sh).astype(np.float32)
+    A, S, N = f(rows, c), f(rows, w), f(rows, max(cb, 1))
+    ws, bs, wb, bb = f(w, c) / np.float32(np.sqrt(w)), f(c), f(max(cb, 1), c) / np.float32(np.sqrt(max(cb, 1))), f(c)
+    wagg, bagg, xyz = f(c, c) / np.float32(np.sqrt(c)), f(c), f(rows, 3)
+    want = A.astype(np.float64) + np.maximum(S.astype(np.float64) @ ws + bs, 0)
+    if cb:
+        want = want + np.maximum(N.astype(np.float64) @ wb + bb, 0)
+    want = np.maximum(want @ wagg.astype(np.float64) + bagg, 0)
+    d = {k: dev(v) for k, v in dict(A=A, S=S, N=N, ws=ws, bs=bs, wb=wb, bb=bb, wagg=wagg, bagg=bagg, xyz=xyz).items()}
+    out = torch.full((rows, c), float("nan"), device="cuda")
+    null = _hip.ptr(None)
+    args = [rows, w, cb, c, _hip.ptr(d["A"]), _hip.ptr(d["S"]), _hip.ptr(d["N"]) if cb else null, _hip.ptr(d["ws"]),
+            _hip.ptr(d["bs"]), _hip.ptr(d["wb"]) if cb else null, _hip.ptr(d["bb"]) if cb else null, _hip.ptr(d["wagg"]),
+            _hip.ptr(d["bagg"]), _hip.ptr(out)]
+    if cat:
+        out_cat = torch.full((rows, c + 4), float("nan"), device="cuda")
+        _hip.launch("pasnl_sa_tail_cat", "sa_tail", *args, _hip.ptr(d["xyz"]), _hip.ptr(out_cat))
+    else:
+        _hip.launch("pasnl_sa_tail", "sa_tail", *args)
+    got = out.cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    if cat:
+        oc = out_cat.cpu().numpy()
+        np.testing.assert_array_equal(oc[:, 0], 0)
+        np.testing.assert_array_equal(oc[:, 1:4], xyz)
+        np.testing.assert_array_equal(oc[:, 4:], got)

@@ -10,6 +10,8 @@ from pointasnl_amd import _hip  # noqa: E402
 
 if os.environ.get("PASNL_PROBE_LIB") == "tuning":
     _hip.LIB_PATH = _hip.LIB_PATH.replace("libpasnl_hip.so", "libpasnl_hip_tuning.so")
+elif os.environ.get("PASNL_PROBE_LIB", "").endswith(".so"):  # an alternative build to compare against
+    _hip.LIB_PATH = os.environ["PASNL_PROBE_LIB"]
 
 g = torch.Generator(device="cuda").manual_seed(0)
 r = lambda *sh: torch.randn(sh, device="cuda", generator=g)
