@@ -30,6 +30,9 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(int rows, int kdim, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
   const int cb = blockIdx.x, ks = blockIdx.y, ncb = gridDim.x;
   const int col = min(cb * 32 + l32, n - 1);
+  // every element a thread finishes lies in column `col` (e = q * 256 + tid keeps its low five bits): ONE bias word, requested
+  // here -- as `bias[c]` inside finish() it was a load -> wait -> store chain per element at the very end of the kernel
+  const float bias_col = bias[col];
   const int per_wave = kchunk >> 2;  // multiple of 8
   const int kbeg = ks * kchunk + wave * per_wave;
   const int kend = min(kbeg + per_wave, kdim);
@@ -117,19 +120,34 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(int rows, int kdim, int
     s[q] = ((red[e] + red[E + e]) + red[2 * E + e]) + red[3 * E + e];
   }
 
-  auto finish = [&](int q, float v) {
-    const int e = q * 256 + tid;  // = (rb * 16 + i) * 64 + lane'
-    const int ln = e & 63, i = (e >> 6) & 15, rb = e >> 10;
-    const int r = rb * 32 + dense_kappa(i, ln >> 5), c = cb * 32 + (ln & 31);
-    if (r < rows && c < n) {
-      v += bias[c];
-      out[(size_t)r * n + c] = relu ? fmaxf(v, 0.f) : v;
+  // a full tile (the usual case) stores without a test per element: tested stores are a branch each, and behind a store that
+  // may or may not have been issued the compiler can only wait for EVERYTHING (vmcnt(0): the previous store's round trip)
+  const bool full_tile = rows == RB * 32 && cb * 32 + 32 <= n;  // uniform
+  auto finish_all = [&](float (&v)[E / 256]) {
+    size_t at[E / 256];
+    bool ok[E / 256];
+#pragma unroll
+    for (int q = 0; q < E / 256; ++q) {
+      const int e = q * 256 + tid;  // = (rb * 16 + i) * 64 + lane'
+      const int ln = e & 63, i = (e >> 6) & 15, rb = e >> 10;
+      const int r = rb * 32 + dense_kappa(i, ln >> 5), c = cb * 32 + (ln & 31);
+      v[q] += bias_col;
+      v[q] = relu ? fmaxf(v[q], 0.f) : v[q];
+      at[q] = (size_t)r * n + c;
+      ok[q] = r < rows && c < n;
+    }
+    if (full_tile) {
+#pragma unroll
+      for (int q = 0; q < E / 256; ++q) out[at[q]] = v[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < E / 256; ++q)
+        if (ok[q]) out[at[q]] = v[q];
     }
   };
 
   if (ksplit == 1) {
-#pragma unroll
-    for (int q = 0; q < E / 256; ++q) finish(q, s[q]);
+    finish_all(s);
     return;
   }
   // ---- K slices of the other workgroups: through the workspace, summed in slice order by the last one to arrive
@@ -167,8 +185,7 @@ __global__ __launch_bounds__(256) void dense_rows_kernel(int rows, int kdim, int
         for (int q = 0; q < E / 256; ++q) v[q] += t[u][q];
       }
   }
-#pragma unroll
-  for (int q = 0; q < E / 256; ++q) finish(q, v[q]);
+  finish_all(v);
 }
 
 struct DensePlan {
