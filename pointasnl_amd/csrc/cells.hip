@@ -1797,8 +1797,9 @@ namespace pasnl {
 // as_cell_narrow_kernel, with the projected operands read from memory in the layouts that kernel computes them in
 // (K^T / Q^T: 16-byte loads of 4 consecutive channels; V: coalesced row reads).  Wb (32 x (1+ch)) sits in LDS.
 // ---------------------------------------------------------------------------------------------
-template <int CBLK>  // cb <= 16 * CBLK (the reference's bottleneck widths are (3 + c) / 2: 33, 65, ... -- any cb works)
-__global__ __launch_bounds__(256) void as_cell_wide_kernel(long groups, int as, int cb, int w, int ch, float qscale,
+template <int CBLK>  // 16 (CBLK - 1) < cb <= 16 CBLK (the reference's bottleneck widths are (3 + c) / 2: 33, 65, ...): only
+                     // the LAST block of 16 channels needs clamped addresses and masks, the others load at constant offsets
+__global__ __launch_bounds__(256, 3) void as_cell_wide_kernel(long groups, int as, int cb, int w, int ch, float qscale,
                                                           const float* __restrict__ kvq, int ld, const float* __restrict__ x,
                                                           const float* __restrict__ wa, const float* __restrict__ ba,
                                                           const float* __restrict__ wb, const float* __restrict__ bb,
@@ -1807,38 +1808,39 @@ __global__ __launch_bounds__(256) void as_cell_wide_kernel(long groups, int as, 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* Wbs = reinterpret_cast<float*>(smem);  // [32][nout]
   const int nout = 1 + ch;
+  float* Bbs = Wbs + 32 * nout;                 // [nout] (+ 16 zeros: the last block of outputs reads past nout)
+  float* Was = Bbs + nout + 16;                 // [16 CBLK][WAS_LD]: Wa, rows past cb zero (the padded channels contribute
+  constexpr int WAS_LD = 36;                    //  nothing); stride 36: the four 16-lane rows of a read hit all 32 banks
   for (int i = threadIdx.x; i < 32 * nout; i += 256) Wbs[i] = wb[i];
+  for (int i = threadIdx.x; i < nout + 16; i += 256) Bbs[i] = i < nout ? bb[i] : 0.f;
+  for (int i = threadIdx.x; i < 16 * CBLK * 32; i += 256) Was[(i >> 5) * WAS_LD + (i & 31)] = (i >> 5) < cb ? wa[i] : 0.f;
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int col = lane & 15, grp = lane >> 4;
-  float wa_r[CBLK][4][2];
   f32x4 ba_r[2];
 #pragma unroll
-  for (int hb = 0; hb < 2; ++hb) {
+  for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) ba_r[hb][r] = ba[hb * 16 + 4 * grp + r];
-#pragma unroll
-    for (int cbk = 0; cbk < CBLK; ++cbk)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = cbk * 16 + 4 * grp + r;  // rows past cb are zero: the padded channels contribute nothing
-        wa_r[cbk][r][hb] = c < cb ? wa[(size_t)c * 32 + hb * 16 + col] : 0.f;
-      }
-  }
   const int noblk = (nout + 15) >> 4;
   const long nwaves = (long)gridDim.x * 4;
   for (long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6); g < groups; g += nwaves) {
     const float* kq = kvq + ((size_t)g * as + min(col, as - 1)) * cb3;  // this lane's [K | V | Q] row
     const float* vb = kvq + (size_t)g * as * cb3 + cb;                  // V rows of the group
     f32x4 S = {0.f, 0.f, 0.f, 0.f};
+    const float mrow = col < as ? 1.f : 0.f;
 #pragma unroll
     for (int cbk = 0; cbk < CBLK; ++cbk)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int c = cbk * 16 + 4 * grp + r;
-        const float kk = kq[min(c, cb - 1)], qq = kq[2 * cb + min(c, cb - 1)];  // unconditional loads, clamped
-        const bool ok = col < as && c < cb;
-        S = __builtin_amdgcn_mfma_f32_16x16x4f32(ok ? kk : 0.f, ok ? qq * qscale : 0.f, S, 0, 0, 0);
+        // unconditional loads (the last block's on clamped addresses), masked by a PRODUCT: behind `ok ? value : 0` the
+        // compiler makes the load itself conditional -- a branch, the load and a full wait in front of every matrix step
+        const bool last = cbk == CBLK - 1;
+        const int cc = last ? min(c, cb - 1) : c;
+        const float kk = kq[cc], qq = kq[2 * cb + cc];
+        const float m = last ? (col < as && c < cb ? 1.f : 0.f) : mrow;
+        S = __builtin_amdgcn_mfma_f32_16x16x4f32(kk * m, qq * (qscale * m), S, 0, 0, 0);
       }
     float tmax = -INFINITY;
 #pragma unroll
@@ -1857,7 +1859,28 @@ __global__ __launch_bounds__(256) void as_cell_wide_kernel(long groups, int as, 
     psum += __shfl_xor(psum, 16);
     psum += __shfl_xor(psum, 32);
     const float inv = 1.0f / psum;
+    // The re-weighting at the end works on TRANSPOSED logits: lane (col, grp) owns output ob*16 + col and the neighbours
+    // 4 grp + r.  What it multiplies: column 2 + o of its four neighbours' rows (coalesced over col), and for output 0 their
+    // coordinates.  The first block's values are requested here, a matrix chain ahead of their use (and after the K / Q
+    // registers have been released) -- not one by one in front of each use.
+    const float* xg = x + (size_t)g * as * w;
+    int xrow[4];
+    float x3[4][3], xo[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xrow[r] = min(4 * grp + r, as - 1) * w;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) x3[r][d] = xg[xrow[r] + min(3 + d, w - 1)];
+      xo[r] = xg[xrow[r] + min(2 + col, w - 1)];
+    }
     f32x4 H[2] = {ba_r[0], ba_r[1]};
+    int vrow[4];
+    float vmask[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      vrow[t] = min(4 * grp + t, as - 1) * cb3;
+      vmask[t] = 4 * grp + t < as ? 1.f : 0.f;
+    }
 #pragma unroll
     for (int cbk = 0; cbk < CBLK; ++cbk) {
       f32x4 O = {0.f, 0.f, 0.f, 0.f};
@@ -1865,14 +1888,16 @@ __global__ __launch_bounds__(256) void as_cell_wide_kernel(long groups, int as, 
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int key = 4 * grp + t;
-        const float v = vb[(size_t)min(key, as - 1) * cb3 + min(vc, cb - 1)];
-        O = __builtin_amdgcn_mfma_f32_16x16x4f32(key < as && vc < cb ? v : 0.f, S[t], O, 0, 0, 0);
+        const bool last = cbk == CBLK - 1;
+        const float v = vb[vrow[t] + (last ? min(vc, cb - 1) : vc)];
+        O = __builtin_amdgcn_mfma_f32_16x16x4f32(v * (last ? (key < as && vc < cb ? 1.f : 0.f) : vmask[t]), S[t], O, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float a = O[r] * inv;
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) H[hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa_r[cbk][r][hb], a, H[hb], 0, 0, 0);
+        for (int hb = 0; hb < 2; ++hb)
+          H[hb] = __builtin_amdgcn_mfma_f32_16x16x4f32(Was[(cbk * 16 + 4 * grp + r) * WAS_LD + hb * 16 + col], a, H[hb], 0, 0, 0);
       }
     }
     float hr[2][4];
@@ -1880,38 +1905,65 @@ __global__ __launch_bounds__(256) void as_cell_wide_kernel(long groups, int as, 
     for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) hr[hb][r] = fmaxf(H[hb][r], 0.f);
-    const float* xp = x + ((size_t)g * as + min(col, as - 1)) * w;  // the row this lane re-weights
-    for (int ob = 0; ob < noblk; ++ob) {
-      // logits of outputs o = ob*16 + 4*grp + r for neighbour `col`
-      f32x4 L;
+    // (a use the compiler cannot move: without it the coordinate loads are sunk into the one branch that reads them)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) L[r] = ob * 16 + 4 * grp + r < nout ? bb[ob * 16 + 4 * grp + r] : 0.f;
+    for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(x3[r][0]), "v"(x3[r][1]), "v"(x3[r][2]));
+    for (int ob = 0; ob < noblk; ++ob) {
+      float xn[4];  // the next block's column, in flight under this block's matrix steps and softmax
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xn[r] = xg[xrow[r] + min(2 + (ob + 1) * 16 + col, w - 1)];
+      // logits, transposed: L[r] = logit of output ob*16 + col for neighbour 4 grp + r (the operands of the reference-order
+      // product, swapped).  The softmax over the neighbours is then three in-lane steps and two exchanges between the four
+      // 16-lane rows per reduction, ONE division per output -- not a 16-lane DPP reduction per (output, reduction)
+      f32x4 L;
+      const float b0 = Bbs[ob * 16 + col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) L[r] = b0;
       const int oc = min(ob * 16 + col, nout - 1);
+      const float mo = ob * 16 + col < nout ? 1.f : 0.f;
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float wv_ = Wbs[(hb * 16 + 4 * grp + r) * nout + oc];
-          L = __builtin_amdgcn_mfma_f32_16x16x4f32(ob * 16 + col < nout ? wv_ : 0.f, hr[hb][r], L, 0, 0, 0);
-        }
+        for (int r = 0; r < 4; ++r)
+          L = __builtin_amdgcn_mfma_f32_16x16x4f32(hr[hb][r], Wbs[(hb * 16 + 4 * grp + r) * nout + oc] * mo, L, 0, 0, 0);
+      float mx = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int o = ob * 16 + 4 * grp + r;
-        const float v = col < as ? L[r] : -INFINITY;
-        const float mx = row16_max(v);
-        const float e = col < as ? fast_exp2((v - mx) * LOG2E) : 0.f;
-        const float wgt = e / row16_sum(e);
-        if (o == 0) {  // (uniform per 16-lane row: only grp 0 of block 0)
+        L[r] = 4 * grp + r < as ? L[r] : -INFINITY;
+        mx = fmaxf(mx, L[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));  // finite: neighbour 0 is always valid
+      float den = 0.f, num = 0.f, n3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-          for (int d = 0; d < 3; ++d) {
-            const float sx = row16_sum(col < as ? wgt * xp[3 + d] : 0.f);
-            if (col == 0) new_xyz[g * 3 + d] = sx;
-          }
-        } else {
-          const float sf = row16_sum(col < as ? wgt * xp[min(2 + o, w - 1)] : 0.f);
-          if (col == 0 && o < nout) new_feature[(size_t)g * ch + (o - 1)] = sf;
+      for (int r = 0; r < 4; ++r) {
+        const float e = fast_exp2((L[r] - mx) * LOG2E);  // 0 for the padding neighbours; their (clamped) rows are finite
+        den += e;
+        num += e * xo[r];
+        if (ob == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) n3[d] += e * x3[r][d];
         }
       }
+      den += __shfl_xor(den, 16);
+      num += __shfl_xor(num, 16);
+      den += __shfl_xor(den, 32);
+      num += __shfl_xor(num, 32);
+      const int o = ob * 16 + col;
+      if (ob == 0) {  // (uniform) output 0 re-weights the coordinates
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          n3[d] += __shfl_xor(n3[d], 16);
+          n3[d] += __shfl_xor(n3[d], 32);
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) new_xyz[g * 3 + d] = n3[d] / den;
+        }
+      }
+      if (grp == 0 && o >= 1 && o < nout) new_feature[(size_t)g * ch + (o - 1)] = num / den;  // 16 consecutive floats
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xo[r] = xn[r];
     }
   }
 }
@@ -1924,7 +1976,7 @@ extern "C" int pasnl_as_cell_wide_ld(int g, int as, int cb, int w, int ch, const
   PASNL_REQUIRE(as <= 16 && cb <= 144 && w == 3 + ch, PASNL_EUNSUPPORTED);
   if (g == 0) return PASNL_OK;
   PASNL_REQUIRE(kvq && x && wa && ba && wb && bb && new_xyz && new_feature, PASNL_ENULL);
-  const size_t lds = (size_t)32 * (1 + ch) * sizeof(float);
+  const size_t lds = ((size_t)33 * (1 + ch) + 16 + (size_t)((cb + 15) / 16 > 9 ? 9 : (cb + 15) / 16) * 16 * 36) * sizeof(float);
   PASNL_REQUIRE(lds <= 64 * 1024, PASNL_EUNSUPPORTED);
   const float qscale = LOG2E / sqrtf((float)cb);
   const long wgs = ((long)g + 3) / 4;
@@ -1941,9 +1993,17 @@ extern "C" int pasnl_as_cell_wide_ld(int g, int as, int cb, int w, int ch, const
     hipLaunchKernelGGL(kern, grid, block, lds, st, (long)g, as, cb, w, ch, qscale, kvq, ld, x, wa, ba, wb, bb, new_xyz,    \
                        new_feature);                                                                                       \
   } while (0)
-  const int cblk = (cb + 15) / 16;
-  if (cblk <= 2) PASNL_AS_GO(2); else if (cblk == 3) PASNL_AS_GO(3); else if (cblk == 4) PASNL_AS_GO(4);
-  else if (cblk == 5) PASNL_AS_GO(5); else if (cblk <= 7) PASNL_AS_GO(7); else PASNL_AS_GO(9);
+  switch ((cb + 15) / 16) {  // exact: the kernel treats every block of 16 channels but the last as full
+    case 1: PASNL_AS_GO(1); break;
+    case 2: PASNL_AS_GO(2); break;
+    case 3: PASNL_AS_GO(3); break;
+    case 4: PASNL_AS_GO(4); break;
+    case 5: PASNL_AS_GO(5); break;
+    case 6: PASNL_AS_GO(6); break;
+    case 7: PASNL_AS_GO(7); break;
+    case 8: PASNL_AS_GO(8); break;
+    default: PASNL_AS_GO(9); break;
+  }
 #undef PASNL_AS_GO
   return pasnl_launch_status();
 }
