@@ -98,11 +98,31 @@ __device__ __forceinline__ void dist2_multi(const float (&qx)[QW], const float (
 // ---- wave-wide bitonic sort (used by the kNN kernels)
 template <typename T>
 __device__ __forceinline__ T shfl_xor_any(T v, int j);
+// partner lane ^ j.  Inside a row of 16 lanes the exchange is one or two DPP moves (quad permutes for j = 1, 2; for j = 4, 8 the
+// banks that read "from the right" and the banks that read "from the left" are two row shifts under complementary bank
+// masks) -- a register-file operation of a few cycles where __shfl_xor is a ds_bpermute round trip through the LDS crossbar
+// (~100 cycles with its wait, and a bitonic sort of 64 keys has 18 such steps of 21).  j is a constant after unrolling.
+__device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int j) {
+  const int x = (int)v;
+  switch (j) {
+    case 1: return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
+    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);  // quad_perm:[2,3,0,1]
+    case 4: {
+      const int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);      // banks 0, 2 <- lane + 4 (row_shl:4)
+      return (uint32_t)__builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);   // banks 1, 3 <- lane - 4 (row_shr:4)
+    }
+    case 8: {
+      const int t = __builtin_amdgcn_update_dpp(x, x, 0x108, 0xf, 0x3, false);      // banks 0, 1 <- lane + 8 (row_shl:8)
+      return (uint32_t)__builtin_amdgcn_update_dpp(t, x, 0x118, 0xf, 0xc, false);   // banks 2, 3 <- lane - 8 (row_shr:8)
+    }
+    default: return (uint32_t)__shfl_xor(x, j);
+  }
+}
 template <>
-__device__ __forceinline__ uint32_t shfl_xor_any<uint32_t>(uint32_t v, int j) { return (uint32_t)__shfl_xor((int)v, j); }
+__device__ __forceinline__ uint32_t shfl_xor_any<uint32_t>(uint32_t v, int j) { return shfl_xor_u32(v, j); }
 template <>
 __device__ __forceinline__ unsigned long long shfl_xor_any<unsigned long long>(unsigned long long v, int j) {
-  uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, j), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), j);
+  uint32_t lo = shfl_xor_u32((uint32_t)v, j), hi = shfl_xor_u32((uint32_t)(v >> 32), j);
   return ((unsigned long long)hi << 32) | lo;
 }
 

@@ -534,7 +534,8 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
     for (int it = 0; it < tcnt; it += 64) {
       int p = it + lane;
       bool in = p < tcnt;
-      float x = in ? sx[p] : 0.f, y = in ? sy[p] : 0.f, z = in ? sz[p] : 0.f;
+      const float x = sx[p], y = sy[p], z = sz[p];  // unconditional (p < SEARCH_TILE; stale words past tcnt are masked by `in` below):
+                                                   // behind `in ? sx[p] : 0` every read was its own exec-masked branch
       float dq[QW];
       dist2_multi<QW>(qx, qy, qz, x, y, z, dq);
 #pragma unroll
@@ -575,7 +576,8 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
     for (int it = 0; it < tcnt; it += 64) {
       int p = it + lane;
       bool in = p < tcnt;
-      float x = in ? sx[p] : 0.f, y = in ? sy[p] : 0.f, z = in ? sz[p] : 0.f;
+      const float x = sx[p], y = sy[p], z = sz[p];  // unconditional (p < SEARCH_TILE; stale words past tcnt are masked by `in` below):
+                                                   // behind `in ? sx[p] : 0` every read was its own exec-masked branch
       float dq[QW];
       dist2_multi<QW>(qx, qy, qz, x, y, z, dq);
 #pragma unroll
