@@ -1795,7 +1795,14 @@ namespace pasnl {
 // The AdaptiveSampling cell of a WIDE layer after its projection GEMM (w = 6 + c > 15: K = w is a GEMM worth running):
 // kvq (g, as, 3cb) = [K | V | Q] rows -> attention -> mlp2 -> softmax over the neighbours -> re-weighted sums, as in
 // as_cell_narrow_kernel, with the projected operands read from memory in the layouts that kernel computes them in
-// (K^T / Q^T: 16-byte loads of 4 consecutive channels; V: coalesced row reads).  Wb (32 x (1+ch)) sits in LDS.
+// (K^T / Q^T: 4 consecutive channels of the lane's row; V: coalesced row reads).  Wa, Wb (32 x (1+ch)) and the second bias
+// sit in LDS.  Differences from the narrow cell, all about what a wave waits for:
+//   * every load is unconditional and masked by a product (a select in front of a load makes the compiler predicate the
+//     load: branch + load + full wait per matrix step -- DESIGN.md 6 "loads behind a select");
+//   * the logits are formed TRANSPOSED (a lane owns an output and four neighbours): the softmax over the neighbours is
+//     in-lane work plus two exchanges between the 16-lane rows per reduction, one division per output, and the 16 outputs of
+//     a block leave as one 64-byte store;
+//   * the features a block re-weights are requested one block ahead; 3 waves per SIMD (__launch_bounds__(256, 3)).
 // ---------------------------------------------------------------------------------------------
 template <int CBLK>  // 16 (CBLK - 1) < cb <= 16 CBLK (the reference's bottleneck widths are (3 + c) / 2: 33, 65, ...): only
                      // the LAST block of 16 channels needs clamped addresses and masks, the others load at constant offsets
