@@ -432,9 +432,10 @@ def test_point_nonlocal_cell_any_bottleneck_width(n, c, p):
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("c,as_", [(100, 12), (122, 8), (200, 12), (256, 6), (280, 4)])
+@pytest.mark.parametrize("c,as_", [(100, 12), (122, 8), (200, 12), (256, 6), (280, 4), (29, 8), (177, 12), (237, 5)])
 def test_adaptive_sampling_fused_wide_bottlenecks(c, as_):
-    """as_cell_wide instantiations beyond the models' own (cb = (3+c)//2 = 51, 62, 101, 129, 141: CBLK 4, 7, 9) and, for
+    """as_cell_wide instantiations beyond the models' own (cb = (3+c)//2 = 51, 62, 101, 129, 141: CBLK 4, 7, 9; 16, 90, 120:
+    CBLK 1, 6, 8 -- the kernel is instantiated per exact block count since only the last block clamps and masks) and, for
     c = 280 (cb = 141 <= 144 still fused; 1 + channel = 284 columns), the gate into the few-kernel chain."""
     from pointasnl_amd.utils import pointasnl_util as U
 
