@@ -2,23 +2,26 @@
 """bench.py -- ModelNet40 pointasnl_cls forward throughput on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: launched by torch.distributed.run, one rank per GPU, RCCL)
+    (N>1: launched by torch.distributed.run, one rank per GPU, RCCL; `python bench.py --gpus N` starts the ranks itself)
 
 A "step" is one inference forward of models/pointasnl_cls.py over one batch of synthetic clouds
-(B=64 x 1024 x 3 per GPU, BASELINE.json configs[1]; --AS selects configs[2]); inputs are resident in HBM before
-the timed region.  The forward is captured into HIP graphs and replayed; consecutive forwards overlap on two
-streams (--pipeline).  With N>1 every rank owns its own 64 clouds (weak scaling, no data-path collective) and the
-per-shard logits are all-gathered over RCCL each step.
+(B=64 x 1024 x 3 per GPU, BASELINE.json configs[1]); inputs are resident in HBM before the timed region.  The forward
+is captured into ONE HIP graph and replayed (what can overlap inside a forward is forked onto side streams by the
+models).  With N>1 every rank owns its own 64 clouds (weak scaling, no data-path collective) and the per-shard logits
+are all-gathered over RCCL each step.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the hand-written kernel that takes the largest share of the
 step: algorithmic bytes/flops / its average launch duration, measured with HIP events on the
 launch stream in an event-instrumented pass of the same forward.  `cpu_baseline` times the CPU restatement of
-the same forward (oracle/, "port") on the host cores over a bounded sample.  `kernels` lists every hand-written
-kernel the same way (extra, for the record).
+the same forward on the host cores over a bounded sample.  `kernels` lists every hand-written kernel the same way.
+At N=1 the same process then measures the other BASELINE configurations the same way (captured, replayed, timed,
+checked against the eager outputs) -> `other_configs`: configs[2] (cls --AS, 10 outliers per cloud), configs[3]
+(pointasnl_sem_seg, 16 x 8192) and the per-GPU share of configs[4] (pointasnl_sem_seg_res, 8 x 10240); and the
+north-star operator sweep -> `ball_query_sweep` (query_ball_point at (B,1024)/(B,512), nsample 32, B = 64..4096).
 
-Every rank's measurement runs in a worker process under a thin supervisor (`supervise`): the worker reports its phase over
-a pipe, and a worker that makes no progress for the phase's allowance (a GPU dead-lock between concurrently replayed
-graphs) is killed and re-run once with --pipeline serial, so that a stall costs a retry instead of the run.
+Every rank's measurement runs in a worker process under a thin supervisor (`supervise`): the worker reports its phase
+over a pipe, and a job in which a worker makes no progress within the phase's allowance is killed (exact PIDs) instead
+of hanging the caller.
 """
 import argparse
 import json
@@ -121,13 +124,13 @@ def algorithmic(symbol, ints):
         return 4 * b * (n * c + m * ns + m * ns * c), 0, "hbm"
     if symbol in ("pasnl_knn_batch", "pasnl_knn_batch_ws"):
         b, n, m, k = ints[:4]
-        return 12 * b * (n + m) + 4 * b * m * k, 8 * b * n * m, "hbm"
+        return 12 * b * (n + m) + 4 * b * m * k, 8 * b * n * m, "valu"  # a search: vector-issue bound
     if symbol == "pasnl_query_ball_point":
         b, n, m, ns = ints
         return 12 * b * (n + m) + 4 * b * m * (ns + 1), 10 * b * n * m, "hbm"
     if symbol == "pasnl_three_nn":
         b, n, m = ints
-        return 12 * b * (n + m) + 24 * b * n, 8 * b * n * m, "hbm"
+        return 12 * b * (n + m) + 24 * b * n, 8 * b * n * m, "valu"
     if symbol == "pasnl_three_interpolate":
         b, m, c, n = ints
         return 24 * b * n + 4 * b * c * (m + n), 5 * b * n * c, "hbm"
@@ -171,6 +174,18 @@ def algorithmic(symbol, ints):
     if symbol in ("pasnl_max_pool_rows", "pasnl_max_pool_rows_strided"):
         b, n, c = ints[:3]
         return 4 * b * c * (n + 1), 0, "hbm"
+    if symbol == "pasnl_as_gather":
+        b, n, c, m, k, as_ = ints
+        return 4 * b * (n * (3 + c) + m * as_ + m * as_ * (6 + c)), 0, "hbm"
+    if symbol == "pasnl_take_neighbor0":
+        b, n, c, m, k = ints
+        return 4 * b * m * (1 + 2 * (3 + c) + 3), 0, "hbm"
+    if symbol in ("pasnl_as_cell_narrow", "pasnl_as_cell_wide", "pasnl_as_cell_wide_ld"):
+        g, as_, cb, w, ch = ints[:5]
+        tail = 4 * as_ * as_ * cb + 5 * as_ * as_ + 2 * as_ * cb * 32 + 2 * as_ * 32 * (1 + ch) + 2 * as_ * (3 + ch)
+        if symbol == "pasnl_as_cell_narrow":  # reads the gathered rows; K, V, Q never reach memory
+            return 4 * g * (as_ * w + 3 + ch), g * (2 * as_ * w * 3 * cb + tail), "mfma"
+        return 4 * g * (as_ * 3 * cb + as_ * w + 3 + ch), g * tail, "mfma"
     if symbol == "pasnl_as_reweight":
         g, as_, ns, ch = ints
         return 4 * g * (as_ * (1 + ch) + as_ * (3 + ch) + 3 + ch), 4 * g * as_ * (1 + ch), "hbm"
@@ -201,22 +216,22 @@ def cpu_baseline(pc_all, params, adaptive, seconds_budget=20.0):
     """The same forward on the host cores, the way BASELINE.md 3 lays it out: the reference's OWN kNN (knn_.cxx + nanoflann,
     OpenMP over the batch like knn_batch(omp=True); oracle/_ref/libref_knn.so) where that build travelled with the tree, C
     ports of the ops the reference only has as CUDA kernels (FPS, gathers; OpenMP over the batch), and torch-CPU fp32 GEMMs
-    on all host threads for the dense layers and the attention (oracle/cells_torch.py).  A baseline, not a target."""
+    on the host threads for the dense layers and the attention (oracle/cells_torch.py).  The sample is the SAME batch the GPU
+    measurement runs on (all B clouds), repeated for about `seconds_budget` seconds.  A baseline, not a target."""
     import torch
 
     from oracle import cells_torch, ops, ref
 
     cores = os.cpu_count() or 1
-    bsz = 16  # BASELINE.json configs[0]: the reference's CPU-runnable case
+    sample = pc_all
+    bsz = sample.shape[0]
     ops.set_threads(min(cores, bsz))  # OpenMP over the batch: more threads than clouds only spin
-    sample = pc_all[:bsz]
-    cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)  # warm-up (thread pools, BLAS)
     # give the CPU its best configuration: the intra-op thread count that runs this forward fastest (all logical cores
     # is NOT it on a 2-socket host with (B*P*K, C<=134) GEMMs)
     best = (None, 1e30)
-    for t in sorted({min(cores, c) for c in (8, 16, 32, 64, 128, cores)}):
+    for t in sorted({min(cores, c) for c in (16, 32, 64)}):
         torch.set_num_threads(t)
-        cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)
+        cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)  # warm-up (thread pools, BLAS)
         t0 = time.perf_counter()
         cells_torch.cls_forward(sample, params, adaptive_sample=adaptive)
         dt = time.perf_counter() - t0
@@ -224,7 +239,7 @@ def cpu_baseline(pc_all, params, adaptive, seconds_budget=20.0):
             best = (t, dt)
     torch.set_num_threads(best[0])
     one = best[1]
-    reps = max(3, min(50, int(seconds_budget / max(one, 1e-3))))
+    reps = max(3, min(30, int(seconds_budget / max(one, 1e-3))))
     ts, pieces = [], {}
     for _ in range(reps):
         cells_torch.TIMES = {}
@@ -245,7 +260,7 @@ def cpu_baseline(pc_all, params, adaptive, seconds_budget=20.0):
         nn = {"shape": [16, 1024, 256], "seconds": round(time.perf_counter() - t0, 4), "threads": 1, "kind": "reference"}
     return {"value": round(bsz / med, 2), "unit": "point-clouds/s", "cores": int(torch.get_num_threads()),
             "kind": "reference" if ref.available("libref_knn.so") else "port",
-            "sample": f"{reps} forwards of B={bsz}x1024 (configs[0]) after 2 warm-ups, median {med * 1e3:.1f} ms/forward; "
+            "sample": f"{reps} forwards of the same B={bsz}x{sample.shape[1]} batch the GPU runs, median {med * 1e3:.1f} ms/forward; "
                       f"kNN = the reference's knn_.cxx + nanoflann with OpenMP over the batch"
                       f"{'' if ref.available('libref_knn.so') else ' (C PORT: oracle/_ref absent)'}, FPS/gathers = C port (the "
                       f"reference has no CPU kernel), dense + attention = torch CPU fp32 on {torch.get_num_threads()} threads "
@@ -287,13 +302,15 @@ def measured_traffic(symbol, dims):
     return data[key], f"profiles/traffic.json@{src.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; {owner} unchanged since)"
 
 
+
 # ---------------------------------------------------------------------------------------------------------------
-# supervisor: progress-watched worker process, one serial retry
+# supervisor: progress-watched worker processes
 # ---------------------------------------------------------------------------------------------------------------
 HEARTBEAT_ENV = "PASNL_BENCH_HEARTBEAT_FD"
 # seconds without a heartbeat that count as a stall, per phase the worker announces.  start: interpreter + first
 # `import torch` on a fresh box (minutes) + RCCL init; setup: eager forwards, BLAS heuristics, graph capture;
-# run: warm-up + timed steps (+ per step, see beat()); post: event-instrumented pass + CPU baseline sample
+# run: warm-up + timed steps (+ per step, see beat()); post: event-instrumented pass, the other configurations,
+# the operator sweep, the CPU baseline sample
 ALLOWANCE = {"start": 900.0, "setup": 600.0, "run": 120.0, "post": 900.0}
 
 
@@ -390,28 +407,20 @@ def _flag(argv, name, default):
 def supervise(argv):
     """Launcher + supervisor.  `python bench.py --gpus N` starts N ranks ITSELF (one process per GPU: RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT); under torch.distributed.run (WORLD_SIZE already set) it is one
-    rank of that job.  Every worker is watched through its heartbeat pipe; if one stalls, all are killed and the job is
-    re-run once with --pipeline serial."""
+    rank of that job.  Every worker is watched through its heartbeat pipe; if one stalls, all are killed (exit code 3)."""
     base = [sys.executable, os.path.abspath(__file__), "--worker"]
     scale = float(os.environ.get("PASNL_BENCH_STALL_SCALE", "1"))
     n = int(_flag(argv, "--gpus", "1"))
-
-    def jobs(extra):
-        if "WORLD_SIZE" in os.environ or n == 1:
-            return [(base + argv + extra, os.environ)]
+    if "WORLD_SIZE" in os.environ or n == 1:
+        jobs = [(base + argv, os.environ)]
+    else:
         port = _free_port()
-        return [(base + argv + extra, dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))) for r in range(n)]
-
-    rc, stalled = watch_many(jobs([]), ALLOWANCE["start"] * scale)
+        jobs = [(base + argv, dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                                   MASTER_PORT=str(port))) for r in range(n)]
+    rc, stalled = watch_many(jobs, ALLOWANCE["start"] * scale)
     if stalled is None:
         return rc
-    print(f"bench.py: a worker made no progress in phase '{stalled}'; all workers were killed, retrying with --pipeline serial",
-          file=sys.stderr, flush=True)
-    rc, stalled2 = watch_many(jobs(["--pipeline", "serial", "--retry-of", stalled]), ALLOWANCE["start"] * scale)
-    if stalled2 is None:
-        return rc
-    print(f"bench.py: the serial retry stalled in phase '{stalled2}' as well; giving up", file=sys.stderr, flush=True)
+    print(f"bench.py: a worker made no progress in phase '{stalled}'; all workers were killed", file=sys.stderr, flush=True)
     return 3
 
 
@@ -464,37 +473,267 @@ def protocol_only(args, rank, world):
                                      "allreduce_check": check, "global_batch": world * B}}), flush=True)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# one configuration: inputs, capture, timed replays, agreement with the eager forward, per-kernel pass
+# ---------------------------------------------------------------------------------------------------------------
+WORKLOADS = {
+    1: dict(model="cls", AS=False, noise=0, batch=64, points=1024, name="configs[1]: ModelNet40 pointasnl_cls, 1024 pts"),
+    2: dict(model="cls", AS=True, noise=10, batch=64, points=1024,
+            name="configs[2]: ModelNet40 pointasnl_cls --AS, 1024 pts + 10 outliers per cloud"),
+    3: dict(model="sem_seg", AS=False, noise=0, batch=16, points=8192, synth="scannet", feature_channel=3,
+            name="configs[3]: ScanNet pointasnl_sem_seg, 8192 pts (xyz + rgb, synthetic 1.5 x 1.5 x 3 m blocks)"),
+    4: dict(model="sem_seg_res", AS=False, noise=0, batch=8, points=10240, synth="kitti", feature_channel=0,
+            name="configs[4]: SemanticKITTI pointasnl_sem_seg_res, 10240 pts (synthetic lidar-like scans in metres; one GPU's "
+                 "share of the batch)"),
+}
+
+
+def make_input(cfg_index, spec, rank):
+    seed = 1234 + cfg_index + 100 * rank
+    if spec.get("synth") == "scannet":
+        return synth_scannet(seed, spec["batch"], spec["points"])
+    if spec.get("synth") == "kitti":
+        return synth_kitti(seed, spec["batch"], spec["points"])
+    pc = synth_clouds(seed, spec["batch"], spec["points"])
+    if spec["AS"]:
+        pc = add_noise(pc, spec["noise"], seed)
+    return pc
+
+
+def roofline_of(rows):
+    """The roofline block of the hand-written kernel with the largest time per step among the bandwidth- / matrix-bound ones
+    (latency- and issue-bound searches have no meaningful fraction of either roof; they are listed in `kernels`)."""
+    cand = [r for r in rows if r["bound"] in ("mfma", "hbm")]
+    if not cand:
+        return None
+    dom = max(cand, key=lambda r: r["avg_us"] * r["launches"])
+    if dom["bound"] == "mfma":
+        ach, peak, unit = dom["TFLOP/s"], F32_MFMA_PEAK_TF, "TFLOP/s"
+    else:
+        ach, peak, unit = dom["GB/s"], HBM_PEAK_GBS, "GB/s"
+    traffic, traffic_source = measured_traffic(dom["kernel"], dom["dims"])
+    if traffic is None:
+        print(f"bench.py: roofline.traffic not reported: {traffic_source}", file=sys.stderr)
+    return {"kernel": dom["kernel"], "dims": dom["dims"], "bound": dom["bound"], "achieved": ach, "peak": peak, "unit": unit,
+            "frac": round(ach / peak, 5), "traffic": traffic, "traffic_source": traffic_source, "avg_us": dom["avg_us"],
+            "alg_bytes": dom["alg_bytes"], "alg_flops": dom["alg_flops"]}
+
+
+def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, graph=True, kernel_pass=True, announce=True):
+    """Measure one workload on the current device -> dict.  The timed region is `steps` forwards bracketed by
+    (barrier +) torch.cuda.synchronize() on both sides, max over ranks."""
+    import importlib
+
+    import torch
+    import torch.distributed as dist
+
+    from pointasnl_amd import _hip, sharding
+    from pointasnl_amd.utils import tf_util
+
+    model = importlib.import_module(f"pointasnl_amd.models.pointasnl_{spec['model']}")
+    B, N = spec["batch"], spec["points"]
+    pc = make_input(cfg_index, spec, rank)
+    x = torch.from_numpy(pc).cuda()
+    store = tf_util.set_store(tf_util.VariableStore(seed=1234))  # identical weights on every rank
+
+    def forward():
+        if spec["model"] == "cls":
+            logits, _ = model.get_model(x, is_training=False, adaptive_sample=spec["AS"])
+            return logits
+        logits, _ = model.get_model(x, False, 20, feature_channel=spec.get("feature_channel", 0))
+        return logits.reshape(B, -1)
+
+    width = 40 if spec["model"] == "cls" else N * 20
+    gather = sharding.LogitsGather(world, B, width, x.device, force=multi) if multi else None
+    if announce:
+        beat("setup")
+    with torch.no_grad():
+        # ---- warm-up (eager: creates weights, BLAS workspaces), then capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                out = forward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = None
+        if graph:
+            side.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            # thread_local: the RCCL watchdog thread must not be able to invalidate the capture
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                out = forward()
+            torch.cuda.current_stream().wait_stream(side)
+
+        def step():
+            if g is not None:
+                with torch.cuda.stream(side):
+                    g.replay()
+                    if gather is not None:
+                        gather.all_gather(out)
+                return out
+            o = forward()
+            if gather is not None:
+                gather.all_gather(o)
+            return o
+
+        if multi:
+            dist.barrier()  # ranks enter the watched region together, so a stall expires every rank's allowance together
+        if announce:
+            beat("run", 0.25 * (warmup + steps))
+            if os.environ.get("PASNL_BENCH_FAKE_STALL") == "run":  # supervisor test hook: the worker hangs in the watched region
+                time.sleep(1e6)
+        for _ in range(warmup):
+            step()
+        # ---- timed region: barrier + sync on both sides, max over ranks
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if announce:
+            beat("post")
+        if multi:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=x.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        gathered_ok, shards_differ = None, None
+        if gather is not None:
+            # this rank's rows of the gathered logits are its own logits, and EVERY rank's rows carry that rank's logits: the
+            # ranks exchange a checksum of their local logits and compare it with the checksum of their rows as received here
+            gathered_ok = bool(torch.equal(gather.out[rank * B:(rank + 1) * B], last))
+            mine = last.double().sum().reshape(1)
+            sums = torch.empty((world,), dtype=torch.float64, device=x.device)
+            dist.all_gather_into_tensor(sums, mine)
+            got = gather.out.view(world, -1).double().sum(1)
+            gathered_ok = gathered_ok and bool(torch.allclose(sums, got, rtol=1e-9, atol=0.0))
+            shards_differ = bool(len(set(sums.tolist())) == world)  # different seeds per rank -> different logits
+        # the replayed graph computes the same function of the same input as the plain eager forward: bit-identical
+        agree = None
+        if g is not None:
+            agree = bool(torch.equal(forward(), out))
+        # ---- per-kernel pass: the same forward, eager, every C-ABI launch bracketed by HIP events
+        rows, launch_order = [], []
+        if kernel_pass and rank == 0:
+            reps = min(steps, 20)
+            _hip.PROFILE = []
+            for _ in range(reps):
+                forward()
+            torch.cuda.synchronize()
+            rows = kernel_table(_hip.PROFILE)
+            per_fwd = len(_hip.PROFILE) // max(1, reps)
+            launch_order = [[sym, list(ints)] for sym, ints, _, _ in _hip.PROFILE[:per_fwd]]
+            _hip.PROFILE = None
+    return {"B": B, "N": N, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "clouds_per_s": world * B * steps / elapsed,
+            "graph": g is not None, "outputs_agree": agree, "gathered_ok": gathered_ok, "shards_differ": shards_differ, "rows": rows,
+            "launch_order": launch_order, "pc": pc, "store": store}
+
+
+def ball_query_sweep(batches=(64, 256, 1024, 4096), iters=20):
+    """The operator north_star puts a number on: query_ball_point at (B,1024) support / (B,512) queries, radius 0.2,
+    nsample 32 (tf_grouping.py:78-88 scaled to the cls layer-1 shape), HIP-event median over `iters` launches."""
+    import torch
+
+    import pointasnl_amd as P
+    from pointasnl_amd import _hip
+
+    out = []
+    for b in batches:
+        x = torch.from_numpy(synth_clouds(4321 + b, min(b, 256), 1024)).cuda()
+        if b > 256:
+            x = x.repeat(b // 256, 1, 1)[torch.randperm(b, device="cuda")].contiguous()
+        q = x[:, :512].contiguous()
+        for _ in range(3):
+            P.tf_grouping.query_ball_point(0.2, 32, x, q)
+        torch.cuda.synchronize()
+        _hip.PROFILE = []
+        for _ in range(iters):
+            P.tf_grouping.query_ball_point(0.2, 32, x, q)
+        torch.cuda.synchronize()
+        us = [e0.elapsed_time(e1) * 1e3 for _, _, e0, e1 in _hip.PROFILE]
+        _hip.PROFILE = None
+        med = float(np.median(us))
+        by, fl, _ = algorithmic("pasnl_query_ball_point", (b, 1024, 512, 32))
+        traffic, src = measured_traffic("pasnl_query_ball_point", [b, 1024, 512, 32])
+        out.append({"B": b, "dims": [b, 1024, 512, 32], "radius": 0.2, "median_us": round(med, 2), "min_us": round(min(us), 2),
+                    "alg_MB": round(by / 1e6, 2), "GB/s": round(by / med / 1e3, 1), "hbm_frac": round(by / med / 1e3 / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_source": src})
+        del x, q
+    return out
+
+
+def traffic_pass(args):
+    """--traffic-pass (run under rocprofv3 --pmc by profiles/collect_traffic.sh): every workload's forward twice, eagerly,
+    then the operator sweep once, with a marker kernel (torch.cuda._sleep) in front of every C-ABI launch, so that the
+    counter rows between two markers belong to one launch whatever number of kernels it starts.  Prints the sequence of
+    launches as one JSON line."""
+    import importlib
+
+    import torch
+
+    import pointasnl_amd as P
+    from pointasnl_amd import _hip
+    from pointasnl_amd.utils import tf_util
+
+    _hip.lib()
+    _hip.require_device()
+    torch.cuda.set_device(0)
+    seq = []
+    _hip.MARK = seq
+    with torch.no_grad():
+        for ci, spec in WORKLOADS.items():
+            model = importlib.import_module(f"pointasnl_amd.models.pointasnl_{spec['model']}")
+            x = torch.from_numpy(make_input(ci, spec, 0)).cuda()
+            tf_util.set_store(tf_util.VariableStore(seed=1234))
+            for it in range(3):
+                _hip.MARK = seq if it else None  # the first forward creates weights and workspaces: unmarked, uncounted
+                if spec["model"] == "cls":
+                    model.get_model(x, is_training=False, adaptive_sample=spec["AS"])
+                else:
+                    model.get_model(x, False, 20, feature_channel=spec.get("feature_channel", 0))
+            torch.cuda.synchronize()
+        for b in (64, 256, 1024, 4096):
+            x = torch.from_numpy(synth_clouds(4321 + b, min(b, 256), 1024)).cuda()
+            if b > 256:
+                x = x.repeat(b // 256, 1, 1).contiguous()
+            q = x[:, :512].contiguous()
+            _hip.MARK = None
+            P.tf_grouping.query_ball_point(0.2, 32, x, q)
+            _hip.MARK = seq
+            P.tf_grouping.query_ball_point(0.2, 32, x, q)
+            torch.cuda.synchronize()
+    _hip.MARK = None
+    print(json.dumps({"launch_sequence": seq}), flush=True)
+
+
 def main():
     if "--worker" not in sys.argv[1:] and os.environ.get("PASNL_BENCH_SUPERVISE", "1") != "0":
         sys.exit(supervise(sys.argv[1:]))
     beat("start")
     ap = argparse.ArgumentParser()
     ap.add_argument("--worker", action="store_true", help="run the measurement in this process without a supervisor (the supervisor passes it; use it under profilers)")
-    ap.add_argument("--retry-of", default=None,
-                    help="(internal) phase in which the first worker stalled; this worker is its serial retry")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=64, help="clouds per GPU (weak scaling)")
-    ap.add_argument("--AS", action="store_true", help="configs[2]: adaptive sampling on, noisy clouds")
+    ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (weak scaling); default: the BASELINE config's")
+    ap.add_argument("--AS", action="store_true", help="time configs[2] (adaptive sampling on, noisy clouds) as the main workload")
     ap.add_argument("--noise", type=int, default=10)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend: nccl = RCCL over xGMI (the product path); gloo only with --model none")
     ap.add_argument("--model", default="cls", choices=["cls", "sem_seg", "sem_seg_res", "none"],
-                    help="cls = the BASELINE metric (default).  sem_seg / sem_seg_res = configs[3] / configs[4] "
-                         "(ScanNet 8192 pts / SemanticKITTI 10240 pts); own measurements, not the driver's metric.  none = "
-                         "no model at all: only the launcher, the rendezvous, the per-step all-gather and the timing protocol "
-                         "(CPU tests drive it with --backend gloo)")
+                    help="cls = the BASELINE metric (default).  sem_seg / sem_seg_res = configs[3] / configs[4] as the main "
+                         "workload.  none = no model at all: only the launcher, the rendezvous, the per-step all-gather and the "
+                         "timing protocol (CPU tests drive it with --backend gloo)")
     ap.add_argument("--points", type=int, default=0, help="points per cloud (default: 1024 cls, 8192 sem_seg, 10240 sem_seg_res)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
-    ap.add_argument("--pipeline", default="auto", choices=["auto", "lanes", "search", "serial", "1", "2"],
-                    help="serial (= auto, the default) = ONE graph of the forward replayed on one stream; what can overlap overlaps "
-                         "inside the forward (fork/join in the models: the next layer's FPS + kNN and the non-local branch run on "
-                         "side streams of the same graph).  lanes = two graph instances of the whole forward round-robin on two "
-                         "streams (forward i+1's latency-bound FPS under forward i's MFMA work); search = only the search prefix of "
-                         "batch i+1 ahead on a second stream.  lanes / search are kept as measurements: two concurrent instances of "
-                         "a hipBLASLt Stream-K GEMM can dead-lock (DESIGN.md 6), which is why neither is the default.  1 = serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip `other_configs` and `ball_query_sweep` (they run at N=1 only)")
+    ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each entry of `other_configs`")
     ap.add_argument("--force-dist", action="store_true",
                     help="take the multi-rank code path (RCCL init, per-step all-gather, barriers, max-over-ranks) even with "
                          "one rank: a 1-GPU box can then exercise everything but the wire")
@@ -502,19 +741,14 @@ def main():
                     help="A/B switch of the host mirror for measurements, e.g. --set tf_util.DENSE_ROWS=0 "
                          "--set pointasnl_util.SA_TAIL_FUSED=0 (modules of pointasnl_amd.utils, or _hip.LIB_PATH='<another build>'; "
                          "the line records them)")
-    ap.add_argument("--launch-order", action="store_true",
-                    help="add the per-forward sequence of C-ABI launches to the JSON line (profiles/pmc_to_traffic.py uses "
-                         "it to attribute rocprofv3 PMC rows to launches)")
+    ap.add_argument("--launch-order", action="store_true", help="add the per-forward sequence of C-ABI launches to the JSON line")
+    ap.add_argument("--traffic-pass", action="store_true", help="see traffic_pass(); used by profiles/collect_traffic.sh")
     args = ap.parse_args()
 
     if args.worker:  # do not outlive the supervisor (PR_SET_PDEATHSIG)
         import ctypes
 
         ctypes.CDLL(None).prctl(1, signal.SIGKILL)
-
-    def fake_stall(phase):  # supervisor test hook: the first worker hangs in the named phase
-        if os.environ.get("PASNL_BENCH_FAKE_STALL") == phase and not args.retry_of:
-            time.sleep(1e6)
 
     if os.environ.get("PASNL_BENCH_WATCHDOG"):  # diagnostics: dump every thread's Python stack and exit if the run stalls
         import faulthandler
@@ -531,6 +765,7 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run", file=sys.stderr)
         sys.exit(4)
     if args.model == "none":
+        args.batch = args.batch or 64
         return protocol_only(args, rank, world)
     if args.backend != "nccl":
         print("bench.py: the product path runs on RCCL (--backend nccl); gloo is for --model none", file=sys.stderr)
@@ -539,10 +774,10 @@ def main():
         print(f"bench.py: rank {rank} needs device {local_rank} but only {torch.cuda.device_count()} HIP device(s) are visible "
               f"(--gpus {args.gpus}): refusing to run", file=sys.stderr)
         sys.exit(4)
+    if args.traffic_pass:
+        return traffic_pass(args)
 
     from pointasnl_amd import _hip
-    from pointasnl_amd.models import pointasnl_cls
-    from pointasnl_amd.utils import tf_util, pointasnl_util
     for item in args.set:  # A/B switches (module-level flags of the host mirror)
         import ast
         import importlib
@@ -552,224 +787,88 @@ def main():
         if not hasattr(m, flag):
             raise SystemExit(f"--set {item}: {m.__name__} has no {flag}")
         setattr(m, flag, ast.literal_eval(value))
-    from pointasnl_amd import sharding
 
     _hip.lib()
     _hip.require_device()
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_dist
+    allreduce_check = None
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        store = None
-        if args.retry_of:  # the first worker's rendezvous keys may still sit in the launcher's store: fresh key space
-            base_store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world))
-            store = dist.PrefixStore("pasnl_retry/", base_store)
-        dist.init_process_group("nccl", store=store, rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         t = torch.tensor([float(rank + 1)], device="cuda")
         dist.all_reduce(t)  # sanity: every rank took part in one RCCL all-reduce
         allreduce_check = float(t.item())
         assert allreduce_check == world * (world + 1) / 2, allreduce_check
 
-    import importlib
-
-    default_pts = {"cls": 1024, "sem_seg": 8192, "sem_seg_res": 10240}[args.model]
-    B, N = args.batch, (args.points or default_pts)
-    if args.model != "cls" and args.batch == 64:
-        B = 16 if args.model == "sem_seg" else 8  # BASELINE configs[3] / per-GPU share of configs[4]
-    seg_model = importlib.import_module(f"pointasnl_amd.models.pointasnl_{args.model}") if args.model != "cls" else None
-    cfg_index = {"cls": 2 if args.AS else 1, "sem_seg": 3, "sem_seg_res": 4}[args.model]
-    pc = synth_clouds(1234 + cfg_index + 100 * rank, B, N)
+    main_index = {"cls": 2 if args.AS else 1, "sem_seg": 3, "sem_seg_res": 4}[args.model]
+    spec = dict(WORKLOADS[main_index])
     if args.AS:
-        pc = add_noise(pc, args.noise, 1234 + cfg_index + 100 * rank)
-    x = torch.from_numpy(pc).cuda()
-    store = tf_util.set_store(tf_util.VariableStore(seed=1234))  # identical weights on every rank
-
-    model_mod = seg_model if seg_model is not None else pointasnl_cls
-    first_layer = model_mod.first_layer(N)
-
-    def search_prefix():
-        # FPS + gathers + kNN of the first set-abstraction layer: hand-written kernels only, no dense layer
-        return pointasnl_util.sa_search(x, x, **first_layer)
-
-    def forward(search=None):
-        if seg_model is not None:
-            logits, _ = seg_model.get_model(x, False, 20, search=search)
-            return logits.reshape(B, -1)
-        logits, _ = pointasnl_cls.get_model(x, is_training=False, adaptive_sample=args.AS, search=search)
-        return logits
-
-    width = 40 if seg_model is None else N * 20
-    gathered = sharding.LogitsGather(world, B, width, x.device, force=multi) if multi else None  # eager path
-    lane_gather = []  # one gather buffer per pipeline lane
-
-    beat("setup")
-    with torch.no_grad():
-        # ---- warm-up (eager: creates weights, BLAS workspaces), then capture
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(2, min(3, args.warmup))):
-                logits = forward()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = None
-        lanes = []  # one entry per buffer set: dict(P=search graph or None, R=graph, out=logits, stream, ...)
-        mode = {"1": "serial", "2": "lanes"}.get(args.pipeline, args.pipeline)
-        if mode == "auto":
-            mode = "serial"  # one graph per forward; the overlap lives INSIDE the forward (fork/join in the models)
-        if args.no_graph:
-            mode = "eager"
-        sp, sr = torch.cuda.Stream(), torch.cuda.Stream()  # search-prefix stream, rest-of-forward stream
-
-        def capture(fn, stream):
-            stream.wait_stream(torch.cuda.current_stream())
-            g = torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread must not be able to invalidate the capture
-            with torch.cuda.graph(g, stream=stream, capture_error_mode="thread_local"):
-                out = fn()
-            torch.cuda.current_stream().wait_stream(stream)
-            return g, out
-
-        if mode != "eager":
-            for li in range(1 if mode == "serial" else 2):
-                lane = {"gather": sharding.LogitsGather(world, B, width, x.device, force=multi) if multi else None, "P": None}
-                if mode == "search":
-                    lane["stream"] = sr
-                    lane["P"], srch = capture(search_prefix, sp)
-                    lane["R"], lane["out"] = capture(lambda: forward(search=srch), sr)
-                    lane["ev_p"], lane["ev_r"] = torch.cuda.Event(), torch.cuda.Event()
-                else:
-                    lane["stream"] = sr if li == 0 else sp  # lanes: every buffer set replays on its own stream
-                    lane["R"], lane["out"] = capture(forward, lane["stream"])
-                lanes.append(lane)
-            graph = lanes[0]["R"]
-            logits = lanes[0]["out"]
-        step_no = [0]
-
-        def step():
-            if lanes:
-                lane = lanes[step_no[0] % len(lanes)]
-                step_no[0] += 1
-                if lane["P"] is not None:
-                    sp.wait_event(lane["ev_r"])  # the rest-graph of two steps ago has finished reading this buffer set
-                    with torch.cuda.stream(sp):
-                        lane["P"].replay()
-                        lane["ev_p"].record(sp)
-                    sr.wait_event(lane["ev_p"])
-                with torch.cuda.stream(lane["stream"]):
-                    lane["R"].replay()
-                    if lane["gather"] is not None:
-                        lane["gather"].all_gather(lane["out"])
-                    if lane["P"] is not None:
-                        lane["ev_r"].record(sr)
-                return lane["out"]
-            out = forward()
-            if gathered is not None:
-                gathered.all_gather(out)
-            return out
-
-        if multi:
-            dist.barrier()  # ranks enter the watched region together, so a stall expires every rank's allowance together
-        beat("run", 0.25 * (args.warmup + args.steps))
-        fake_stall("run")
-        for _ in range(args.warmup):
-            step()
-
-        # ---- timed region: barrier + sync on both sides, max over ranks
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        if multi:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        beat("post")
-        if multi:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=x.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-
-        # both buffer sets compute the same function of the same input, and so does the plain eager forward:
-        # the outputs must be bit-identical
-        lanes_agree = None
-        if lanes:
-            ref_out = forward()
-            lanes_agree = all(torch.equal(ref_out, l["out"]) for l in lanes)
-
-        # ---- per-kernel pass: the same forward, eager, every C-ABI launch bracketed by HIP events
-        rows = []
-        if rank == 0:
-            _hip.PROFILE = []
-            for _ in range(min(args.steps, 20)):
-                forward()
-            torch.cuda.synchronize()
-            rows = kernel_table(_hip.PROFILE)
-            per_fwd = len(_hip.PROFILE) // max(1, min(args.steps, 20))
-            launch_order = [[sym, list(ints)] for sym, ints, _, _ in _hip.PROFILE[:per_fwd]]
-            _hip.PROFILE = None
-
+        spec["noise"] = args.noise
+    if args.batch:
+        spec["batch"] = args.batch
+    if args.points:
+        spec["points"] = args.points
+    res = run_config(main_index, spec, args.steps, args.warmup, rank=rank, world=world, multi=multi, graph=not args.no_graph)
+    rccl_ranks = dist.get_world_size() if multi else 1
     if rank != 0:
         if multi:
             dist.destroy_process_group()
         return
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
-
-    # dominant hand-written kernel = largest total time per step
-    roofline = None
-    if rows:
-        dom = max((r for r in rows if r["bound"] in ("mfma", "hbm")), key=lambda r: r["avg_us"] * r["launches"])
-        if dom["bound"] == "mfma":
-            ach, peak, unit = dom["TFLOP/s"], F32_MFMA_PEAK_TF, "TFLOP/s"
-        else:
-            ach, peak, unit = dom["GB/s"], HBM_PEAK_GBS, "GB/s"
-        traffic, traffic_source = measured_traffic(dom["kernel"], dom["dims"])
-        if traffic is None:
-            print(f"bench.py: roofline.traffic not reported: {traffic_source}", file=sys.stderr)
-        roofline = {"kernel": dom["kernel"], "dims": dom["dims"], "bound": dom["bound"], "achieved": ach, "peak": peak,
-                    "unit": unit, "frac": round(ach / peak, 5), "traffic": traffic, "traffic_source": traffic_source,
-                    "avg_us": dom["avg_us"],
-                    "alg_bytes": dom["alg_bytes"], "alg_flops": dom["alg_flops"]}
-
+    rows = res["rows"]
     cpu = None
     if not args.no_cpu_baseline and args.model == "cls" and world == 1:  # rank 0 at N=1 only
-        cpu = cpu_baseline(pc, store.export_numpy(), args.AS)
+        cpu = cpu_baseline(res["pc"], res["store"].export_numpy(), spec["AS"])
+        beat("post")
 
-    handwritten_us = sum(r["avg_us"] for r in rows)
+    others, sweep = None, None
+    if world == 1 and not args.no_others and not args.force_dist:
+        others = []
+        for ci, ospec in WORKLOADS.items():
+            if ci == main_index:
+                continue
+            r = run_config(ci, ospec, args.other_steps, 3, graph=not args.no_graph, announce=False)
+            beat("post")
+            others.append({"workload": ospec["name"] + f", batch={r['B']}", "steps": args.other_steps, "warmup": 3,
+                           "ms_per_step": round(r["ms_per_step"], 4), "clouds_per_s": round(r["clouds_per_s"], 2),
+                           "points_per_s": round(r["clouds_per_s"] * r["N"], 1), "hip_graph": r["graph"],
+                           "outputs_agree": r["outputs_agree"], "roofline": roofline_of(r["rows"]),
+                           "handwritten_kernel_us_per_step": round(sum(k["avg_us"] * k["launches"] for k in r["rows"]) /
+                                                                   max(1, min(args.other_steps, 20)), 1),
+                           "kernels": sorted(r["rows"], key=lambda k: -k["avg_us"])[:8]})
+        sweep = ball_query_sweep()
+        beat("post")
+
     out = {
         "metric": "point-clouds/sec fwd (Bx1024 pts, ModelNet40 cls)" if args.model == "cls" else
-                  f"point-clouds/sec fwd (Bx{N} pts, pointasnl_{args.model})",
-        "value": round(value, 2),
+                  f"point-clouds/sec fwd (Bx{res['N']} pts, pointasnl_{args.model})",
+        "value": round(res["clouds_per_s"], 2),
         "unit": "point-clouds/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step": round(res["ms_per_step"], 4),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": (("configs[2]: ModelNet40 pointasnl_cls --AS, 1024 pts + noise" if args.AS else
-                                 "configs[1]: ModelNet40 pointasnl_cls, 1024 pts") if args.model == "cls" else
-                                f"configs[{cfg_index}]: pointasnl_{args.model}, {N} pts") + f", batch={B}/GPU, seeded random weights",
-                   "global_batch": world * B, "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
-                   "rccl_ranks": dist.get_world_size() if multi else 1,
-                   "hip_graph": graph is not None, "pipeline": mode, "switches": args.set, "outputs_agree": lanes_agree,
-                   "retry_of_stalled_phase": args.retry_of},
-        "roofline": roofline,
+        "config": {"workload": spec["name"] + f", batch={res['B']}/GPU, seeded random weights",
+                   "global_batch": world * res["B"], "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
+                   "rccl_ranks": rccl_ranks, "allreduce_check": allreduce_check, "gathered_rows_match_local": res["gathered_ok"],
+                   "shards_differ": res["shards_differ"],
+                   "hip_graph": res["graph"], "pipeline": "serial", "switches": args.set, "outputs_agree": res["outputs_agree"]},
+        "roofline": roofline_of(rows),
         "cpu_baseline": cpu,
-        "handwritten_kernel_us_per_step": round(handwritten_us, 1),
+        "handwritten_kernel_us_per_step": round(sum(r["avg_us"] * r["launches"] for r in rows) / max(1, min(args.steps, 20)), 1),
         "kernels": rows,
+        "other_configs": others,
+        "ball_query_sweep": sweep,
     }
     if args.launch_order:
-        out["launch_order"] = launch_order
+        out["launch_order"] = res["launch_order"]
     if multi:
         dist.destroy_process_group()
     # the JSON line is the LAST line on stdout: RCCL leaves a version banner in the C stdio buffer, which would otherwise

@@ -81,6 +81,12 @@ def ptr(t):
 PROFILE = None
 
 
+# Attribution of hardware-counter rows to launches (bench.py --traffic-pass under rocprofv3 --pmc): when MARK is a list, a
+# marker kernel (torch.cuda._sleep -> "spin_kernel") is enqueued in front of every C-ABI launch and (symbol, integer-arguments)
+# is appended; the counter rows between two markers then belong to one launch whatever number of kernels it starts.
+MARK = None
+
+
 TRACE = bool(os.environ.get("PASNL_TRACE"))  # debugging: print + synchronise around every launch
 
 
@@ -97,6 +103,9 @@ def launch(symbol, what, *args):
         torch.cuda.synchronize()
         print(f"[pasnl]   done {1e3 * (time.perf_counter() - t0):.2f} ms", file=sys.stderr, flush=True)
         return
+    if MARK is not None:
+        torch.cuda._sleep(1)
+        MARK.append([symbol, [a if isinstance(a, int) else a.value for a in args if isinstance(a, (int, ctypes.c_long))]])
     if PROFILE is None:
         check(fn(*args, stream_ptr()), what)
         return

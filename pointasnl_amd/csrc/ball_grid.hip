@@ -1,0 +1,472 @@
+// Ball query, grid-pruned, for clouds that fit LDS (n <= 2048): the kernel behind pasnl_query_ball_point for every
+// in-model use and the north-star shape.  Contract: reference tf_ops/grouping/tf_grouping_g.cu:3-36 -- the FIRST
+// nsample points in ascending index with max(sqrtf(d2),1e-20f) < radius, padded with the first hit; restated in
+// oracle/pasnl_oracle.c.  The brute-force kernel for larger clouds lives in grouping.hip.
+//
+// One workgroup bins its cloud into a uniform grid held in LDS (cell edge h >= 1.001*radius in y and z, h/2 in x;
+// counting sort into 16-byte records {x,y,z,index}).  ONE LANE OWNS ONE QUERY: its candidates are the 3x3 runs of
+// x-adjacent cells around it (5 half-cells each, contiguous in the cell-sorted array), evaluated with the canonical
+// arithmetic, so the hit SET is bit-identical to the brute-force scan; what remains is to put it in index order.
+//
+//  tier 1 (sparse clouds, the usual case): the nine runs go into a small lane-private table and are walked as ONE
+//    flat sequence, two candidates per step (no per-run loop: a wave's step count is the largest candidate TOTAL
+//    over its lanes, not the sum of the largest runs); a hit appends its 16-bit index to the lane's list in LDS
+//    (slot-major, lane-minor) with an unconditional store + carry add; afterwards the list is loaded into
+//    registers and sorted by a fixed compare-exchange network (8 / 16 / 32 inputs, chosen per wave by the largest
+//    count) -- no data-dependent branch, no scan.
+//  tier 2 (a lane would exceed 31 hits, or the cloud is dense): a hit sets bit k of the lane's n-bit row
+//    (ds_or_b32, word-major / lane-minor: conflict-free) and scanning the row yields ascending order.  Exact for any
+//    input; tier 1 falls back to it per wave and round.
+//
+// Why no hit can be missed: cell coordinate u = fl(fl(x - min) * fl(1/h)); two points closer than radius along an axis
+// have |u_q - u_p| <= radius/h + 2*(G+1)*2^-23 <= 0.99901 < 1 in y and z (cells differ by at most one) and
+// <= 1.99801 < 2 in x (half cells: at most two); points are clamped into the grid and queries into one (two) cells
+// beyond it, which only widens the search.  A cloud whose extent is not finite degenerates to a single cell (= brute
+// force), never to a wrong answer.
+#include <math.h>
+#include <algorithm>
+#include "common.hpp"
+#include "sortnet.inc"
+
+namespace pasnl {
+
+constexpr int BG_THREADS = 256;
+constexpr int BG_G = 10;                       // cells per axis in y and z (10: with n = 1024, nsample = 32 the workgroup
+                                               // needs 52 KiB of LDS -> three workgroups per CU)
+constexpr int BG_XS = 2;                       // x cells per cell edge
+constexpr int BG_GX = BG_G * BG_XS;
+constexpr int BG_NC = BG_GX * BG_G * BG_G;     // 2000 cells at most
+constexpr int BG_NMAX = 2048;                  // points per cloud (16-bit list entries, LDS-resident records)
+constexpr int BG_L = 32;                       // tier-1 list slots per lane
+constexpr int BG_HL_BYTES = (BG_L + 1) * 128;  // u16 [slot][lane]; slot BG_L only ever takes the closing sentinel
+constexpr int BG_TAB_OFF = BG_HL_BYTES;        // u32 [10][lane]: the lane's non-empty runs (start | end << 16), then zeros
+constexpr int BG_TAB_SLOTS = 10;
+constexpr int BG_U = 4;                        // tier 2: candidates per lane and step
+constexpr float BG_DENSE_HITS = 12.f;          // expected hits per query above which a workgroup starts in tier 2
+
+#ifdef PASNL_TUNING
+// phase probe (tuning build only; tools/ball_probe.py): cycles of wave 0 of workgroup (0, gridDim.y / 2), summed over its rounds
+// [0] build  [1] round set-up + run table  [2] walk  [3] sort + staging  [4] copy-out  [5] rounds  [6] tier-2 rounds  [7] steps
+__device__ unsigned long long bg_probe[8];
+#define BG_MARK(i)                                                                         \
+  do {                                                                                     \
+    if (probe) { const long long t_ = clock64(); atomicAdd(&bg_probe[i], (unsigned long long)(t_ - tmark)); tmark = clock64(); } \
+  } while (0)
+#define BG_COUNT(i, v) do { if (probe) atomicAdd(&bg_probe[i], (unsigned long long)(v)); } while (0)
+#else
+#define BG_MARK(i) do { } while (0)
+#define BG_COUNT(i, v) do { } while (0)
+#endif
+
+__device__ __forceinline__ float bg_dist2(float qx, float qy, float qz, const float4 v) {
+  // ((dx*dx)+(dy*dy))+(dz*dz) with x and y on one packed instruction each (identical IEEE operations per component)
+  const pasnl_f32x2 d = pasnl_f32x2{v.x, v.y} - pasnl_f32x2{qx, qy};
+  const pasnl_f32x2 s = d * d;
+  const float dz = v.z - qz;
+  return (s[0] + s[1]) + dz * dz;
+}
+
+template <int NW32>  // bit-row words per lane in tier 2: n <= 32*NW32
+__global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, float rpad, float thr2, float r3, int nsample, int rw,
+                                                               uint32_t ns_magic, int qchunk,
+                                                               const float* __restrict__ xyz1, const float* __restrict__ xyz2,
+                                                               int* __restrict__ idx, int* __restrict__ pts_cnt) {
+  constexpr int PPT = NW32 * 32 / BG_THREADS > 0 ? NW32 * 32 / BG_THREADS : 1;  // points per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* spt = reinterpret_cast<float4*>(smem);                                  // [n] cell-sorted {x,y,z,index bits}
+  uint32_t* regions = reinterpret_cast<uint32_t*>(spt + n);                       // [4 waves][64 lanes * rw words]
+  unsigned short* cstart = reinterpret_cast<unsigned short*>(regions + (size_t)BG_THREADS * rw);  // [BG_NC + 2]
+  int* ccount = reinterpret_cast<int*>(regions);  // cell counters during the build (the regions are not live yet)
+  float* red = reinterpret_cast<float*>(ccount + BG_NC);  // [4][6] bbox partials, [4] scan partials (build only)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bi = blockIdx.y;
+  const float* cloud = xyz1 + (size_t)bi * n * 3;
+#ifdef PASNL_TUNING
+  const bool probe = tid == 0 && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2;
+  long long tmark = clock64();
+#endif
+
+  // ---- A. points into registers, bounding box
+  float px[PPT], py[PPT], pz[PPT];
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = i * BG_THREADS + tid;
+    if (k < n) {
+      px[i] = cloud[k * 3]; py[i] = cloud[k * 3 + 1]; pz[i] = cloud[k * 3 + 2];
+      lo[0] = fminf(lo[0], px[i]); hi[0] = fmaxf(hi[0], px[i]);
+      lo[1] = fminf(lo[1], py[i]); hi[1] = fmaxf(hi[1], py[i]);
+      lo[2] = fminf(lo[2], pz[i]); hi[2] = fmaxf(hi[2], pz[i]);
+    } else {
+      px[i] = py[i] = pz[i] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[wave * 6 + a] = lo[a]; red[wave * 6 + 3 + a] = hi[a]; }
+  }
+  for (int c = tid; c < BG_NC; c += BG_THREADS) ccount[c] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = fminf(fminf(red[a], red[6 + a]), fminf(red[12 + a], red[18 + a]));
+    hi[a] = fmaxf(fmaxf(red[3 + a], red[9 + a]), fmaxf(red[15 + a], red[21 + a]));
+  }
+  // ---- B. grid geometry (identical in every thread)
+  const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+  const float maxext = fmaxf(ex, fmaxf(ey, ez));
+  float inv_h = 0.f, inv_hx = 0.f, hcell = INFINITY;
+  int gx = 1, gy = 1, gz = 1;
+  if (maxext < INFINITY && rpad < INFINITY) {  // false for NaN / inf extents and for empty clouds (-inf)
+    const float h = fmaxf(rpad, maxext / (float)BG_G);
+    if (h > 0.f && h < INFINITY) {
+      inv_h = 1.0f / h;
+      inv_hx = inv_h * (float)BG_XS;
+      if (inv_hx < INFINITY) {
+        hcell = h;
+        gx = min(BG_GX, (int)(ex * inv_hx) + 1);
+        gy = min(BG_G, (int)(ey * inv_h) + 1);
+        gz = min(BG_G, (int)(ez * inv_h) + 1);
+      } else {
+        inv_h = inv_hx = 0.f;
+      }
+    }
+  }
+  const int ncell = gx * gy * gz;
+  // expected hits per query if the points were uniform in the box: decides the tier the workgroup starts in
+  // (a heuristic only: both tiers are exact)
+  const float vol = fmaxf(ex, hcell) * fmaxf(ey, hcell) * fmaxf(ez, hcell);
+  const bool dense = !((float)n * 4.18879f * r3 <= BG_DENSE_HITS * vol);  // also true for NaN / inf
+  // ---- C. counting sort of the points by cell (the order inside a cell is irrelevant)
+  int pcell[PPT], prank[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = i * BG_THREADS + tid;
+    pcell[i] = 0; prank[i] = 0;
+    if (k < n) {
+      const int cx = min((int)fmaxf((px[i] - lo[0]) * inv_hx, 0.f), gx - 1);
+      const int cy = min((int)fmaxf((py[i] - lo[1]) * inv_h, 0.f), gy - 1);
+      const int cz = min((int)fmaxf((pz[i] - lo[2]) * inv_h, 0.f), gz - 1);
+      pcell[i] = (cz * gy + cy) * gx + cx;
+      prank[i] = atomicAdd(&ccount[pcell[i]], 1);
+    }
+  }
+  __syncthreads();
+  {
+    // exclusive scan of the cell counts: thread t owns cells [t*CPT, t*CPT+CPT)
+    constexpr int CPT = (BG_NC + BG_THREADS - 1) / BG_THREADS;
+    int cnts[CPT], sum = 0;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const int c = tid * CPT + j;
+      cnts[j] = c < ncell ? ccount[c] : 0;
+      sum += cnts[j];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    int* wsum = reinterpret_cast<int*>(red + 24);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      const int c = tid * CPT + j;
+      if (c < ncell) cstart[c] = (unsigned short)base;
+      base += cnts[j];
+    }
+    if (tid == 0) cstart[ncell] = (unsigned short)n;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = i * BG_THREADS + tid;
+    if (k < n) spt[(int)cstart[pcell[i]] + prank[i]] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
+  }
+  __syncthreads();  // last workgroup barrier: `ccount` (aliasing the regions) is dead, spt / cstart are complete
+  BG_MARK(0);
+
+  // ---- D. queries: one per lane and round; a wave works in its own region only (no workgroup barrier from here on)
+  char* wr = reinterpret_cast<char*>(regions + (size_t)wave * 64 * rw);            // this wave's region
+  unsigned short* hl = reinterpret_cast<unsigned short*>(wr);                      // tier 1: hit lists
+  uint32_t* tab = reinterpret_cast<uint32_t*>(wr + BG_TAB_OFF);                    // tier 1: run tables
+  uint32_t* brow = reinterpret_cast<uint32_t*>(wr);                                // tier 2: bit rows [word][lane]
+  uint32_t* row = regions + (size_t)tid * rw;                                      // staging: this lane's padded list
+  // staging rows are XOR-swizzled by 16-byte chunk so that lane-private rows need no padding and the copy-out reads
+  // 16 bytes per lane without bank conflicts (rw is a multiple of 32 words = 8 chunks)
+  const int swz = (lane & 7) << 2;
+  const int qbase = blockIdx.x * qchunk;  // qchunk: a multiple of 64 (a wave owns whole rounds of 64 queries)
+  const int qend = min(m, qbase + qchunk);
+  const int last = n > 0 ? n - 1 : 0;
+  const bool vec4 = (nsample & 3) == 0;
+  const int nchunk = (nsample + 3) >> 2;
+  for (int q0 = qbase + wave * 64; q0 < qend; q0 += BG_THREADS) {
+    const int j = q0 + lane;
+    const bool live = j < qend;
+    const float* qp = xyz2 + ((size_t)bi * m + (live ? j : qbase)) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const int cx = (int)floorf(fminf(fmaxf((qx - lo[0]) * inv_hx, -2.f), (float)(gx + 1)));
+    const int cy = (int)floorf(fminf(fmaxf((qy - lo[1]) * inv_h, -1.f), (float)gy));
+    const int cz = (int)floorf(fminf(fmaxf((qz - lo[2]) * inv_h, -1.f), (float)gz));
+    const int x0 = max(cx - BG_XS, 0), x1 = min(cx + BG_XS, gx - 1);  // x0 <= x1 since -2 <= cx <= gx + 1
+    int c = 0;             // hits (tier 1: all of them; tier 2: capped at nsample)
+    bool done = false;     // wave-uniform: tier 1 has produced the staging rows
+
+    if (!dense) {
+      // ---- tier 1.  (1) closing sentinels of the lists, zeros (= "no more runs") in the tables
+      {
+        const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u), zz = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < BG_L * 128 / 1024; ++i) *reinterpret_cast<uint4*>(wr + i * 1024 + lane * 16) = ff;
+        *reinterpret_cast<uint4*>(wr + BG_TAB_OFF + lane * 16) = zz;
+        *reinterpret_cast<uint4*>(wr + BG_TAB_OFF + 1024 + lane * 16) = zz;
+        *reinterpret_cast<uint2*>(wr + BG_TAB_OFF + 2048 + lane * 8) = make_uint2(0u, 0u);
+      }
+      // (2) the lane's non-empty runs, compacted (all bounds requested before any is used)
+      uint32_t rpk[9];
+#pragma unroll
+      for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int z = cz + dz, y = cy + dy, r = (dz + 1) * 3 + dy + 1;
+          const bool ok = live && z >= 0 && z < gz && y >= 0 && y < gy;
+          const int cb = ok ? (z * gy + y) * gx : 0;
+          const uint32_t s = cstart[cb + x0], e = cstart[cb + x1 + 1];
+          rpk[r] = (ok && e > s) ? (s | (e << 16)) : 0u;
+        }
+      {
+        int cntr = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+          tab[cntr * 64 + lane] = rpk[r];  // an empty run writes the zero that closes the table (or is overwritten)
+          cntr += rpk[r] != 0u;
+        }
+      }
+      BG_MARK(1);
+      // (3) the flat walk: two candidates per step
+      uint32_t p = 0, e = 0, ti = 0, nx = tab[lane];
+      bool overflow = false;
+      for (;;) {
+        const bool adv = p >= e;
+        p = adv ? (nx & 0xFFFFu) : p;
+        e = adv ? (nx >> 16) : e;
+        ti = adv ? min(ti + 1u, (uint32_t)(BG_TAB_SLOTS - 1)) : ti;  // slot 9 is always zero
+        nx = tab[ti * 64 + lane];                                    // used in the NEXT step: its latency is covered
+        const bool a0 = p < e, a1 = p + 1u < e;
+        if (!__any(a0)) break;                                       // a lane that reached its zeros never leaves them
+        if (__any(a0 && c > BG_L - 2)) { overflow = true; break; }   // two more hits might not fit: tier 2 redoes the round
+        const float4 v0 = spt[p], v1 = spt[p + 1u];  // p + 1 <= n: at worst the 16 bytes behind the records, read and not used
+        const float d0 = bg_dist2(qx, qy, qz, v0), d1 = bg_dist2(qx, qy, qz, v1);
+        hl[c * 64 + lane] = (unsigned short)__float_as_uint(v0.w);   // unconditional: a miss is overwritten by the next store
+        c += (a0 && d0 < thr2) ? 1 : 0;
+        hl[c * 64 + lane] = (unsigned short)__float_as_uint(v1.w);
+        c += (a1 && d1 < thr2) ? 1 : 0;
+        p += 2u;
+        BG_COUNT(7, 1);
+      }
+      BG_MARK(2);
+      if (!overflow) {
+        hl[c * 64 + lane] = 0xFFFFu;  // whatever a miss left behind the last hit
+        // (4) lists -> registers -> sorting network -> padded rows.  The network size follows the wave's largest count.
+        uint32_t v[32];
+        const bool big = __any(c > 16), mid = __any(c > 8);
+#define PASNL_CE(a, b) { const uint32_t lo_ = min(v[a], v[b]), hi_ = max(v[a], v[b]); v[a] = lo_; v[b] = hi_; }
+        if (big) {
+#pragma unroll
+          for (int s = 0; s < 32; ++s) v[s] = hl[s * 64 + lane];
+          PASNL_SORTNET_32
+        } else if (mid) {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) v[s] = hl[s * 64 + lane];
+#pragma unroll
+          for (int s = 16; s < 32; ++s) v[s] = 0xFFFFu;
+          PASNL_SORTNET_16
+        } else {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) v[s] = hl[s * 64 + lane];
+#pragma unroll
+          for (int s = 8; s < 32; ++s) v[s] = 0xFFFFu;
+          PASNL_SORTNET_8
+        }
+#undef PASNL_CE
+        const uint32_t first = c > 0 ? v[0] : 0u;  // zero-hit rows -> 0
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // every lane's list is in registers: the region becomes the staging rows
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint4* r4 = reinterpret_cast<uint4*>(row);
+        const int top = big ? 8 : (mid ? 4 : 2);  // chunks that can hold anything but `first`
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+          if (ch < nchunk && ch < top) {
+            uint4 o;
+            o.x = v[4 * ch] == 0xFFFFu ? first : v[4 * ch];
+            o.y = v[4 * ch + 1] == 0xFFFFu ? first : v[4 * ch + 1];
+            o.z = v[4 * ch + 2] == 0xFFFFu ? first : v[4 * ch + 2];
+            o.w = v[4 * ch + 3] == 0xFFFFu ? first : v[4 * ch + 3];
+            r4[ch ^ (lane & 7)] = o;
+          }
+        }
+        for (int ch = top; ch < nchunk; ++ch) r4[ch ^ (lane & 7)] = make_uint4(first, first, first, first);
+        c = min(c, nsample);
+        done = true;
+        BG_MARK(3);
+      }
+    }
+
+    if (!done) {
+      BG_COUNT(6, 1);
+      // ---- tier 2: bit rows.  Word w of this lane's row is brow[w*64 + lane].
+      {
+        const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int i = 0; i < NW32 / 4; ++i) *reinterpret_cast<uint4*>(wr + i * 1024 + lane * 16) = zz;
+      }
+      int rs[9], re[9];
+#pragma unroll
+      for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+          const int z = cz + dz, y = cy + dy, r = (dz + 1) * 3 + dy + 1;
+          const bool ok = live && z >= 0 && z < gz && y >= 0 && y < gy;
+          const int cb = ok ? (z * gy + y) * gx : 0;
+          rs[r] = ok ? (int)cstart[cb + x0] : 0;
+          re[r] = ok ? (int)cstart[cb + x1 + 1] : 0;
+        }
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        for (int p = rs[r]; __any(p < re[r]); p += BG_U) {
+          float4 v[BG_U];
+#pragma unroll
+          for (int u = 0; u < BG_U; ++u) v[u] = spt[min(p + u, last)];
+#pragma unroll
+          for (int u = 0; u < BG_U; ++u) {
+            if (p + u < re[r] && bg_dist2(qx, qy, qz, v[u]) < thr2) {
+              const int k = __float_as_int(v[u].w);
+              atomicOr(&brow[(k >> 5) * 64 + lane], 1u << (k & 31));  // ds_or_b32, no return: nothing waits for it
+            }
+          }
+        }
+      }
+      // bit row -> ascending list (first nsample, then the first hit as padding), through registers: the staging rows
+      // overlay other lanes' bit rows
+      uint32_t wreg[NW32];
+      const int mw = (n + 31) >> 5;
+#pragma unroll
+      for (int w = 0; w < NW32; ++w) wreg[w] = w < mw ? brow[w * 64 + lane] : 0u;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      int first = 0;
+      c = 0;
+#pragma unroll
+      for (int w = 0; w < NW32; ++w) {
+        uint32_t bits = wreg[w];
+        while (bits != 0u && c < nsample) {
+          const int k = w * 32 + (int)__builtin_ctz(bits);
+          bits &= bits - 1u;
+          if (c == 0) first = k;
+          row[c ^ swz] = (uint32_t)k;
+          ++c;
+        }
+      }
+      for (int sp = c; sp < nchunk * 4; ++sp) row[sp ^ swz] = (uint32_t)first;
+    }
+
+    // ---- F. the wave copies its 64 padded lists out (16 bytes per lane and step when nsample % 4 == 0)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nq = min(64, qend - q0);
+    if (nq > 0) {
+      int* o = idx + ((size_t)bi * m + q0) * nsample;
+      const uint32_t* wrows = regions + (size_t)(wave * 64) * rw;
+      if (vec4) {
+        const int g4n = nsample >> 2, total = nq * g4n;
+#pragma unroll 2
+        for (int e0 = 0; e0 < total; e0 += 64) {
+          const int e = min(e0 + lane, total - 1);
+          const int q = ns_magic ? (int)__umulhi((uint32_t)e, ns_magic) : e;  // e / (nsample / 4)
+          const int g4 = e - q * g4n;
+          const uint4 v = *reinterpret_cast<const uint4*>(wrows + (size_t)q * rw + ((g4 ^ (q & 7)) << 2));
+          if (e0 + lane < total) *reinterpret_cast<uint4*>(o + (size_t)q * nsample + (g4 << 2)) = v;
+        }
+      } else {
+        const int total = nq * nsample;
+#pragma unroll 2
+        for (int e0 = 0; e0 < total; e0 += 64) {
+          const int e = min(e0 + lane, total - 1);
+          const int q = ns_magic ? (int)__umulhi((uint32_t)e, ns_magic) : e;  // e / nsample
+          const int sidx = e - q * nsample;
+          const uint32_t v = wrows[(size_t)q * rw + (sidx ^ ((q & 7) << 2))];
+          if (e0 + lane < total) o[e0 + lane] = (int)v;
+        }
+      }
+      if (live) pts_cnt[(size_t)bi * m + j] = c;
+    }
+    __builtin_amdgcn_wave_barrier();  // the region is recycled by the next round
+    BG_MARK(4);
+    BG_COUNT(5, 1);
+  }
+}
+
+// Host side.  Returns PASNL_OK / PASNL_ELAUNCH, or PASNL_EUNSUPPORTED when the shape is not covered (the caller then
+// launches the brute-force kernel).
+int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample, const float* xyz1, const float* xyz2, int* idx,
+                     int* pts_cnt, hipStream_t stream) {
+  if (n > BG_NMAX || nsample > 1024) return PASNL_EUNSUPPORTED;
+  const int nw32 = n <= 256 ? 8 : (n <= 512 ? 16 : (n <= 1024 ? 32 : 64));
+  // words per lane of a wave's region: the tier-2 bit row, the tier-1 lists + tables (27 words), the padded list;
+  // a multiple of 32 (the chunk swizzle permutes groups of 8 chunks)
+  int rw = std::max(nw32, 32);
+  while (rw < ((nsample + 3) & ~3)) rw += 32;
+  const size_t lds = (size_t)n * 16 + (size_t)BG_THREADS * rw * 4 + (size_t)((BG_NC + 2 + 1) & ~1) * 2;
+  if (lds > 160 * 1024 || (size_t)BG_THREADS * rw < (size_t)BG_NC + 32) return PASNL_EUNSUPPORTED;
+  // queries per workgroup: 512 (two rounds per lane) amortises the grid build when the launch fills the GPU anyway; a small
+  // batch is latency-bound, so its queries are spread over more workgroups (each rebuilds the cloud's grid) down to one
+  // round of 64 queries per wave
+  int qchunk = 512;
+  while (qchunk > 256 && (long)b * ((m + qchunk - 1) / qchunk) < 768) qchunk >>= 1;
+  dim3 grid((m + qchunk - 1) / qchunk, b);
+  const float rpad = radius * 1.001f;
+  const float r3 = radius * radius * radius;
+  // e / d for e < 2^16 as umulhi(e, magic); d = list entries (or 16-byte groups of entries) per query
+  const unsigned div = (nsample & 3) == 0 ? (unsigned)nsample / 4 : (unsigned)nsample;
+  const uint32_t ns_magic = div == 1 ? 0u : (uint32_t)((0x100000000ull / div) + 1ull);  // 0: divisor 1
+#define PASNL_BG(NW)                                                                                                     \
+  {                                                                                                                      \
+    auto gk = ball_grid_kernel<NW>;                                                                                      \
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(gk),                                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
+      return PASNL_ELAUNCH;                                                                                              \
+    hipLaunchKernelGGL(gk, grid, dim3(BG_THREADS), lds, stream, n, m, rpad, thr2, r3, nsample, rw, ns_magic, qchunk, xyz1, \
+                       xyz2, idx, pts_cnt);                                                                              \
+  }
+  if (nw32 == 8) PASNL_BG(8)
+  else if (nw32 == 16) PASNL_BG(16)
+  else if (nw32 == 32) PASNL_BG(32)
+  else PASNL_BG(64)
+#undef PASNL_BG
+  return pasnl_launch_status();
+}
+
+}  // namespace pasnl
+
+#ifdef PASNL_TUNING
+extern "C" int pasnl_ball_probe_read(unsigned long long* host8) {
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(pasnl::bg_probe), sizeof(pasnl::bg_probe)) != hipSuccess) return -1;
+  unsigned long long zero[8] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(pasnl::bg_probe), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -103,271 +103,9 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void ball_query_kernel(int n, in
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Ball query, grid-pruned (clouds of <= BQG_NMAX points).  The brute-force kernel above evaluates all n*m
-// distances (~60 flop per algorithmic byte: VALU-bound, ~3 % of the HBM roofline).  Here one workgroup bins its
-// cloud into a uniform grid held in LDS (cell edge h >= 1.001*radius, <= BQG_GMAX cells per axis), and ONE LANE
-// OWNS ONE QUERY: it walks the 3x3 runs of x-adjacent cells around the query (27 cells, 9 contiguous runs of
-// the cell-sorted point array) and evaluates only those points -- with the same canonical arithmetic, so the
-// hit set is bit-identical.  "First nsample in index order" (tf_grouping_g.cu:13-35) does not need an ordered
-// traversal: a hit sets bit k of the lane's private n-bit row in LDS, and scanning the row afterwards yields the
-// hits in ascending index.  The row is then overwritten in place by the 16-bit hit list (the words are cached in
-// registers first) and the workgroup copies the lists out with coalesced stores, padding with the first hit.
-//
-// Why no hit can be missed: cell coordinate u = fl(fl(x - min) * fl(1/h)); for two points closer than
-// radius along an axis, |fl(u_q) - fl(u_p)| <= radius/h + 2*(G+1)*2^-23 <= 0.99901 < 1, so their cells differ
-// by at most one; points are clamped into [0, G-1] and queries into [-1, G], which only widens the search.
-// A cloud whose extent is not finite degenerates to a single cell (= brute force), never to a wrong answer.
-// ---------------------------------------------------------------------------------------------
-constexpr int BQG_THREADS = 256;
-constexpr int BQG_GMAX = 12;      // cells per axis
-constexpr int BQG_NMAX = 2048;    // points per cloud
-constexpr int BQG_QCHUNK = 512;   // queries per workgroup (two rounds of one query per lane)
-constexpr int BQG_NC = BQG_GMAX * BQG_GMAX * BQG_GMAX;
-constexpr int BQG_U = 4;          // candidates examined per lane and step (independent LDS reads in flight)
-
-// LDS budget (n = 1024, nsample <= 64): 16 KiB points + 3.4 KiB cell starts + 32 KiB rows = 52.7 KiB -> 3 workgroups
-// (12 waves) per CU.  Everything after the grid build is wave-local: a wave owns the rows of its 64 lanes, turns
-// them into hit lists and copies them out itself, so there is no workgroup barrier in the query phase.
-template <int MWT>  // mask words per query row held in registers during the bit-row -> list step: n <= 32*MWT
-__global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int n, int m, float rpad, float thr2, int nsample,
-                                                                     int rw, uint32_t ns_magic, int qchunk,
-                                                                     const float* __restrict__ xyz1,
-                                                                     const float* __restrict__ xyz2, int* __restrict__ idx,
-                                                                     int* __restrict__ pts_cnt, long long* __restrict__ dbg) {
-  // dbg != nullptr (PASNL_BALL_PROBE, diagnostics only): workgroup 0 records clock64() at the phase boundaries
-  long long tp[8];
-  int ntp = 0;
-#define PASNL_BQ_MARK() do { if (dbg) tp[ntp++ & 7] = clock64(); } while (0)
-  PASNL_BQ_MARK();
-  constexpr int PPT = MWT * 32 / BQG_THREADS > 0 ? MWT * 32 / BQG_THREADS : 1;  // points per thread
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float4* spt = reinterpret_cast<float4*>(smem);                                   // [n] cell-sorted {x,y,z,index bits}
-  uint32_t* rows = reinterpret_cast<uint32_t*>(spt + n);                           // [256][rw] hit bit rows / 16-bit lists
-  unsigned short* cstart = reinterpret_cast<unsigned short*>(rows + (size_t)BQG_THREADS * rw);  // [BQG_NC + 2]
-  float* red = reinterpret_cast<float*>(cstart + ((BQG_NC + 2 + 1) & ~1));          // [4][6] bbox partials, [4] scan partials
-  int* ccount = reinterpret_cast<int*>(rows);  // cell counters during the build (the rows are not live yet)
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bi = blockIdx.y;
-  const float* cloud = xyz1 + (size_t)bi * n * 3;
-
-  // ---- A. points into registers, bounding box
-  float px[PPT], py[PPT], pz[PPT];
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-  for (int i = 0; i < PPT; ++i) {
-    const int k = i * BQG_THREADS + tid;
-    if (k < n) {
-      px[i] = cloud[k * 3]; py[i] = cloud[k * 3 + 1]; pz[i] = cloud[k * 3 + 2];
-      lo[0] = fminf(lo[0], px[i]); hi[0] = fmaxf(hi[0], px[i]);
-      lo[1] = fminf(lo[1], py[i]); hi[1] = fmaxf(hi[1], py[i]);
-      lo[2] = fminf(lo[2], pz[i]); hi[2] = fmaxf(hi[2], pz[i]);
-    } else {
-      px[i] = py[i] = pz[i] = 0.f;
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
-      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
-    }
-  if (lane == 0) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { red[wave * 6 + a] = lo[a]; red[wave * 6 + 3 + a] = hi[a]; }
-  }
-  for (int c = tid; c < BQG_NC; c += BQG_THREADS) ccount[c] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    lo[a] = fminf(fminf(red[a], red[6 + a]), fminf(red[12 + a], red[18 + a]));
-    hi[a] = fmaxf(fmaxf(red[3 + a], red[9 + a]), fmaxf(red[15 + a], red[21 + a]));
-  }
-  PASNL_BQ_MARK();
-  // ---- B. grid geometry (identical in every thread)
-  const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-  const float maxext = fmaxf(ex, fmaxf(ey, ez));
-  float inv_h = 0.f;
-  int gx = 1, gy = 1, gz = 1;
-  if (maxext < INFINITY && rpad < INFINITY) {  // false for NaN / inf extents and for empty clouds (-inf)
-    const float h = fmaxf(rpad, maxext / (float)BQG_GMAX);
-    if (h > 0.f && h < INFINITY) {
-      inv_h = 1.0f / h;
-      if (inv_h < INFINITY) {
-        gx = min(BQG_GMAX, (int)(ex * inv_h) + 1);
-        gy = min(BQG_GMAX, (int)(ey * inv_h) + 1);
-        gz = min(BQG_GMAX, (int)(ez * inv_h) + 1);
-      } else {
-        inv_h = 0.f;
-      }
-    }
-  }
-  const int ncell = gx * gy * gz;
-  // ---- C. counting sort of the points by cell (order inside a cell is irrelevant: hits go through the bit row)
-  int pcell[PPT], prank[PPT];
-#pragma unroll
-  for (int i = 0; i < PPT; ++i) {
-    const int k = i * BQG_THREADS + tid;
-    pcell[i] = 0; prank[i] = 0;
-    if (k < n) {
-      const int cx = min((int)fmaxf((px[i] - lo[0]) * inv_h, 0.f), gx - 1);
-      const int cy = min((int)fmaxf((py[i] - lo[1]) * inv_h, 0.f), gy - 1);
-      const int cz = min((int)fmaxf((pz[i] - lo[2]) * inv_h, 0.f), gz - 1);
-      pcell[i] = (cz * gy + cy) * gx + cx;
-      prank[i] = atomicAdd(&ccount[pcell[i]], 1);
-    }
-  }
-  __syncthreads();
-  {
-    // exclusive scan of the cell counts: thread t owns cells [t*CPT, t*CPT+CPT)
-    constexpr int CPT = (BQG_NC + BQG_THREADS - 1) / BQG_THREADS;
-    int cnts[CPT], sum = 0;
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      const int c = tid * CPT + j;
-      cnts[j] = c < ncell ? ccount[c] : 0;
-      sum += cnts[j];
-    }
-    int incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      int o = __shfl_up(incl, off);
-      if (lane >= off) incl += o;
-    }
-    int* wsum = reinterpret_cast<int*>(red + 24);
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int base = incl - sum;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) {
-      const int c = tid * CPT + j;
-      if (c < ncell) cstart[c] = (unsigned short)base;
-      base += cnts[j];
-    }
-    if (tid == 0) cstart[ncell] = (unsigned short)n;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < PPT; ++i) {
-    const int k = i * BQG_THREADS + tid;
-    if (k < n) spt[(int)cstart[pcell[i]] + prank[i]] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
-  }
-  __syncthreads();  // last workgroup barrier: `ccount` (aliasing the rows) is dead, spt / cstart are complete
-  PASNL_BQ_MARK();
-
-  // ---- D. queries: one per lane; a wave never touches another wave's rows
-  const int mw = (n + 31) >> 5;
-  // XOR swizzle of the 16-byte group index: lane-private rows without padding, and 4 consecutive list entries stay
-  // contiguous so that the copy-out moves 16 bytes per lane
-  const int swmask = (min(rw >> 2, 8) - 1) << 2;
-  const int swz = (lane << 2) & swmask;
-  uint32_t* row = rows + (size_t)tid * rw;
-  const int qbase = blockIdx.x * qchunk;  // qchunk: a multiple of 64 (a wave owns whole rounds of 64 queries)
-  const int qend = min(m, qbase + qchunk);
-  const int last = n > 0 ? n - 1 : 0;
-  const bool vec4 = (nsample & 3) == 0;
-  for (int q0 = qbase + wave * 64; q0 < qend; q0 += BQG_THREADS) {
-    const int j = q0 + lane;
-    const bool live = j < qend;
-    {
-      uint4* r4 = reinterpret_cast<uint4*>(row);
-      for (int w = 0; w < rw / 4; ++w) r4[w] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    const float* qp = xyz2 + ((size_t)bi * m + (live ? j : qbase)) * 3;
-    const float qx = qp[0], qy = qp[1], qz = qp[2];
-    const int cx = (int)floorf(fminf(fmaxf((qx - lo[0]) * inv_h, -1.f), (float)gx));
-    const int cy = (int)floorf(fminf(fmaxf((qy - lo[1]) * inv_h, -1.f), (float)gy));
-    const int cz = (int)floorf(fminf(fmaxf((qz - lo[2]) * inv_h, -1.f), (float)gz));
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, gx - 1);
-    // the 9 runs of x-adjacent cells: all bounds requested before any is used
-    int rs[9], re[9];
-#pragma unroll
-    for (int dz = -1; dz <= 1; ++dz)
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int z = cz + dz, y = cy + dy, r = (dz + 1) * 3 + dy + 1;
-        const bool ok = live && x0 <= x1 && z >= 0 && z < gz && y >= 0 && y < gy;
-        const int cb = ok ? (z * gy + y) * gx : 0;
-        rs[r] = ok ? (int)cstart[cb + x0] : 0;
-        re[r] = ok ? (int)cstart[cb + x1 + 1] : 0;
-      }
-#pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      // BQG_U candidates per step, loads issued together; a run longer than that (rare) takes another step
-      for (int p = rs[r]; __any(p < re[r]); p += BQG_U) {
-        float4 v[BQG_U];
-#pragma unroll
-        for (int u = 0; u < BQG_U; ++u) v[u] = spt[min(p + u, last)];
-#pragma unroll
-        for (int u = 0; u < BQG_U; ++u) {
-          if (p + u < re[r] && dist2(qx, qy, qz, v[u].x, v[u].y, v[u].z) < thr2) {
-            const int k = __float_as_int(v[u].w);
-            atomicOr(&row[(k >> 5) ^ swz], 1u << (k & 31));  // ds_or_b32, no return: nothing waits for it
-          }
-        }
-      }
-    }
-    PASNL_BQ_MARK();
-    // ---- E. bit row -> ascending hit list (first nsample, then the first hit as padding; zero-hit rows -> 0,
-    // SURVEY A.3), in place: the mask words are cached in registers first
-    uint32_t wreg[MWT];
-#pragma unroll
-    for (int w = 0; w < MWT; ++w) wreg[w] = w < mw ? row[w ^ swz] : 0u;
-    int c = 0, first = 0;
-#pragma unroll
-    for (int w = 0; w < MWT; ++w) {
-      uint32_t bits = wreg[w];
-      while (bits != 0u && c < nsample) {
-        const int k = w * 32 + (int)__builtin_ctz(bits);
-        bits &= bits - 1u;
-        if (c == 0) first = k;
-        row[c ^ swz] = (uint32_t)k;
-        ++c;
-      }
-    }
-    for (int sp = c; sp < nsample; ++sp) row[sp ^ swz] = (uint32_t)first;
-    PASNL_BQ_MARK();
-    // ---- F. the wave copies its 64 lists out (16 bytes per lane and step when nsample % 4 == 0)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int nq = min(64, qend - q0);
-    if (nq > 0) {
-      int* o = idx + ((size_t)bi * m + q0) * nsample;
-      const uint32_t* wrows = rows + (size_t)(wave * 64) * rw;
-      if (vec4) {
-        const int g4n = nsample >> 2, total = nq * g4n;
-#pragma unroll 2
-        for (int e0 = 0; e0 < total; e0 += 64) {
-          const int e = min(e0 + lane, total - 1);
-          const int q = ns_magic ? (int)__umulhi((uint32_t)e, ns_magic) : e;  // e / (nsample / 4)
-          const int g4 = e - q * g4n;
-          const uint4 v = *reinterpret_cast<const uint4*>(wrows + (size_t)q * rw + ((g4 << 2) ^ ((q << 2) & swmask)));
-          if (e0 + lane < total) *reinterpret_cast<uint4*>(o + (size_t)q * nsample + (g4 << 2)) = v;
-        }
-      } else {
-        const int total = nq * nsample;
-#pragma unroll 2
-        for (int e0 = 0; e0 < total; e0 += 64) {
-          const int e = min(e0 + lane, total - 1);
-          const int q = ns_magic ? (int)__umulhi((uint32_t)e, ns_magic) : e;  // e / nsample
-          const int sidx = e - q * nsample;
-          const uint32_t v = wrows[(size_t)q * rw + (sidx ^ ((q << 2) & swmask))];
-          if (e0 + lane < total) o[e0 + lane] = (int)v;
-        }
-      }
-      if (live) pts_cnt[(size_t)bi * m + j] = c;
-    }
-    __builtin_amdgcn_wave_barrier();  // the rows are recycled by the next round
-    PASNL_BQ_MARK();
-  }
-  if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
-    for (int i = 0; i < 8; ++i) dbg[i] = tp[i];
-#undef PASNL_BQ_MARK
-}
+// The grid-pruned kernel for LDS-sized clouds (every in-model use, the north-star shape) is ball_grid.hip.
+int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample, const float* xyz1, const float* xyz2, int* idx,
+                     int* pts_cnt, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // Exact kNN, K <= 64*SLOTS.  The running result of a query is a list sorted ascending by
@@ -1025,44 +763,11 @@ extern "C" int pasnl_query_ball_point(int b, int n, int m, float radius, int nsa
   constexpr int QW = 4;
   // max(sqrtf(d2),1e-20f) < radius: for radius <= 1e-20f nothing can hit -> threshold 0 (d2 < 0 never true)
   float thr2 = (radius > 1e-20f) ? ball_threshold(radius) : 0.f;
-  // Grid-pruned kernel for LDS-sized clouds (every in-model use and the north-star shape); PASNL_BALL_BRUTE=1 forces
-  // the brute-force kernel (A/B measurements), which also serves larger clouds.
-  if (n <= BQG_NMAX && nsample <= 1024 && !tune_env("PASNL_BALL_BRUTE")) {
-    // words per query row: the n-bit mask, later the nsample 16-bit hits; a power of two (XOR-swizzled, unpadded)
-    int mwt = n <= 256 ? 8 : (n <= 512 ? 16 : (n <= 1024 ? 32 : 64));
-    int rw = mwt;
-    while (rw < nsample) rw *= 2;
-    size_t glds = (size_t)n * 16 + (size_t)BQG_THREADS * rw * 4 + (size_t)((BQG_NC + 2 + 1) & ~1) * 2 + 32 * 4;
-    if (glds <= 160 * 1024 && (size_t)BQG_THREADS * rw >= (size_t)BQG_NC) {
-      // queries per workgroup: 512 (two rounds per lane) amortises the grid build when the launch fills the GPU anyway; a
-      // small batch is latency-bound (one round = ~20 us of dependent LDS work per wave), so its queries are spread over
-      // more workgroups -- each rebuilds the cloud's grid (1.6 us) -- down to one round of 64 queries per workgroup
-      int qchunk = BQG_QCHUNK;
-      while (qchunk > 64 && (long)b * ((m + qchunk - 1) / qchunk) < 1024) qchunk >>= 1;
-      dim3 grid((m + qchunk - 1) / qchunk, b);
-      const float rpad = radius * 1.001f;
-      // diagnostics: PASNL_BALL_PROBE=<device pointer to 8 int64, hex> makes workgroup 0 record its phase clocks
-      long long* dbg = nullptr;
-      if (const char* pe = tune_env("PASNL_BALL_PROBE")) dbg = reinterpret_cast<long long*>(strtoull(pe, nullptr, 16));
-      // e / d for e < 2^16 as umulhi(e, magic); d = list entries (or 16-byte groups of entries) per query
-      const unsigned div = (nsample & 3) == 0 ? (unsigned)nsample / 4 : (unsigned)nsample;
-      const uint32_t ns_magic = div == 1 ? 0u : (uint32_t)((0x100000000ull / div) + 1ull);  // 0: divisor 1
-#define PASNL_BQG(MWT)                                                                                                  \
-  {                                                                                                                     \
-    auto gk = ball_query_grid_kernel<MWT>;                                                                              \
-    if (glds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(gk),                                      \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds) != hipSuccess)   \
-      return PASNL_ELAUNCH;                                                                                             \
-    hipLaunchKernelGGL(gk, grid, dim3(BQG_THREADS), glds, pasnl_hip_stream(stream), n, m, rpad, thr2, nsample, rw,      \
-                       ns_magic, qchunk, xyz1, xyz2, idx, pts_cnt, dbg);                                                        \
-  }
-      if (mwt == 8) PASNL_BQG(8)
-      else if (mwt == 16) PASNL_BQG(16)
-      else if (mwt == 32) PASNL_BQG(32)
-      else PASNL_BQG(64)
-#undef PASNL_BQG
-      return pasnl_launch_status();
-    }
+  // Grid-pruned kernel for LDS-sized clouds (every in-model use and the north-star shape); PASNL_BALL_BRUTE=1 (tuning
+  // build only) forces the brute-force kernel, which also serves larger clouds.
+  if (!tune_env("PASNL_BALL_BRUTE")) {
+    const int rc = ball_grid_launch(b, n, m, radius, thr2, nsample, xyz1, xyz2, idx, pts_cnt, pasnl_hip_stream(stream));
+    if (rc != PASNL_EUNSUPPORTED) return rc;
   }
   size_t lds = (size_t)SEARCH_TILE * 12 + (size_t)SEARCH_WAVES * QW * nsample * sizeof(int);
   PASNL_REQUIRE(lds <= 160 * 1024, PASNL_EUNSUPPORTED);

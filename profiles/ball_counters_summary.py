@@ -6,7 +6,7 @@ root, out = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "ballpmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "ball_query_grid_kernel" not in r["Kernel_Name"]:
+        if "ball_grid_kernel" not in r["Kernel_Name"] and "ball_query_grid_kernel" not in r["Kernel_Name"]:
             continue
         b = int(r.get("Grid_Size_Y") or r.get("Grid_Size", "0")) if "Grid_Size_Y" in r else int(r["Grid_Size"]) // 256
         acc[b][r["Counter_Name"]].append(float(r["Counter_Value"]))

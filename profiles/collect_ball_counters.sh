@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC counters of ball_query_grid_kernel: occupancy, VALU / LDS issue, LDS bank conflicts.  Counter passes
+# PMC counters of the grid ball-query kernel (ball_grid.hip): occupancy, VALU / LDS issue, LDS bank conflicts.  Counter passes
 # only (--kernel-trace + --pmc, nothing else); one small group per pass.
 #   gpurun -- 'bash profiles/collect_ball_counters.sh'   then   python profiles/ball_counters_summary.py gpurun_out profiles/r02_ball_counters.json
 export TMPDIR=/tmp

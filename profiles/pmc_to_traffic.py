@@ -4,10 +4,11 @@ Units and corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE / WRITE_SIZE are in
 half the bytes of a wide coalesced read stream, so the read side is doubled (an upper bound for narrow access
 patterns; Infinity-Cache hits are counted too).  The two counters are collected in SEPARATE passes.
 
-Attribution: `bench.py --no-graph --launch-order` prints the per-forward sequence of C-ABI launches; every launch
-of the forward path starts exactly one `pasnl::` kernel, and every forward of the run is the same sequence, so the
-j-th pasnl dispatch of the trace (ordered by dispatch id) belongs to launch j mod len(sequence).  The script checks
-that the kernel name at each position is the same in every period before trusting the alignment.
+Attribution: `bench.py --traffic-pass` enqueues a marker kernel (torch.cuda._sleep -> "spin_kernel") in front of every
+C-ABI launch and prints the sequence of launches; the `pasnl::` rows between marker i and marker i+1 of the trace
+(ordered by dispatch id) are launch i -- whatever number of kernels the entry point starts (grid build + query, sort +
+sample ...).  Vendor GEMMs and torch kernels between the markers are not pasnl:: rows and are ignored.  The script
+checks that the number of markers equals the number of launches before trusting the alignment.
 
     bash profiles/collect_traffic.sh          (on the GPU box)
     python profiles/pmc_to_traffic.py gpurun_out profiles/traffic.json
@@ -24,50 +25,44 @@ def dispatches(root, counter):
     rows = {}
     for f in glob.glob(os.path.join(root, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if r.get("Counter_Name") == counter and "pasnl::" in r["Kernel_Name"]:
+            if r.get("Counter_Name") == counter:
                 rows[int(r["Dispatch_Id"])] = (r["Kernel_Name"].split("(")[0], float(r["Counter_Value"]))
     return [rows[k] for k in sorted(rows)]
 
 
-def per_position(root, counter, order):
-    d = dispatches(root, counter)
-    n = len(order)
-    if not d or len(d) % n:
-        raise SystemExit(f"{counter}: {len(d)} pasnl dispatches is not a multiple of the {n} launches of one forward")
-    names = [None] * n
-    acc = defaultdict(list)
-    for j, (name, val) in enumerate(d):
-        p = j % n
-        if names[p] is None:
-            names[p] = name
-        elif names[p] != name:
-            raise SystemExit(f"{counter}: position {p} is {names[p]} in one forward and {name} in another")
-        acc[p].append(val)
-    return names, [sum(acc[p]) / len(acc[p]) for p in range(n)]
+def per_launch(root, counter, nlaunch):
+    """-> [(kernel names, summed counter value)] per marked launch"""
+    out, cur = [], None
+    for name, val in dispatches(root, counter):
+        if "spin_kernel" in name:
+            cur = [[], 0.0]
+            out.append(cur)
+        elif cur is not None and "pasnl::" in name:
+            cur[0].append(name)
+            cur[1] += val
+    if len(out) != nlaunch:
+        raise SystemExit(f"{counter}: {len(out)} markers in the trace but {nlaunch} launches in the sequence")
+    return out
 
 
 def main(root, out):
-    order = None
-    try:  # the bench line printed under rocprofv3 by profiles/collect_traffic.sh
-        order = json.load(open(os.path.join(root, "pmc_FETCH_SIZE.json")))["launch_order"]
-    except Exception:
-        pass
-    if not order:
-        raise SystemExit("no bench line with launch_order found (run profiles/collect_traffic.sh)")
-    names, fetch = per_position(root, "FETCH_SIZE", order)
-    _, write = per_position(root, "WRITE_SIZE", order)
-    agg = defaultdict(list)
-    kern = {}
-    for p, (sym, dims) in enumerate(order):
+    try:  # the line printed under rocprofv3 by profiles/collect_traffic.sh
+        seq = json.loads(open(os.path.join(root, "pmc_FETCH_SIZE.json")).read().strip().splitlines()[-1])["launch_sequence"]
+    except Exception as e:
+        raise SystemExit(f"no launch_sequence line found (run profiles/collect_traffic.sh): {e}")
+    fetch = per_launch(root, "FETCH_SIZE", len(seq))
+    write = per_launch(root, "WRITE_SIZE", len(seq))
+    agg, kern = defaultdict(list), {}
+    for (sym, dims), (names, f), (_, w) in zip(seq, fetch, write):
         key = sym + ":" + ",".join(map(str, dims))
-        agg[key].append((fetch[p], write[p]))
-        kern[key] = names[p]
+        agg[key].append((f, w))
+        kern[key] = " + ".join(n.replace("void pasnl::", "").split("<")[0] for n in names)
     traffic, detail = {}, {}
     for key, v in agg.items():
         f = sum(a for a, _ in v) / len(v)
         w = sum(b for _, b in v) / len(v)
         traffic[key] = int((2 * f + w) * 1024)
-        detail[key] = {"kernel": kern[key], "launches_per_forward": len(v), "fetch_KiB_raw": round(f, 1),
+        detail[key] = {"kernels": kern[key], "launches_measured": len(v), "fetch_KiB_raw": round(f, 1),
                        "write_KiB": round(w, 1), "hbm_bytes_corrected": traffic[key]}
     # provenance: the commit and the digests of the kernel sources the counters were collected on; bench.py refuses to
     # report a figure whose kernel source has changed since (bench.measured_traffic)
@@ -81,7 +76,7 @@ def main(root, out):
     del traffic["_source"]
     json.dump(detail, open(out.replace(".json", "_detail.json"), "w"), indent=1, sort_keys=True)
     for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]):
-        print(f"{k:60s} {v/1e6:10.2f} MB   {kern[k][:60]}")
+        print(f"{k:64s} {v/1e6:10.2f} MB   {kern[k][:60]}")
 
 
 if __name__ == "__main__":

@@ -101,14 +101,45 @@ def test_refuses_instead_of_degrading():
 
 
 @pytest.mark.gpu
-def test_stalled_pipelined_run_falls_back_to_serial():
-    """The first worker hangs in the watched region (test hook); the supervisor kills it and the serial retry delivers
-    the JSON line, marked as a retry."""
+def test_stalled_run_is_killed_not_hung():
+    """The worker hangs in the watched region (test hook); the supervisor kills it (exact PID), prints no JSON line and
+    exits with code 3 long before the worker's own sleep would end."""
     env = dict(os.environ, PASNL_BENCH_FAKE_STALL="run", PASNL_BENCH_STALL_SCALE="0.1")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--no-others"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 3, (p.returncode, p.stderr[-2000:])
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "all workers were killed" in p.stderr and time.perf_counter() - t0 < 400
+
+
+@pytest.mark.gpu
+def test_rccl_path_with_one_rank():
+    """Everything of the multi-rank path but the wire, on one GPU: RCCL init, the all-reduce check, the per-step
+    all-gather of the logits (captured forward + collective on the same stream), barriers, max-over-ranks timing."""
+    p = _bench("--gpus", "1", "--force-dist", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
-    line = json.loads(p.stdout.strip().splitlines()[-1])
-    assert line["config"]["pipeline"] == "serial" and line["config"]["retry_of_stalled_phase"] == "run"
-    assert "retrying with --pipeline serial" in p.stderr
-    assert line["value"] > 0
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["rccl_ranks"] == 1 and cfg["allreduce_check"] == 1.0
+    assert cfg["gathered_rows_match_local"] is True and cfg["outputs_agree"] is True and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl():
+    """Two ranks on two GPUs (skipped on a 1-GPU box): n_gpus, RCCL world size, all-reduce over both ranks, every rank's
+    rows of the gathered logits equal its own logits, throughput counts both shards."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    p = _bench("--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["rccl_ranks"] == 2 and cfg["allreduce_check"] == 3.0 and cfg["global_batch"] == 128
+    assert cfg["gathered_rows_match_local"] is True and cfg["shards_differ"] is True  # per-rank seeds, rows arrive intact
+    one = _bench("--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-others", timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    v1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["value"]
+    assert line["value"] > 1.2 * v1, (line["value"], v1)  # two shards in about the time of one

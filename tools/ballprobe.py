@@ -1,20 +1,27 @@
-"""Diagnostics: phase clocks of workgroup 0 of the grid ball query (PASNL_BALL_PROBE; tuning build only:
-make -C pointasnl_amd/csrc tuning -> libpasnl_hip_tuning.so, loaded here instead of the product library)."""
-import os, sys
+"""Diagnostics: phase cycles of one wave of the grid ball query (tuning build only: make -C pointasnl_amd/csrc tuning ->
+libpasnl_hip_tuning.so, loaded here instead of the product library; pasnl_ball_probe_read is not in the product library)."""
+import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench as B
 import pointasnl_amd as P
 from pointasnl_amd import _hip
 _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libpasnl_hip_tuning.so")
-for b in (64, 4096):
-    x = torch.from_numpy(B.synth_clouds(1, b, 1024)).cuda()
+lib = _hip.lib()
+names = ["build", "setup+table", "walk", "sort+staging", "copy-out", "rounds", "tier2 rounds", "steps"]
+for b in (64, 1024, 4096):
+    x = torch.from_numpy(B.synth_clouds(1, min(b, 256), 1024)).cuda()
+    if b > 256:
+        x = x.repeat(b // 256, 1, 1).contiguous()
     q = x[:, :512].contiguous()
-    dbg = torch.zeros(8, dtype=torch.int64, device="cuda")
-    os.environ["PASNL_BALL_PROBE"] = hex(dbg.data_ptr())
-    for _ in range(3):
+    P.tf_grouping.query_ball_point(0.2, 32, x, q)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 8)()
+    lib.pasnl_ball_probe_read(buf)
+    reps = 5
+    for _ in range(reps):
         P.tf_grouping.query_ball_point(0.2, 32, x, q)
     torch.cuda.synchronize()
-    t = dbg.cpu().tolist()
-    names = ["A load+bbox", "B/C grid build", "D search r1", "E emit r1", "F copy r1", "D search r2", "E emit r2"]
-    print(f"B={b}: " + ", ".join(f"{n} {t[i+1]-t[i]}" for i, n in enumerate(names)), " | F copy r2", t[0] - t[7])
+    lib.pasnl_ball_probe_read(buf)
+    t = [v / reps for v in buf]
+    print(f"B={b}: " + ", ".join(f"{n} {t[i]:.0f}" for i, n in enumerate(names)), flush=True)
