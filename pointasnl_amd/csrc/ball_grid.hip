@@ -62,8 +62,12 @@ __device__ __forceinline__ float bg_dist2(float qx, float qy, float qz, const fl
   // ((dx*dx)+(dy*dy))+(dz*dz) with x and y on one packed instruction each (identical IEEE operations per component)
   const pasnl_f32x2 d = pasnl_f32x2{v.x, v.y} - pasnl_f32x2{qx, qy};
   const pasnl_f32x2 s = d * d;
-  const float dz = v.z - qz;
-  return (s[0] + s[1]) + dz * dz;
+  float dz = v.z - qz;
+  asm volatile("" : "+v"(dz));  // keeps the z terms of two candidates out of one packed instruction (the register shuffles
+                                // that pairing needs cost more than it saves, and they wait for both records)
+  float zz = dz * dz;
+  asm volatile("" : "+v"(zz));
+  return (s[0] + s[1]) + zz;
 }
 
 template <int NW32>  // bit-row words per lane in tier 2: n <= 32*NW32
@@ -255,27 +259,43 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
         }
       }
       BG_MARK(1);
-      // (3) the flat walk: two candidates per step
+      // (3) the flat walk: two candidates per step, software-pipelined: the records of the NEXT pair are requested before the
+      // current pair is evaluated (a wave alone on its SIMD otherwise waits out one LDS round trip per step), and the
+      // table entry one step earlier still
       uint32_t p = 0, e = 0, ti = 0, nx = tab[lane];
       bool overflow = false;
-      for (;;) {
+      auto advance = [&]() {  // (p, e) <- the pair to examine next; a lane that reached its zeros never leaves them
         const bool adv = p >= e;
         p = adv ? (nx & 0xFFFFu) : p;
         e = adv ? (nx >> 16) : e;
-        ti = adv ? min(ti + 1u, (uint32_t)(BG_TAB_SLOTS - 1)) : ti;  // slot 9 is always zero
-        nx = tab[ti * 64 + lane];                                    // used in the NEXT step: its latency is covered
-        const bool a0 = p < e, a1 = p + 1u < e;
-        if (!__any(a0)) break;                                       // a lane that reached its zeros never leaves them
-        if (__any(a0 && c > BG_L - 2)) { overflow = true; break; }   // two more hits might not fit: tier 2 redoes the round
-        const float4 v0 = spt[p], v1 = spt[p + 1u];  // p + 1 <= n: at worst the 16 bytes behind the records, read and not used
-        const float d0 = bg_dist2(qx, qy, qz, v0), d1 = bg_dist2(qx, qy, qz, v1);
-        hl[c * 64 + lane] = (unsigned short)__float_as_uint(v0.w);   // unconditional: a miss is overwritten by the next store
-        c += (a0 && d0 < thr2) ? 1 : 0;
-        hl[c * 64 + lane] = (unsigned short)__float_as_uint(v1.w);
-        c += (a1 && d1 < thr2) ? 1 : 0;
-        p += 2u;
-        BG_COUNT(7, 1);
+        ti += adv ? 1u : 0u;
+        nx = tab[min(ti, (uint32_t)(BG_TAB_SLOTS - 1)) * 64 + lane];  // slot 9 is always zero
+      };
+      // one step: evaluate the pair whose records are (c0, c1); request the next pair's records into (n0, n1)
+#define PASNL_BG_STEP(c0, c1, n0, n1)                                                                                   \
+      {                                                                                                                 \
+        const bool a0 = p < e, a1 = p + 1u < e;                                                                         \
+        if (__builtin_amdgcn_ballot_w64(a0) == 0ull) break;                                                             \
+        if (__builtin_amdgcn_ballot_w64(a0 && c > BG_L - 2) != 0ull) { overflow = true; break; } /* two more hits might \
+                                                                                             not fit: tier 2 */        \
+        p += 2u;                                                                                                        \
+        advance();                                                                                                      \
+        n0 = spt[p]; n1 = spt[p + 1u]; /* p + 1 <= n: at worst the 16 bytes behind the records, read and not used */    \
+        __builtin_amdgcn_sched_barrier(0); /* the requests go out before the current pair's arithmetic */               \
+        const float d0 = bg_dist2(qx, qy, qz, c0), d1 = bg_dist2(qx, qy, qz, c1);                                       \
+        hl[c * 64 + lane] = (unsigned short)__float_as_uint(c0.w); /* unconditional: a miss is overwritten */           \
+        c += (a0 && d0 < thr2) ? 1 : 0;                                                                                 \
+        hl[c * 64 + lane] = (unsigned short)__float_as_uint(c1.w);                                                      \
+        c += (a1 && d1 < thr2) ? 1 : 0;                                                                                 \
+        BG_COUNT(7, 1);                                                                                                 \
       }
+      advance();
+      float4 ra0 = spt[p], ra1 = spt[p + 1u], rb0, rb1;
+      for (;;) {
+        PASNL_BG_STEP(ra0, ra1, rb0, rb1)
+        PASNL_BG_STEP(rb0, rb1, ra0, ra1)
+      }
+#undef PASNL_BG_STEP
       BG_MARK(2);
       if (!overflow) {
         hl[c * 64 + lane] = 0xFFFFu;  // whatever a miss left behind the last hit
