@@ -34,6 +34,41 @@ def test_fps(P, b, n, m, kind):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("case", ["ragged_2050", "ragged_5003", "ragged_9999", "lattice_4100", "lattice_8192", "lattice16_10240",
+                                  "duplicates_6000", "exhausted_3000", "kitti_10240", "scannet_8192", "plane_5000", "line_3000"])
+def test_fps_large_clouds_exact(P, case):
+    """The kernels of the large clouds (n > 2048: Morton-sorted blobs, box-pruned updates, several picks per round) against the
+    oracle, bit for bit, on what their shortcuts could get wrong: cloud sizes that are not multiples of 4 (LDS layout),
+    lattices (distance ties: the (distance, k mod 512, k) rule across lanes, waves and picks of one round), duplicated
+    points, more samples than distinct points (the field of zeros), metre-scale lidar-like coordinates, degenerate extents."""
+    import bench as B
+    rng = np.random.default_rng(sum(map(ord, case)))
+    if case.startswith("ragged"):
+        n = int(case.split("_")[1]); xyz, m = clouds(41, 2, n, "ball"), n // 8
+    elif case == "lattice_4100":
+        xyz, m = clouds(42, 2, 4100, "lattice"), 600        # 729 distinct positions: ties everywhere, then exhaustion
+    elif case == "lattice_8192":
+        xyz, m = clouds(43, 1, 8192, "lattice"), 1024
+    elif case == "lattice16_10240":
+        xyz, m = (np.round(rng.random((1, 10240, 3)) * 16) / 16).astype(np.float32), 1280   # 4913 positions
+    elif case == "duplicates_6000":
+        base = clouds(44, 2, 1500, "cube"); xyz, m = np.tile(base, (1, 4, 1)), 800
+        xyz = xyz[:, rng.permutation(6000)].copy()
+    elif case == "exhausted_3000":
+        base = clouds(45, 1, 100, "cube"); xyz, m = np.tile(base, (1, 30, 1)).copy(), 300   # 100 distinct points, 300 samples
+    elif case == "kitti_10240":
+        xyz, m = B.synth_kitti(46, 2, 10240), 1280
+    elif case == "scannet_8192":
+        xyz, m = B.synth_scannet(47, 2, 8192)[..., :3].copy(), 1024
+    elif case == "plane_5000":
+        xyz, m = clouds(48, 1, 5000, "cube"), 700; xyz[..., 2] = 0.5
+    else:
+        xyz, m = clouds(49, 1, 3000, "cube"), 400; xyz[..., 1:] = 0.25
+    want = O.farthest_point_sample(m, xyz)
+    got = P.tf_sampling.farthest_point_sample(m, dev(xyz)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
 def test_fps_exhausted_cloud(P):
     # more samples than distinct points: once every distance is 0 the reference keeps returning index 0
     xyz = np.repeat(clouds(5, 1, 4, "cube"), 8, axis=1)
