@@ -476,6 +476,8 @@ def protocol_only(args, rank, world):
 # ---------------------------------------------------------------------------------------------------------------
 # one configuration: inputs, capture, timed replays, agreement with the eager forward, per-kernel pass
 # ---------------------------------------------------------------------------------------------------------------
+_FORWARD_STREAM = None
+PREFETCH_SLOTS = tuple(int(v) for v in os.environ.get('PASNL_BENCH_PREFETCH_SLOTS', '3,4').split(','))  # side streams of the prefetch
 WORKLOADS = {
     1: dict(model="cls", AS=False, noise=0, batch=64, points=1024, name="configs[1]: ModelNet40 pointasnl_cls, 1024 pts"),
     2: dict(model="cls", AS=True, noise=10, batch=64, points=1024,
@@ -519,28 +521,40 @@ def roofline_of(rows):
             "alg_bytes": dom["alg_bytes"], "alg_flops": dom["alg_flops"]}
 
 
-def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, graph=True, kernel_pass=True, announce=True):
+def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, graph=True, kernel_pass=True, announce=True,
+               pipeline="serial"):
     """Measure one workload on the current device -> dict.  The timed region is `steps` forwards bracketed by
-    (barrier +) torch.cuda.synchronize() on both sides, max over ranks."""
+    (barrier +) torch.cuda.synchronize() on both sides, max over ranks.
+
+    pipeline = "serial": one captured graph per forward, replayed back to back on one stream.
+    pipeline = "prefetch": a serving loop over a stream of batches with two input buffers.  The search prefix of a forward
+    (farthest point sampling + the gather + the kNN of the first set-abstraction layer) reads coordinates only and keeps
+    64 of the 256 CUs busy for ~0.2 ms of dependent rounds; so the graph of step k computes the rest of forward k (from the
+    prefix results step k-1 left in a buffer) and, on a side stream of the same graph, the prefix of forward k+1 on the OTHER
+    input buffer.  Every step still does one full forward's worth of work, every output is the output of a complete forward
+    on its own input (checked bit for bit against the eager forward of both buffers), and only hand-written kernels run on
+    the side stream (two concurrent vendor Stream-K GEMMs can dead-lock)."""
     import importlib
 
     import torch
     import torch.distributed as dist
 
-    from pointasnl_amd import _hip, sharding
-    from pointasnl_amd.utils import tf_util
+    from pointasnl_amd import _hip, sharding, tf_sampling
+    from pointasnl_amd.utils import pointasnl_util, tf_util
 
     model = importlib.import_module(f"pointasnl_amd.models.pointasnl_{spec['model']}")
     B, N = spec["batch"], spec["points"]
     pc = make_input(cfg_index, spec, rank)
     x = torch.from_numpy(pc).cuda()
     store = tf_util.set_store(tf_util.VariableStore(seed=1234))  # identical weights on every rank
+    fch = spec.get("feature_channel", 0)
 
-    def forward():
+    def forward(xin=None, search=None, before_head=None):
+        xin = x if xin is None else xin
         if spec["model"] == "cls":
-            logits, _ = model.get_model(x, is_training=False, adaptive_sample=spec["AS"])
+            logits, _ = model.get_model(xin, is_training=False, adaptive_sample=spec["AS"], search=search, before_head=before_head)
             return logits
-        logits, _ = model.get_model(x, False, 20, feature_channel=spec.get("feature_channel", 0))
+        logits, _ = model.get_model(xin, False, 20, feature_channel=fch, search=search, before_head=before_head)
         return logits.reshape(B, -1)
 
     width = 40 if spec["model"] == "cls" else N * 20
@@ -549,29 +563,103 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
         beat("setup")
     with torch.no_grad():
         # ---- warm-up (eager: creates weights, BLAS workspaces), then capture
-        side = torch.cuda.Stream()
+        # ONE forward stream for every workload of the process (a new stream per workload lands on another hardware queue
+        # and changes which side streams it collides with: measured 1.70 -> 2.07 ms on configs[2])
+        global _FORWARD_STREAM
+        if _FORWARD_STREAM is None:
+            _FORWARD_STREAM = torch.cuda.Stream(priority=-1)  # outranks the prefetching side streams
+        side = _FORWARD_STREAM
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
                 out = forward()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g = None
-        if graph:
+        graphs, outs, xs = [], [], [x]
+        if graph and pipeline == "prefetch":
+            spec2 = dict(spec)
+            x2 = torch.from_numpy(make_input(cfg_index + 50, spec2, rank)).cuda()  # the batch behind the current one
+            xs = [x, x2]
+            first = model.first_layer(N)
+
+            def xyz_of(t):
+                return t if t.shape[2] == 3 else t[:, :, :3].contiguous()
+
+            nsamp, npnt = first["nsample"], first["npoint"]
+            res = spec["model"] == "sem_seg_res"
+
+            def prefix(t, kf=None):
+                """The coordinate-only searches at the head of a forward, as the model itself computes them (bit-identical
+                results: exact kNN, the same sampler): cls / sem_seg -- layer1's sa_search = FPS + gather + kNN of the sampled
+                points -> [new_xyz, idx]; sem_seg_res -- layer0's self-kNN (kf: already running on another side stream, or
+                computed here) and layer1's FPS, whose neighbour lists are rows of that kNN -> [k_all, new_xyz, idx]."""
+                xyz = xyz_of(t)
+                if not res:
+                    _, new_xyz = tf_sampling.farthest_point_sample_gather(npnt, xyz)
+                    return [new_xyz, pointasnl_util.knn_query(nsamp, xyz, new_xyz)]
+                fps_idx, new_xyz = tf_sampling.farthest_point_sample_gather(N // 8, xyz)
+                k_all = kf.get() if kf is not None else pointasnl_util.knn_query(32, xyz, xyz)
+                return [k_all, new_xyz, pointasnl_util._gather_index_rows(k_all, fps_idx)]
+
+            def as_search(t, bufs):
+                if not res:
+                    return (bufs[0], None, bufs[1])
+                return {0: (xyz_of(t), None, bufs[0]), 1: (bufs[1], None, bufs[2])}
+
+            # the hand-over buffers between consecutive steps, one set per input buffer
+            S = [[r.clone() for r in prefix(t_in)] for t_in in xs]
+            torch.cuda.synchronize()
+
+            def body(cur, nxt):
+                fk = []
+
+                def fork():  # sibling forks from the forward's own stream, each joined to it (a fork of a fork crashes
+                    #          hipStreamEndCapture on ROCm 7.2)
+                    kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt])), slot=PREFETCH_SLOTS[1]) \
+                        if res else None
+
+                    def run_prefix():
+                        for dst, src in zip(S[nxt], prefix(xs[nxt], kf)):
+                            dst.copy_(src)
+                        return True
+                    fk.append(pointasnl_util.Forked(run_prefix, slot=PREFETCH_SLOTS[0]))
+                    if kf is not None:
+                        fk.append(kf)
+                if spec.get("prefetch_at", "head") == "start":
+                    fork()
+                o = forward(xs[cur], search=as_search(xs[cur], S[cur]), before_head=None if fk else fork)
+                for f in fk:
+                    f.get()  # join: the graph ends when everything has finished
+                return o
+
+            for cur in (0, 1):
+                side.wait_stream(torch.cuda.current_stream())
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    o = body(cur, 1 - cur)
+                torch.cuda.current_stream().wait_stream(side)
+                graphs.append(g)
+                outs.append(o)
+            out = outs[0]
+        elif graph:
             side.wait_stream(torch.cuda.current_stream())
             g = torch.cuda.CUDAGraph()
             # thread_local: the RCCL watchdog thread must not be able to invalidate the capture
             with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
                 out = forward()
             torch.cuda.current_stream().wait_stream(side)
+            graphs, outs = [g], [out]
+        step_no = [0]
 
         def step():
-            if g is not None:
+            if graphs:
+                i = step_no[0] % len(graphs)
+                step_no[0] += 1
                 with torch.cuda.stream(side):
-                    g.replay()
+                    graphs[i].replay()
                     if gather is not None:
-                        gather.all_gather(out)
-                return out
+                        gather.all_gather(outs[i])
+                return outs[i]
             o = forward()
             if gather is not None:
                 gather.all_gather(o)
@@ -583,7 +671,7 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
             beat("run", 0.25 * (warmup + steps))
             if os.environ.get("PASNL_BENCH_FAKE_STALL") == "run":  # supervisor test hook: the worker hangs in the watched region
                 time.sleep(1e6)
-        for _ in range(warmup):
+        for _ in range(warmup + (warmup + len(graphs)) % max(1, len(graphs))):  # an even number of steps: buffer 0 is next
             step()
         # ---- timed region: barrier + sync on both sides, max over ranks
         if multi:
@@ -613,10 +701,11 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
             got = gather.out.view(world, -1).double().sum(1)
             gathered_ok = gathered_ok and bool(torch.allclose(sums, got, rtol=1e-9, atol=0.0))
             shards_differ = bool(len(set(sums.tolist())) == world)  # different seeds per rank -> different logits
-        # the replayed graph computes the same function of the same input as the plain eager forward: bit-identical
+        # the replayed graphs compute the same function of the same input as the plain eager forward: bit-identical, for every
+        # input buffer (prefetch: the last two steps left the outputs of both buffers)
         agree = None
-        if g is not None:
-            agree = bool(torch.equal(forward(), out))
+        if graphs:
+            agree = all(bool(torch.equal(forward(xs[i]), outs[i])) for i in range(len(graphs)))
         # ---- per-kernel pass: the same forward, eager, every C-ABI launch bracketed by HIP events
         rows, launch_order = [], []
         if kernel_pass and rank == 0:
@@ -630,8 +719,8 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
             launch_order = [[sym, list(ints)] for sym, ints, _, _ in _hip.PROFILE[:per_fwd]]
             _hip.PROFILE = None
     return {"B": B, "N": N, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "clouds_per_s": world * B * steps / elapsed,
-            "graph": g is not None, "outputs_agree": agree, "gathered_ok": gathered_ok, "shards_differ": shards_differ, "rows": rows,
-            "launch_order": launch_order, "pc": pc, "store": store}
+            "graph": bool(graphs), "pipeline": pipeline if graphs else "eager", "outputs_agree": agree, "gathered_ok": gathered_ok,
+            "shards_differ": shards_differ, "rows": rows, "launch_order": launch_order, "pc": pc, "store": store}
 
 
 def ball_query_sweep(batches=(64, 256, 1024, 4096), iters=20):
@@ -731,6 +820,11 @@ def main():
                          "timing protocol (CPU tests drive it with --backend gloo)")
     ap.add_argument("--points", type=int, default=0, help="points per cloud (default: 1024 cls, 8192 sem_seg, 10240 sem_seg_res)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--pipeline", default="prefetch", choices=["serial", "prefetch"],
+                    help="prefetch (default): a serving loop -- the coordinate-only search prefix of batch k+1 (FPS + gather + kNN "
+                         "of the input level, hand-written kernels only) runs on a side stream of batch k's graph, two input "
+                         "buffers (see run_config); the line also carries the serial figure.  serial: one graph per forward, back "
+                         "to back")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip `other_configs` and `ball_query_sweep` (they run at N=1 only)")
     ap.add_argument("--other-steps", type=int, default=10, help="timed steps of each entry of `other_configs`")
@@ -810,7 +904,14 @@ def main():
         spec["batch"] = args.batch
     if args.points:
         spec["points"] = args.points
-    res = run_config(main_index, spec, args.steps, args.warmup, rank=rank, world=world, multi=multi, graph=not args.no_graph)
+    res = run_config(main_index, spec, args.steps, args.warmup, rank=rank, world=world, multi=multi, graph=not args.no_graph,
+                     pipeline=args.pipeline)
+    serial = None
+    if args.pipeline != "serial" and not args.no_graph and not multi:  # the same workload without the cross-batch overlap
+        r0 = run_config(main_index, spec, min(args.steps, 20), 3, graph=True, kernel_pass=False, announce=False, pipeline="serial")
+        serial = {"ms_per_step": round(r0["ms_per_step"], 4), "clouds_per_s": round(r0["clouds_per_s"], 2),
+                  "outputs_agree": r0["outputs_agree"], "steps": min(args.steps, 20)}
+        beat("post")
     rccl_ranks = dist.get_world_size() if multi else 1
     if rank != 0:
         if multi:
@@ -829,9 +930,13 @@ def main():
         for ci, ospec in WORKLOADS.items():
             if ci == main_index:
                 continue
-            r = run_config(ci, ospec, args.other_steps, 3, graph=not args.no_graph, announce=False)
+            r = run_config(ci, ospec, args.other_steps, 4, graph=not args.no_graph, announce=False, pipeline=args.pipeline)
             beat("post")
-            others.append({"workload": ospec["name"] + f", batch={r['B']}", "steps": args.other_steps, "warmup": 3,
+            rs = run_config(ci, ospec, args.other_steps, 3, graph=not args.no_graph, kernel_pass=False, announce=False,
+                            pipeline="serial") if args.pipeline != "serial" and not args.no_graph else None
+            beat("post")
+            others.append({"workload": ospec["name"] + f", batch={r['B']}", "steps": args.other_steps, "warmup": 4,
+                           "pipeline": r["pipeline"], "serial_ms_per_step": round(rs["ms_per_step"], 4) if rs else None,
                            "ms_per_step": round(r["ms_per_step"], 4), "clouds_per_s": round(r["clouds_per_s"], 2),
                            "points_per_s": round(r["clouds_per_s"] * r["N"], 1), "hip_graph": r["graph"],
                            "outputs_agree": r["outputs_agree"], "roofline": roofline_of(r["rows"]),
@@ -859,7 +964,7 @@ def main():
                    "global_batch": world * res["B"], "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
                    "rccl_ranks": rccl_ranks, "allreduce_check": allreduce_check, "gathered_rows_match_local": res["gathered_ok"],
                    "shards_differ": res["shards_differ"],
-                   "hip_graph": res["graph"], "pipeline": "serial", "switches": args.set, "outputs_agree": res["outputs_agree"]},
+                   "hip_graph": res["graph"], "pipeline": res["pipeline"], "serial": serial, "switches": args.set, "outputs_agree": res["outputs_agree"]},
         "roofline": roofline_of(rows),
         "cpu_baseline": cpu,
         "handwritten_kernel_us_per_step": round(sum(r["avg_us"] * r["launches"] for r in rows) / max(1, min(args.steps, 20)), 1),

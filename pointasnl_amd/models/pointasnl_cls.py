@@ -15,8 +15,11 @@ def first_layer(num_point=None):
 
 
 def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, weight_decay=None, num_class=40,
-              adaptive_sample=False, search=None):
-    """ Classification PointNet, input is BxNx3 (BxNx6 with normals), output Bx40 """
+              adaptive_sample=False, search=None, before_head=None):
+    """ Classification PointNet, input is BxNx3 (BxNx6 with normals), output Bx40
+    search / before_head (not in the reference signature; both optional): the search prefix of layer1 computed ahead by the
+    caller, and a callback invoked once the set-abstraction layers are enqueued -- a serving loop forks the NEXT batch's
+    search prefix there, beside the classifier head, which leaves most of the GPU idle (bench.py --pipeline prefetch). """
     batch_size = point_cloud.shape[0]
     end_points = {}
     if use_normal:
@@ -41,6 +44,8 @@ def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, w
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
                                                 scope='layer2', as_neighbor=as_neighbor[1], search=search2[0], xyz_concat=True)
     end_points['l2_xyz'] = l1_xyz  # sic: the reference stores l1_xyz here (pointasnl_cls.py:38)
+    if before_head is not None:
+        before_head()
     # the two pooled vectors are written side by side into fc1's input: tf.concat([l3_points, l3_points_res]) for free
     net = torch.empty((batch_size, 1024 + 512), dtype=torch.float32, device=point_cloud.device)
     _, l3_points_res, _ = pointnet_sa_module(l1_xyz, l1_points, npoint=None, radius=None, nsample=None,

@@ -13,7 +13,7 @@ def first_layer(num_point):
     return dict(npoint=num_point // 8, nsample=32)
 
 
-def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=None, feature_channel=0, search=None):
+def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=None, feature_channel=0, search=None, before_head=None):
     """ Semantic segmentation PointNet, input is B x N x (3+feature_channel), output B x N x num_class """
     end_points = {}
     num_point = point_cloud.shape[1]
@@ -63,6 +63,8 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
                                                 after_sampling=lambda x: (l1_xyz_box.append(x), level1(x)), **kw)
     l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=num_points[1], nsample=32, mlp=[64, 64, 128],
                                                 scope='layer2', as_neighbor=4, search=srch[2], after_sampling=level2, **kw)
+    if before_head is not None:  # a serving loop forks the next batch's search prefix here, beside the deep layers and the
+        before_head()            # decoder (long chains of small kernels that leave most of the GPU idle); bench.py --pipeline prefetch
     deep = srch["deep"].get()
     l3_xyz, l3_points = PointASNLSetAbstraction(l2_xyz, l2_points, npoint=num_points[2], nsample=32, mlp=[128, 128, 256],
                                                 scope='layer3', as_neighbor=0, search=deep["s3"], **kw)

@@ -14,7 +14,7 @@ def first_layer(num_point):
     return dict(npoint=num_point, nsample=32)
 
 
-def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=None, feature_channel=0, search=None):
+def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=None, feature_channel=0, search=None, before_head=None):
     """ Semantic segmentation PointNet, input is B x N x (3+feature_channel), output B x N x num_class """
     end_points = {}
     num_point = point_cloud.shape[1]
@@ -32,9 +32,12 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
     # (same support, queries = sampled support points: rows of it), which also share one FPS (the reference runs both twice,
     # pointasnl_sem_seg_res.py:35-36); layer1's FPS (num_point/8 dependent rounds) starts at t = 0 beside that kNN.
     srch, nn = {}, {}
-    knn0 = Forked(lambda: knn_query(32, l0_xyz, l0_xyz), slot=1)
-    srch[1] = Forked(lambda: sa_search(l0_xyz, None, num_points[0], 32, knn_all=knn0), slot=0)
-    srch[0] = search if search is not None else sa_search(l0_xyz, None, num_point, 32, knn_all=knn0)
+    if isinstance(search, dict):  # a serving loop computed both coordinate-only searches of the input level ahead:
+        srch[0], srch[1] = search[0], search[1]  # {0: layer0's (xyz, None, self-kNN), 1: layer1's (new_xyz, None, idx)}
+    else:
+        knn0 = Forked(lambda: knn_query(32, l0_xyz, l0_xyz), slot=1)
+        srch[1] = Forked(lambda: sa_search(l0_xyz, None, num_points[0], 32, knn_all=knn0), slot=0)
+        srch[0] = search if search is not None else sa_search(l0_xyz, None, num_point, 32, knn_all=knn0)
 
     def level1(xyz1):  # l1_xyz final (layer1_1's AdaptiveSampling)
         srch[2] = Forked(lambda: sa_search(xyz1, None, num_points[1], 32), slot=0)
@@ -69,6 +72,8 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
     l2_xyz, l2_1_points = PointASNLSetAbstraction(l1_xyz, l1_2_points, npoint=num_points[1], nsample=32,
                                                   mlp=[64, 64, 128], scope='layer2_1', as_neighbor=4, search=srch[2],
                                                   after_sampling=level2, **kw)
+    if before_head is not None:  # a serving loop forks the next batch's search prefix here, beside the deep layers and the
+        before_head()            # decoder (long chains of small kernels that leave most of the GPU idle); bench.py --pipeline prefetch
     deep = srch["deep"].get()
     _, l2_2_points = PointASNLSetAbstraction(l2_xyz, l2_1_points, npoint=num_points[1], nsample=32, mlp=[128, 128],
                                              scope='layer2_2', as_neighbor=0, NL=False, search=deep["s22"], **kw)
