@@ -3,7 +3,8 @@
 // nsample points in ascending index with max(sqrtf(d2),1e-20f) < radius, padded with the first hit; restated in
 // oracle/pasnl_oracle.c.  The brute-force kernel for larger clouds lives in grouping.hip.
 //
-// One workgroup bins its cloud into a uniform grid held in LDS (cell edge h >= 1.001*radius in y and z, h/2 in x;
+// One workgroup of 8 waves (16 waves per CU: the kernel is a chain of LDS round trips and vector issue, and the fourth wave per
+// SIMD is what fills the gaps) bins its cloud into a uniform grid held in LDS (cell edge h >= 1.001*radius in y and z, h/2 in x;
 // counting sort into 16-byte records {x,y,z,index}).  ONE LANE OWNS ONE QUERY: its candidates are the 3x3 runs of
 // x-adjacent cells around it (5 half-cells each, contiguous in the cell-sorted array), evaluated with the canonical
 // arithmetic, so the hit SET is bit-identical to the brute-force scan; what remains is to put it in index order.
@@ -13,10 +14,11 @@
 //    over its lanes, not the sum of the largest runs); a hit appends its 16-bit index to the lane's list in LDS
 //    (slot-major, lane-minor) with an unconditional store + carry add; afterwards the list is loaded into
 //    registers and sorted by a fixed compare-exchange network (8 / 16 / 32 inputs, chosen per wave by the largest
-//    count) -- no data-dependent branch, no scan.
+//    count) -- no data-dependent branch, no scan; the padded rows leave through a 4 KiB staging area, 32 rows at a
+//    time, as 16-byte stores that cover whole 128-byte rows.
 //  tier 2 (a lane would exceed 31 hits, or the cloud is dense): a hit sets bit k of the lane's n-bit row
-//    (ds_or_b32, word-major / lane-minor: conflict-free) and scanning the row yields ascending order.  Exact for any
-//    input; tier 1 falls back to it per wave and round.
+//    (ds_or_b32, word-major / lane-minor: conflict-free; 4 KiB hold the rows of 64 / 32 / 16 lanes at a time) and scanning
+//    the row yields ascending order.  Exact for any input; tier 1 falls back to it per wave and round.
 //
 // Why no hit can be missed: cell coordinate u = fl(fl(x - min) * fl(1/h)); two points closer than radius along an axis
 // have |u_q - u_p| <= radius/h + 2*(G+1)*2^-23 <= 0.99901 < 1 in y and z (cells differ by at most one) and
@@ -30,9 +32,9 @@
 
 namespace pasnl {
 
-constexpr int BG_THREADS = 256;
-constexpr int BG_G = 10;                       // cells per axis in y and z (10: with n = 1024, nsample = 32 the workgroup
-                                               // needs 52 KiB of LDS -> three workgroups per CU)
+constexpr int BG_WAVES = 8;
+constexpr int BG_THREADS = BG_WAVES * 64;
+constexpr int BG_G = 10;                       // cells per axis in y and z
 constexpr int BG_XS = 2;                       // x cells per cell edge
 constexpr int BG_GX = BG_G * BG_XS;
 constexpr int BG_NC = BG_GX * BG_G * BG_G;     // 2000 cells at most
@@ -41,12 +43,15 @@ constexpr int BG_L = 32;                       // tier-1 list slots per lane
 constexpr int BG_HL_BYTES = (BG_L + 1) * 128;  // u16 [slot][lane]; slot BG_L only ever takes the closing sentinel
 constexpr int BG_TAB_OFF = BG_HL_BYTES;        // u32 [10][lane]: the lane's non-empty runs (start | end << 16), then zeros
 constexpr int BG_TAB_SLOTS = 10;
+constexpr int BG_REGION = BG_TAB_OFF + BG_TAB_SLOTS * 256;  // 6784 bytes per wave: lists | tables
+constexpr int BG_STAGE_ROWS = 32;              // rows of 32 entries the first 4 KiB of a region stage at a time
 constexpr int BG_U = 4;                        // tier 2: candidates per lane and step
 constexpr float BG_DENSE_HITS = 12.f;          // expected hits per query above which a workgroup starts in tier 2
 
 #ifdef PASNL_TUNING
 // phase probe (tuning build only; tools/ball_probe.py): cycles of wave 0 of workgroup (0, gridDim.y / 2), summed over its rounds
-// [0] build  [1] round set-up + run table  [2] walk  [3] sort + staging  [4] copy-out  [5] rounds  [6] tier-2 rounds  [7] steps
+// [0] build  [1] -  [2] round set-up + run table  [3] walk  [4] sorting network + rows out  [5] tier 2 / round end
+// [6] tier-2 rounds  [7] steps
 __device__ unsigned long long bg_probe[8];
 #define BG_MARK(i)                                                                         \
   do {                                                                                     \
@@ -71,17 +76,18 @@ __device__ __forceinline__ float bg_dist2(float qx, float qy, float qz, const fl
 }
 
 template <int NW32>  // bit-row words per lane in tier 2: n <= 32*NW32
-__global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, float rpad, float thr2, float r3, int nsample, int rw,
+__global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, float rpad, float thr2, float r3, int nsample,
                                                                uint32_t ns_magic, int qchunk,
                                                                const float* __restrict__ xyz1, const float* __restrict__ xyz2,
                                                                int* __restrict__ idx, int* __restrict__ pts_cnt) {
   constexpr int PPT = NW32 * 32 / BG_THREADS > 0 ? NW32 * 32 / BG_THREADS : 1;  // points per thread
+  constexpr int LP = 1024 / NW32 > 64 ? 64 : 1024 / NW32;                        // tier 2: lanes whose bit rows fit 4 KiB
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* spt = reinterpret_cast<float4*>(smem);                                  // [n] cell-sorted {x,y,z,index bits}
-  uint32_t* regions = reinterpret_cast<uint32_t*>(spt + n);                       // [4 waves][64 lanes * rw words]
-  unsigned short* cstart = reinterpret_cast<unsigned short*>(regions + (size_t)BG_THREADS * rw);  // [BG_NC + 2]
+  char* regions = reinterpret_cast<char*>(spt + n);                               // [BG_WAVES][BG_REGION bytes]
+  unsigned short* cstart = reinterpret_cast<unsigned short*>(regions + BG_WAVES * BG_REGION);  // [BG_NC + 2]
   int* ccount = reinterpret_cast<int*>(regions);  // cell counters during the build (the regions are not live yet)
-  float* red = reinterpret_cast<float*>(ccount + BG_NC);  // [4][6] bbox partials, [4] scan partials (build only)
+  float* red = reinterpret_cast<float*>(ccount + BG_NC);  // [BG_WAVES][6] bbox partials, [BG_WAVES] scan partials (build only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.y;
@@ -107,12 +113,7 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
     }
   }
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
-      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
-    }
+  for (int a = 0; a < 3; ++a) { lo[a] = wave_min_f32(lo[a]); hi[a] = wave_max_f32(hi[a]); }
   if (lane == 0) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) { red[wave * 6 + a] = lo[a]; red[wave * 6 + 3 + a] = hi[a]; }
@@ -121,8 +122,10 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
   __syncthreads();
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    lo[a] = fminf(fminf(red[a], red[6 + a]), fminf(red[12 + a], red[18 + a]));
-    hi[a] = fmaxf(fmaxf(red[3 + a], red[9 + a]), fmaxf(red[15 + a], red[21 + a]));
+    float l = red[a], h = red[3 + a];
+#pragma unroll
+    for (int w = 1; w < BG_WAVES; ++w) { l = fminf(l, red[w * 6 + a]); h = fmaxf(h, red[w * 6 + 3 + a]); }
+    lo[a] = l; hi[a] = h;
   }
   // ---- B. grid geometry (identical in every thread)
   const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
@@ -174,13 +177,8 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
       cnts[j] = c < ncell ? ccount[c] : 0;
       sum += cnts[j];
     }
-    int incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      int o = __shfl_up(incl, off);
-      if (lane >= off) incl += o;
-    }
-    int* wsum = reinterpret_cast<int*>(red + 24);
+    const int incl = wave_inclusive_sum_i32(sum);
+    int* wsum = reinterpret_cast<int*>(red + BG_WAVES * 6);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     int base = incl - sum;
@@ -199,34 +197,53 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
     const int k = i * BG_THREADS + tid;
     if (k < n) spt[(int)cstart[pcell[i]] + prank[i]] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
   }
-  __syncthreads();  // last workgroup barrier: `ccount` (aliasing the regions) is dead, spt / cstart are complete
   BG_MARK(0);
 
-  // ---- D. queries: one per lane and round; a wave works in its own region only (no workgroup barrier from here on)
-  char* wr = reinterpret_cast<char*>(regions + (size_t)wave * 64 * rw);            // this wave's region
-  unsigned short* hl = reinterpret_cast<unsigned short*>(wr);                      // tier 1: hit lists
-  uint32_t* tab = reinterpret_cast<uint32_t*>(wr + BG_TAB_OFF);                    // tier 1: run tables
-  uint32_t* brow = reinterpret_cast<uint32_t*>(wr);                                // tier 2: bit rows [word][lane]
-  uint32_t* row = regions + (size_t)tid * rw;                                      // staging: this lane's padded list
-  // staging rows are XOR-swizzled by 16-byte chunk so that lane-private rows need no padding and the copy-out reads
-  // 16 bytes per lane without bank conflicts (rw is a multiple of 32 words = 8 chunks)
-  const int swz = (lane & 7) << 2;
-  const int qbase = blockIdx.x * qchunk;  // qchunk: a multiple of 64 (a wave owns whole rounds of 64 queries)
+  const int qbase = blockIdx.x * qchunk;  // qchunk: a multiple of 64
   const int qend = min(m, qbase + qchunk);
-  const int last = n > 0 ? n - 1 : 0;
-  const bool vec4 = (nsample & 3) == 0;
-  const int nchunk = (nsample + 3) >> 2;
-  for (int q0 = qbase + wave * 64; q0 < qend; q0 += BG_THREADS) {
-    const int j = q0 + lane;
-    const bool live = j < qend;
-    const float* qp = xyz2 + ((size_t)bi * m + (live ? j : qbase)) * 3;
-    const float qx = qp[0], qy = qp[1], qz = qp[2];
+  const int rounds = (qend - qbase + BG_THREADS - 1) / BG_THREADS;
+  const float* qcloud = xyz2 + (size_t)bi * m * 3;
+
+  // the nine runs of x-adjacent cells around a query, packed start | end << 16, zero when empty or outside the grid
+  auto runs_of = [&](float qx, float qy, float qz, bool live, uint32_t (&rpk)[9]) {
     const int cx = (int)floorf(fminf(fmaxf((qx - lo[0]) * inv_hx, -2.f), (float)(gx + 1)));
     const int cy = (int)floorf(fminf(fmaxf((qy - lo[1]) * inv_h, -1.f), (float)gy));
     const int cz = (int)floorf(fminf(fmaxf((qz - lo[2]) * inv_h, -1.f), (float)gz));
     const int x0 = max(cx - BG_XS, 0), x1 = min(cx + BG_XS, gx - 1);  // x0 <= x1 since -2 <= cx <= gx + 1
+#pragma unroll
+    for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int z = cz + dz, y = cy + dy, r = (dz + 1) * 3 + dy + 1;
+        const bool ok = live && z >= 0 && z < gz && y >= 0 && y < gy;
+        const int cb = ok ? (z * gy + y) * gx : 0;
+        const uint32_t s = cstart[cb + x0], e = cstart[cb + x1 + 1];  // all bounds requested before any is used
+        rpk[r] = (ok && e > s) ? (s | (e << 16)) : 0u;
+      }
+  };
+
+  __syncthreads();  // last workgroup barrier: `ccount` (aliasing the regions) is dead, spt / cstart are complete
+
+  // ---- D. queries: one per lane and round; a wave works in its own region only (no workgroup barrier from here on)
+  char* wr = regions + wave * BG_REGION;                                           // this wave's region
+  unsigned short* hl = reinterpret_cast<unsigned short*>(wr);                      // tier 1: hit lists
+  uint32_t* tab = reinterpret_cast<uint32_t*>(wr + BG_TAB_OFF);                    // tier 1: run tables
+  uint32_t* brow = reinterpret_cast<uint32_t*>(wr);                                // tier 2: bit rows [word][lane % LP]
+  uint32_t* stage = reinterpret_cast<uint32_t*>(wr);                               // tier 1: 32 padded rows of 32 entries
+  const int last = n > 0 ? n - 1 : 0;
+  const bool vec4 = (nsample & 3) == 0;
+  const int nchunk = (nsample + 3) >> 2;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int j = qbase + (rd * BG_WAVES + wave) * 64 + lane;
+    const bool live = j < qend;
+    if (!__any(live)) continue;
+    const float* qp = qcloud + (size_t)(live ? j : qbase) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    uint32_t rpk[9];
+    runs_of(qx, qy, qz, live, rpk);
+    int* orow = idx + ((size_t)bi * m + (live ? j : qbase)) * nsample;
     int c = 0;             // hits (tier 1: all of them; tier 2: capped at nsample)
-    bool done = false;     // wave-uniform: tier 1 has produced the staging rows
+    bool done = false;     // wave-uniform: tier 1 has written the rows
 
     if (!dense) {
       // ---- tier 1.  (1) closing sentinels of the lists, zeros (= "no more runs") in the tables
@@ -238,18 +255,7 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
         *reinterpret_cast<uint4*>(wr + BG_TAB_OFF + 1024 + lane * 16) = zz;
         *reinterpret_cast<uint2*>(wr + BG_TAB_OFF + 2048 + lane * 8) = make_uint2(0u, 0u);
       }
-      // (2) the lane's non-empty runs, compacted (all bounds requested before any is used)
-      uint32_t rpk[9];
-#pragma unroll
-      for (int dz = -1; dz <= 1; ++dz)
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-          const int z = cz + dz, y = cy + dy, r = (dz + 1) * 3 + dy + 1;
-          const bool ok = live && z >= 0 && z < gz && y >= 0 && y < gy;
-          const int cb = ok ? (z * gy + y) * gx : 0;
-          const uint32_t s = cstart[cb + x0], e = cstart[cb + x1 + 1];
-          rpk[r] = (ok && e > s) ? (s | (e << 16)) : 0u;
-        }
+      // (2) the lane's non-empty runs, compacted
       {
         int cntr = 0;
 #pragma unroll
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
           cntr += rpk[r] != 0u;
         }
       }
-      BG_MARK(1);
+      BG_MARK(2);
       // (3) the flat walk: two candidates per step, software-pipelined: the records of the NEXT pair are requested before the
       // current pair is evaluated (a wave alone on its SIMD otherwise waits out one LDS round trip per step), and the
       // table entry one step earlier still
@@ -296,10 +302,10 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
         PASNL_BG_STEP(rb0, rb1, ra0, ra1)
       }
 #undef PASNL_BG_STEP
-      BG_MARK(2);
+      BG_MARK(3);
       if (!overflow) {
         hl[c * 64 + lane] = 0xFFFFu;  // whatever a miss left behind the last hit
-        // (4) lists -> registers -> sorting network -> padded rows.  The network size follows the wave's largest count.
+        // (4) lists -> registers -> sorting network.  The network size follows the wave's largest count.
         uint32_t v[32];
         const bool big = __any(c > 16), mid = __any(c > 8);
 #define PASNL_CE(a, b) { const uint32_t lo_ = min(v[a], v[b]), hi_ = max(v[a], v[b]); v[a] = lo_; v[b] = hi_; }
@@ -322,122 +328,120 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
         }
 #undef PASNL_CE
         const uint32_t first = c > 0 ? v[0] : 0u;  // zero-hit rows -> 0
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();  // every lane's list is in registers: the region becomes the staging rows
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint4* r4 = reinterpret_cast<uint4*>(row);
-        const int top = big ? 8 : (mid ? 4 : 2);  // chunks that can hold anything but `first`
+        const int top = big ? 8 : (mid ? 4 : 2);   // 16-byte chunks that can hold anything but `first`
+        // (5) the rows leave through the first 4 KiB of the region, 32 rows (lanes) at a time: row q of a half is
+        // 8 chunks of 16 bytes, chunk g stored at g ^ (q & 7) (conflict-free for the writers and for the readers)
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();  // lists are in registers / the previous half has been copied out
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if ((lane >> 5) == half) {
+            uint4* r4 = reinterpret_cast<uint4*>(stage + (lane & 31) * 32);
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-          if (ch < nchunk && ch < top) {
-            uint4 o;
-            o.x = v[4 * ch] == 0xFFFFu ? first : v[4 * ch];
-            o.y = v[4 * ch + 1] == 0xFFFFu ? first : v[4 * ch + 1];
-            o.z = v[4 * ch + 2] == 0xFFFFu ? first : v[4 * ch + 2];
-            o.w = v[4 * ch + 3] == 0xFFFFu ? first : v[4 * ch + 3];
-            r4[ch ^ (lane & 7)] = o;
+            for (int ch = 0; ch < 8; ++ch) {
+              uint4 o = make_uint4(first, first, first, first);
+              if (ch < top) {
+                o.x = v[4 * ch] == 0xFFFFu ? first : v[4 * ch];
+                o.y = v[4 * ch + 1] == 0xFFFFu ? first : v[4 * ch + 1];
+                o.z = v[4 * ch + 2] == 0xFFFFu ? first : v[4 * ch + 2];
+                o.w = v[4 * ch + 3] == 0xFFFFu ? first : v[4 * ch + 3];
+              }
+              r4[ch ^ (lane & 7)] = o;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (vec4) {
+            const int total = BG_STAGE_ROWS * nchunk;
+            for (int e0 = 0; e0 < total; e0 += 64) {
+              const int ee = min(e0 + lane, total - 1);
+              const int q = ns_magic ? (int)__umulhi((uint32_t)ee, ns_magic) : ee;  // ee / nchunk
+              const int g = ee - q * nchunk;
+              const int jq = j - lane + half * 32 + q;         // the query of row q of this half (consecutive in a wave)
+              const uint4 w4 = *reinterpret_cast<const uint4*>(stage + q * 32 + ((min(g, 7) ^ (q & 7)) << 2));
+              const uint32_t f0 = stage[q * 32 + ((q & 7) << 2)];  // entry 0 of the row = its first hit
+              const uint4 o = g < 8 ? w4 : make_uint4(f0, f0, f0, f0);
+              if (e0 + lane < total && jq < qend)
+                *reinterpret_cast<uint4*>(idx + ((size_t)bi * m + jq) * nsample + (g << 2)) = o;
+            }
+          } else {
+            const int total = BG_STAGE_ROWS * nsample;
+            for (int e0 = 0; e0 < total; e0 += 64) {
+              const int ee = min(e0 + lane, total - 1);
+              const int q = ns_magic ? (int)__umulhi((uint32_t)ee, ns_magic) : ee;  // ee / nsample
+              const int sidx = ee - q * nsample;
+              const int jq = j - lane + half * 32 + q;
+              const uint32_t o = stage[q * 32 + (min(sidx, 31) ^ ((q & 7) << 2))];
+              const uint32_t f0 = stage[q * 32 + ((q & 7) << 2)];
+              if (e0 + lane < total && jq < qend) idx[((size_t)bi * m + jq) * nsample + sidx] = (int)(sidx < 32 ? o : f0);
+            }
           }
         }
-        for (int ch = top; ch < nchunk; ++ch) r4[ch ^ (lane & 7)] = make_uint4(first, first, first, first);
-        c = min(c, nsample);
+        if (live) pts_cnt[(size_t)bi * m + j] = min(c, nsample);
         done = true;
-        BG_MARK(3);
+        BG_MARK(4);
       }
     }
 
     if (!done) {
       BG_COUNT(6, 1);
-      // ---- tier 2: bit rows.  Word w of this lane's row is brow[w*64 + lane].
-      {
-        const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int i = 0; i < NW32 / 4; ++i) *reinterpret_cast<uint4*>(wr + i * 1024 + lane * 16) = zz;
-      }
+      // ---- tier 2: bit rows, LP lanes at a time.  Word w of an active lane's row is brow[w*LP + lane % LP]; the rows go
+      // straight to global memory (the rare path: no staging)
       int rs[9], re[9];
 #pragma unroll
-      for (int dz = -1; dz <= 1; ++dz)
+      for (int r = 0; r < 9; ++r) { rs[r] = (int)(rpk[r] & 0xFFFFu); re[r] = (int)(rpk[r] >> 16); }
+#pragma unroll 1
+      for (int pass = 0; pass < 64 / LP; ++pass) {
+        const bool act = live && (lane / LP) == pass;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {
+          const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-          const int z = cz + dz, y = cy + dy, r = (dz + 1) * 3 + dy + 1;
-          const bool ok = live && z >= 0 && z < gz && y >= 0 && y < gy;
-          const int cb = ok ? (z * gy + y) * gx : 0;
-          rs[r] = ok ? (int)cstart[cb + x0] : 0;
-          re[r] = ok ? (int)cstart[cb + x1 + 1] : 0;
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(wr + i * 1024 + lane * 16) = zz;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t* myrow = brow + (lane % LP);
 #pragma unroll
-      for (int r = 0; r < 9; ++r) {
-        for (int p = rs[r]; __any(p < re[r]); p += BG_U) {
-          float4 v[BG_U];
+        for (int r = 0; r < 9; ++r) {
+          for (int p = rs[r]; __any(act && p < re[r]); p += BG_U) {
+            float4 v[BG_U];
 #pragma unroll
-          for (int u = 0; u < BG_U; ++u) v[u] = spt[min(p + u, last)];
+            for (int u = 0; u < BG_U; ++u) v[u] = spt[min(p + u, last)];
 #pragma unroll
-          for (int u = 0; u < BG_U; ++u) {
-            if (p + u < re[r] && bg_dist2(qx, qy, qz, v[u]) < thr2) {
-              const int k = __float_as_int(v[u].w);
-              atomicOr(&brow[(k >> 5) * 64 + lane], 1u << (k & 31));  // ds_or_b32, no return: nothing waits for it
+            for (int u = 0; u < BG_U; ++u) {
+              if (act && p + u < re[r] && bg_dist2(qx, qy, qz, v[u]) < thr2) {
+                const int k = __float_as_int(v[u].w);
+                atomicOr(&myrow[(k >> 5) * LP], 1u << (k & 31));  // ds_or_b32, no return: nothing waits for it
+              }
             }
           }
         }
-      }
-      // bit row -> ascending list (first nsample, then the first hit as padding), through registers: the staging rows
-      // overlay other lanes' bit rows
-      uint32_t wreg[NW32];
-      const int mw = (n + 31) >> 5;
-#pragma unroll
-      for (int w = 0; w < NW32; ++w) wreg[w] = w < mw ? brow[w * 64 + lane] : 0u;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      int first = 0;
-      c = 0;
-#pragma unroll
-      for (int w = 0; w < NW32; ++w) {
-        uint32_t bits = wreg[w];
-        while (bits != 0u && c < nsample) {
-          const int k = w * 32 + (int)__builtin_ctz(bits);
-          bits &= bits - 1u;
-          if (c == 0) first = k;
-          row[c ^ swz] = (uint32_t)k;
-          ++c;
+        if (act) {
+          const int mw = (n + 31) >> 5;
+          int first = 0, cc = 0;
+          for (int w = 0; w < mw && cc < nsample; ++w) {
+            uint32_t bits = myrow[w * LP];
+            while (bits != 0u && cc < nsample) {
+              const int k = w * 32 + (int)__builtin_ctz(bits);
+              bits &= bits - 1u;
+              if (cc == 0) first = k;
+              orow[cc] = k;
+              ++cc;
+            }
+          }
+          for (int sp = cc; sp < nsample; ++sp) orow[sp] = first;
+          pts_cnt[(size_t)bi * m + j] = cc;
         }
       }
-      for (int sp = c; sp < nchunk * 4; ++sp) row[sp ^ swz] = (uint32_t)first;
     }
-
-    // ---- F. the wave copies its 64 padded lists out (16 bytes per lane and step when nsample % 4 == 0)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int nq = min(64, qend - q0);
-    if (nq > 0) {
-      int* o = idx + ((size_t)bi * m + q0) * nsample;
-      const uint32_t* wrows = regions + (size_t)(wave * 64) * rw;
-      if (vec4) {
-        const int g4n = nsample >> 2, total = nq * g4n;
-#pragma unroll 2
-        for (int e0 = 0; e0 < total; e0 += 64) {
-          const int e = min(e0 + lane, total - 1);
-          const int q = ns_magic ? (int)__umulhi((uint32_t)e, ns_magic) : e;  // e / (nsample / 4)
-          const int g4 = e - q * g4n;
-          const uint4 v = *reinterpret_cast<const uint4*>(wrows + (size_t)q * rw + ((g4 ^ (q & 7)) << 2));
-          if (e0 + lane < total) *reinterpret_cast<uint4*>(o + (size_t)q * nsample + (g4 << 2)) = v;
-        }
-      } else {
-        const int total = nq * nsample;
-#pragma unroll 2
-        for (int e0 = 0; e0 < total; e0 += 64) {
-          const int e = min(e0 + lane, total - 1);
-          const int q = ns_magic ? (int)__umulhi((uint32_t)e, ns_magic) : e;  // e / nsample
-          const int sidx = e - q * nsample;
-          const uint32_t v = wrows[(size_t)q * rw + (sidx ^ ((q & 7) << 2))];
-          if (e0 + lane < total) o[e0 + lane] = (int)v;
-        }
-      }
-      if (live) pts_cnt[(size_t)bi * m + j] = c;
-    }
     __builtin_amdgcn_wave_barrier();  // the region is recycled by the next round
-    BG_MARK(4);
-    BG_COUNT(5, 1);
+    BG_MARK(5);
   }
 }
 
@@ -447,21 +451,15 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
                      int* pts_cnt, hipStream_t stream) {
   if (n > BG_NMAX || nsample > 1024) return PASNL_EUNSUPPORTED;
   const int nw32 = n <= 256 ? 8 : (n <= 512 ? 16 : (n <= 1024 ? 32 : 64));
-  // words per lane of a wave's region: the tier-2 bit row, the tier-1 lists + tables (27 words), the padded list;
-  // a multiple of 32 (the chunk swizzle permutes groups of 8 chunks)
-  int rw = std::max(nw32, 32);
-  while (rw < ((nsample + 3) & ~3)) rw += 32;
-  const size_t lds = (size_t)n * 16 + (size_t)BG_THREADS * rw * 4 + (size_t)((BG_NC + 2 + 1) & ~1) * 2;
-  if (lds > 160 * 1024 || (size_t)BG_THREADS * rw < (size_t)BG_NC + 32) return PASNL_EUNSUPPORTED;
-  // queries per workgroup: 512 (two rounds per lane) amortises the grid build when the launch fills the GPU anyway; a small
-  // batch is latency-bound, so its queries are spread over more workgroups (each rebuilds the cloud's grid) down to one
-  // round of 64 queries per wave
-  int qchunk = 512;
-  while (qchunk > 256 && (long)b * ((m + qchunk - 1) / qchunk) < 768) qchunk >>= 1;
+  const size_t lds = (size_t)n * 16 + BG_WAVES * BG_REGION + (size_t)((BG_NC + 2 + 1) & ~1) * 2;
+  static_assert(BG_WAVES * BG_REGION >= BG_NC * 4 + (BG_WAVES * 7 + 8) * 4, "the cell counters and the build's partials alias the wave regions");
+  if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
+  // queries per workgroup: one round of 64 per wave
+  const int qchunk = BG_THREADS;
   dim3 grid((m + qchunk - 1) / qchunk, b);
   const float rpad = radius * 1.001f;
   const float r3 = radius * radius * radius;
-  // e / d for e < 2^16 as umulhi(e, magic); d = list entries (or 16-byte groups of entries) per query
+  // e / d for e < 2^16 as umulhi(e, magic); d = 16-byte chunks (or entries) per row
   const unsigned div = (nsample & 3) == 0 ? (unsigned)nsample / 4 : (unsigned)nsample;
   const uint32_t ns_magic = div == 1 ? 0u : (uint32_t)((0x100000000ull / div) + 1ull);  // 0: divisor 1
 #define PASNL_BG(NW)                                                                                                     \
@@ -470,7 +468,7 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(gk),                                        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
       return PASNL_ELAUNCH;                                                                                              \
-    hipLaunchKernelGGL(gk, grid, dim3(BG_THREADS), lds, stream, n, m, rpad, thr2, r3, nsample, rw, ns_magic, qchunk, xyz1, \
+    hipLaunchKernelGGL(gk, grid, dim3(BG_THREADS), lds, stream, n, m, rpad, thr2, r3, nsample, ns_magic, qchunk, xyz1,   \
                        xyz2, idx, pts_cnt);                                                                              \
   }
   if (nw32 == 8) PASNL_BG(8)

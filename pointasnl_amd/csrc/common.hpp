@@ -67,6 +67,32 @@ __device__ __forceinline__ float wave_shr1_f(float v) {
 }
 __device__ __forceinline__ int wave_shr1_i(int v) { return __builtin_amdgcn_update_dpp(v, v, DPP_WAVE_SHR1, 0xf, 0xf, false); }
 
+// Wave-wide min / max of a float and inclusive prefix sum of an int by DPP (rows of 16: shr 1, 2, 4, 8, then the two row
+// broadcasts): register-file moves of a few cycles each where __shfl_xor / __shfl_up are ds_bpermute round trips.
+// wave_min_f32 / wave_max_f32: the result is wave-uniform (taken from lane 63).
+#define PASNL_DPP_F32(OP, CTRL, RM, IDENT)                                                                          \
+  v = OP(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(IDENT), __float_as_int(v), CTRL, RM, 0xf, false)));
+__device__ __forceinline__ float wave_min_f32(float v) {
+  const float inf = __builtin_inff();
+  PASNL_DPP_F32(fminf, DPP_ROW_SHR1, 0xf, inf) PASNL_DPP_F32(fminf, DPP_ROW_SHR2, 0xf, inf) PASNL_DPP_F32(fminf, DPP_ROW_SHR4, 0xf, inf)
+  PASNL_DPP_F32(fminf, DPP_ROW_SHR8, 0xf, inf) PASNL_DPP_F32(fminf, DPP_ROW_BCAST15, 0xa, inf) PASNL_DPP_F32(fminf, DPP_ROW_BCAST31, 0xc, inf)
+  return readlane_f(v, 63);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+  const float ninf = -__builtin_inff();
+  PASNL_DPP_F32(fmaxf, DPP_ROW_SHR1, 0xf, ninf) PASNL_DPP_F32(fmaxf, DPP_ROW_SHR2, 0xf, ninf) PASNL_DPP_F32(fmaxf, DPP_ROW_SHR4, 0xf, ninf)
+  PASNL_DPP_F32(fmaxf, DPP_ROW_SHR8, 0xf, ninf) PASNL_DPP_F32(fmaxf, DPP_ROW_BCAST15, 0xa, ninf) PASNL_DPP_F32(fmaxf, DPP_ROW_BCAST31, 0xc, ninf)
+  return readlane_f(v, 63);
+}
+#undef PASNL_DPP_F32
+__device__ __forceinline__ int wave_inclusive_sum_i32(int v) {
+#define PASNL_DPP_ADD(CTRL, RM) v += __builtin_amdgcn_update_dpp(0, v, CTRL, RM, 0xf, false);
+  PASNL_DPP_ADD(DPP_ROW_SHR1, 0xf) PASNL_DPP_ADD(DPP_ROW_SHR2, 0xf) PASNL_DPP_ADD(DPP_ROW_SHR4, 0xf) PASNL_DPP_ADD(DPP_ROW_SHR8, 0xf)
+  PASNL_DPP_ADD(DPP_ROW_BCAST15, 0xa) PASNL_DPP_ADD(DPP_ROW_BCAST31, 0xc)
+#undef PASNL_DPP_ADD
+  return v;
+}
+
 // Canonical squared distance: ((dx*dx)+(dy*dy))+(dz*dz), no contraction.
 __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
   float dx = ax - bx, dy = ay - by, dz = az - bz;

@@ -8,7 +8,7 @@ import pointasnl_amd as P
 from pointasnl_amd import _hip
 _hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libpasnl_hip_tuning.so")
 lib = _hip.lib()
-names = ["build", "setup+table", "walk", "sort+staging", "copy-out", "rounds", "tier2 rounds", "steps"]
+names = ["build", "-", "setup+table", "walk", "network+rows out", "tier2/round end", "tier2 rounds", "steps"]
 for b in (64, 1024, 4096):
     x = torch.from_numpy(B.synth_clouds(1, min(b, 256), 1024)).cuda()
     if b > 256:
