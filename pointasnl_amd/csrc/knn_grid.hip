@@ -280,6 +280,8 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, in
   const int cx = kg_cell1(qx, P.x0, P.inv_h, P.gx), cy = kg_cell1(qy, P.y0, P.inv_h, P.gy), cz = kg_cell1(qz, P.z0, P.inv_h, P.gz);
   unsigned long long* cb = cand[wave];
 
+  const float coord_mag = fmaxf(fmaxf(fmaxf(fabsf(P.x0) + (float)P.gx * P.h, fabsf(P.y0) + (float)P.gy * P.h),
+                                      fabsf(P.z0) + (float)P.gz * P.h), fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz)));
   // squared distance below which nothing outside the block [xl..xh] x [yl..yh] x [zl..zh] of cells can lie (see the header)
   auto bound_of = [&](int xl, int xh, int yl, int yh, int zl, int zh) {
     float b = INFINITY;
@@ -290,7 +292,9 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, in
     if (zl > 0) b = fminf(b, qz - (P.z0 + (float)zl * P.h));
     if (zh < P.gz - 1) b = fminf(b, (P.z0 + (float)(zh + 1) * P.h) - qz);
     if (b == INFINITY) return INFINITY;  // the block is the whole grid
-    b = fmaxf(b - 1e-3f * P.h, 0.f);
+    // margins: a thousandth of a cell for the cell arithmetic, and four ulps of the LARGEST coordinate in play for the
+    // rounding of the face planes x0 + c*h and of b itself (clouds far from the origin: |x0| >> h)
+    b = fmaxf(b - 1e-3f * P.h - coord_mag * 4.76837158203125e-07f, 0.f);
     return b * b * (1.f - 9.5367431640625e-07f);
   };
 

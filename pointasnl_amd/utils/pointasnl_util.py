@@ -633,17 +633,26 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                 wagg, bagg = st.layer(c_out, c_out, bn, weight_decay)
             rows = batch_size * npoint
             after, skip_spatial = after.contiguous(), skip_spatial.contiguous()
+            att = att.contiguous() if NL else None  # bound to a name: the buffer has to outlive the launch
             out = torch.empty((batch_size, npoint, c_out), dtype=torch.float32, device=xyz.device)
             args = (rows, int(w_in), int(cb if NL else 0), int(c_out), _hip.ptr(after), _hip.ptr(skip_spatial),
-                    _hip.ptr(att.contiguous() if NL else None), _hip.ptr(ws), _hip.ptr(bs), _hip.ptr(wb if NL else None),
+                    _hip.ptr(att), _hip.ptr(ws), _hip.ptr(bs), _hip.ptr(wb if NL else None),
                     _hip.ptr(bb if NL else None), _hip.ptr(wagg), _hip.ptr(bagg), _hip.ptr(out))
-            if xyz_concat and XYZ_CONCAT:
-                new_xyz = new_xyz.contiguous()
-                cat = torch.empty((batch_size, npoint, 4 + c_out), dtype=torch.float32, device=xyz.device)
-                _hip.launch("pasnl_sa_tail_cat", "sa_tail", *args, _hip.ptr(new_xyz), _hip.ptr(cat))
-                out.xyz_concat = (new_xyz, cat)
-            else:
-                _hip.launch("pasnl_sa_tail", "sa_tail", *args)
+            try:
+                if xyz_concat and XYZ_CONCAT:
+                    new_xyz = new_xyz.contiguous()
+                    cat = torch.empty((batch_size, npoint, 4 + c_out), dtype=torch.float32, device=xyz.device)
+                    _hip.launch("pasnl_sa_tail_cat", "sa_tail", *args, _hip.ptr(new_xyz), _hip.ptr(cat))
+                    out.xyz_concat = (new_xyz, cat)
+                else:
+                    _hip.launch("pasnl_sa_tail", "sa_tail", *args)
+            except _hip.PasnlUnsupported:
+                # weights too wide for the kernel's LDS tile (e.g. c_out = 512 with ~480 input channels): the same tail op by
+                # op on the vendor BLAS, from the pieces above -- out = relu((after + relu(skip) + relu(back_project)) . Wagg)
+                tail = after.reshape(rows, c_out) + torch.relu_(torch.addmm(bs, skip_spatial.reshape(rows, w_in), ws))
+                if NL:
+                    tail = tail + torch.relu_(torch.addmm(bb, att.reshape(rows, cb), wb))
+                out = torch.relu_(torch.addmm(bagg, tail, wagg)).reshape(batch_size, npoint, c_out)
             return new_xyz, out
 
         # ---- non-local cell (:251-255)

@@ -189,14 +189,14 @@ _DENSE_WS = {}
 
 
 def _dense_rows_workspace(nbytes, device):
-    """Zero-filled scratch of pasnl_dense_rows, one per (device, stream): a workspace serves one stream at a time, and a
-    captured graph keeps using the buffer it was captured with (entries are never freed or replaced by smaller ones)."""
+    """Zero-filled scratch of pasnl_dense_rows, one per (device, stream): a workspace serves one stream at a time.  Buffers
+    are only ever ADDED: a captured graph keeps writing its partial sums and counters into the buffer it was captured with,
+    so a buffer that proved too small for a later, larger layer stays alive (in the list) next to its replacement."""
     key = (device.index, torch.cuda.current_stream().cuda_stream)
-    ws = _DENSE_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _DENSE_WS[key] = ws
-    return ws
+    bufs = _DENSE_WS.setdefault(key, [])
+    if not bufs or bufs[-1].numel() < nbytes:
+        bufs.append(torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device))
+    return bufs[-1]
 
 
 def _dense_rows(x2d, w, b, relu):

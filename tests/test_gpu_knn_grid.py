@@ -56,6 +56,11 @@ def _cases():
     out["k64"] = (B.synth_clouds(12, 2, 4100), None, 64)
     out["k1"] = (B.synth_clouds(13, 2, 4096), B.synth_clouds(14, 2, 333), 1)
     out["n16384"] = (B.synth_clouds(15, 1, 16384), B.synth_clouds(15, 1, 16384)[:, :2000].copy(), 32)
+    # clouds far from the origin (un-normalised / UTM-like coordinates): the cell faces x0 + c*h and the distances to them are
+    # rounded relative to |x0| >> h, which the acceptance bound has to allow for
+    far = (B.synth_clouds(16, 2, 6000) * 4.0 + np.float32(1.0e4)).astype(np.float32)
+    out["translated_1e4"] = (far, None, 32)
+    out["translated_3e5"] = ((B.synth_clouds(17, 1, 5000) * 50.0 + np.array([3.0e5, -2.0e5, 1.0e3])).astype(np.float32), None, 16)
     return out
 
 
