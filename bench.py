@@ -757,21 +757,23 @@ def ball_query_sweep(batches=(64, 256, 1024, 4096), iters=20):
 
 
 def traffic_pass(args):
-    """--traffic-pass (run under rocprofv3 --pmc by profiles/collect_traffic.sh): every workload's forward twice, eagerly,
-    then the operator sweep once, with a marker kernel (torch.cuda._sleep) in front of every C-ABI launch, so that the
-    counter rows between two markers belong to one launch whatever number of kernels it starts.  Prints the sequence of
-    launches as one JSON line."""
+    """--traffic-pass (run under rocprofv3 --pmc by profiles/collect_traffic.sh): every workload's forward three times, eagerly
+    and with every kernel on ONE stream in program order (no forks), then the operator sweep, with a marker kernel
+    (torch.cuda._sleep) in front of every C-ABI launch, so that the counter rows between two markers belong to one launch
+    whatever number of kernels it starts.  Prints the sequence of launches as one JSON line; the first forward of a workload
+    (weights and workspaces are created) is marked "_unmeasured"."""
     import importlib
 
     import torch
 
     import pointasnl_amd as P
     from pointasnl_amd import _hip
-    from pointasnl_amd.utils import tf_util
+    from pointasnl_amd.utils import pointasnl_util, tf_util
 
     _hip.lib()
     _hip.require_device()
     torch.cuda.set_device(0)
+    pointasnl_util.OVERLAP = False
     seq = []
     _hip.MARK = seq
     with torch.no_grad():
@@ -780,7 +782,7 @@ def traffic_pass(args):
             x = torch.from_numpy(make_input(ci, spec, 0)).cuda()
             tf_util.set_store(tf_util.VariableStore(seed=1234))
             for it in range(3):
-                _hip.MARK = seq if it else None  # the first forward creates weights and workspaces: unmarked, uncounted
+                _hip.MARK_SKIP = it == 0
                 if spec["model"] == "cls":
                     model.get_model(x, is_training=False, adaptive_sample=spec["AS"])
                 else:
@@ -791,10 +793,9 @@ def traffic_pass(args):
             if b > 256:
                 x = x.repeat(b // 256, 1, 1).contiguous()
             q = x[:, :512].contiguous()
-            _hip.MARK = None
-            P.tf_grouping.query_ball_point(0.2, 32, x, q)
-            _hip.MARK = seq
-            P.tf_grouping.query_ball_point(0.2, 32, x, q)
+            for it in range(3):
+                _hip.MARK_SKIP = it == 0
+                P.tf_grouping.query_ball_point(0.2, 32, x, q)
             torch.cuda.synchronize()
     _hip.MARK = None
     print(json.dumps({"launch_sequence": seq}), flush=True)

@@ -85,6 +85,7 @@ PROFILE = None
 # marker kernel (torch.cuda._sleep -> "spin_kernel") is enqueued in front of every C-ABI launch and (symbol, integer-arguments)
 # is appended; the counter rows between two markers then belong to one launch whatever number of kernels it starts.
 MARK = None
+MARK_SKIP = False  # marked, but not to be counted (first launches that also create workspaces)
 
 
 TRACE = bool(os.environ.get("PASNL_TRACE"))  # debugging: print + synchronise around every launch
@@ -105,7 +106,8 @@ def launch(symbol, what, *args):
         return
     if MARK is not None:
         torch.cuda._sleep(1)
-        MARK.append([symbol, [a if isinstance(a, int) else a.value for a in args if isinstance(a, (int, ctypes.c_long))]])
+        MARK.append(["_unmeasured" if MARK_SKIP else symbol,
+                     [a if isinstance(a, int) else a.value for a in args if isinstance(a, (int, ctypes.c_long))]])
     if PROFILE is None:
         check(fn(*args, stream_ptr()), what)
         return

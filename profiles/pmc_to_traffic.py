@@ -26,7 +26,7 @@ def dispatches(root, counter):
     for f in glob.glob(os.path.join(root, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == counter:
-                rows[int(r["Dispatch_Id"])] = (r["Kernel_Name"].split("(")[0], float(r["Counter_Value"]))
+                rows[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]))
     return [rows[k] for k in sorted(rows)]
 
 
@@ -54,9 +54,11 @@ def main(root, out):
     write = per_launch(root, "WRITE_SIZE", len(seq))
     agg, kern = defaultdict(list), {}
     for (sym, dims), (names, f), (_, w) in zip(seq, fetch, write):
+        if sym.startswith("_"):  # "_unmeasured": first launches, which also create weights and workspaces
+            continue
         key = sym + ":" + ",".join(map(str, dims))
         agg[key].append((f, w))
-        kern[key] = " + ".join(n.replace("void pasnl::", "").split("<")[0] for n in names)
+        kern[key] = " + ".join(n.replace("void pasnl::", "").split("(")[0].split("<")[0] for n in names)
     traffic, detail = {}, {}
     for key, v in agg.items():
         f = sum(a for a, _ in v) / len(v)
