@@ -242,6 +242,16 @@ size_t pasnl_dense_rows_workspace_bytes(int rows, int kdim, int n);
 int pasnl_dense_rows(int rows, int kdim, int n, const float* x, const float* w, const float* bias, int relu, float* out,
                      void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
 
+/* out (rows,n) = act(x (rows,kdim; row stride lda) . w (kdim,n) + bias) for THIN products with a long contraction -- the
+ * [1,C] after_conv / decode_after_conv windows of the deep levels (pointasnl_util.py:277-280, :329-331 through tf_util.conv2d,
+ * tf_util.py:120-185; BN folded by the caller): few 128 x 128 output tiles, kdim in the thousands.  128 x 128 tiles x K slices
+ * on fp32 MFMA; the slices' partial tiles meet in `workspace` (pasnl_dense_splitk_workspace_bytes bytes, no initialisation
+ * needed; one workspace serves one stream at a time) and are summed in slice order (bit-reproducible).
+ * kdim % 16 == 0, lda % 4 == 0, n % 4 == 0, x / out / bias 16-byte aligned, else PASNL_EUNSUPPORTED. */
+size_t pasnl_dense_splitk_workspace_bytes(int rows, int kdim, int n);
+int pasnl_dense_splitk(int rows, int kdim, int n, int lda, const float* x, const float* w, const float* bias, int relu,
+                       float* out, void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
+
 /* Two projections of NARROW rows in one launch: out_i (rows_i, n_i) = x_i (rows_i, kdim_i) . w_i + bias_i, kdim_i <= 16,
  * n_i in {32, 64, 128, 256}, no activation: conv_kv and conv_query of the first layer's non-local cell, whose inputs are
  * coordinates (3 or 6 channels) -- pointasnl_util.py:186-193, two tf_util.conv2d with activation_fn=None.  rows_1 == 0

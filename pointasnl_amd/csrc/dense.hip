@@ -251,6 +251,207 @@ extern "C" int pasnl_dense_rows(int rows, int kdim, int n, const float* x, const
 }
 
 // ---------------------------------------------------------------------------------------------
+// THIN products with a long contraction: out (M,N) = act(A (M,K) . W (K,N) + bias) where M*N is a few hundred 128 x 128
+// tiles at most and K is thousands -- the after_conv / decode_after_conv layers of the deep levels of the segmentation
+// models ((M,K,N) = (320,16384,512), (2560,4096,128), (640,8192,256), ...: pointasnl_util.py:277-280, :329-331).  The vendor
+// library does not split K for these (40-53 TF, and 3.9 TF on (4096,384,256)); this kernel does:
+//   * a workgroup (4 waves) owns one 128 x 128 output tile and one K slice; a wave owns 64 x 64 of it as 2 x 2
+//     v_mfma_f32_32x32x2_f32 accumulators;
+//   * chunks of 16 contraction indices go through LDS, double-buffered: A rows as they are (k contiguous: 64-byte runs per
+//     row from global), W TRANSPOSED on the way in (a thread loads 8 words of one column, 256-byte runs per wave, and
+//     writes two 16-byte pieces of Ws[col][k]); both tiles have rows of 20 floats, so the 16-byte operand reads of 16
+//     lanes hit 16 different bank quads;
+//   * MFMA step t of a group of 8 indices contracts k0+t and k0+4+t (any pairing is legal as long as A and B agree), so a
+//     lane's operand for four steps is ONE ds_read_b128;
+//   * ksplit > 1: the slices' partial tiles go to a workspace and a second kernel adds them IN SLICE ORDER, with bias and
+//     activation (bit-reproducible; one workgroup adding all slices of a tile itself would be a serial tail of ~1 MB).
+// K % 16 == 0, lda % 4 == 0, A 16-byte aligned, else PASNL_EUNSUPPORTED (the caller then takes the vendor GEMM).
+// ---------------------------------------------------------------------------------------------
+namespace pasnl {
+
+constexpr int SK_BM = 128, SK_BN = 128, SK_KC = 16, SK_LD = 20;
+
+__global__ __launch_bounds__(256) void dense_splitk_kernel(int M, int K, int N, int lda, int kslice, int ksplit,
+                                                          const float* __restrict__ A, const float* __restrict__ W,
+                                                          const float* __restrict__ bias, int relu, float* __restrict__ out,
+                                                          float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) float As[2][SK_BM * SK_LD];
+  __shared__ __attribute__((aligned(16))) float Ws[2][SK_BN * SK_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * SK_BN, m0 = blockIdx.y * SK_BM, ks = blockIdx.z;
+  const int kbeg = ks * kslice, kend = min(kbeg + kslice, K);
+  const int nchunks = (kend - kbeg) / SK_KC;
+
+  // global -> registers: A: thread t takes row t/2, 8 contraction indices (two float4); W: column t%128, 8 indices
+  const int arow = tid >> 1, akq = (tid & 1) * 8;
+  const float* ap = A + (size_t)min(m0 + arow, M - 1) * lda + kbeg + akq;
+  const int wcol = tid & 127, wkh = (tid >> 7) * 8;
+  const float* wp = W + (size_t)(kbeg + wkh) * N + min(n0 + wcol, N - 1);
+  float4 ra0, ra1;
+  float rw[8];
+  auto gload = [&](int c) {
+    ra0 = *reinterpret_cast<const float4*>(ap + c * SK_KC);
+    ra1 = *reinterpret_cast<const float4*>(ap + c * SK_KC + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rw[j] = wp[(size_t)(c * SK_KC + j) * N];
+  };
+  auto lstore = [&](int buf) {
+    *reinterpret_cast<float4*>(&As[buf][arow * SK_LD + akq]) = ra0;
+    *reinterpret_cast<float4*>(&As[buf][arow * SK_LD + akq + 4]) = ra1;
+    *reinterpret_cast<float4*>(&Ws[buf][wcol * SK_LD + wkh]) = make_float4(rw[0], rw[1], rw[2], rw[3]);
+    *reinterpret_cast<float4*>(&Ws[buf][wcol * SK_LD + wkh + 4]) = make_float4(rw[4], rw[5], rw[6], rw[7]);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nchunks > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) gload(c + 1);  // in flight under this chunk's products
+    const float* as = &As[buf][(wm * 64 + l32) * SK_LD + 4 * h];
+    const float* ws = &Ws[buf][(wn * 64 + l32) * SK_LD + 4 * h];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const float4*>(as + i * 32 * SK_LD + g * 8);
+        b[i] = *reinterpret_cast<const float4*>(ws + i * 32 * SK_LD + g * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (c + 1 < nchunks) lstore(buf ^ 1);  // the other buffer: its readers finished before the barrier that opened this chunk
+    __syncthreads();
+  }
+
+  // D element e of lane (l32, h) of block (i, j): row = wm*64 + i*32 + kappa(e, h), column = wn*64 + j*32 + l32
+  if (ksplit == 1) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l32;
+      const float bv = bias[min(col, N - 1)];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm * 64 + i * 32 + dense_kappa(e, h);
+          float v = acc[i][j][e] + bv;
+          v = relu ? fmaxf(v, 0.f) : v;
+          if (row < M && col < N) out[(size_t)row * N + col] = v;
+        }
+    }
+    return;
+  }
+  // partial tile, in (row, column) order of the OUTPUT matrix inside a slice: part[ks][row][col] over the padded M x N
+  const int Mp = gridDim.y * SK_BM, Np = gridDim.x * SK_BN;
+  float* mine = part + (size_t)ks * Mp * Np;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + l32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + dense_kappa(e, h);
+        mine[(size_t)row * Np + col] = acc[i][j][e];
+      }
+  }
+}
+
+// out[r][c] = act(bias[c] + sum over the slices, in slice order, of part[s][r][c]); a thread owns 4 consecutive columns
+__global__ __launch_bounds__(256) void dense_splitk_reduce_kernel(int M, int N, int Mp, int Np, int ksplit,
+                                                                 const float* __restrict__ part, const float* __restrict__ bias,
+                                                                 int relu, float* __restrict__ out) {
+  const int q = N >> 2;  // N % 4 == 0
+  const long total = (long)M * q;
+  const size_t slice = (size_t)Mp * Np;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int r = (int)(e / q), c = (int)(e - (long)r * q) * 4;
+    const float* p = part + (size_t)r * Np + c;
+    float4 v = *reinterpret_cast<const float4*>(p);
+    for (int s = 1; s < ksplit; ++s) {
+      const float4 t = *reinterpret_cast<const float4*>(p + s * slice);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const float4 b = *reinterpret_cast<const float4*>(bias + c);
+    v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(out + (size_t)r * N + c) = v;
+  }
+}
+
+struct SplitKPlan {
+  int mt, nt, ksplit, kslice;
+  size_t bytes;
+};
+
+static SplitKPlan splitk_plan(int M, int K, int N) {
+  SplitKPlan p;
+  p.mt = (M + SK_BM - 1) / SK_BM;
+  p.nt = (N + SK_BN - 1) / SK_BN;
+  const int tiles = p.mt * p.nt;
+  int want = (256 + tiles - 1) / tiles;  // ~1 workgroup per CU: a slice is long enough to amortise prologue, partial tile and reduce
+  const int most = K / 64 > 0 ? K / 64 : 1;  // slices of at least 64 contraction indices
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  p.kslice = (((K + want - 1) / want) + SK_KC - 1) / SK_KC * SK_KC;
+  p.ksplit = (K + p.kslice - 1) / p.kslice;
+  p.bytes = p.ksplit > 1 ? (size_t)p.ksplit * p.mt * SK_BM * p.nt * SK_BN * 4 : 0;
+  return p;
+}
+
+}  // namespace pasnl
+
+extern "C" size_t pasnl_dense_splitk_workspace_bytes(int rows, int kdim, int n) {
+  if (rows <= 0 || kdim <= 0 || n <= 0) return 0;
+  return splitk_plan(rows, kdim, n).bytes;
+}
+
+extern "C" int pasnl_dense_splitk(int rows, int kdim, int n, int lda, const float* x, const float* w, const float* bias, int relu,
+                                  float* out, void* workspace, size_t workspace_bytes, pasnl_stream_t stream) {
+  PASNL_REQUIRE(rows >= 0 && kdim > 0 && n > 0 && lda >= kdim, PASNL_EINVAL);
+  if (rows == 0) return PASNL_OK;
+  PASNL_REQUIRE(x && w && bias && out, PASNL_ENULL);
+  PASNL_REQUIRE(kdim % SK_KC == 0 && lda % 4 == 0 && n % 4 == 0, PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) % 16 == 0,
+                PASNL_EUNSUPPORTED);
+  const SplitKPlan p = splitk_plan(rows, kdim, n);
+  PASNL_REQUIRE(p.mt <= 65535 && p.ksplit <= 65535, PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE(p.bytes == 0 || (workspace && workspace_bytes >= p.bytes), PASNL_EWORKSPACE);
+  hipStream_t st = pasnl_hip_stream(stream);
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(dense_splitk_kernel, dim3(p.nt, p.mt, p.ksplit), dim3(256), 0, st, rows, kdim, n, lda, p.kslice, p.ksplit, x,
+                     w, bias, relu, out, part);
+  if (p.ksplit > 1) {
+    const long total = (long)rows * (n / 4);
+    long g = (total + 255) / 256;
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    hipLaunchKernelGGL(dense_splitk_reduce_kernel, dim3((int)g), dim3(256), 0, st, rows, n, p.mt * SK_BM, p.nt * SK_BN, p.ksplit,
+                       part, bias, relu, out);
+  }
+  return pasnl_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Projections of NARROW rows (kdim <= 16: coordinates, coordinates + normals): out (rows,n) = x (rows,kdim) . w + bias.
 // The first layer's non-local cell projects 3 / 6 input channels to its keys|values and queries (pointasnl_util.py:186-193):
 // as GEMMs these are two launches bound by their own start-up (11.7 + 6.8 us at cls B = 64 for 21 MB of output).  Here

@@ -199,6 +199,38 @@ def _dense_rows_workspace(nbytes, device):
     return bufs[-1]
 
 
+# Thin products with a long contraction on pasnl_dense_splitk -- only where it was measured to beat the vendor library WITH its
+# transposed-weights trick (tools/splitk_probe.py): one column block of tiles, thousands of rows, K >= 4096, e.g. sem_seg_res's
+# (2560, 4096, 128): 62 -> 51 us.  Everywhere else the vendor kernels are as fast or faster (EXPERIMENTS.md).
+DENSE_SPLITK = True
+SPLITK_MIN_K = 4096
+SPLITK_MAX_N = 128
+SPLITK_MIN_ROWS = 2048
+SPLITK_MAX_TILES = 96
+_SPLITK_WS = {}
+
+
+def _dense_splitk(x2d, w, b, relu):
+    """act(x2d . w + b) for a thin product with a long contraction: csrc/dense.hip (128 x 128 tiles x K slices, partial tiles
+    summed in slice order by a second kernel).  The workspace is per (device, stream) and only ever grows by ADDING buffers
+    (a captured graph keeps the one it was captured with)."""
+    import ctypes
+    rows, cin = x2d.shape
+    cout = w.shape[1]
+    if x2d.stride(1) != 1:
+        x2d = x2d.contiguous()
+    nbytes = int(_hip.lib().pasnl_dense_splitk_workspace_bytes(rows, cin, cout))
+    key = (x2d.device.index, torch.cuda.current_stream().cuda_stream)
+    bufs = _SPLITK_WS.setdefault(key, [])
+    if not bufs or bufs[-1].numel() < nbytes:
+        bufs.append(torch.empty(max(nbytes, 1 << 22), dtype=torch.uint8, device=x2d.device))
+    ws = bufs[-1]
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x2d.device)
+    _hip.launch("pasnl_dense_splitk", "dense_splitk", rows, cin, cout, int(x2d.stride(0)), _hip.ptr(x2d), _hip.ptr(w), _hip.ptr(b),
+                int(bool(relu)), _hip.ptr(out), _hip.ptr(ws), ctypes.c_size_t(ws.numel()))
+    return out
+
+
 def _dense_rows(x2d, w, b, relu):
     """act(x2d . w + b) for a handful of rows: csrc/dense.hip (K slices over ~128 workgroups, fixed summation order)."""
     import ctypes
@@ -234,6 +266,15 @@ def _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay=N
             and x2d.dtype == torch.float32):
         try:
             out = _dense_rows(x2d, w, b, is_relu)
+            return out.reshape(*inputs.shape[:-1], num_output_channels)
+        except _hip.PasnlUnsupported:
+            pass  # e.g. an unaligned view: the vendor GEMM below
+    if (DENSE_SPLITK and x2d.is_cuda and x2d.dtype == torch.float32 and (is_relu or activation_fn is None)
+            and cin >= SPLITK_MIN_K and cin % 16 == 0 and num_output_channels % 4 == 0
+            and num_output_channels <= SPLITK_MAX_N and x2d.shape[0] >= SPLITK_MIN_ROWS
+            and -(-x2d.shape[0] // 128) * -(-num_output_channels // 128) <= SPLITK_MAX_TILES):
+        try:
+            out = _dense_splitk(x2d, w, b, is_relu)
             return out.reshape(*inputs.shape[:-1], num_output_channels)
         except _hip.PasnlUnsupported:
             pass  # e.g. an unaligned view: the vendor GEMM below

@@ -50,6 +50,48 @@ def test_dense_rows_matches_fp64(P, rows, k, n, relu):
     assert np.abs(got - want).max() <= 1e-5 * max(scale, 1.0)
 
 
+@pytest.mark.parametrize("rows,k,n,relu", [
+    (320, 16384, 512, True), (2560, 4096, 128, True), (640, 8192, 256, True), (4096, 384, 256, True),   # sem_seg(_res) deep layers
+    (1024, 16480, 512, True), (130, 272, 132, False), (129, 64, 4, True), (257, 2048, 260, False), (3000, 256, 96, True),
+])
+def test_dense_splitk_matches_fp64(P, rows, k, n, relu):
+    """pasnl_dense_splitk (128 x 128 tiles x K slices + ordered reduce): 1e-5 of the output scale against the fp64 product,
+    ragged tiles in both directions, a row stride larger than K, one slice and many."""
+    from pointasnl_amd.utils import tf_util
+    x, w, b = _dense_case(rows, k, n, 300 + rows + n)
+    want = x.astype(np.float64) @ w.astype(np.float64) + b
+    if relu:
+        want = np.maximum(want, 0)
+    xd = dev(np.concatenate([x, np.full((rows, 8), 7.0, np.float32)], axis=1))[:, :k]   # lda = k + 8, not contiguous
+    got = tf_util._dense_splitk(xd, dev(w), dev(b), relu)
+    again = tf_util._dense_splitk(xd, dev(w), dev(b), relu)
+    assert torch.equal(got, again), "slice-ordered sums are bit-reproducible"
+    got = got.cpu().numpy()
+    assert got.shape == (rows, n) and got.dtype == np.float32
+    assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0)
+
+
+def test_dense_layer_takes_the_splitk_kernel_for_thin_long_products(P, monkeypatch):
+    """tf_util._dense routes the products pasnl_dense_splitk was measured to win (one column block of tiles, thousands of rows,
+    K >= 4096) to it and leaves the rest to the vendor library."""
+    from pointasnl_amd.utils import tf_util
+    from pointasnl_amd import _hip
+    launched = []
+    real = _hip.launch
+    monkeypatch.setattr(_hip, "launch", lambda sym, *a: (launched.append(sym), real(sym, *a))[1])
+    tf_util.set_store(tf_util.VariableStore(seed=3))
+    for rows, k, n, expect in [(2560, 4096, 128, True), (320, 16384, 512, False), (131072, 128, 128, False), (640, 100, 64, False)]:
+        del launched[:]
+        x = torch.randn(rows, k, device="cuda")
+        out = tf_util._dense(x, n, f"probe_{rows}_{k}", False, "relu")
+        st = tf_util.store()
+        with tf_util.variable_scope(f"probe_{rows}_{k}"):
+            w, b = st.layer(k, n, False, None)
+        want = torch.relu(torch.addmm(b.double(), x.double(), w.double()))
+        assert ("pasnl_dense_splitk" in launched) == expect, (rows, k, n, launched)
+        assert float((out.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+
+
 def test_dense_rows_is_reproducible_and_leaves_its_counters_clean(P):
     # the K slices are summed in slice order by whichever workgroup arrives last: every run gives the same bits, and the
     # counters are back at zero for the next launch (50 back-to-back launches on one workspace)
