@@ -525,8 +525,13 @@ using namespace pasnl;
 extern "C" int pasnl_knn_batch(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
                                int idx_is_i64, float* dist2, pasnl_stream_t stream);
 
+static int kg_min_n() {
+  if (const char* e = tune_env("PASNL_KNN_GRID_MIN_N")) return atoi(e);  // tuning build only
+  return PASNL_KNN_GRID_MIN_N;
+}
+
 extern "C" size_t pasnl_knn_workspace_bytes(int b, int n) {
-  if (b <= 0 || n < PASNL_KNN_GRID_MIN_N || n > KG_BUILD_T * KG_PPT) return 0;
+  if (b <= 0 || n < kg_min_n() || n > KG_BUILD_T * KG_PPT) return 0;
   return (size_t)b * kg_stride(n);
 }
 
