@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out; rm -rf gpurun_out/pmc_mfma
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA -d gpurun_out/pmc_mfma -o cls -f csv -- \
-  python bench.py --worker --steps 3 --warmup 1 --no-cpu-baseline --no-graph > gpurun_out/pmc_mfma.json 2> gpurun_out/pmc_mfma.err || true
+  python bench.py --worker --steps 3 --warmup 1 --no-cpu-baseline --no-graph --no-others > gpurun_out/pmc_mfma.json 2> gpurun_out/pmc_mfma.err || true
 python - <<'PY'
 import csv, glob, json, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
