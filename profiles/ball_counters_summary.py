@@ -8,7 +8,8 @@ for f in glob.glob(os.path.join(root, "ballpmc_*", "**", "*counter_collection.cs
     for r in csv.DictReader(open(f)):
         if "ball_grid_kernel" not in r["Kernel_Name"] and "ball_query_grid_kernel" not in r["Kernel_Name"]:
             continue
-        b = int(r.get("Grid_Size_Y") or r.get("Grid_Size", "0")) if "Grid_Size_Y" in r else int(r["Grid_Size"]) // 256
+        # clouds of the launch: one workgroup of Workgroup_Size threads per cloud at the profiled shape (512 queries)
+        b = int(r["Grid_Size"]) // max(1, int(r.get("Workgroup_Size") or 256))
         acc[b][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
 for b in sorted(acc):
