@@ -139,6 +139,18 @@ size_t pasnl_knn_workspace_bytes(int b, int n);
 int pasnl_knn_batch_ws(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
                        float* dist2, void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
 
+/* The same K nearest neighbours in the REFERENCE'S order among exactly equal distances (and with the reference's choice of
+ * which of several tied candidates is the K-th): nanoflann keeps candidates of equal distance in the order its KD-tree visits
+ * them (nanoflann.hpp:115-134, :1351-1410; tree: divideTree / middleSplit_ / planeSplit :916-1043, leaf size 10,
+ * knn_.cxx:83).  Replaces cpp_knn_batch knn_.cxx:72-101 bit for bit, ties included, by rebuilding that tree and that search on
+ * the GPU -- an optional exactness mode (one lane builds a cloud's tree), not a fast path; pasnl_knn_batch returns the
+ * canonical (distance, index) order, identical whenever distances are distinct.  k <= n.  workspace:
+ * pasnl_knn_tree_workspace_bytes(b, n, m, k) bytes; its first int32 is non-zero afterwards if a tree or a search was deeper
+ * than 96 levels (pathological clustering: the result is then not valid). */
+size_t pasnl_knn_tree_workspace_bytes(int b, int n, int m, int k);
+int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
+                         void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
+
 /* ------------------------------------------------------- interpolation (tf_ops/3d_interpolation) */
 
 /* Three nearest known points, squared distances ascending, lowest index first on ties.

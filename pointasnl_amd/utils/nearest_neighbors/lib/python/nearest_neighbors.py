@@ -19,7 +19,29 @@ from pointasnl_amd import _hip
 GRID = True  # False: brute-force kernels for every size (A/B, and the reference point of the grid kernel's parity test)
 
 
-def _knn_dev(pts, queries, K, i64):
+def _knn_tree_dev(pts, queries, K, i64):
+    """The reference's own order among equal distances (csrc/knn_tree.hip): nanoflann's tree and search rebuilt on the GPU."""
+    b, n, _ = pts.shape
+    m = queries.shape[1]
+    if K > n:
+        raise ValueError("knn_batch(tie_order='nanoflann') needs K <= number of points")
+    out = torch.empty((b, m, int(K)), dtype=torch.int64 if i64 else torch.int32, device=pts.device)
+    nbytes = int(_hip.lib().pasnl_knn_tree_workspace_bytes(b, n, m, int(K)))
+    ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=pts.device)
+    _hip.launch("pasnl_knn_batch_tree", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
+                _hip.ptr(ws), ctypes.c_size_t(nbytes))
+    if int(ws[:4].view(torch.int32).item()) != 0:  # (a synchronisation: this mode is about exactness, not speed)
+        raise _hip.PasnlUnsupported("knn_batch(tie_order='nanoflann'): a KD-tree deeper than 96 levels (pathologically clustered cloud)")
+    return out
+
+
+def _knn_dev(pts, queries, K, i64, tie_order="index"):
+    if tie_order == "nanoflann":
+        if pts.dim() != 3 or pts.shape[2] != 3 or queries.dim() != 3 or queries.shape[2] != 3 or queries.shape[0] != pts.shape[0]:
+            raise ValueError("knn_batch expects (B,N,3) pts and (B,M,3) queries")
+        return _knn_tree_dev(pts, queries, K, i64)
+    if tie_order != "index":
+        raise ValueError("tie_order is 'index' (canonical (distance, index) order) or 'nanoflann' (the reference's visit order)")
     if pts.dim() != 3 or pts.shape[2] != 3 or queries.dim() != 3 or queries.shape[2] != 3:
         raise ValueError("knn_batch expects (B,N,3) pts and (B,M,3) queries")
     if queries.shape[0] != pts.shape[0]:
@@ -38,14 +60,17 @@ def _knn_dev(pts, queries, K, i64):
     return out
 
 
-def knn_batch(pts, queries, K, omp=False, dtype=None):
+def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="index"):
     """(B,N,3), (B,M,3) -> (B,M,K) neighbour indices (int64 like the reference; ``dtype=torch.int32`` skips
-    the cast the models do at pointasnl_util.py:30).  ``omp`` is accepted and ignored."""
+    the cast the models do at pointasnl_util.py:30).  ``omp`` is accepted and ignored.
+    tie_order: "index" (default) = ascending (distance, index), the canonical order and what the models use; "nanoflann" =
+    the reference's own order among EXACTLY equal distances (its KD-tree's visit order), bit-identical to cpp_knn_batch on
+    lattices and duplicated points too -- slower (the tree is rebuilt per call), for exact reproduction only."""
     host = not isinstance(pts, torch.Tensor)
     p = _hip.as_dev(pts, torch.float32)
     q = _hip.as_dev(queries, torch.float32)
     i64 = dtype in (None, torch.int64, np.int64)
-    out = _knn_dev(p, q, K, i64)
+    out = _knn_dev(p, q, K, i64, tie_order)
     return out.cpu().numpy() if host else out
 
 

@@ -60,6 +60,10 @@ def make_cpu():
     for seed, b, n, nq, k, kind in PICK_CASES:  # cpp_knn_batch_distance_pick with its time(0) seed pinned to `seed`
         i, q = ref.knn_batch_distance_pick(clouds(seed, b, n, kind), nq, k, seed)
         out[f"pick_idx_{seed}"], out[f"pick_q_{seed}"] = i.astype(np.int32), q
+    from golden import ref_cases as RC
+    for seed, b, n, m, k, kind in RC.KNN_TIE_CASES:  # exact ties: nanoflann's visit order
+        sup, qry = RC.knn_tie_cloud(seed, b, n, m, kind)
+        out[f"knn_tie_{seed}"] = ref.knn_batch(sup, qry, k, omp=False).astype(np.int32)
     np.savez_compressed(os.path.join(HERE, "ref_knn.npz"), **out)
     out = {}
     for seed, b, n, m, kind in NN_CASES:

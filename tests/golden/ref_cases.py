@@ -187,3 +187,37 @@ def loss_inputs(case):
     smpw = r.random((b, n)).astype(np.float32)
     smpw[:, :100] = 0.0
     return dict(pc=pc, label=r.integers(0, 20, (b, n)).astype(np.int32), smpw=smpw)
+
+
+# ---- kNN on clouds with EXACTLY equal distances: the reference's (nanoflann's) order among ties is its KD-tree's visit order.
+# (seed, b, n, m, k, kind); the product reproduces it with knn_batch(..., tie_order="nanoflann") (csrc/knn_tree.hip)
+KNN_TIE_CASES = [
+    (801, 2, 1024, 512, 32, "lattice"), (802, 2, 512, 128, 64, "lattice"), (803, 1, 5000, 700, 32, "lattice16"),
+    (804, 2, 1024, 300, 16, "dup"), (805, 1, 300, 300, 40, "same"), (806, 1, 2000, 400, 20, "line"),
+    (807, 2, 700, 90, 8, "lattice_q_off"), (808, 1, 37, 37, 37, "lattice"), (809, 2, 1024, 512, 32, "ball"),
+]
+
+
+def knn_tie_cloud(seed, b, n, m, kind):
+    """-> (support (b,n,3), queries (b,m,3)) float32"""
+    import numpy as np
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if kind in ("lattice", "lattice_q_off"):
+        sup = (np.round(rng.random((b, n, 3)) * 8) / 8).astype(np.float32)
+    elif kind == "lattice16":
+        sup = (np.round(rng.random((b, n, 3)) * 16) / 16).astype(np.float32)
+    elif kind == "dup":
+        half = rng.random((b, n // 2, 3)).astype(np.float32)
+        sup = np.concatenate([half, half], axis=1)[:, rng.permutation(n)].copy()
+    elif kind == "same":
+        sup = np.full((b, n, 3), 0.375, np.float32)
+    elif kind == "line":
+        sup = np.zeros((b, n, 3), np.float32)
+        sup[..., 0] = np.round(rng.random((b, n)) * 64) / 64
+    else:
+        v = rng.standard_normal((b, n, 3))
+        sup = (v / np.linalg.norm(v, axis=-1, keepdims=True) * rng.random((b, n, 1)) ** (1 / 3)).astype(np.float32)
+    qry = sup[:, :m].copy()
+    if kind == "lattice_q_off":  # queries at cell centres: equidistant from the surrounding lattice points, none of them a support point
+        qry = (np.floor(rng.random((b, m, 3)) * 8) / 8 + 1 / 16).astype(np.float32)
+    return sup, qry

@@ -99,3 +99,47 @@ def test_grid_knn_distances_and_int64():
     with pytest.raises(_hip.PasnlError):  # a workspace that is too small is refused before anything is launched
         _hip.launch("pasnl_knn_batch_ws", "knn", b, n, n, k, _hip.ptr(s), _hip.ptr(s), _hip.ptr(idx), 1, _hip.ptr(d), _hip.ptr(ws),
                     ctypes.c_size_t(nbytes - 1))
+
+
+# ---- the reference's own order among exactly equal distances (csrc/knn_tree.hip): nanoflann's tree and search on the GPU
+import os  # noqa: E402
+import sys  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from golden import ref_cases as RC  # noqa: E402
+import pointasnl_amd as P  # noqa: E402
+
+GOLD_KNN = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_knn.npz"))
+
+
+@pytest.mark.parametrize("case", RC.KNN_TIE_CASES, ids=lambda c: f"{c[0]}_{c[5]}")
+def test_knn_nanoflann_tie_order_matches_the_reference(case):
+    """knn_batch(..., tie_order="nanoflann") equals the reference's cpp_knn_batch (knn_.cxx + nanoflann compiled where it lies:
+    tests/golden/ref_knn.npz, made by tests/golden/make_golden.py) INDEX FOR INDEX on lattices, duplicated points, identical
+    points, collinear points and queries equidistant from several points -- where the canonical (distance, index) order of
+    the default kernels differs inside the runs of equal distance."""
+    seed, b, n, m, k, kind = case
+    sup, qry = RC.knn_tie_cloud(seed, b, n, m, kind)
+    want = GOLD_KNN[f"knn_tie_{seed}"]
+    s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    got = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="nanoflann").cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    got64 = P.nearest_neighbors.knn_batch(s, q, k, tie_order="nanoflann")
+    assert got64.dtype == torch.int64 and np.array_equal(got64.cpu().numpy(), want)
+    # the default order: the same distances position by position, a different order only inside runs of equal distance
+    canon = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32).cpu().numpy()
+    d = lambda idx: ((qry[:, :, None, :] - np.take_along_axis(sup[:, None, :, :], idx[..., None].astype(np.int64), axis=2)) ** 2).sum(-1)
+    np.testing.assert_array_equal(d(canon), d(want))
+    if kind in ("lattice", "lattice16", "dup", "same", "line", "lattice_q_off"):
+        assert (canon != want).any(), "these clouds are built to have ties the two orders resolve differently"
+
+
+def test_knn_nanoflann_matches_live_reference_when_built():
+    from oracle import ref
+    if not ref.available("libref_knn.so"):
+        pytest.skip("oracle/_ref/libref_knn.so not built here")
+    sup = (np.round(np.random.default_rng(5).random((2, 1500, 3)) * 12) / 12).astype(np.float32)
+    qry = np.random.default_rng(6).random((2, 200, 3)).astype(np.float32)
+    want = ref.knn_batch(sup, qry, 24)
+    got = P.nearest_neighbors.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), 24, tie_order="nanoflann")
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
