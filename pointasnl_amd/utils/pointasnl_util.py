@@ -22,10 +22,15 @@ from pointasnl_amd.utils import tf_util
 NL_VARIANT = 0  # 0 auto / 1 vector-FMA / 2 MFMA  (pasnl_nl_attention); bench.py --ops sweeps it
 
 
+KNN_TIE_ORDER = "index"  # "nanoflann": neighbour lists in the reference's own order among exactly equal distances (its KD-tree's
+#                          visit order, csrc/knn_tree.hip) -- for bit-exact reproduction on clouds with duplicated / lattice
+#                          coordinates; slower (a tree per call).  Distinct distances: both orders are the same list.
+
+
 def knn_query(k, support_pts, query_pts):
     """Mirror of pointasnl_util.py:22-30.  support_pts (B,N1,3), query_pts (B,N2,3) -> (B,N2,k) int32: for every query the
     indices of its k nearest support points, nearest first.  No host round trip here: the search is a gfx950 kernel."""
-    return nearest_neighbors.knn_batch(support_pts, query_pts, k, omp=True, dtype=torch.int32)
+    return nearest_neighbors.knn_batch(support_pts, query_pts, k, omp=True, dtype=torch.int32, tie_order=KNN_TIE_ORDER)
 
 
 def _gather_rows(points, idx):
