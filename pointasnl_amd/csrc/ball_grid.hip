@@ -205,19 +205,37 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
   const float* qcloud = xyz2 + (size_t)bi * m * 3;
 
   // the nine runs of x-adjacent cells around a query, packed start | end << 16, zero when empty or outside the grid
+  // Per row of cells the x window is as wide as the ball is THERE: a point of row (dy, dz) is at least day / daz cell edges
+  // away from the query in y / z (its distance to the row's slab), so it can only be a hit within
+  // sqrt(rho^2 - day^2 - daz^2) edges in x (rho = 1.001 radius / h <= 1); rows beyond rho are dropped.  Margins of a
+  // thousandth of a cell dwarf the rounding of the cell coordinates (points and queries go through the same monotone map).
+  const float rho2 = (rpad * inv_h) * (rpad * inv_h);
   auto runs_of = [&](float qx, float qy, float qz, bool live, uint32_t (&rpk)[9]) {
-    const int cx = (int)floorf(fminf(fmaxf((qx - lo[0]) * inv_hx, -2.f), (float)(gx + 1)));
-    const int cy = (int)floorf(fminf(fmaxf((qy - lo[1]) * inv_h, -1.f), (float)gy));
-    const int cz = (int)floorf(fminf(fmaxf((qz - lo[2]) * inv_h, -1.f), (float)gz));
-    const int x0 = max(cx - BG_XS, 0), x1 = min(cx + BG_XS, gx - 1);  // x0 <= x1 since -2 <= cx <= gx + 1
+    const float ux = (qx - lo[0]) * inv_hx, uy = (qy - lo[1]) * inv_h, uz = (qz - lo[2]) * inv_h;
+    const int cx = (int)floorf(fminf(fmaxf(ux, -2.f), (float)(gx + 1)));
+    const int cy = (int)floorf(fminf(fmaxf(uy, -1.f), (float)gy));
+    const int cz = (int)floorf(fminf(fmaxf(uz, -1.f), (float)gz));
+    // squared distance (cell edges) from the query to the slabs of rows cy-1, cy, cy+1 (clamped cell coordinates keep this
+    // right for queries outside the grid: the rows that exist are then all on one side)
+    float ay2[3], az2[3];
+    {
+      const float a0 = fmaxf(uy - (float)cy - 1e-3f, 0.f), a2 = fmaxf((float)(cy + 1) - uy - 1e-3f, 0.f);
+      const float b0 = fmaxf(uz - (float)cz - 1e-3f, 0.f), b2 = fmaxf((float)(cz + 1) - uz - 1e-3f, 0.f);
+      ay2[0] = a0 * a0; ay2[1] = 0.f; ay2[2] = a2 * a2;
+      az2[0] = b0 * b0; az2[1] = 0.f; az2[2] = b2 * b2;
+    }
+    const int xl = max(cx - BG_XS, 0), xh = min(cx + BG_XS, gx - 1);  // the proven outer bounds (header); xl <= xh
 #pragma unroll
     for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy) {
         const int z = cz + dz, y = cy + dy, r = (dz + 1) * 3 + dy + 1;
-        const bool ok = live && z >= 0 && z < gz && y >= 0 && y < gy;
+        const float rem = rho2 - (ay2[dy + 1] + az2[dz + 1]);
+        const float wc = __builtin_amdgcn_sqrtf(fmaxf(rem, 0.f)) * (float)BG_XS + 2e-3f * (float)BG_XS;
+        const int x0 = max((int)floorf(fmaxf(ux - wc, -1.f)), xl), x1 = min((int)floorf(fminf(ux + wc, (float)gx)), xh);
+        const bool ok = live && z >= 0 && z < gz && y >= 0 && y < gy && rem > 0.f && x0 <= x1;
         const int cb = ok ? (z * gy + y) * gx : 0;
-        const uint32_t s = cstart[cb + x0], e = cstart[cb + x1 + 1];  // all bounds requested before any is used
+        const uint32_t s = cstart[cb + (ok ? x0 : 0)], e = cstart[cb + (ok ? x1 + 1 : 0)];  // all bounds requested before any is used
         rpk[r] = (ok && e > s) ? (s | (e << 16)) : 0u;
       }
   };
