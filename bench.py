@@ -277,7 +277,11 @@ def _sha256(path):
 
 def csrc_digests():
     d = os.path.join(ROOT, "pointasnl_amd", "csrc")
-    return {f: _sha256(os.path.join(d, f)) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".hpp"))}
+    return {f: _sha256(os.path.join(d, f)) for f in sorted(os.listdir(d)) if f.endswith((".hip", ".hpp", ".inc"))}
+
+
+# kernels that live in another file than the entry point that launches them
+EXTRA_SOURCES = {"pasnl_query_ball_point": ["ball_grid.hip", "sortnet.inc"], "pasnl_knn_batch_ws": ["grouping.hip"]}
 
 
 def measured_traffic(symbol, dims):
@@ -296,7 +300,7 @@ def measured_traffic(symbol, dims):
     now, then = csrc_digests(), src.get("csrc_sha256", {})
     owner = next((f for f in now if f.endswith(".hip") and f'extern "C" int {symbol}(' in
                   open(os.path.join(ROOT, "pointasnl_amd", "csrc", f)).read()), None)
-    changed = [f for f in (owner, "common.hpp") if f and now.get(f) != then.get(f)]
+    changed = [f for f in [owner, "common.hpp"] + EXTRA_SOURCES.get(symbol, []) if f and now.get(f) != then.get(f)]
     if changed:
         return None, f"stale: {', '.join(changed)} changed since profiles/traffic.json was collected at {src.get('commit', '?')}"
     return data[key], f"profiles/traffic.json@{src.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; {owner} unchanged since)"
