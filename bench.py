@@ -125,6 +125,12 @@ def algorithmic(symbol, ints):
     if symbol in ("pasnl_knn_batch", "pasnl_knn_batch_ws"):
         b, n, m, k = ints[:4]
         return 12 * b * (n + m) + 4 * b * m * k, 8 * b * n * m, "valu"  # a search: vector-issue bound
+    if symbol == "pasnl_knn_batch_tree":
+        b, n, m, k = ints[:4]
+        return 12 * b * (n + m) + 4 * b * m * k, 8 * b * n * m, "valu"
+    if symbol in ("pasnl_dense_splitk", "pasnl_dense_splitk_workspace"):
+        rows, k, n = ints[:3]
+        return 4 * (rows * k + k * n + n + rows * n), 2 * rows * k * n, "mfma"
     if symbol == "pasnl_query_ball_point":
         b, n, m, ns = ints
         return 12 * b * (n + m) + 4 * b * m * (ns + 1), 10 * b * n * m, "hbm"

@@ -96,6 +96,15 @@ def main():
         rows += timeit(lambda: P.nearest_neighbors.knn_batch(x, x, 16, dtype=torch.int32), "knn scannet-fa4 self B=16")
         x = cloud(8, 10240)
         rows += timeit(lambda: P.nearest_neighbors.knn_batch(x, x, 32, dtype=torch.int32), "knn kitti-L0 B=8")
+    if want("knn_tree"):
+        # the reference's own order among equal distances (csrc/knn_tree.hip): an exactness mode, timed so that its cost is known
+        for (b, n, m, k, name) in [(64, 1024, 512, 32, "cls-L1"), (16, 8192, 1024, 32, "scannet-L1"), (16, 8192, 8192, 16, "scannet-fa4 self"),
+                                   (8, 10240, 10240, 32, "kitti-L0")]:
+            x = cloud(b, n)
+            q = x[:, :m].contiguous()
+            rows += timeit(lambda: P.nearest_neighbors.knn_batch(x, q, k, dtype=torch.int32, tie_order="nanoflann"),
+                           f"knn nanoflann-order {name} B={b}")
+            rows += timeit(lambda: P.nearest_neighbors.knn_batch(x, q, k, dtype=torch.int32), f"knn canonical {name} B={b}")
     if want("ball"):
         for b in batches:
             x = cloud(b, 1024)

@@ -108,8 +108,13 @@ def launch(symbol, what, *args):
         return
     if MARK is not None:
         torch.cuda._sleep(1)
-        MARK.append(["_unmeasured" if MARK_SKIP else symbol,
+        code = fn(*args, stream_ptr())
+        # a launch that answered PASNL_EUNSUPPORTED started no kernel: its marker interval is empty and must not be read as a
+        # zero-traffic measurement (profiles/pmc_to_traffic.py skips "_unsupported")
+        MARK.append(["_unmeasured" if MARK_SKIP else (symbol if code == 0 else "_unsupported"),
                      [a if isinstance(a, int) else a.value for a in args if isinstance(a, (int, ctypes.c_long))]])
+        check(code, what)
+        return
     if PROFILE is None:
         check(fn(*args, stream_ptr()), what)
         return

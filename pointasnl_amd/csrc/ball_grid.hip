@@ -3,28 +3,30 @@
 // nsample points in ascending index with max(sqrtf(d2),1e-20f) < radius, padded with the first hit; restated in
 // oracle/pasnl_oracle.c.  The brute-force kernel for larger clouds lives in grouping.hip.
 //
-// One workgroup of 8 waves (16 waves per CU: the kernel is a chain of LDS round trips and vector issue, and the fourth wave per
-// SIMD is what fills the gaps) bins its cloud into a uniform grid held in LDS (cell edge h >= 1.001*radius in y and z, h/2 in x;
-// counting sort into 16-byte records {x,y,z,index}).  ONE LANE OWNS ONE QUERY: its candidates are the 3x3 runs of
-// x-adjacent cells around it (5 half-cells each, contiguous in the cell-sorted array), evaluated with the canonical
-// arithmetic, so the hit SET is bit-identical to the brute-force scan; what remains is to put it in index order.
+// One workgroup of 8 waves bins its cloud into a uniform grid held in LDS (cell edge h >= 1.001*radius in y and z, h/2 in
+// x; counting sort into 16-byte records {x,y,z,index}).  The kernel is a chain of LDS round trips and vector issue, so
+// what it needs is waves per SIMD: a workgroup is sized to THREE per CU for clouds of up to 1024 points (<= 53 760 bytes
+// of LDS: records 16 KiB + cell starts 4 KiB + 8 wave regions of exactly 4 KiB; <= 80 VGPRs = 6 waves per SIMD).
+// ONE LANE OWNS ONE QUERY: its candidates are the 3x3 runs of x-adjacent cells around it (each as wide in x as the
+// ball's chord in that row of cells, contiguous in the cell-sorted array), evaluated with the canonical arithmetic, so
+// the hit SET is bit-identical to the brute-force scan; what remains is to put it in index order.
 //
-//  tier 1 (sparse clouds, the usual case): the nine runs go into a small lane-private table and are walked as ONE
-//    flat sequence, two candidates per step (no per-run loop: a wave's step count is the largest candidate TOTAL
-//    over its lanes, not the sum of the largest runs); a hit appends its 16-bit index to the lane's list in LDS
-//    (slot-major, lane-minor) with an unconditional store + carry add; afterwards the list is loaded into
-//    registers and sorted by a fixed compare-exchange network (8 / 16 / 32 inputs, chosen per wave by the largest
-//    count) -- no data-dependent branch, no scan; the padded rows leave through a 4 KiB staging area, 32 rows at a
-//    time, as 16-byte stores that cover whole 128-byte rows.
-//  tier 2 (a lane would exceed 31 hits, or the cloud is dense): a hit sets bit k of the lane's n-bit row
-//    (ds_or_b32, word-major / lane-minor: conflict-free; 4 KiB hold the rows of 64 / 32 / 16 lanes at a time) and scanning
-//    the row yields ascending order.  Exact for any input; tier 1 falls back to it per wave and round.
+//  tier 1 (sparse clouds, the usual case): the nine runs go into a small lane-private table (16-bit entries: start |
+//    length << 11) and are walked as ONE flat sequence, two candidates per step (a wave's step count is the largest
+//    candidate TOTAL over its lanes, not the sum of the largest runs); a hit appends its 16-bit index to the lane's list
+//    in LDS (slot-major, lane-minor) with an unconditional store + carry add, the count clamped instead of tested;
+//    afterwards the list is loaded into registers and sorted by a fixed compare-exchange network (8 / 16 / 20 inputs,
+//    chosen per wave by the largest count) -- no data-dependent branch, no scan; the padded rows leave through the
+//    wave's 4 KiB region, 32 rows at a time, as 16-byte stores that cover whole 128-byte rows.
+//  tier 2 (a LANE with more than 19 hits or a run longer than 31 records, or a dense cloud): a hit sets bit k of the
+//    lane's n-bit row (ds_or_b32, word-major / lane-minor: conflict-free; 4 KiB hold the rows of 64 / 32 / 16 lanes at a
+//    time) and scanning the row yields ascending order.  Exact for any input; only the lanes that need it take it.
 //
 // Why no hit can be missed: cell coordinate u = fl(fl(x - min) * fl(1/h)); two points closer than radius along an axis
 // have |u_q - u_p| <= radius/h + 2*(G+1)*2^-23 <= 0.99901 < 1 in y and z (cells differ by at most one) and
 // <= 1.99801 < 2 in x (half cells: at most two); points are clamped into the grid and queries into one (two) cells
-// beyond it, which only widens the search.  A cloud whose extent is not finite degenerates to a single cell (= brute
-// force), never to a wrong answer.
+// beyond it, which only widens the search.  A cloud whose extent is not finite (or an infinite radius) degenerates to a
+// single cell whose one run every query walks in full (= brute force, through tier 2), never to a wrong answer.
 #include <math.h>
 #include <algorithm>
 #include "common.hpp"
@@ -38,20 +40,21 @@ constexpr int BG_G = 10;                       // cells per axis in y and z
 constexpr int BG_XS = 2;                       // x cells per cell edge
 constexpr int BG_GX = BG_G * BG_XS;
 constexpr int BG_NC = BG_GX * BG_G * BG_G;     // 2000 cells at most
-constexpr int BG_NMAX = 2048;                  // points per cloud (16-bit list entries, LDS-resident records)
-constexpr int BG_L = 32;                       // tier-1 list slots per lane
-constexpr int BG_HL_BYTES = (BG_L + 1) * 128;  // u16 [slot][lane]; slot BG_L only ever takes the closing sentinel
-constexpr int BG_TAB_OFF = BG_HL_BYTES;        // u32 [10][lane]: the lane's non-empty runs (start | end << 16), then zeros
+constexpr int BG_NMAX = 2048;                  // points per cloud (11-bit record positions, 16-bit list entries)
+constexpr int BG_CAP = 20;                     // tier 1: a lane's count is clamped here; counts below it are exact
+constexpr int BG_SLOTS = BG_CAP + 2;           // u16 [slot][lane]: appends go to slots <= BG_CAP + 1
+constexpr int BG_TAB_OFF = BG_SLOTS * 128;     // u16 [10][lane]: the lane's non-empty runs (start | length << 11), then zeros
 constexpr int BG_TAB_SLOTS = 10;
-constexpr int BG_REGION = BG_TAB_OFF + BG_TAB_SLOTS * 256;  // 6784 bytes per wave: lists | tables
-constexpr int BG_STAGE_ROWS = 32;              // rows of 32 entries the first 4 KiB of a region stage at a time
+constexpr int BG_REGION = BG_TAB_OFF + BG_TAB_SLOTS * 128;  // 4096 bytes per wave: lists | tables
+constexpr int BG_STAGE_ROWS = 32;              // rows of 32 entries a region stages at a time
 constexpr int BG_U = 4;                        // tier 2: candidates per lane and step
 constexpr float BG_DENSE_HITS = 12.f;          // expected hits per query above which a workgroup starts in tier 2
+static_assert(BG_REGION == 4096 && BG_REGION >= BG_STAGE_ROWS * 128, "a wave region stages 32 rows of 128 bytes and holds 4 KiB of bit rows");
 
 #ifdef PASNL_TUNING
-// phase probe (tuning build only; tools/ball_probe.py): cycles of wave 0 of workgroup (0, gridDim.y / 2), summed over its rounds
+// phase probe (tuning build only; tools/ballprobe.py): cycles of wave 0 of workgroup (0, gridDim.y / 2), summed over its rounds
 // [0] build  [1] -  [2] round set-up + run table  [3] walk  [4] sorting network + rows out  [5] tier 2 / round end
-// [6] tier-2 rounds  [7] steps
+// [6] tier-2 passes  [7] steps
 __device__ unsigned long long bg_probe[8];
 #define BG_MARK(i)                                                                         \
   do {                                                                                     \
@@ -67,25 +70,35 @@ __device__ __forceinline__ float bg_dist2(float qx, float qy, float qz, const fl
   // ((dx*dx)+(dy*dy))+(dz*dz) with x and y on one packed instruction each (identical IEEE operations per component)
   const pasnl_f32x2 d = pasnl_f32x2{v.x, v.y} - pasnl_f32x2{qx, qy};
   const pasnl_f32x2 s = d * d;
-  float dz = v.z - qz;
-  asm volatile("" : "+v"(dz));  // keeps the z terms of two candidates out of one packed instruction (the register shuffles
-                                // that pairing needs cost more than it saves, and they wait for both records)
-  float zz = dz * dz;
-  asm volatile("" : "+v"(zz));
-  return (s[0] + s[1]) + zz;
+  const float dz = v.z - qz;
+  return (s[0] + s[1]) + dz * dz;
 }
 
+// float -> int, truncating and SATURATING (v_cvt_i32_f32; +-inf from a degenerate grid's unbounded windows are meant)
+__device__ __forceinline__ int bg_cvt_i32(float x) {
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// two cell-adjacent records as the walk wants them: (x, y) of each as a pair, the two z as a pair, the two indices
+struct BgPair {
+  pasnl_f32x2 xy0, xy1, zz;
+  uint32_t k0, k1;
+};
+
 template <int NW32>  // bit-row words per lane in tier 2: n <= 32*NW32
-__global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, float rpad, float thr2, float r3, int nsample,
-                                                               uint32_t ns_magic, int qchunk,
-                                                               const float* __restrict__ xyz1, const float* __restrict__ xyz2,
-                                                               int* __restrict__ idx, int* __restrict__ pts_cnt) {
+__global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kernel(
+    int n, int m, float rpad, float thr2, float r3, int nsample, uint32_t ns_magic, int qchunk, int aligned,
+    const float* __restrict__ xyz1, const float* __restrict__ xyz2, int* __restrict__ idx, int* __restrict__ pts_cnt) {
   constexpr int PPT = NW32 * 32 / BG_THREADS > 0 ? NW32 * 32 / BG_THREADS : 1;  // points per thread
+  constexpr int V4PT = (NW32 * 32 * 3 / 4 + BG_THREADS - 1) / BG_THREADS;        // 16-byte pieces of the cloud per thread
   constexpr int LP = 1024 / NW32 > 64 ? 64 : 1024 / NW32;                        // tier 2: lanes whose bit rows fit 4 KiB
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* spt = reinterpret_cast<float4*>(smem);                                  // [n] cell-sorted {x,y,z,index bits}
+  float* raw = reinterpret_cast<float*>(smem);                                    // build: the (n,3) array as it is in memory
   char* regions = reinterpret_cast<char*>(spt + n);                               // [BG_WAVES][BG_REGION bytes]
-  unsigned short* cstart = reinterpret_cast<unsigned short*>(regions + BG_WAVES * BG_REGION);  // [BG_NC + 2]
+  unsigned short* cstart = reinterpret_cast<unsigned short*>(regions + BG_WAVES * BG_REGION);  // [BG_NC + 3]
   int* ccount = reinterpret_cast<int*>(regions);  // cell counters during the build (the regions are not live yet)
   float* red = reinterpret_cast<float*>(ccount + BG_NC);  // [BG_WAVES][6] bbox partials, [BG_WAVES] scan partials (build only)
 
@@ -97,19 +110,48 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
   long long tmark = clock64();
 #endif
 
-  // ---- A. points into registers, bounding box
+  // ---- A. the cloud: flat 16-byte loads into LDS (768 requests for 1024 points where a load per coordinate is 3072),
+  // bounding box straight from the loaded registers: piece q holds elements 4q .. 4q+3 of the flat array, element e of it
+  // belongs to axis (q + e) mod 3
   float px[PPT], py[PPT], pz[PPT];
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (aligned) {
+    const float4* c4 = reinterpret_cast<const float4*>(cloud);
+    const int n4 = (n * 3) >> 2;
+    // t[a] / T[a]: min / max over the thread's pieces of the axis (tid + a) mod 3
+    float t[3] = {INFINITY, INFINITY, INFINITY}, T[3] = {-INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-  for (int i = 0; i < PPT; ++i) {
-    const int k = i * BG_THREADS + tid;
-    if (k < n) {
-      px[i] = cloud[k * 3]; py[i] = cloud[k * 3 + 1]; pz[i] = cloud[k * 3 + 2];
-      lo[0] = fminf(lo[0], px[i]); hi[0] = fmaxf(hi[0], px[i]);
-      lo[1] = fminf(lo[1], py[i]); hi[1] = fmaxf(hi[1], py[i]);
-      lo[2] = fminf(lo[2], pz[i]); hi[2] = fmaxf(hi[2], pz[i]);
-    } else {
+    for (int i = 0; i < V4PT; ++i) {
+      const int q = i * BG_THREADS + tid;
+      if (q < n4) {
+        const float4 v = c4[q];
+        reinterpret_cast<float4*>(raw)[q] = v;
+        // piece q starts at axis q mod 3 = (tid + 2 i) mod 3 (BG_THREADS = 512 = 2 mod 3): a compile-time rotation of t[]
+        constexpr int R[3] = {0, 2, 1};
+        const int r0 = R[i % 3];
+        t[r0] = fminf(t[r0], fminf(v.x, v.w)); T[r0] = fmaxf(T[r0], fmaxf(v.x, v.w));
+        t[(r0 + 1) % 3] = fminf(t[(r0 + 1) % 3], v.y); T[(r0 + 1) % 3] = fmaxf(T[(r0 + 1) % 3], v.y);
+        t[(r0 + 2) % 3] = fminf(t[(r0 + 2) % 3], v.z); T[(r0 + 2) % 3] = fmaxf(T[(r0 + 2) % 3], v.z);
+      }
+    }
+    // axis a = (tid + j) mod 3  ->  t[j] with j = (a - tid) mod 3
+    const int s = tid % 3;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = s == 0 ? t[a] : (s == 1 ? t[(a + 2) % 3] : t[(a + 1) % 3]);
+      hi[a] = s == 0 ? T[a] : (s == 1 ? T[(a + 2) % 3] : T[(a + 1) % 3]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int k = i * BG_THREADS + tid;
       px[i] = py[i] = pz[i] = 0.f;
+      if (k < n) {
+        px[i] = cloud[k * 3]; py[i] = cloud[k * 3 + 1]; pz[i] = cloud[k * 3 + 2];
+        lo[0] = fminf(lo[0], px[i]); hi[0] = fmaxf(hi[0], px[i]);
+        lo[1] = fminf(lo[1], py[i]); hi[1] = fmaxf(hi[1], py[i]);
+        lo[2] = fminf(lo[2], pz[i]); hi[2] = fmaxf(hi[2], pz[i]);
+      }
     }
   }
 #pragma unroll
@@ -120,6 +162,14 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
   }
   for (int c = tid; c < BG_NC; c += BG_THREADS) ccount[c] = 0;
   __syncthreads();
+  if (aligned) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int k = i * BG_THREADS + tid;
+      px[i] = py[i] = pz[i] = 0.f;
+      if (k < n) { px[i] = raw[k * 3]; py[i] = raw[k * 3 + 1]; pz[i] = raw[k * 3 + 2]; }  // stride 3 dwords: conflict-free
+    }
+  }
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     float l = red[a], h = red[3 + a];
@@ -162,7 +212,7 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
       const int cx = min((int)fmaxf((px[i] - lo[0]) * inv_hx, 0.f), gx - 1);
       const int cy = min((int)fmaxf((py[i] - lo[1]) * inv_h, 0.f), gy - 1);
       const int cz = min((int)fmaxf((pz[i] - lo[2]) * inv_h, 0.f), gz - 1);
-      pcell[i] = (cz * gy + cy) * gx + cx;
+      pcell[i] = __mul24(__mul24(cz, gy) + cy, gx) + cx;
       prank[i] = atomicAdd(&ccount[pcell[i]], 1);
     }
   }
@@ -189,9 +239,9 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
       if (c < ncell) cstart[c] = (unsigned short)base;
       base += cnts[j];
     }
-    if (tid == 0) cstart[ncell] = (unsigned short)n;
+    if (tid == 0) { cstart[ncell] = (unsigned short)n; cstart[ncell + 1] = (unsigned short)n; cstart[ncell + 2] = (unsigned short)n; }
   }
-  __syncthreads();
+  __syncthreads();  // every thread has read its points from `raw` long ago: the records may overwrite it
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int k = i * BG_THREADS + tid;
@@ -204,15 +254,19 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
   const int rounds = (qend - qbase + BG_THREADS - 1) / BG_THREADS;
   const float* qcloud = xyz2 + (size_t)bi * m * 3;
 
-  // the nine runs of x-adjacent cells around a query, packed start | end << 16, zero when empty or outside the grid
+  // The nine runs of x-adjacent cells around a query, packed start | end << 16, zero when empty or outside the grid.
   // Per row of cells the x window is as wide as the ball is THERE: a point of row (dy, dz) is at least day / daz cell edges
   // away from the query in y / z (its distance to the row's slab), so it can only be a hit within
   // sqrt(rho^2 - day^2 - daz^2) edges in x (rho = 1.001 radius / h <= 1); rows beyond rho are dropped.  Margins of a
   // thousandth of a cell dwarf the rounding of the cell coordinates (points and queries go through the same monotone map).
-  const float rho2 = (rpad * inv_h) * (rpad * inv_h);
+  // A degenerate grid (inv_h == 0: one cell) has no geometry to prune with: rho = inf keeps its single row and run.
+  const float rho2 = inv_h > 0.f ? (rpad * inv_h) * (rpad * inv_h) : INFINITY;
+  const int cbase2 = (int)((reinterpret_cast<char*>(cstart) - smem) >> 1);  // cstart's offset in 16-bit units
+  const int rowz = gy * gx;
   auto runs_of = [&](float qx, float qy, float qz, bool live, uint32_t (&rpk)[9]) {
     const float ux = (qx - lo[0]) * inv_hx, uy = (qy - lo[1]) * inv_h, uz = (qz - lo[2]) * inv_h;
-    const int cx = (int)floorf(fminf(fmaxf(ux, -2.f), (float)(gx + 1)));
+    const float uxc = fminf(fmaxf(ux, -2.f), (float)(gx + 1));  // a query outside the grid looks from its border: a superset
+    const int cx = (int)floorf(uxc);
     const int cy = (int)floorf(fminf(fmaxf(uy, -1.f), (float)gy));
     const int cz = (int)floorf(fminf(fmaxf(uz, -1.f), (float)gz));
     // squared distance (cell edges) from the query to the slabs of rows cy-1, cy, cy+1 (clamped cell coordinates keep this
@@ -225,17 +279,25 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
       az2[0] = b0 * b0; az2[1] = 0.f; az2[2] = b2 * b2;
     }
     const int xl = max(cx - BG_XS, 0), xh = min(cx + BG_XS, gx - 1);  // the proven outer bounds (header); xl <= xh
+    // rows that exist: y = cy + dy in [0, gy), z = cz + dz in [0, gz)   (cy in [-1, gy], cz in [-1, gz])
+    const bool yok[3] = {cy >= 1, cy >= 0 && cy < gy, cy + 1 < gy};
+    const bool zok[3] = {live && cz >= 1, live && cz >= 0 && cz < gz, live && cz + 1 < gz};
+    const int cbc = __mul24(__mul24(cz, gy) + cy, gx) + cbase2;  // 16-bit index of the query's own row of cells in LDS
 #pragma unroll
     for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy) {
-        const int z = cz + dz, y = cy + dy, r = (dz + 1) * 3 + dy + 1;
+        const int r = (dz + 1) * 3 + dy + 1;
         const float rem = rho2 - (ay2[dy + 1] + az2[dz + 1]);
         const float wc = __builtin_amdgcn_sqrtf(fmaxf(rem, 0.f)) * (float)BG_XS + 2e-3f * (float)BG_XS;
-        const int x0 = max((int)floorf(fmaxf(ux - wc, -1.f)), xl), x1 = min((int)floorf(fminf(ux + wc, (float)gx)), xh);
-        const bool ok = live && z >= 0 && z < gz && y >= 0 && y < gy && rem > 0.f && x0 <= x1;
-        const int cb = ok ? (z * gy + y) * gx : 0;
-        const uint32_t s = cstart[cb + (ok ? x0 : 0)], e = cstart[cb + (ok ? x1 + 1 : 0)];  // all bounds requested before any is used
+        // truncation instead of floor: the lower bound is clamped at xl >= 0 anyway, the upper bound only gets wider
+        const int x0 = max(bg_cvt_i32(uxc - wc), xl), x1 = min(bg_cvt_i32(uxc + wc), xh);
+        const bool ok = yok[dy + 1] && zok[dz + 1] && rem > 0.f;
+        const int cb = ok ? cbc + dy * gx + dz * rowz : cbase2;
+        // x0 in [0, gx + 1], x1 + 1 in [-2 + 1, gx]: an inverted window reads e <= s (the cell starts are monotone, three
+        // entries of padding follow the last cell) and is dropped below
+        const uint32_t s = reinterpret_cast<const unsigned short*>(smem)[cb + x0];
+        const uint32_t e = reinterpret_cast<const unsigned short*>(smem)[cb + max(x1 + 1, 0)];
         rpk[r] = (ok && e > s) ? (s | (e << 16)) : 0u;
       }
   };
@@ -245,7 +307,7 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
   // ---- D. queries: one per lane and round; a wave works in its own region only (no workgroup barrier from here on)
   char* wr = regions + wave * BG_REGION;                                           // this wave's region
   unsigned short* hl = reinterpret_cast<unsigned short*>(wr);                      // tier 1: hit lists
-  uint32_t* tab = reinterpret_cast<uint32_t*>(wr + BG_TAB_OFF);                    // tier 1: run tables
+  unsigned short* tab = reinterpret_cast<unsigned short*>(wr + BG_TAB_OFF);        // tier 1: run tables
   uint32_t* brow = reinterpret_cast<uint32_t*>(wr);                                // tier 2: bit rows [word][lane % LP]
   uint32_t* stage = reinterpret_cast<uint32_t*>(wr);                               // tier 1: 32 padded rows of 32 entries
   const int last = n > 0 ? n - 1 : 0;
@@ -257,100 +319,129 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
     if (!__any(live)) continue;
     const float* qp = qcloud + (size_t)(live ? j : qbase) * 3;
     const float qx = qp[0], qy = qp[1], qz = qp[2];
-    uint32_t rpk[9];
-    runs_of(qx, qy, qz, live, rpk);
-    int* orow = idx + ((size_t)bi * m + (live ? j : qbase)) * nsample;
-    int c = 0;             // hits (tier 1: all of them; tier 2: capped at nsample)
-    bool done = false;     // wave-uniform: tier 1 has written the rows
+    bool need2 = live;     // the lane's row still has to come from tier 2
 
     if (!dense) {
-      // ---- tier 1.  (1) closing sentinels of the lists, zeros (= "no more runs") in the tables
+      // ---- tier 1.  (1) closing sentinels of the lists (0xFFFF), zeros (= "no more runs") in the tables: 22 + 10 slots of
+      // 128 bytes = 4 KiB = four 16-byte stores per lane
       {
         const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u), zz = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-        for (int i = 0; i < BG_L * 128 / 1024; ++i) *reinterpret_cast<uint4*>(wr + i * 1024 + lane * 16) = ff;
-        *reinterpret_cast<uint4*>(wr + BG_TAB_OFF + lane * 16) = zz;
-        *reinterpret_cast<uint4*>(wr + BG_TAB_OFF + 1024 + lane * 16) = zz;
-        *reinterpret_cast<uint2*>(wr + BG_TAB_OFF + 2048 + lane * 8) = make_uint2(0u, 0u);
+        static_assert(BG_TAB_OFF == 2 * 1024 + 768 && BG_REGION == 4096, "the fill below is written for 22 list and 10 table slots");
+        *reinterpret_cast<uint4*>(wr + lane * 16) = ff;
+        *reinterpret_cast<uint4*>(wr + 1024 + lane * 16) = ff;
+        const uint32_t edge = lane < 48 ? ~0u : 0u;  // the lists end 768 bytes into the third KiB
+        *reinterpret_cast<uint4*>(wr + 2048 + lane * 16) = make_uint4(edge, edge, edge, edge);
+        *reinterpret_cast<uint4*>(wr + 3072 + lane * 16) = zz;
       }
-      // (2) the lane's non-empty runs, compacted
+      // (2) the lane's non-empty runs, compacted: 16-bit entries start | length << 11
+      uint32_t seen = 0u;
       {
+        uint32_t rpk[9];
+        runs_of(qx, qy, qz, live, rpk);
         int cntr = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-          tab[cntr * 64 + lane] = rpk[r];  // an empty run writes the zero that closes the table (or is overwritten)
+          const uint32_t st = rpk[r] & 0xFFFFu, len = (rpk[r] >> 16) - st;  // an empty run: 0, 0
+          const uint32_t ent = st | (len << 11);
+          seen |= ent;
+          tab[cntr * 64 + lane] = (unsigned short)ent;  // an empty run writes the zero that closes the table (or is overwritten)
           cntr += rpk[r] != 0u;
         }
+      }
+      const bool longrun = (seen >> 16) != 0u;  // a run of more than 31 records does not fit its entry: this lane -> tier 2
+      if (longrun) {                            // ... and walks nothing here (rare: the block is skipped when no lane is)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) tab[t * 64 + lane] = 0;
       }
       BG_MARK(2);
       // (3) the flat walk: two candidates per step, software-pipelined: the records of the NEXT pair are requested before the
       // current pair is evaluated (a wave alone on its SIMD otherwise waits out one LDS round trip per step), and the
-      // table entry one step earlier still
-      uint32_t p = 0, e = 0, ti = 0, nx = tab[lane];
-      bool overflow = false;
-      auto advance = [&]() {  // (p, e) <- the pair to examine next; a lane that reached its zeros never leaves them
-        const bool adv = p >= e;
-        p = adv ? (nx & 0xFFFFu) : p;
-        e = adv ? (nx >> 16) : e;
+      // table entry one step earlier still.  (p, left): the record position and how many records of the current run remain.
+      uint32_t p = 0, ti = 0, nx = tab[lane];
+      int left = 0, c = 0;
+      const pasnl_f32x2 qxy{qx, qy}, qzz{qz, qz};
+      auto advance = [&]() {  // (p, left) <- the pair to examine next; a lane that reached its zeros never leaves them
+        const bool adv = left <= 0;
+        p = adv ? (nx & 0x7FFu) : p;
+        left = adv ? (int)(nx >> 11) : left;
         ti += adv ? 1u : 0u;
         nx = tab[min(ti, (uint32_t)(BG_TAB_SLOTS - 1)) * 64 + lane];  // slot 9 is always zero
       };
-      // one step: evaluate the pair whose records are (c0, c1); request the next pair's records into (n0, n1)
-#define PASNL_BG_STEP(c0, c1, n0, n1)                                                                                   \
+      auto fetch = [&](BgPair& r) {  // p + 1 <= n: at worst the 16 bytes behind the records, read and not used
+        const char* a = reinterpret_cast<const char*>(spt) + (p << 4);
+        r.xy0 = *reinterpret_cast<const pasnl_f32x2*>(a);
+        r.xy1 = *reinterpret_cast<const pasnl_f32x2*>(a + 16);
+        r.zz = pasnl_f32x2{*reinterpret_cast<const float*>(a + 8), *reinterpret_cast<const float*>(a + 24)};
+        r.k0 = *reinterpret_cast<const uint32_t*>(a + 12);
+        r.k1 = *reinterpret_cast<const uint32_t*>(a + 28);
+      };
+      // one step: evaluate the pair `cur`; request the next pair's records into `nxt`
+#define PASNL_BG_STEP(cur, nxt)                                                                                         \
       {                                                                                                                 \
-        const bool a0 = p < e, a1 = p + 1u < e;                                                                         \
+        const bool a0 = left > 0, a1 = left > 1;                                                                        \
         if (__builtin_amdgcn_ballot_w64(a0) == 0ull) break;                                                             \
-        if (__builtin_amdgcn_ballot_w64(a0 && c > BG_L - 2) != 0ull) { overflow = true; break; } /* two more hits might \
-                                                                                             not fit: tier 2 */        \
         p += 2u;                                                                                                        \
+        left -= 2;                                                                                                      \
         advance();                                                                                                      \
-        n0 = spt[p]; n1 = spt[p + 1u]; /* p + 1 <= n: at worst the 16 bytes behind the records, read and not used */    \
+        fetch(nxt);                                                                                                     \
         __builtin_amdgcn_sched_barrier(0); /* the requests go out before the current pair's arithmetic */               \
-        const float d0 = bg_dist2(qx, qy, qz, c0), d1 = bg_dist2(qx, qy, qz, c1);                                       \
-        hl[c * 64 + lane] = (unsigned short)__float_as_uint(c0.w); /* unconditional: a miss is overwritten */           \
-        c += (a0 && d0 < thr2) ? 1 : 0;                                                                                 \
-        hl[c * 64 + lane] = (unsigned short)__float_as_uint(c1.w);                                                      \
-        c += (a1 && d1 < thr2) ? 1 : 0;                                                                                 \
+        const pasnl_f32x2 e0 = cur.xy0 - qxy, e1 = cur.xy1 - qxy, ez2 = cur.zz - qzz;                                   \
+        const pasnl_f32x2 s0 = e0 * e0, s1 = e1 * e1, sz = ez2 * ez2;                                                   \
+        float t0 = s0[0] + s0[1], t1 = s1[0] + s1[1];                                                                   \
+        asm("" : "+v"(t0), "+v"(t1)); /* two plain adds into a register pair, not a packed add behind three moves */    \
+        const pasnl_f32x2 dd = pasnl_f32x2{t0, t1} + sz; /* ((dx*dx)+(dy*dy))+(dz*dz), twice */                         \
+        hl[c * 64 + lane] = (unsigned short)cur.k0; /* unconditional: a miss is overwritten */                          \
+        c += (a0 && dd[0] < thr2) ? 1 : 0;                                                                              \
+        hl[c * 64 + lane] = (unsigned short)cur.k1;                                                                     \
+        c += (a1 && dd[1] < thr2) ? 1 : 0;                                                                              \
+        c = min(c, BG_CAP); /* a count that reaches BG_CAP stays there: the lane's row then comes from tier 2 */        \
         BG_COUNT(7, 1);                                                                                                 \
       }
       advance();
-      float4 ra0 = spt[p], ra1 = spt[p + 1u], rb0, rb1;
+      BgPair ra, rb;
+      fetch(ra);
       for (;;) {
-        PASNL_BG_STEP(ra0, ra1, rb0, rb1)
-        PASNL_BG_STEP(rb0, rb1, ra0, ra1)
+        PASNL_BG_STEP(ra, rb)
+        PASNL_BG_STEP(rb, ra)
       }
 #undef PASNL_BG_STEP
       BG_MARK(3);
-      if (!overflow) {
+      const bool done = live && !longrun && c < BG_CAP;  // the lane's list is complete and exact
+      need2 = live && !done;
+      const unsigned long long donemask = __builtin_amdgcn_ballot_w64(done);
+      if (donemask != 0ull) {
         hl[c * 64 + lane] = 0xFFFFu;  // whatever a miss left behind the last hit
         // (4) lists -> registers -> sorting network.  The network size follows the wave's largest count.
-        uint32_t v[32];
-        const bool big = __any(c > 16), mid = __any(c > 8);
+        uint32_t v[20];
+        const int cs = done ? c : 0;
+        const bool big = __any(cs > 16), mid = __any(cs > 8);
 #define PASNL_CE(a, b) { const uint32_t lo_ = min(v[a], v[b]), hi_ = max(v[a], v[b]); v[a] = lo_; v[b] = hi_; }
         if (big) {
 #pragma unroll
-          for (int s = 0; s < 32; ++s) v[s] = hl[s * 64 + lane];
-          PASNL_SORTNET_32
+          for (int s = 0; s < 20; ++s) v[s] = hl[s * 64 + lane];
+          PASNL_SORTNET_20
         } else if (mid) {
 #pragma unroll
           for (int s = 0; s < 16; ++s) v[s] = hl[s * 64 + lane];
 #pragma unroll
-          for (int s = 16; s < 32; ++s) v[s] = 0xFFFFu;
+          for (int s = 16; s < 20; ++s) v[s] = 0xFFFFu;
           PASNL_SORTNET_16
         } else {
 #pragma unroll
           for (int s = 0; s < 8; ++s) v[s] = hl[s * 64 + lane];
 #pragma unroll
-          for (int s = 8; s < 32; ++s) v[s] = 0xFFFFu;
+          for (int s = 8; s < 20; ++s) v[s] = 0xFFFFu;
           PASNL_SORTNET_8
         }
 #undef PASNL_CE
-        const uint32_t first = c > 0 ? v[0] : 0u;  // zero-hit rows -> 0
-        const int top = big ? 8 : (mid ? 4 : 2);   // 16-byte chunks that can hold anything but `first`
-        // (5) the rows leave through the first 4 KiB of the region, 32 rows (lanes) at a time: row q of a half is
-        // 8 chunks of 16 bytes, chunk g stored at g ^ (q & 7) (conflict-free for the writers and for the readers)
+        const uint32_t first = cs > 0 ? v[0] : 0u;  // zero-hit rows -> 0
+        const int top = big ? 5 : (mid ? 4 : 2);    // 16-byte chunks that can hold anything but `first`
+        // (5) the rows leave through the region, 32 rows (lanes) at a time: row q of a half is 8 chunks of 16 bytes, chunk g
+        // stored at g ^ (q & 7) (conflict-free for the writers and for the readers)
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
+          const uint32_t rowmask = (uint32_t)(donemask >> (half * 32));  // rows of this half that tier 1 owns
+          if (rowmask == 0u) continue;
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();  // lists are in registers / the previous half has been copied out
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -359,7 +450,7 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
 #pragma unroll
             for (int ch = 0; ch < 8; ++ch) {
               uint4 o = make_uint4(first, first, first, first);
-              if (ch < top) {
+              if (ch < 5 && ch < top) {
                 o.x = v[4 * ch] == 0xFFFFu ? first : v[4 * ch];
                 o.y = v[4 * ch + 1] == 0xFFFFu ? first : v[4 * ch + 1];
                 o.z = v[4 * ch + 2] == 0xFFFFu ? first : v[4 * ch + 2];
@@ -381,7 +472,7 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
               const uint4 w4 = *reinterpret_cast<const uint4*>(stage + q * 32 + ((min(g, 7) ^ (q & 7)) << 2));
               const uint32_t f0 = stage[q * 32 + ((q & 7) << 2)];  // entry 0 of the row = its first hit
               const uint4 o = g < 8 ? w4 : make_uint4(f0, f0, f0, f0);
-              if (e0 + lane < total && jq < qend)
+              if (e0 + lane < total && ((rowmask >> q) & 1u) != 0u)
                 *reinterpret_cast<uint4*>(idx + ((size_t)bi * m + jq) * nsample + (g << 2)) = o;
             }
           } else {
@@ -393,26 +484,27 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
               const int jq = j - lane + half * 32 + q;
               const uint32_t o = stage[q * 32 + (min(sidx, 31) ^ ((q & 7) << 2))];
               const uint32_t f0 = stage[q * 32 + ((q & 7) << 2)];
-              if (e0 + lane < total && jq < qend) idx[((size_t)bi * m + jq) * nsample + sidx] = (int)(sidx < 32 ? o : f0);
+              if (e0 + lane < total && ((rowmask >> q) & 1u) != 0u)
+                idx[((size_t)bi * m + jq) * nsample + sidx] = (int)(sidx < 32 ? o : f0);
             }
           }
         }
-        if (live) pts_cnt[(size_t)bi * m + j] = min(c, nsample);
-        done = true;
+        if (done) pts_cnt[(size_t)bi * m + j] = min(c, nsample);
         BG_MARK(4);
       }
     }
 
-    if (!done) {
-      BG_COUNT(6, 1);
-      // ---- tier 2: bit rows, LP lanes at a time.  Word w of an active lane's row is brow[w*LP + lane % LP]; the rows go
-      // straight to global memory (the rare path: no staging)
-      int rs[9], re[9];
-#pragma unroll
-      for (int r = 0; r < 9; ++r) { rs[r] = (int)(rpk[r] & 0xFFFFu); re[r] = (int)(rpk[r] >> 16); }
+    if (__any(need2)) {
+      // ---- tier 2: bit rows, LP lanes at a time, for the lanes that need it.  Word w of an active lane's row is
+      // brow[w*LP + lane % LP]; the rows go straight to global memory (the rare path: no staging)
+      int* orow = idx + ((size_t)bi * m + (live ? j : qbase)) * nsample;
+      uint32_t rpk[9];
+      runs_of(qx, qy, qz, need2, rpk);
 #pragma unroll 1
       for (int pass = 0; pass < 64 / LP; ++pass) {
-        const bool act = live && (lane / LP) == pass;
+        const bool act = need2 && (lane / LP) == pass;
+        if (!__any(act)) continue;
+        BG_COUNT(6, 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         {
@@ -424,16 +516,20 @@ __global__ __launch_bounds__(BG_THREADS) void ball_grid_kernel(int n, int m, flo
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint32_t* myrow = brow + (lane % LP);
-#pragma unroll
+#pragma unroll 1
         for (int r = 0; r < 9; ++r) {
-          for (int p = rs[r]; __any(act && p < re[r]); p += BG_U) {
-            float4 v[BG_U];
+          uint32_t rk = rpk[0];  // rpk[r] without a dynamically indexed register array
 #pragma unroll
-            for (int u = 0; u < BG_U; ++u) v[u] = spt[min(p + u, last)];
+          for (int t = 1; t < 9; ++t) rk = r == t ? rpk[t] : rk;
+          const int rs = (int)(rk & 0xFFFFu), re = (int)(rk >> 16);
+          for (int pp = rs; __any(act && pp < re); pp += BG_U) {
+            float4 cv[BG_U];
+#pragma unroll
+            for (int u = 0; u < BG_U; ++u) cv[u] = spt[min(pp + u, last)];
 #pragma unroll
             for (int u = 0; u < BG_U; ++u) {
-              if (act && p + u < re[r] && bg_dist2(qx, qy, qz, v[u]) < thr2) {
-                const int k = __float_as_int(v[u].w);
+              if (act && pp + u < re && bg_dist2(qx, qy, qz, cv[u]) < thr2) {
+                const int k = __float_as_int(cv[u].w);
                 atomicOr(&myrow[(k >> 5) * LP], 1u << (k & 31));  // ds_or_b32, no return: nothing waits for it
               }
             }
@@ -469,14 +565,17 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
                      int* pts_cnt, hipStream_t stream) {
   if (n > BG_NMAX || nsample > 1024) return PASNL_EUNSUPPORTED;
   const int nw32 = n <= 256 ? 8 : (n <= 512 ? 16 : (n <= 1024 ? 32 : 64));
-  const size_t lds = (size_t)n * 16 + BG_WAVES * BG_REGION + (size_t)((BG_NC + 2 + 1) & ~1) * 2;
+  const size_t lds = (size_t)n * 16 + BG_WAVES * BG_REGION + (size_t)((BG_NC + 3 + 1) & ~1) * 2;
   static_assert(BG_WAVES * BG_REGION >= BG_NC * 4 + (BG_WAVES * 7 + 8) * 4, "the cell counters and the build's partials alias the wave regions");
+  static_assert(1024 * 16 + BG_WAVES * BG_REGION + ((BG_NC + 3 + 1) & ~1) * 2 <= 53760, "three workgroups per CU at n <= 1024");
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
   // queries per workgroup: one round of 64 per wave
   const int qchunk = BG_THREADS;
   dim3 grid((m + qchunk - 1) / qchunk, b);
   const float rpad = radius * 1.001f;
   const float r3 = radius * radius * radius;
+  // the cloud is fetched in 16-byte pieces when every cloud of the batch starts on a 16-byte boundary
+  const int aligned = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(xyz1) % 16 == 0);
   // e / d for e < 2^16 as umulhi(e, magic); d = 16-byte chunks (or entries) per row
   const unsigned div = (nsample & 3) == 0 ? (unsigned)nsample / 4 : (unsigned)nsample;
   const uint32_t ns_magic = div == 1 ? 0u : (uint32_t)((0x100000000ull / div) + 1ull);  // 0: divisor 1
@@ -486,8 +585,8 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(gk),                                        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
       return PASNL_ELAUNCH;                                                                                              \
-    hipLaunchKernelGGL(gk, grid, dim3(BG_THREADS), lds, stream, n, m, rpad, thr2, r3, nsample, ns_magic, qchunk, xyz1,   \
-                       xyz2, idx, pts_cnt);                                                                              \
+    hipLaunchKernelGGL(gk, grid, dim3(BG_THREADS), lds, stream, n, m, rpad, thr2, r3, nsample, ns_magic, qchunk, aligned, \
+                       xyz1, xyz2, idx, pts_cnt);                                                                        \
   }
   if (nw32 == 8) PASNL_BG(8)
   else if (nw32 == 16) PASNL_BG(16)

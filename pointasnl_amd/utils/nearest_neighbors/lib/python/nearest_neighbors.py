@@ -25,6 +25,9 @@ def _knn_tree_dev(pts, queries, K, i64):
     m = queries.shape[1]
     if K > n:
         raise ValueError("knn_batch(tie_order='nanoflann') needs K <= number of points")
+    if torch.cuda.is_current_stream_capturing():  # the overflow flag below is read back on the host: eager-only
+        raise _hip.PasnlUnsupported("knn_batch(tie_order='nanoflann') synchronises with the host (tree-depth flag) and cannot be "
+                                    "captured into a HIP graph: run it eagerly (pointasnl_util.KNN_TIE_ORDER='nanoflann' is eager-only)")
     out = torch.empty((b, m, int(K)), dtype=torch.int64 if i64 else torch.int32, device=pts.device)
     nbytes = int(_hip.lib().pasnl_knn_tree_workspace_bytes(b, n, m, int(K)))
     ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=pts.device)

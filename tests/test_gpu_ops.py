@@ -109,7 +109,8 @@ def test_query_ball_point(P, b, n, m, ns, r, kind):
 
 
 @pytest.mark.parametrize("case", ["outside", "huge_radius", "degenerate", "plane", "many_queries", "nmax", "tiny", "dense",
-                                  "far_outlier", "odd_nsample"])
+                                  "far_outlier", "odd_nsample", "inf_point", "inf_radius", "unaligned", "clustered",
+                                  "crowded_lanes"])
 def test_query_ball_point_grid_edges(P, case):
     """Geometry the grid-pruned kernel must survive with bit-identical results: queries outside the cloud's bounding
     box, a radius larger than the cloud (single cell), coincident points, flat clouds, more queries than one
@@ -145,6 +146,18 @@ def test_query_ball_point_grid_edges(P, case):
         xyz2[:, 3] = 1e6
     elif case == "odd_nsample":
         ns = 37
+    elif case == "inf_point":
+        xyz1[:, 7, 1] = np.inf  # the bounding box is not finite: one cell, every query walks every point
+    elif case == "inf_radius":
+        r, ns = float("inf"), 24  # everything is a hit: the first nsample indices
+    elif case == "unaligned":
+        n = 701  # clouds of 701 * 12 bytes: no 16-byte pieces
+        xyz1 = clouds(37, b, n, "cube")
+    elif case == "clustered":
+        xyz1[:, 100:400] = xyz1[:, 100:101] + (rng.random((b, 300, 3)).astype(np.float32) - 0.5) * 0.02  # runs of > 31 records
+        xyz2[:, :50] = xyz1[:, 100:150]
+    elif case == "crowded_lanes":
+        r, ns = 0.17, 32  # ~14 expected hits: some lanes exceed the in-register list and take the bit rows, most do not
     want_idx, want_cnt = O.query_ball_point(r, ns, xyz1, xyz2)
     idx, cnt = P.tf_grouping.query_ball_point(r, ns, dev(xyz1), dev(xyz2))
     np.testing.assert_array_equal(cnt.cpu().numpy(), want_cnt)
