@@ -18,9 +18,11 @@
 //    afterwards the list is loaded into registers and sorted by a fixed compare-exchange network (8 / 16 / 20 inputs,
 //    chosen per wave by the largest count) -- no data-dependent branch, no scan; the padded rows leave through the
 //    wave's 4 KiB region, 32 rows at a time, as 16-byte stores that cover whole 128-byte rows.
-//  tier 2 (a LANE with more than 19 hits or a run longer than 31 records, or a dense cloud): a hit sets bit k of the
-//    lane's n-bit row (ds_or_b32, word-major / lane-minor: conflict-free; 4 KiB hold the rows of 64 / 32 / 16 lanes at a
-//    time) and scanning the row yields ascending order.  Exact for any input; only the lanes that need it take it.
+//  tier 1.5 (a LANE with more than 19 hits or a run longer than 31 records, or a dense cloud; at most 128 candidates):
+//    the whole wave serves that query -- one candidate (two) per lane, the hits' indices sorted across the wave.
+//  tier 2 (more than 128 candidates): a hit sets bit k of the lane's n-bit row (ds_or_b32, word-major / lane-minor:
+//    conflict-free; 4 KiB hold the rows of 64 / 32 / 16 lanes at a time) and scanning the row yields ascending order.
+//    Exact for any input; only the lanes that need it take it.
 //
 // Why no hit can be missed: cell coordinate u = fl(fl(x - min) * fl(1/h)); two points closer than radius along an axis
 // have |u_q - u_p| <= radius/h + 2*(G+1)*2^-23 <= 0.99901 < 1 in y and z (cells differ by at most one) and
@@ -61,6 +63,8 @@ __device__ unsigned long long bg_probe[8];
     if (probe) { const long long t_ = clock64(); atomicAdd(&bg_probe[i], (unsigned long long)(t_ - tmark)); tmark = clock64(); } \
   } while (0)
 #define BG_COUNT(i, v) do { if (probe) atomicAdd(&bg_probe[i], (unsigned long long)(v)); } while (0)
+// workgroup timeline (tools/ballprobe.py --timeline): {start, end, HW_ID, XCC_ID} of the first 8192 workgroups of a launch
+__device__ unsigned long long bg_trace[8192 * 4];
 #else
 #define BG_MARK(i) do { } while (0)
 #define BG_COUNT(i, v) do { } while (0)
@@ -80,6 +84,11 @@ __device__ __forceinline__ int bg_cvt_i32(float x) {
   asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
   return r;
 }
+
+// A value every lane of the wave holds (read from LDS, or computed from such values) moved to a scalar register: the
+// grid's geometry would otherwise occupy ~20 vector registers for the whole kernel
+__device__ __forceinline__ float bg_uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+__device__ __forceinline__ int bg_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // two cell-adjacent records as the walk wants them: (x, y) of each as a pair, the two z as a pair, the two indices
 struct BgPair {
@@ -108,6 +117,12 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
 #ifdef PASNL_TUNING
   const bool probe = tid == 0 && blockIdx.x == 0 && blockIdx.y == gridDim.y / 2;
   long long tmark = clock64();
+  const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+  if (tid == 0 && wgid < 8192) {
+    bg_trace[wgid * 4] = __builtin_amdgcn_s_memrealtime();
+    bg_trace[wgid * 4 + 2] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+    bg_trace[wgid * 4 + 3] = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (31 << 11));
+  }
 #endif
 
   // ---- A. the cloud: flat 16-byte loads into LDS (768 requests for 1024 points where a load per coordinate is 3072),
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
     float l = red[a], h = red[3 + a];
 #pragma unroll
     for (int w = 1; w < BG_WAVES; ++w) { l = fminf(l, red[w * 6 + a]); h = fmaxf(h, red[w * 6 + 3 + a]); }
-    lo[a] = l; hi[a] = h;
+    lo[a] = bg_uni(l); hi[a] = bg_uni(h);
   }
   // ---- B. grid geometry (identical in every thread)
   const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
@@ -197,11 +212,13 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
       }
     }
   }
+  inv_h = bg_uni(inv_h); inv_hx = bg_uni(inv_hx); hcell = bg_uni(hcell);
+  gx = bg_uni(gx); gy = bg_uni(gy); gz = bg_uni(gz);
   const int ncell = gx * gy * gz;
   // expected hits per query if the points were uniform in the box: decides the tier the workgroup starts in
   // (a heuristic only: both tiers are exact)
   const float vol = fmaxf(ex, hcell) * fmaxf(ey, hcell) * fmaxf(ez, hcell);
-  const bool dense = !((float)n * 4.18879f * r3 <= BG_DENSE_HITS * vol);  // also true for NaN / inf
+  const bool dense = bg_uni((int)!((float)n * 4.18879f * r3 <= BG_DENSE_HITS * vol)) != 0;  // also true for NaN / inf
   // ---- C. counting sort of the points by cell (the order inside a cell is irrelevant)
   int pcell[PPT], prank[PPT];
 #pragma unroll
@@ -249,9 +266,8 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   }
   BG_MARK(0);
 
-  const int qbase = blockIdx.x * qchunk;  // qchunk: a multiple of 64
+  const int qbase = blockIdx.x * qchunk;  // qchunk = BG_THREADS: one query per thread
   const int qend = min(m, qbase + qchunk);
-  const int rounds = (qend - qbase + BG_THREADS - 1) / BG_THREADS;
   const float* qcloud = xyz2 + (size_t)bi * m * 3;
 
   // The nine runs of x-adjacent cells around a query, packed start | end << 16, zero when empty or outside the grid.
@@ -260,15 +276,16 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   // sqrt(rho^2 - day^2 - daz^2) edges in x (rho = 1.001 radius / h <= 1); rows beyond rho are dropped.  Margins of a
   // thousandth of a cell dwarf the rounding of the cell coordinates (points and queries go through the same monotone map).
   // A degenerate grid (inv_h == 0: one cell) has no geometry to prune with: rho = inf keeps its single row and run.
-  const float rho2 = inv_h > 0.f ? (rpad * inv_h) * (rpad * inv_h) : INFINITY;
+  const float rho2 = bg_uni(inv_h > 0.f ? (rpad * inv_h) * (rpad * inv_h) : INFINITY);
+  const float gxf1 = bg_uni((float)(gx + 1)), gyf = bg_uni((float)gy), gzf = bg_uni((float)gz);
   const int cbase2 = (int)((reinterpret_cast<char*>(cstart) - smem) >> 1);  // cstart's offset in 16-bit units
   const int rowz = gy * gx;
   auto runs_of = [&](float qx, float qy, float qz, bool live, uint32_t (&rpk)[9]) {
     const float ux = (qx - lo[0]) * inv_hx, uy = (qy - lo[1]) * inv_h, uz = (qz - lo[2]) * inv_h;
-    const float uxc = fminf(fmaxf(ux, -2.f), (float)(gx + 1));  // a query outside the grid looks from its border: a superset
+    const float uxc = fminf(fmaxf(ux, -2.f), gxf1);  // a query outside the grid looks from its border: a superset
     const int cx = (int)floorf(uxc);
-    const int cy = (int)floorf(fminf(fmaxf(uy, -1.f), (float)gy));
-    const int cz = (int)floorf(fminf(fmaxf(uz, -1.f), (float)gz));
+    const int cy = (int)floorf(fminf(fmaxf(uy, -1.f), gyf));
+    const int cz = (int)floorf(fminf(fmaxf(uz, -1.f), gzf));
     // squared distance (cell edges) from the query to the slabs of rows cy-1, cy, cy+1 (clamped cell coordinates keep this
     // right for queries outside the grid: the rows that exist are then all on one side)
     float ay2[3], az2[3];
@@ -313,10 +330,10 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   const int last = n > 0 ? n - 1 : 0;
   const bool vec4 = (nsample & 3) == 0;
   const int nchunk = (nsample + 3) >> 2;
-  for (int rd = 0; rd < rounds; ++rd) {
-    const int j = qbase + (rd * BG_WAVES + wave) * 64 + lane;
+  {  // one round: a workgroup owns qchunk = BG_THREADS queries (no loop: nothing for the compiler to hoist into registers)
+    const int j = qbase + wave * 64 + lane;
     const bool live = j < qend;
-    if (!__any(live)) continue;
+    if (!__any(live)) return;
     const float* qp = qcloud + (size_t)(live ? j : qbase) * 3;
     const float qx = qp[0], qy = qp[1], qz = qp[2];
     bool need2 = live;     // the lane's row still has to come from tier 2
@@ -500,6 +517,58 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
       int* orow = idx + ((size_t)bi * m + (live ? j : qbase)) * nsample;
       uint32_t rpk[9];
       runs_of(qx, qy, qz, need2, rpk);
+      // ---- tier 1.5: a lane whose list overflowed but whose runs hold at most 128 candidates is served by the WHOLE wave:
+      // lane l takes candidates l and l + 64 of the query's runs, the hits' indices are sorted across the wave (bitonic,
+      // DPP) and lane s stores entry s of the row -- ~200 instructions per such query where a bit-row pass costs thousands
+      {
+        int tot = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) tot += (int)(rpk[r] >> 16) - (int)(rpk[r] & 0xFFFFu);
+        unsigned long long coop = __builtin_amdgcn_ballot_w64(need2 && tot <= 128);
+        need2 = need2 && tot > 128;
+        while (coop != 0ull) {
+          const int src = (int)__builtin_ctzll(coop);
+          coop &= coop - 1ull;
+          const float ax = readlane_f(qx, src), ay = readlane_f(qy, src), az = readlane_f(qz, src);
+          int rs[9], rl[9], total = 0;
+#pragma unroll
+          for (int r = 0; r < 9; ++r) {
+            const uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)rpk[r], src);
+            rs[r] = (int)(rk & 0xFFFFu);
+            rl[r] = (int)(rk >> 16) - rs[r];
+            total += rl[r];
+          }
+          auto key_of = [&](int t) {  // the index of candidate t of the query if it is a hit, else the sentinel that sorts last
+            int pos = 0, cum = 0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+              pos = (t >= cum && t < cum + rl[r]) ? rs[r] + (t - cum) : pos;
+              cum += rl[r];
+            }
+            const float4 rec = spt[t < total ? pos : 0];
+            return (t < total && bg_dist2(ax, ay, az, rec) < thr2) ? (uint32_t)__float_as_int(rec.w) : 0xFFFFFFFFu;
+          };
+          uint32_t key[2];
+          key[0] = key_of(lane);
+          int cnt = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[0] != 0xFFFFFFFFu));
+          if (total > 64) {
+            key[1] = key_of(lane + 64);
+            cnt += (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(key[1] != 0xFFFFFFFFu));
+            wave_bitonic_sort<2, uint32_t>(key, lane);
+          } else {
+            key[1] = 0xFFFFFFFFu;
+            uint32_t k1[1] = {key[0]};
+            wave_bitonic_sort<1, uint32_t>(k1, lane);
+            key[0] = k1[0];
+          }
+          const uint32_t first = cnt > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)key[0], 0) : 0u;
+          int* row = idx + ((size_t)bi * m + (j - lane + src)) * nsample;
+          if (lane < nsample) row[lane] = (int)(lane < cnt ? key[0] : first);
+          if (lane + 64 < nsample) row[lane + 64] = (int)(lane + 64 < cnt ? key[1] : first);
+          for (int sp = lane + 128; sp < nsample; sp += 64) row[sp] = (int)first;  // cnt <= 128
+          if (lane == 0) pts_cnt[(size_t)bi * m + (j - lane + src)] = min(cnt, nsample);
+        }
+      }
 #pragma unroll 1
       for (int pass = 0; pass < 64 / LP; ++pass) {
         const bool act = need2 && (lane / LP) == pass;
@@ -553,10 +622,11 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();  // the region is recycled by the next round
     BG_MARK(5);
   }
+#ifdef PASNL_TUNING
+  if (tid == 0 && wgid < 8192) bg_trace[wgid * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Host side.  Returns PASNL_OK / PASNL_ELAUNCH, or PASNL_EUNSUPPORTED when the shape is not covered (the caller then
@@ -599,6 +669,15 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
 }  // namespace pasnl
 
 #ifdef PASNL_TUNING
+extern "C" int pasnl_ball_trace_read(unsigned long long* host, int count) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(pasnl::bg_trace), sizeof(unsigned long long) * 4 * count) == hipSuccess ? 0 : -1;
+}
+extern "C" int pasnl_ball_occupancy(int n) {  // workgroups per CU the runtime computes for the n <= 1024 instantiation
+  int nb = -1;
+  const size_t lds = (size_t)n * 16 + pasnl::BG_WAVES * pasnl::BG_REGION + (size_t)((pasnl::BG_NC + 3 + 1) & ~1) * 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pasnl::ball_grid_kernel<32>, pasnl::BG_THREADS, lds) != hipSuccess) return -1;
+  return nb;
+}
 extern "C" int pasnl_ball_probe_read(unsigned long long* host8) {
   if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(pasnl::bg_probe), sizeof(pasnl::bg_probe)) != hipSuccess) return -1;
   unsigned long long zero[8] = {};

@@ -25,3 +25,32 @@ for b in (64, 1024, 4096):
     lib.pasnl_ball_probe_read(buf)
     t = [v / reps for v in buf]
     print(f"B={b}: " + ", ".join(f"{n} {t[i]:.0f}" for i, n in enumerate(names)), flush=True)
+
+# workgroup timeline of one launch at B = 4096: how many workgroups a CU really holds at a time
+import ctypes as C, collections
+print("runtime occupancy (workgroups per CU, n = 1024):", lib.pasnl_ball_occupancy(1024))
+x = torch.from_numpy(B.synth_clouds(1, 256, 1024)).cuda().repeat(16, 1, 1).contiguous()
+q = x[:, :512].contiguous()
+P.tf_grouping.query_ball_point(0.2, 32, x, q)
+torch.cuda.synchronize()
+nwg = 4096
+buf = (C.c_ulonglong * (4 * nwg))()
+lib.pasnl_ball_trace_read(buf, nwg)
+per_cu = collections.defaultdict(list)
+t0 = min(buf[4 * i] for i in range(nwg))
+for i in range(nwg):
+    st, en, hw, xcc = buf[4 * i], buf[4 * i + 1], buf[4 * i + 2], buf[4 * i + 3]
+    cu = (xcc & 0xF, (hw >> 13) & 0x7, (hw >> 12) & 1, (hw >> 8) & 0xF)  # xcc, se, sh, cu
+    per_cu[cu].append((st - t0, en - t0))
+conc = []
+for cu, iv in per_cu.items():
+    ev = sorted([(a, 1) for a, _ in iv] + [(b, -1) for _, b in iv])
+    cur = mx = 0
+    for _, d in ev:
+        cur += d
+        mx = max(mx, cur)
+    conc.append(mx)
+dur = [b - a for iv in per_cu.values() for a, b in iv]
+import numpy as np
+print(f"CUs seen {len(per_cu)}, workgroups per CU {nwg / len(per_cu):.1f}, max concurrent workgroups per CU: min {min(conc)} median {int(np.median(conc))} max {max(conc)}")
+print(f"workgroup duration (100 MHz ticks): median {np.median(dur):.0f}, p10 {np.percentile(dur, 10):.0f}, p90 {np.percentile(dur, 90):.0f}; span {max(b for iv in per_cu.values() for _, b in iv)} ticks")
