@@ -96,7 +96,9 @@ struct BgPair {
   uint32_t k0, k1;
 };
 
-template <int NW32>  // bit-row words per lane in tier 2: n <= 32*NW32
+// NW32: bit-row words per lane in tier 2 (n <= 32*NW32).  SORTQ: the workgroup's queries are dealt to the lanes in the order of
+// their candidate totals, so that the 64 lanes of a wave walk lists of nearly the same length (see D below).
+template <int NW32, bool SORTQ>
 __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kernel(
     int n, int m, float rpad, float thr2, float r3, int nsample, uint32_t ns_magic, int qchunk, int aligned,
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, int* __restrict__ idx, int* __restrict__ pts_cnt) {
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   float* raw = reinterpret_cast<float*>(smem);                                    // build: the (n,3) array as it is in memory
   char* regions = reinterpret_cast<char*>(spt + n);                               // [BG_WAVES][BG_REGION bytes]
   unsigned short* cstart = reinterpret_cast<unsigned short*>(regions + BG_WAVES * BG_REGION);  // [BG_NC + 3]
+  int* qbucket = reinterpret_cast<int*>(cstart + ((BG_NC + 3 + 1) & ~1));  // [64] queries per candidate total (SORTQ)
   int* ccount = reinterpret_cast<int*>(regions);  // cell counters during the build (the regions are not live yet)
   float* red = reinterpret_cast<float*>(ccount + BG_NC);  // [BG_WAVES][6] bbox partials, [BG_WAVES] scan partials (build only)
 
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
     for (int a = 0; a < 3; ++a) { red[wave * 6 + a] = lo[a]; red[wave * 6 + 3 + a] = hi[a]; }
   }
   for (int c = tid; c < BG_NC; c += BG_THREADS) ccount[c] = 0;
+  if (SORTQ && tid < 64) qbucket[tid] = 0;
   __syncthreads();
   if (aligned) {
 #pragma unroll
@@ -331,44 +335,79 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   const bool vec4 = (nsample & 3) == 0;
   const int nchunk = (nsample + 3) >> 2;
   {  // one round: a workgroup owns qchunk = BG_THREADS queries (no loop: nothing for the compiler to hoist into registers)
-    const int j = qbase + wave * 64 + lane;
-    const bool live = j < qend;
-    if (!__any(live)) return;
+    int j = qbase + wave * 64 + lane;
+    bool live = j < qend;
     const float* qp = qcloud + (size_t)(live ? j : qbase) * 3;
-    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    float qx = qp[0], qy = qp[1], qz = qp[2];
     bool need2 = live;     // the lane's row still has to come from tier 2
 
     if (!dense) {
-      // ---- tier 1.  (1) closing sentinels of the lists (0xFFFF), zeros (= "no more runs") in the tables: 22 + 10 slots of
-      // 128 bytes = 4 KiB = four 16-byte stores per lane
+      // ---- tier 1.  (1) zeros (= "no more runs") in the wave's tables: 10 slots of 128 bytes
       {
-        const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u), zz = make_uint4(0u, 0u, 0u, 0u);
-        static_assert(BG_TAB_OFF == 2 * 1024 + 768 && BG_REGION == 4096, "the fill below is written for 22 list and 10 table slots");
-        *reinterpret_cast<uint4*>(wr + lane * 16) = ff;
-        *reinterpret_cast<uint4*>(wr + 1024 + lane * 16) = ff;
-        const uint32_t edge = lane < 48 ? ~0u : 0u;  // the lists end 768 bytes into the third KiB
-        *reinterpret_cast<uint4*>(wr + 2048 + lane * 16) = make_uint4(edge, edge, edge, edge);
-        *reinterpret_cast<uint4*>(wr + 3072 + lane * 16) = zz;
+        const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
+        static_assert(BG_TAB_OFF == 2 * 1024 + 768 && BG_REGION == 4096, "the fills are written for 22 list and 10 table slots");
+        *reinterpret_cast<uint4*>(wr + 2816 + lane * 16) = zz;
+        if (lane < 16) *reinterpret_cast<uint4*>(wr + 3840 + lane * 16) = zz;
       }
-      // (2) the lane's non-empty runs, compacted: 16-bit entries start | length << 11
+      uint32_t rpk[9];
+      runs_of(qx, qy, qz, live, rpk);
+      // (2) SORTQ: a wave walks as long as its longest list (25 steps of two candidates where the mean lane needs 14), so the
+      // workgroup deals its 512 queries to the lanes in the order of their candidate totals: a counting sort over the totals
+      // (one LDS atomic per query, the scan of the 64 buckets redone by every wave in registers), and a query's table and
+      // coordinates are written straight into the region and lane that will walk it.  Two workgroup barriers; every row
+      // still leaves as a whole 128-byte line, now addressed per row.
+      char* dr = wr;      // the region ...
+      int dl = lane;      // ... and lane that walk this lane's query
+      if (SORTQ) {
+        int tot = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) tot += (int)(rpk[r] >> 16) - (int)(rpk[r] & 0xFFFFu);
+        const int bk = min(tot, 63);
+        const int off = atomicAdd(&qbucket[bk], 1);
+        __syncthreads();
+        const int cbk = qbucket[lane];
+        const int excl = wave_inclusive_sum_i32(cbk) - cbk;
+        const int dest = __builtin_amdgcn_ds_bpermute(bk << 2, excl) + off;  // a permutation of [0, 512)
+        dr = regions + (dest >> 6) * BG_REGION;
+        dl = dest & 63;
+      }
+      // (3) the lane's non-empty runs, compacted: 16-bit entries start | length << 11
       uint32_t seen = 0u;
       {
-        uint32_t rpk[9];
-        runs_of(qx, qy, qz, live, rpk);
+        unsigned short* dtab = reinterpret_cast<unsigned short*>(dr + BG_TAB_OFF) + dl;
         int cntr = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
           const uint32_t st = rpk[r] & 0xFFFFu, len = (rpk[r] >> 16) - st;  // an empty run: 0, 0
           const uint32_t ent = st | (len << 11);
           seen |= ent;
-          tab[cntr * 64 + lane] = (unsigned short)ent;  // an empty run writes the zero that closes the table (or is overwritten)
+          dtab[cntr * 64] = (unsigned short)ent;  // an empty run writes the zero that closes the table (or is overwritten)
           cntr += rpk[r] != 0u;
         }
-      }
-      const bool longrun = (seen >> 16) != 0u;  // a run of more than 31 records does not fit its entry: this lane -> tier 2
-      if (longrun) {                            // ... and walks nothing here (rare: the block is skipped when no lane is)
+        if ((seen >> 16) != 0u) {  // a run of more than 31 records does not fit its entry: the query walks nothing here and
+                                   // goes to tier 1.5 / 2 (rare: the block is skipped when no lane has one)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) tab[t * 64 + lane] = 0;
+          for (int t = 0; t < 9; ++t) dtab[t * 64] = 0;
+        }
+      }
+      bool longrun = (seen >> 16) != 0u;
+      if (SORTQ) {
+        // the query itself travels through the first KiB of the walker's region (its lists are not live yet)
+        *reinterpret_cast<float4*>(dr + dl * 16) = make_float4(qx, qy, qz, __int_as_float(j | (longrun ? 0x40000000 : 0)));
+        __syncthreads();
+        const float4 rec = *reinterpret_cast<const float4*>(wr + lane * 16);
+        qx = rec.x; qy = rec.y; qz = rec.z;
+        j = __float_as_int(rec.w) & 0x3FFFFFFF;
+        longrun = (__float_as_int(rec.w) & 0x40000000) != 0;
+        live = j < qend;
+        need2 = live;
+      }
+      // (4) closing sentinels of the lists (0xFFFF): 22 slots of 128 bytes
+      {
+        const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
+        *reinterpret_cast<uint4*>(wr + lane * 16) = ff;
+        *reinterpret_cast<uint4*>(wr + 1024 + lane * 16) = ff;
+        if (lane < 48) *reinterpret_cast<uint4*>(wr + 2048 + lane * 16) = ff;
       }
       BG_MARK(2);
       // (3) the flat walk: two candidates per step, software-pipelined: the records of the NEXT pair are requested before the
@@ -485,7 +524,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
               const int ee = min(e0 + lane, total - 1);
               const int q = ns_magic ? (int)__umulhi((uint32_t)ee, ns_magic) : ee;  // ee / nchunk
               const int g = ee - q * nchunk;
-              const int jq = j - lane + half * 32 + q;         // the query of row q of this half (consecutive in a wave)
+              const int jq = __builtin_amdgcn_ds_bpermute((half * 32 + q) << 2, j);  // the query of row q of this half
               const uint4 w4 = *reinterpret_cast<const uint4*>(stage + q * 32 + ((min(g, 7) ^ (q & 7)) << 2));
               const uint32_t f0 = stage[q * 32 + ((q & 7) << 2)];  // entry 0 of the row = its first hit
               const uint4 o = g < 8 ? w4 : make_uint4(f0, f0, f0, f0);
@@ -498,7 +537,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
               const int ee = min(e0 + lane, total - 1);
               const int q = ns_magic ? (int)__umulhi((uint32_t)ee, ns_magic) : ee;  // ee / nsample
               const int sidx = ee - q * nsample;
-              const int jq = j - lane + half * 32 + q;
+              const int jq = __builtin_amdgcn_ds_bpermute((half * 32 + q) << 2, j);
               const uint32_t o = stage[q * 32 + (min(sidx, 31) ^ ((q & 7) << 2))];
               const uint32_t f0 = stage[q * 32 + ((q & 7) << 2)];
               if (e0 + lane < total && ((rowmask >> q) & 1u) != 0u)
@@ -562,11 +601,12 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
             key[0] = k1[0];
           }
           const uint32_t first = cnt > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)key[0], 0) : 0u;
-          int* row = idx + ((size_t)bi * m + (j - lane + src)) * nsample;
+          const int jsrc = __builtin_amdgcn_readlane(j, src);
+          int* row = idx + ((size_t)bi * m + jsrc) * nsample;
           if (lane < nsample) row[lane] = (int)(lane < cnt ? key[0] : first);
           if (lane + 64 < nsample) row[lane + 64] = (int)(lane + 64 < cnt ? key[1] : first);
           for (int sp = lane + 128; sp < nsample; sp += 64) row[sp] = (int)first;  // cnt <= 128
-          if (lane == 0) pts_cnt[(size_t)bi * m + (j - lane + src)] = min(cnt, nsample);
+          if (lane == 0) pts_cnt[(size_t)bi * m + jsrc] = min(cnt, nsample);
         }
       }
 #pragma unroll 1
@@ -635,9 +675,10 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
                      int* pts_cnt, hipStream_t stream) {
   if (n > BG_NMAX || nsample > 1024) return PASNL_EUNSUPPORTED;
   const int nw32 = n <= 256 ? 8 : (n <= 512 ? 16 : (n <= 1024 ? 32 : 64));
-  const size_t lds = (size_t)n * 16 + BG_WAVES * BG_REGION + (size_t)((BG_NC + 3 + 1) & ~1) * 2;
+  const size_t lds = (size_t)n * 16 + BG_WAVES * BG_REGION + (size_t)((BG_NC + 3 + 1) & ~1) * 2 + 64 * 4;
   static_assert(BG_WAVES * BG_REGION >= BG_NC * 4 + (BG_WAVES * 7 + 8) * 4, "the cell counters and the build's partials alias the wave regions");
-  static_assert(1024 * 16 + BG_WAVES * BG_REGION + ((BG_NC + 3 + 1) & ~1) * 2 <= 53760, "three workgroups per CU at n <= 1024");
+  static_assert(1024 * 16 + BG_WAVES * BG_REGION + ((BG_NC + 3 + 1) & ~1) * 2 + 64 * 4 <= 53760, "three workgroups per CU at n <= 1024");
+  const bool sortq = tune_env("PASNL_BALL_NOSORT") == nullptr;
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
   // queries per workgroup: one round of 64 per wave
   const int qchunk = BG_THREADS;
@@ -651,7 +692,7 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
   const uint32_t ns_magic = div == 1 ? 0u : (uint32_t)((0x100000000ull / div) + 1ull);  // 0: divisor 1
 #define PASNL_BG(NW)                                                                                                     \
   {                                                                                                                      \
-    auto gk = ball_grid_kernel<NW>;                                                                                      \
+    auto gk = sortq ? ball_grid_kernel<NW, true> : ball_grid_kernel<NW, false>;                                          \
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(gk),                                        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
       return PASNL_ELAUNCH;                                                                                              \
@@ -674,8 +715,8 @@ extern "C" int pasnl_ball_trace_read(unsigned long long* host, int count) {
 }
 extern "C" int pasnl_ball_occupancy(int n) {  // workgroups per CU the runtime computes for the n <= 1024 instantiation
   int nb = -1;
-  const size_t lds = (size_t)n * 16 + pasnl::BG_WAVES * pasnl::BG_REGION + (size_t)((pasnl::BG_NC + 3 + 1) & ~1) * 2;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pasnl::ball_grid_kernel<32>, pasnl::BG_THREADS, lds) != hipSuccess) return -1;
+  const size_t lds = (size_t)n * 16 + pasnl::BG_WAVES * pasnl::BG_REGION + (size_t)((pasnl::BG_NC + 3 + 1) & ~1) * 2 + 64 * 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pasnl::ball_grid_kernel<32, true>, pasnl::BG_THREADS, lds) != hipSuccess) return -1;
   return nb;
 }
 extern "C" int pasnl_ball_probe_read(unsigned long long* host8) {

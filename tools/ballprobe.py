@@ -54,3 +54,19 @@ dur = [b - a for iv in per_cu.values() for a, b in iv]
 import numpy as np
 print(f"CUs seen {len(per_cu)}, workgroups per CU {nwg / len(per_cu):.1f}, max concurrent workgroups per CU: min {min(conc)} median {int(np.median(conc))} max {max(conc)}")
 print(f"workgroup duration (100 MHz ticks): median {np.median(dur):.0f}, p10 {np.percentile(dur, 10):.0f}, p90 {np.percentile(dur, 90):.0f}; span {max(b for iv in per_cu.values() for _, b in iv)} ticks")
+
+# slot utilisation and dispatch gaps per CU
+util, gaps = [], []
+for cu, iv in per_cu.items():
+    iv = sorted(iv)
+    first, lastend = iv[0][0], max(b for _, b in iv)
+    util.append(sum(b - a for a, b in iv) / (3.0 * (lastend - first)))
+    ends = sorted(b for _, b in iv)
+    starts = sorted(a for a, _ in iv)
+    # the k-th start (k >= 3) follows the (k-3)-th end: the slot's idle time between two workgroups
+    for k in range(3, len(starts)):
+        gaps.append(starts[k] - ends[k - 3])
+starts_all = sorted(a for iv in per_cu.values() for a, _ in iv)
+print(f"slot utilisation per CU: median {np.median(util):.2f} min {min(util):.2f}; gap between a workgroup's end and the next start in its slot (ticks): median {np.median(gaps):.0f} p90 {np.percentile(gaps, 90):.0f}")
+print("start time of the k-th workgroup (ticks): " + ", ".join(f"{k}:{starts_all[k]}" for k in (0, 255, 511, 767, 1023, 2047, 4095)))
+print("per-CU first start -> last end (ticks): median", int(np.median([max(b for _, b in iv) - min(a for a, _ in iv) for iv in per_cu.values()])))
