@@ -90,15 +90,21 @@ __device__ __forceinline__ int bg_cvt_i32(float x) {
 __device__ __forceinline__ float bg_uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 __device__ __forceinline__ int bg_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-// two cell-adjacent records as the walk wants them: (x, y) of each as a pair, the two z as a pair, the two indices
+// c + (the lane's bit of `mask`, a scalar-ALU result): one v_addc with the mask as carry-in
+__device__ __forceinline__ int bg_add_bit(int c, unsigned long long mask) {
+  asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(c) : "s"(mask) : "vcc");
+  return c;
+}
+
+// two cell-adjacent records as the walk wants them: (x, y) of each as a pair, the two z as a pair, the two indices.  Two
+// ds_read_b128 (the compiler's choice; 4 LDS cycles each) and two moves for the z pair: three ds_read2 that deliver the pairs
+// directly cost 16 LDS cycles and were measured slower (155 -> 185 us at B = 4096: the LDS pipe is half busy as it is)
 struct BgPair {
   pasnl_f32x2 xy0, xy1, zz;
   uint32_t k0, k1;
 };
 
-// NW32: bit-row words per lane in tier 2 (n <= 32*NW32).  SORTQ: the workgroup's queries are dealt to the lanes in the order of
-// their candidate totals, so that the 64 lanes of a wave walk lists of nearly the same length (see D below).
-template <int NW32, bool SORTQ>
+template <int NW32>  // bit-row words per lane in tier 2: n <= 32*NW32
 __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kernel(
     int n, int m, float rpad, float thr2, float r3, int nsample, uint32_t ns_magic, int qchunk, int aligned,
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, int* __restrict__ idx, int* __restrict__ pts_cnt) {
@@ -110,7 +116,6 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   float* raw = reinterpret_cast<float*>(smem);                                    // build: the (n,3) array as it is in memory
   char* regions = reinterpret_cast<char*>(spt + n);                               // [BG_WAVES][BG_REGION bytes]
   unsigned short* cstart = reinterpret_cast<unsigned short*>(regions + BG_WAVES * BG_REGION);  // [BG_NC + 3]
-  int* qbucket = reinterpret_cast<int*>(cstart + ((BG_NC + 3 + 1) & ~1));  // [64] queries per candidate total (SORTQ)
   int* ccount = reinterpret_cast<int*>(regions);  // cell counters during the build (the regions are not live yet)
   float* red = reinterpret_cast<float*>(ccount + BG_NC);  // [BG_WAVES][6] bbox partials, [BG_WAVES] scan partials (build only)
 
@@ -179,7 +184,6 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
     for (int a = 0; a < 3; ++a) { red[wave * 6 + a] = lo[a]; red[wave * 6 + 3 + a] = hi[a]; }
   }
   for (int c = tid; c < BG_NC; c += BG_THREADS) ccount[c] = 0;
-  if (SORTQ && tid < 64) qbucket[tid] = 0;
   __syncthreads();
   if (aligned) {
 #pragma unroll
@@ -335,79 +339,44 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   const bool vec4 = (nsample & 3) == 0;
   const int nchunk = (nsample + 3) >> 2;
   {  // one round: a workgroup owns qchunk = BG_THREADS queries (no loop: nothing for the compiler to hoist into registers)
-    int j = qbase + wave * 64 + lane;
-    bool live = j < qend;
+    const int j = qbase + wave * 64 + lane;
+    const bool live = j < qend;
+    if (!__any(live)) return;
     const float* qp = qcloud + (size_t)(live ? j : qbase) * 3;
-    float qx = qp[0], qy = qp[1], qz = qp[2];
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
     bool need2 = live;     // the lane's row still has to come from tier 2
 
     if (!dense) {
-      // ---- tier 1.  (1) zeros (= "no more runs") in the wave's tables: 10 slots of 128 bytes
+      // ---- tier 1.  (1) closing sentinels of the lists (0xFFFF), zeros (= "no more runs") in the tables: 22 + 10 slots of
+      // 128 bytes = 4 KiB = four 16-byte stores per lane
       {
-        const uint4 zz = make_uint4(0u, 0u, 0u, 0u);
-        static_assert(BG_TAB_OFF == 2 * 1024 + 768 && BG_REGION == 4096, "the fills are written for 22 list and 10 table slots");
-        *reinterpret_cast<uint4*>(wr + 2816 + lane * 16) = zz;
-        if (lane < 16) *reinterpret_cast<uint4*>(wr + 3840 + lane * 16) = zz;
+        const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u), zz = make_uint4(0u, 0u, 0u, 0u);
+        static_assert(BG_TAB_OFF == 2 * 1024 + 768 && BG_REGION == 4096, "the fill below is written for 22 list and 10 table slots");
+        *reinterpret_cast<uint4*>(wr + lane * 16) = ff;
+        *reinterpret_cast<uint4*>(wr + 1024 + lane * 16) = ff;
+        const uint32_t edge = lane < 48 ? ~0u : 0u;  // the lists end 768 bytes into the third KiB
+        *reinterpret_cast<uint4*>(wr + 2048 + lane * 16) = make_uint4(edge, edge, edge, edge);
+        *reinterpret_cast<uint4*>(wr + 3072 + lane * 16) = zz;
       }
-      uint32_t rpk[9];
-      runs_of(qx, qy, qz, live, rpk);
-      // (2) SORTQ: a wave walks as long as its longest list (25 steps of two candidates where the mean lane needs 14), so the
-      // workgroup deals its 512 queries to the lanes in the order of their candidate totals: a counting sort over the totals
-      // (one LDS atomic per query, the scan of the 64 buckets redone by every wave in registers), and a query's table and
-      // coordinates are written straight into the region and lane that will walk it.  Two workgroup barriers; every row
-      // still leaves as a whole 128-byte line, now addressed per row.
-      char* dr = wr;      // the region ...
-      int dl = lane;      // ... and lane that walk this lane's query
-      if (SORTQ) {
-        int tot = 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) tot += (int)(rpk[r] >> 16) - (int)(rpk[r] & 0xFFFFu);
-        const int bk = min(tot, 63);
-        const int off = atomicAdd(&qbucket[bk], 1);
-        __syncthreads();
-        const int cbk = qbucket[lane];
-        const int excl = wave_inclusive_sum_i32(cbk) - cbk;
-        const int dest = __builtin_amdgcn_ds_bpermute(bk << 2, excl) + off;  // a permutation of [0, 512)
-        dr = regions + (dest >> 6) * BG_REGION;
-        dl = dest & 63;
-      }
-      // (3) the lane's non-empty runs, compacted: 16-bit entries start | length << 11
+      // (2) the lane's non-empty runs, compacted: 16-bit entries start | length << 11
       uint32_t seen = 0u;
       {
-        unsigned short* dtab = reinterpret_cast<unsigned short*>(dr + BG_TAB_OFF) + dl;
+        uint32_t rpk[9];
+        runs_of(qx, qy, qz, live, rpk);
         int cntr = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
           const uint32_t st = rpk[r] & 0xFFFFu, len = (rpk[r] >> 16) - st;  // an empty run: 0, 0
           const uint32_t ent = st | (len << 11);
           seen |= ent;
-          dtab[cntr * 64] = (unsigned short)ent;  // an empty run writes the zero that closes the table (or is overwritten)
+          tab[cntr * 64 + lane] = (unsigned short)ent;  // an empty run writes the zero that closes the table (or is overwritten)
           cntr += rpk[r] != 0u;
         }
-        if ((seen >> 16) != 0u) {  // a run of more than 31 records does not fit its entry: the query walks nothing here and
-                                   // goes to tier 1.5 / 2 (rare: the block is skipped when no lane has one)
+      }
+      const bool longrun = (seen >> 16) != 0u;  // a run of more than 31 records does not fit its entry: this lane -> tier 2
+      if (longrun) {                            // ... and walks nothing here (rare: the block is skipped when no lane is)
 #pragma unroll
-          for (int t = 0; t < 9; ++t) dtab[t * 64] = 0;
-        }
-      }
-      bool longrun = (seen >> 16) != 0u;
-      if (SORTQ) {
-        // the query itself travels through the first KiB of the walker's region (its lists are not live yet)
-        *reinterpret_cast<float4*>(dr + dl * 16) = make_float4(qx, qy, qz, __int_as_float(j | (longrun ? 0x40000000 : 0)));
-        __syncthreads();
-        const float4 rec = *reinterpret_cast<const float4*>(wr + lane * 16);
-        qx = rec.x; qy = rec.y; qz = rec.z;
-        j = __float_as_int(rec.w) & 0x3FFFFFFF;
-        longrun = (__float_as_int(rec.w) & 0x40000000) != 0;
-        live = j < qend;
-        need2 = live;
-      }
-      // (4) closing sentinels of the lists (0xFFFF): 22 slots of 128 bytes
-      {
-        const uint4 ff = make_uint4(~0u, ~0u, ~0u, ~0u);
-        *reinterpret_cast<uint4*>(wr + lane * 16) = ff;
-        *reinterpret_cast<uint4*>(wr + 1024 + lane * 16) = ff;
-        if (lane < 48) *reinterpret_cast<uint4*>(wr + 2048 + lane * 16) = ff;
+        for (int t = 0; t < 9; ++t) tab[t * 64 + lane] = 0;
       }
       BG_MARK(2);
       // (3) the flat walk: two candidates per step, software-pipelined: the records of the NEXT pair are requested before the
@@ -434,8 +403,8 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
       // one step: evaluate the pair `cur`; request the next pair's records into `nxt`
 #define PASNL_BG_STEP(cur, nxt)                                                                                         \
       {                                                                                                                 \
-        const bool a0 = left > 0, a1 = left > 1;                                                                        \
-        if (__builtin_amdgcn_ballot_w64(a0) == 0ull) break;                                                             \
+        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(left > 0), m1 = __builtin_amdgcn_ballot_w64(left > 1); \
+        if (m0 == 0ull) break;                                                                                          \
         p += 2u;                                                                                                        \
         left -= 2;                                                                                                      \
         advance();                                                                                                      \
@@ -447,9 +416,9 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
         asm("" : "+v"(t0), "+v"(t1)); /* two plain adds into a register pair, not a packed add behind three moves */    \
         const pasnl_f32x2 dd = pasnl_f32x2{t0, t1} + sz; /* ((dx*dx)+(dy*dy))+(dz*dz), twice */                         \
         hl[c * 64 + lane] = (unsigned short)cur.k0; /* unconditional: a miss is overwritten */                          \
-        c += (a0 && dd[0] < thr2) ? 1 : 0;                                                                              \
+        c = bg_add_bit(c, m0 & __builtin_amdgcn_ballot_w64(dd[0] < thr2));                                              \
         hl[c * 64 + lane] = (unsigned short)cur.k1;                                                                     \
-        c += (a1 && dd[1] < thr2) ? 1 : 0;                                                                              \
+        c = bg_add_bit(c, m1 & __builtin_amdgcn_ballot_w64(dd[1] < thr2));                                              \
         c = min(c, BG_CAP); /* a count that reaches BG_CAP stays there: the lane's row then comes from tier 2 */        \
         BG_COUNT(7, 1);                                                                                                 \
       }
@@ -472,25 +441,28 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
         const int cs = done ? c : 0;
         const bool big = __any(cs > 16), mid = __any(cs > 8);
 #define PASNL_CE(a, b) { const uint32_t lo_ = min(v[a], v[b]), hi_ = max(v[a], v[b]); v[a] = lo_; v[b] = hi_; }
+        // entries are read sign-extended: the closing 0xFFFF becomes 0xFFFFFFFF, last for the unsigned network and -1 for
+        // the signed maximum that turns it into the row's padding below
+        const short* hs = reinterpret_cast<const short*>(hl);
         if (big) {
 #pragma unroll
-          for (int s = 0; s < 20; ++s) v[s] = hl[s * 64 + lane];
+          for (int s = 0; s < 20; ++s) v[s] = (uint32_t)(int)hs[s * 64 + lane];
           PASNL_SORTNET_20
         } else if (mid) {
 #pragma unroll
-          for (int s = 0; s < 16; ++s) v[s] = hl[s * 64 + lane];
+          for (int s = 0; s < 16; ++s) v[s] = (uint32_t)(int)hs[s * 64 + lane];
 #pragma unroll
-          for (int s = 16; s < 20; ++s) v[s] = 0xFFFFu;
+          for (int s = 16; s < 20; ++s) v[s] = 0xFFFFFFFFu;
           PASNL_SORTNET_16
         } else {
 #pragma unroll
-          for (int s = 0; s < 8; ++s) v[s] = hl[s * 64 + lane];
+          for (int s = 0; s < 8; ++s) v[s] = (uint32_t)(int)hs[s * 64 + lane];
 #pragma unroll
-          for (int s = 8; s < 20; ++s) v[s] = 0xFFFFu;
+          for (int s = 8; s < 20; ++s) v[s] = 0xFFFFFFFFu;
           PASNL_SORTNET_8
         }
 #undef PASNL_CE
-        const uint32_t first = cs > 0 ? v[0] : 0u;  // zero-hit rows -> 0
+        const int first = cs > 0 ? (int)v[0] : 0;  // zero-hit rows -> 0
         const int top = big ? 5 : (mid ? 4 : 2);    // 16-byte chunks that can hold anything but `first`
         // (5) the rows leave through the region, 32 rows (lanes) at a time: row q of a half is 8 chunks of 16 bytes, chunk g
         // stored at g ^ (q & 7) (conflict-free for the writers and for the readers)
@@ -505,12 +477,12 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
             uint4* r4 = reinterpret_cast<uint4*>(stage + (lane & 31) * 32);
 #pragma unroll
             for (int ch = 0; ch < 8; ++ch) {
-              uint4 o = make_uint4(first, first, first, first);
-              if (ch < 5 && ch < top) {
-                o.x = v[4 * ch] == 0xFFFFu ? first : v[4 * ch];
-                o.y = v[4 * ch + 1] == 0xFFFFu ? first : v[4 * ch + 1];
-                o.z = v[4 * ch + 2] == 0xFFFFu ? first : v[4 * ch + 2];
-                o.w = v[4 * ch + 3] == 0xFFFFu ? first : v[4 * ch + 3];
+              uint4 o = make_uint4((uint32_t)first, (uint32_t)first, (uint32_t)first, (uint32_t)first);
+              if (ch < 5 && ch < top) {  // a hit is >= the first hit, the sentinel is -1: one signed maximum pads the row
+                o.x = (uint32_t)max((int)v[4 * ch], first);
+                o.y = (uint32_t)max((int)v[4 * ch + 1], first);
+                o.z = (uint32_t)max((int)v[4 * ch + 2], first);
+                o.w = (uint32_t)max((int)v[4 * ch + 3], first);
               }
               r4[ch ^ (lane & 7)] = o;
             }
@@ -518,13 +490,23 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          if (vec4) {
+          if (nsample == 32) {
+            // the usual row of 32 entries: lane l copies chunk l & 7 of rows (l >> 3) + 8 it, it = 0 .. 3 -- every address is a
+            // per-lane constant plus an immediate
+            const int q0 = lane >> 3, g = lane & 7;
+            const uint4* src = reinterpret_cast<const uint4*>(stage + q0 * 32 + ((g ^ q0) << 2));
+            uint4* dst = reinterpret_cast<uint4*>(idx + ((size_t)bi * m + (j - lane + half * 32 + q0)) * 32 + (g << 2));
+            const uint32_t rm = rowmask >> q0;
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+              if ((rm >> (8 * it)) & 1u) dst[it * 8 * 8] = src[it * 8 * 8];  // 8 rows of 8 chunks further
+          } else if (vec4) {
             const int total = BG_STAGE_ROWS * nchunk;
             for (int e0 = 0; e0 < total; e0 += 64) {
               const int ee = min(e0 + lane, total - 1);
               const int q = ns_magic ? (int)__umulhi((uint32_t)ee, ns_magic) : ee;  // ee / nchunk
               const int g = ee - q * nchunk;
-              const int jq = __builtin_amdgcn_ds_bpermute((half * 32 + q) << 2, j);  // the query of row q of this half
+              const int jq = j - lane + half * 32 + q;         // the query of row q of this half (consecutive in a wave)
               const uint4 w4 = *reinterpret_cast<const uint4*>(stage + q * 32 + ((min(g, 7) ^ (q & 7)) << 2));
               const uint32_t f0 = stage[q * 32 + ((q & 7) << 2)];  // entry 0 of the row = its first hit
               const uint4 o = g < 8 ? w4 : make_uint4(f0, f0, f0, f0);
@@ -537,7 +519,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
               const int ee = min(e0 + lane, total - 1);
               const int q = ns_magic ? (int)__umulhi((uint32_t)ee, ns_magic) : ee;  // ee / nsample
               const int sidx = ee - q * nsample;
-              const int jq = __builtin_amdgcn_ds_bpermute((half * 32 + q) << 2, j);
+              const int jq = j - lane + half * 32 + q;
               const uint32_t o = stage[q * 32 + (min(sidx, 31) ^ ((q & 7) << 2))];
               const uint32_t f0 = stage[q * 32 + ((q & 7) << 2)];
               if (e0 + lane < total && ((rowmask >> q) & 1u) != 0u)
@@ -601,12 +583,11 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
             key[0] = k1[0];
           }
           const uint32_t first = cnt > 0 ? (uint32_t)__builtin_amdgcn_readlane((int)key[0], 0) : 0u;
-          const int jsrc = __builtin_amdgcn_readlane(j, src);
-          int* row = idx + ((size_t)bi * m + jsrc) * nsample;
+          int* row = idx + ((size_t)bi * m + (j - lane + src)) * nsample;
           if (lane < nsample) row[lane] = (int)(lane < cnt ? key[0] : first);
           if (lane + 64 < nsample) row[lane + 64] = (int)(lane + 64 < cnt ? key[1] : first);
           for (int sp = lane + 128; sp < nsample; sp += 64) row[sp] = (int)first;  // cnt <= 128
-          if (lane == 0) pts_cnt[(size_t)bi * m + jsrc] = min(cnt, nsample);
+          if (lane == 0) pts_cnt[(size_t)bi * m + (j - lane + src)] = min(cnt, nsample);
         }
       }
 #pragma unroll 1
@@ -675,10 +656,9 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
                      int* pts_cnt, hipStream_t stream) {
   if (n > BG_NMAX || nsample > 1024) return PASNL_EUNSUPPORTED;
   const int nw32 = n <= 256 ? 8 : (n <= 512 ? 16 : (n <= 1024 ? 32 : 64));
-  const size_t lds = (size_t)n * 16 + BG_WAVES * BG_REGION + (size_t)((BG_NC + 3 + 1) & ~1) * 2 + 64 * 4;
+  const size_t lds = (size_t)n * 16 + BG_WAVES * BG_REGION + (size_t)((BG_NC + 3 + 1) & ~1) * 2;
   static_assert(BG_WAVES * BG_REGION >= BG_NC * 4 + (BG_WAVES * 7 + 8) * 4, "the cell counters and the build's partials alias the wave regions");
-  static_assert(1024 * 16 + BG_WAVES * BG_REGION + ((BG_NC + 3 + 1) & ~1) * 2 + 64 * 4 <= 53760, "three workgroups per CU at n <= 1024");
-  const bool sortq = tune_env("PASNL_BALL_NOSORT") == nullptr;
+  static_assert(1024 * 16 + BG_WAVES * BG_REGION + ((BG_NC + 3 + 1) & ~1) * 2 <= 53760, "three workgroups per CU at n <= 1024");
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
   // queries per workgroup: one round of 64 per wave
   const int qchunk = BG_THREADS;
@@ -692,7 +672,7 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
   const uint32_t ns_magic = div == 1 ? 0u : (uint32_t)((0x100000000ull / div) + 1ull);  // 0: divisor 1
 #define PASNL_BG(NW)                                                                                                     \
   {                                                                                                                      \
-    auto gk = sortq ? ball_grid_kernel<NW, true> : ball_grid_kernel<NW, false>;                                          \
+    auto gk = ball_grid_kernel<NW>;                                                                                      \
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(gk),                                        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
       return PASNL_ELAUNCH;                                                                                              \
@@ -715,8 +695,8 @@ extern "C" int pasnl_ball_trace_read(unsigned long long* host, int count) {
 }
 extern "C" int pasnl_ball_occupancy(int n) {  // workgroups per CU the runtime computes for the n <= 1024 instantiation
   int nb = -1;
-  const size_t lds = (size_t)n * 16 + pasnl::BG_WAVES * pasnl::BG_REGION + (size_t)((pasnl::BG_NC + 3 + 1) & ~1) * 2 + 64 * 4;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pasnl::ball_grid_kernel<32, true>, pasnl::BG_THREADS, lds) != hipSuccess) return -1;
+  const size_t lds = (size_t)n * 16 + pasnl::BG_WAVES * pasnl::BG_REGION + (size_t)((pasnl::BG_NC + 3 + 1) & ~1) * 2;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pasnl::ball_grid_kernel<32>, pasnl::BG_THREADS, lds) != hipSuccess) return -1;
   return nb;
 }
 extern "C" int pasnl_ball_probe_read(unsigned long long* host8) {
