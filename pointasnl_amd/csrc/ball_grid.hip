@@ -133,6 +133,17 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   }
 #endif
 
+  // the thread's query, requested before anything else: it arrives during the build (under load a global load takes
+  // microseconds, and the round would start by waiting for it)
+  const int qbase = blockIdx.x * qchunk;  // qchunk = BG_THREADS: one query per thread
+  const int qend = min(m, qbase + qchunk);
+  const int j = qbase + tid;
+  const bool live = j < qend;
+  float qx, qy, qz;
+  {
+    const float* qp = xyz2 + ((size_t)bi * m + (live ? j : qbase)) * 3;
+    qx = qp[0]; qy = qp[1]; qz = qp[2];
+  }
   // ---- A. the cloud: flat 16-byte loads into LDS (768 requests for 1024 points where a load per coordinate is 3072),
   // bounding box straight from the loaded registers: piece q holds elements 4q .. 4q+3 of the flat array, element e of it
   // belongs to axis (q + e) mod 3
@@ -274,9 +285,6 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   }
   BG_MARK(0);
 
-  const int qbase = blockIdx.x * qchunk;  // qchunk = BG_THREADS: one query per thread
-  const int qend = min(m, qbase + qchunk);
-  const float* qcloud = xyz2 + (size_t)bi * m * 3;
 
   // The nine runs of x-adjacent cells around a query, packed start | end << 16, zero when empty or outside the grid.
   // Per row of cells the x window is as wide as the ball is THERE: a point of row (dy, dz) is at least day / daz cell edges
@@ -339,11 +347,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   const bool vec4 = (nsample & 3) == 0;
   const int nchunk = (nsample + 3) >> 2;
   {  // one round: a workgroup owns qchunk = BG_THREADS queries (no loop: nothing for the compiler to hoist into registers)
-    const int j = qbase + wave * 64 + lane;
-    const bool live = j < qend;
     if (!__any(live)) return;
-    const float* qp = qcloud + (size_t)(live ? j : qbase) * 3;
-    const float qx = qp[0], qy = qp[1], qz = qp[2];
     bool need2 = live;     // the lane's row still has to come from tier 2
 
     if (!dense) {
