@@ -690,6 +690,7 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
         t0 = time.perf_counter()
         for _ in range(steps):
             last = step()
+        enqueued = time.perf_counter() - t0  # host time to issue the K steps (replay + collective): no host sync inside a step
         torch.cuda.synchronize()
         if multi:
             dist.barrier()
@@ -733,7 +734,7 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
             per_fwd = len(_hip.PROFILE) // max(1, reps)
             launch_order = [[sym, list(ints)] for sym, ints, _, _ in _hip.PROFILE[:per_fwd]]
             _hip.PROFILE = None
-    return {"B": B, "N": N, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "clouds_per_s": world * B * steps / elapsed,
+    return {"B": B, "N": N, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "enqueue_ms_per_step": enqueued / steps * 1e3, "clouds_per_s": world * B * steps / elapsed,
             "graph": bool(graphs), "pipeline": pipeline if graphs else "eager", "outputs_agree": agree, "gathered_ok": gathered_ok,
             "shards_differ": shards_differ, "rows": rows, "launch_order": launch_order, "pc": pc, "store": store}
 
@@ -746,7 +747,7 @@ def ball_query_sweep(batches=(64, 256, 1024, 4096), iters=20):
     import pointasnl_amd as P
     from pointasnl_amd import _hip
 
-    out = []
+    out, sources = [], set()
     for b in batches:
         x = torch.from_numpy(synth_clouds(4321 + b, min(b, 256), 1024)).cuda()
         if b > 256:
@@ -766,9 +767,10 @@ def ball_query_sweep(batches=(64, 256, 1024, 4096), iters=20):
         traffic, src = measured_traffic("pasnl_query_ball_point", [b, 1024, 512, 32])
         out.append({"B": b, "dims": [b, 1024, 512, 32], "radius": 0.2, "median_us": round(med, 2), "min_us": round(min(us), 2),
                     "alg_MB": round(by / 1e6, 2), "GB/s": round(by / med / 1e3, 1), "hbm_frac": round(by / med / 1e3 / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "traffic_source": src})
+                    "traffic": traffic})
+        sources.add(src)
         del x, q
-    return out
+    return out, "; ".join(sorted(sources))
 
 
 def traffic_pass(args):
@@ -903,7 +905,11 @@ def main():
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_dist
     allreduce_check = None
+    numa_node, cpus_bound = None, 0
     if multi:
+        from pointasnl_amd import sharding as _sh
+
+        numa_node, cpus_bound = _sh.bind_to_gpu_numa(local_rank)  # before RCCL starts its proxy thread (it inherits the mask)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -923,8 +929,9 @@ def main():
     res = run_config(main_index, spec, args.steps, args.warmup, rank=rank, world=world, multi=multi, graph=not args.no_graph,
                      pipeline=args.pipeline)
     serial = None
-    if args.pipeline != "serial" and not args.no_graph and not multi:  # the same workload without the cross-batch overlap
-        r0 = run_config(main_index, spec, min(args.steps, 20), 3, graph=True, kernel_pass=False, announce=False, pipeline="serial")
+    if args.pipeline != "serial" and not args.no_graph:  # the same workload without the cross-batch overlap (every rank takes part)
+        r0 = run_config(main_index, spec, min(args.steps, 20), 3, rank=rank, world=world, multi=multi, graph=True, kernel_pass=False,
+                        announce=False, pipeline="serial")
         serial = {"ms_per_step": round(r0["ms_per_step"], 4), "clouds_per_s": round(r0["clouds_per_s"], 2),
                   "outputs_agree": r0["outputs_agree"], "steps": min(args.steps, 20)}
         beat("post")
@@ -940,7 +947,7 @@ def main():
         cpu = cpu_baseline(res["pc"], res["store"].export_numpy(), spec["AS"])
         beat("post")
 
-    others, sweep = None, None
+    others, sweep, sweep_traffic_source = None, None, None
     if world == 1 and not args.no_others and not args.force_dist:
         others = []
         for ci, ospec in WORKLOADS.items():
@@ -959,9 +966,37 @@ def main():
                            "handwritten_kernel_us_per_step": round(sum(k["avg_us"] * k["launches"] for k in r["rows"]) /
                                                                    max(1, min(args.other_steps, 20)), 1),
                            "kernels": sorted(r["rows"], key=lambda k: -k["avg_us"])[:8]})
-        sweep = ball_query_sweep()
+        sweep, sweep_traffic_source = ball_query_sweep()
         beat("post")
 
+    # The driver's record keeps the SCALAR values of `config` and the last 2 KB of this line: every figure the line is about is
+    # repeated as a scalar in `config`, the long arrays come first and the compact summaries last.
+    config = {"workload": spec["name"] + f", batch={res['B']}/GPU, seeded random weights",
+              "global_batch": world * res["B"], "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
+              "rccl_ranks": rccl_ranks, "allreduce_check": allreduce_check, "gathered_rows_match_local": res["gathered_ok"],
+              "shards_differ": res["shards_differ"], "numa_node": numa_node, "cpus_bound": cpus_bound,
+              "enqueue_ms_per_step": round(res["enqueue_ms_per_step"], 4),
+              "hip_graph": res["graph"], "pipeline": res["pipeline"],
+              "outputs_agree": res["outputs_agree"],
+              "serial_ms_per_step": serial["ms_per_step"] if serial else None,
+              "serial_clouds_per_s": serial["clouds_per_s"] if serial else None,
+              "serial_outputs_agree": serial["outputs_agree"] if serial else None,
+              "switches": ",".join(args.set) if args.set else ""}
+    summary = None
+    if others is not None:
+        summary = []
+        for tag, o in zip(("cfg2", "cfg3", "cfg4") if main_index == 1 else tuple(f"cfg{ci}" for ci in WORKLOADS if ci != main_index), others):
+            config[f"{tag}_ms"] = o["ms_per_step"]
+            config[f"{tag}_serial_ms"] = o["serial_ms_per_step"]
+            config[f"{tag}_outputs_agree"] = o["outputs_agree"]
+            r = o["roofline"] or {}
+            summary.append({"cfg": tag, "ms": o["ms_per_step"], "serial_ms": o["serial_ms_per_step"], "clouds_per_s": o["clouds_per_s"],
+                            "agree": o["outputs_agree"], "dominant": r.get("kernel"), "dims": r.get("dims"), "bound": r.get("bound"),
+                            "frac": r.get("frac"), "avg_us": r.get("avg_us"), "traffic": r.get("traffic"), "alg_bytes": r.get("alg_bytes")})
+    if sweep is not None:
+        for e in sweep:
+            config[f"ball_hbm_frac_b{e['B']}"] = e["hbm_frac"]
+            config[f"ball_us_b{e['B']}"] = e["median_us"]
     out = {
         "metric": "point-clouds/sec fwd (Bx1024 pts, ModelNet40 cls)" if args.model == "cls" else
                   f"point-clouds/sec fwd (Bx{res['N']} pts, pointasnl_{args.model})",
@@ -976,16 +1011,15 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": spec["name"] + f", batch={res['B']}/GPU, seeded random weights",
-                   "global_batch": world * res["B"], "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
-                   "rccl_ranks": rccl_ranks, "allreduce_check": allreduce_check, "gathered_rows_match_local": res["gathered_ok"],
-                   "shards_differ": res["shards_differ"],
-                   "hip_graph": res["graph"], "pipeline": res["pipeline"], "serial": serial, "switches": args.set, "outputs_agree": res["outputs_agree"]},
+        "config": config,
         "roofline": roofline_of(rows),
         "cpu_baseline": cpu,
         "handwritten_kernel_us_per_step": round(sum(r["avg_us"] * r["launches"] for r in rows) / max(1, min(args.steps, 20)), 1),
         "kernels": rows,
         "other_configs": others,
+        "ball_traffic_source": sweep_traffic_source,
+        "serial": serial,
+        "other_configs_summary": summary,
         "ball_query_sweep": sweep,
     }
     if args.launch_order:

@@ -630,381 +630,8 @@ static int fps_pruned_launch(int b, int n, int m, const float* xyz, int* idx, hi
 }
 
 #ifdef PASNL_TUNING
-// ---------------------------------------------------------------------------------------------
-// Large clouds, SEVERAL PICKS PER ROUND (fps_multi_kernel) -- A MEASUREMENT, compiled into the tuning build only
-// (PASNL_FPS_K = 2..4; tools/fps_k_sweep.py, tools/fps_active.py).  Exact (all sampling parity tests pass with it) and it
-// does cut the rounds to 0.53 / 0.38 / 0.31 of the picks, but a round got 2.3-3.5x longer: the waves the two or three picks
-// touch (6-9 of 16 instead of ~3) queue on the four SIMDs and the barrier waits for the slowest, the second-largest distance
-// and the candidate's coordinates lengthen the touched wave's chain, and the merge is paid by one wave between two barriers
-// (or by all sixteen, four deep per SIMD).  16x8192->1024: 790 us (K = 3) against 700 us for one pick per round.  EXPERIMENTS.md.
-// A round of the pruned kernel is one dependent chain -- box test, (update, in-lane / in-wave reduction), slot, barrier,
-// merge of the 16 wave candidates -- of ~1500 cycles, most of it fixed cost.  Here the merge takes up to K picks out of
-// the SAME 16 candidates, and they are exactly the picks the one-per-round sequence would make:
-//   every wave publishes its best point c_w = (distance, tie key, coordinates) AND m2_w, the largest distance among its OTHER
-//   points.  Let c_0 > c_1 > ... be the candidates in (distance, key) order.  c_0 is the pick.  c_s (s >= 1) is the pick
-//   that follows c_0 .. c_{s-1} if  (i) dist(c_s) > 0,  (ii) dist(c_s) > m2 of the wave of every earlier c_t (strictly: no
-//   other point of those waves can reach it),  (iii) |c_s - c_t|^2 >= dist(c_s) for every earlier c_t, evaluated with the
-//   update's own fp32 expression (so the updates by c_t leave dist(c_s) bit for bit as it is).  Then after those updates
-//   every other point is at or below its old distance, which was at or below c_s in (distance, key) order (points of
-//   untouched waves by the candidate order, points of the touched waves by (ii), the earlier picks themselves have
-//   distance 0 < dist(c_s) by (i)), and dist(c_s) is unchanged by (iii): c_s is the reference's next pick.  The first
-//   candidate that fails ends the round.  Measured (ball / lidar-like / indoor-block clouds, 8192-10240 points): rounds
-//   per pick 0.53 (K = 2), 0.38 (K = 3), 0.31 (K = 4).
-// Next round every wave tests its boxes against each of the picks and applies the updates of those that can reach it (min
-// is commutative); the picks of one round are far apart (iii), so they are mostly different waves' work.
-// ---------------------------------------------------------------------------------------------
-template <int WAVES, int NB, int K>
-__global__ __launch_bounds__(WAVES * 64) void fps_multi_kernel(int n, int m, const float* __restrict__ xyz, int* __restrict__ idx,
-                                                              float* __restrict__ out_xyz) {
-  static_assert(WAVES <= 16 && K >= 1 && K <= 4, "one row of 16 lanes merges the wave candidates");
-  constexpr int T = WAVES * 64;
-  constexpr int NCELL = 4096;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* spt = reinterpret_cast<float*>(smem);                                   // [n][3], ORIGINAL order
-  unsigned short* order = reinterpret_cast<unsigned short*>(spt + (size_t)n * 3);  // [n]: sorted position -> original index
-  // 16-byte aligned whatever n is (the launcher sizes the allocation the same way)
-  char* tailp = smem + (((size_t)n * 12 + (size_t)((n + 1) & ~1) * 2 + 15) & ~(size_t)15);
-  int* hist = reinterpret_cast<int*>(tailp);                                      // [4096] during the sort ...
-  float4* slotA = reinterpret_cast<float4*>(tailp);                               // ... then [2][16] {distance, ~key, m2, x}
-  float2* slotB = reinterpret_cast<float2*>(tailp + 2 * 16 * 16);                 //          [2][16] {y, z}
-  float* wbox = reinterpret_cast<float*>(tailp + 2 * 16 * 16 + 2 * 16 * 8);       //          [16][6] wave bounding boxes
-  uint32_t* bcast = reinterpret_cast<uint32_t*>(tailp + 2 * 16 * 16 + 2 * 16 * 8 + 16 * 6 * 4);  // [2][32] the round's picks
-  int* picks = reinterpret_cast<int*>(tailp + 2 * 16 * 16 + 2 * 16 * 8 + 16 * 6 * 4 + 2 * 32 * 4);  // ... and [m] picks
-  __shared__ float red[6][WAVES];
-  __shared__ int wsum[WAVES];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* cloud = xyz + (size_t)blockIdx.x * n * 3;
-
-  // ---- stage the cloud, bounding box
-  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  for (int f = tid; f < n * 3; f += T) spt[f] = cloud[f];  // coalesced flat copy
-  __syncthreads();
-  for (int k = tid; k < n; k += T) {
-    const float x = spt[k * 3], y = spt[k * 3 + 1], z = spt[k * 3 + 2];
-    mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
-    mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
-    mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-      mn[a] = fminf(mn[a], __shfl_xor(mn[a], sft));
-      mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], sft));
-    }
-    if (lane == 0) { red[a][wave] = mn[a]; red[3 + a][wave] = mx[a]; }
-  }
-  for (int c = tid; c < NCELL; c += T) hist[c] = 0;
-  __syncthreads();
-  float lo[3], sc[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float l = red[a][0], u = red[3 + a][0];
-    for (int w = 1; w < WAVES; ++w) { l = fminf(l, red[a][w]); u = fmaxf(u, red[3 + a][w]); }
-    lo[a] = l;
-    sc[a] = u > l ? 15.999f / (u - l) : 0.f;
-  }
-  // ---- Morton counting sort: histogram, scan, scatter of the original indices
-  auto code_of = [&](int k) {
-    const uint32_t cx = (uint32_t)min(15, max(0, (int)((spt[k * 3] - lo[0]) * sc[0])));
-    const uint32_t cy = (uint32_t)min(15, max(0, (int)((spt[k * 3 + 1] - lo[1]) * sc[1])));
-    const uint32_t cz = (uint32_t)min(15, max(0, (int)((spt[k * 3 + 2] - lo[2]) * sc[2])));
-    return (int)(fps_spread3(cx) | (fps_spread3(cy) << 1) | (fps_spread3(cz) << 2));
-  };
-  for (int k = tid; k < n; k += T) atomicAdd(&hist[code_of(k)], 1);
-  __syncthreads();
-  {
-    constexpr int PER = NCELL / T;  // cells per thread (T divides 4096)
-    int v[PER], tsum = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) { v[i] = hist[tid * PER + i]; tsum += v[i]; }
-    int incl = tsum;
-#pragma unroll
-    for (int sft = 1; sft < 64; sft <<= 1) {
-      const int o = __shfl_up(incl, sft);
-      if (lane >= sft) incl += o;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int run = incl - tsum;
-    for (int w = 0; w < wave; ++w) run += wsum[w];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) { hist[tid * PER + i] = run; run += v[i]; }
-  }
-  __syncthreads();
-  for (int k = tid; k < n; k += T) order[atomicAdd(&hist[code_of(k)], 1)] = (unsigned short)k;
-  __syncthreads();
-
-  // ---- this lane's NB consecutive points of the sorted order
-  f32x2 px[NB / 2], py[NB / 2], pz[NB / 2];
-  uint32_t td[NB], nkey[NB];  // running distance bits; ~tie key (0 = padding: loses every comparison)
-  float bmn[3] = {INFINITY, INFINITY, INFINITY}, bmx[3] = {-INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int pos = (wave * 64 + lane) * NB + i;
-    const bool ok = pos < n;
-    const int k = ok ? (int)order[pos] : 0;
-    const float x = ok ? spt[k * 3] : 0.f, y = ok ? spt[k * 3 + 1] : 0.f, z = ok ? spt[k * 3 + 2] : 0.f;
-    px[i / 2][i % 2] = x; py[i / 2][i % 2] = y; pz[i / 2][i % 2] = z;
-    td[i] = ok ? __float_as_uint(1e38f) : 0u;
-    nkey[i] = ok ? ~fps_tiekey(k) : 0u;
-    if (ok) {
-      bmn[0] = fminf(bmn[0], x); bmx[0] = fmaxf(bmx[0], x);
-      bmn[1] = fminf(bmn[1], y); bmx[1] = fmaxf(bmx[1], y);
-      bmn[2] = fminf(bmn[2], z); bmx[2] = fmaxf(bmx[2], z);
-    }
-  }
-  __syncthreads();  // everybody has read hist-as-fill-pointers / order: the region becomes the slots + picks[]
-  // this LANE's bounding box (its NB consecutive points of the Morton order: a tight cluster), inflated by 1e-5 of its size
-  // (rounding of the test below).  The wave skips a pick iff NO lane's box is closer to it than that lane's largest running
-  // distance.
-  float blo[3], bhi[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float pad = 1e-5f * fmaxf(fabsf(bmn[a]), fabsf(bmx[a])) + 1e-30f;
-    blo[a] = bmn[a] - pad;
-    bhi[a] = bmx[a] + pad;
-  }
-  const bool empty_lane = !(bmn[0] <= bmx[0]);
-  {  // the wave's box = union of its lanes' (inflated) boxes: the merging wave tests the picks against these sixteen
-    float wl_[3], wh_[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      wl_[a] = empty_lane ? INFINITY : blo[a];
-      wh_[a] = empty_lane ? -INFINITY : bhi[a];
-#pragma unroll
-      for (int sft = 32; sft >= 1; sft >>= 1) {
-        wl_[a] = fminf(wl_[a], __shfl_xor(wl_[a], sft));
-        wh_[a] = fmaxf(wh_[a], __shfl_xor(wh_[a], sft));
-      }
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { wbox[wave * 6 + a] = wl_[a]; wbox[wave * 6 + 3 + a] = wh_[a]; }
-    }
-  }
-  if (tid == 0) picks[0] = 0;
-  if (lane == 0) {  // a wave without points is never touched: its slot must lose every comparison from the start
-    slotA[wave] = make_float4(0.f, 0.f, 0.f, 0.f);
-    slotB[wave] = make_float2(0.f, 0.f);
-  }
-  // the picks of the previous round (wave-uniform): coordinates, np of them, and for each the waves it can reach (bit w)
-  float qx[K], qy[K], qz[K];
-  uint32_t qmask[K];
-  int np = 1;
-  qx[0] = spt[0]; qy[0] = spt[1]; qz[0] = spt[2];
-  qmask[0] = 0xffffu;
-#pragma unroll
-  for (int s = 1; s < K; ++s) { qx[s] = qx[0]; qy[s] = qy[0]; qz[s] = qz[0]; qmask[s] = 0u; }
-  float thr = empty_lane ? -1.f : INFINITY;  // the lane can change while dist^2(pick, its box) < thr (= its largest running distance, inflated)
-  // the wave's candidate, cached while no pick reaches the wave: largest running distance (bits), ~tie key, second-largest
-  // distance, the candidate's coordinates
-  uint32_t cand_d = 0u, cand_k = 0u, cand_m2 = 0u;
-  float cand_x = 0.f, cand_y = 0.f, cand_z = 0.f;
-  __syncthreads();
-  // merging wave: lane w < WAVES keeps wave w's box
-  float mbl[3] = {0.f, 0.f, 0.f}, mbh[3] = {0.f, 0.f, 0.f};
-  if (wave == 0 && lane < WAVES) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { mbl[a] = wbox[lane * 6 + a]; mbh[a] = wbox[lane * 6 + 3 + a]; }
-  }
-
-  int j = 1;        // picks made so far
-  int parity = 0;   // slot / broadcast buffer of this round
-  while (j < m) {
-#ifdef PASNL_TUNING
-    const long long t_round = clock64();
+#include "experimental/fps_multi.inc"  // several picks per round: measured slower, tuning build only (EXPERIMENTS.md)
 #endif
-    bool touched = false;  // wave-uniform
-#pragma unroll
-    for (int s = 0; s < K; ++s) {
-      if (s < np && ((qmask[s] >> wave) & 1u)) {  // scalar: the pick can reach this wave's box at all
-        const float ex = fmaxf(fmaxf(blo[0] - qx[s], qx[s] - bhi[0]), 0.f), ey = fmaxf(fmaxf(blo[1] - qy[s], qy[s] - bhi[1]), 0.f),
-                    ez = fmaxf(fmaxf(blo[2] - qz[s], qz[s] - bhi[2]), 0.f);
-        const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-        if (__ballot(lb < thr) != 0ull) {  // wave-uniform
-          touched = true;
-#pragma unroll
-          for (int q = 0; q < NB / 2; ++q) {
-            const f32x2 dx = px[q] - qx[s], dy = py[q] - qy[s], dz = pz[q] - qz[s];
-            const f32x2 d = (dx * dx + dy * dy) + dz * dz;
-            td[2 * q] = min(td[2 * q], __float_as_uint(d[0]));
-            td[2 * q + 1] = min(td[2 * q + 1], __float_as_uint(d[1]));
-          }
-        }
-      }
-    }
-    if (touched) {
-      // in-lane top two distances (a tie at the top counts twice), then the largest key among the slots that hold the top
-      uint32_t h1[NB], h2[NB];
-#pragma unroll
-      for (int i = 0; i < NB; ++i) { h1[i] = td[i]; h2[i] = 0u; }
-#pragma unroll
-      for (int stp = 1; stp < NB; stp *= 2)
-#pragma unroll
-        for (int i = 0; i + stp < NB; i += 2 * stp) {
-          const uint32_t a1 = h1[i], b1 = h1[i + stp];
-          h2[i] = max(min(a1, b1), max(h2[i], h2[i + stp]));
-          h1[i] = max(a1, b1);
-        }
-      const uint32_t bd = h1[0];
-      uint32_t k2[NB];
-#pragma unroll
-      for (int i = 0; i < NB; ++i) k2[i] = td[i] == bd ? nkey[i] : 0u;
-#pragma unroll
-      for (int stp = 1; stp < NB; stp *= 2)
-#pragma unroll
-        for (int i = 0; i + stp < NB; i += 2 * stp) k2[i] = max(k2[i], k2[i + stp]);
-      const uint32_t bkey = k2[0];
-      // wave top two distances: (m1, m2) merged over the lanes by DPP (distances are >= +0: signed order is fine)
-      int m1 = (int)bd, m2 = (int)h2[0];
-#define PASNL_TOP2(CTRL, RM)                                                                    \
-      {                                                                                         \
-        const int o1 = __builtin_amdgcn_update_dpp(-1, m1, CTRL, RM, 0xf, false);               \
-        const int o2 = __builtin_amdgcn_update_dpp(-1, m2, CTRL, RM, 0xf, false);               \
-        m2 = max(min(m1, o1), max(m2, o2));                                                     \
-        m1 = max(m1, o1);                                                                       \
-      }
-      PASNL_TOP2(DPP_ROW_SHR1, 0xf)
-      PASNL_TOP2(DPP_ROW_SHR2, 0xf)
-      PASNL_TOP2(DPP_ROW_SHR4, 0xf)
-      PASNL_TOP2(DPP_ROW_SHR8, 0xf)
-      PASNL_TOP2(DPP_ROW_BCAST15, 0xa)
-      PASNL_TOP2(DPP_ROW_BCAST31, 0xc)
-#undef PASNL_TOP2
-      const int wmaxi = __builtin_amdgcn_readlane(m1, 63);
-      cand_m2 = (uint32_t)__builtin_amdgcn_readlane(m2, 63);
-      unsigned long long tie = __ballot(bd == (uint32_t)wmaxi);
-      uint32_t wkey = (uint32_t)__builtin_amdgcn_readlane((int)bkey, (int)__builtin_ctzll(tie));
-      if (__builtin_popcountll(tie) > 1) {
-        tie &= tie - 1;
-        while (tie) {
-          const int l = (int)__builtin_ctzll(tie);
-          tie &= tie - 1;
-          const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)bkey, l);
-          wkey = kk > wkey ? kk : wkey;
-        }
-      }
-      cand_d = (uint32_t)wmaxi;
-      cand_k = wkey;
-      const int ck = (int)(~wkey & 0x3fffffu);  // padding-only waves: key 0 -> an index past the cloud; clamp (never picked)
-      const int cki = ck < n ? ck : 0;
-      cand_x = spt[cki * 3]; cand_y = spt[cki * 3 + 1]; cand_z = spt[cki * 3 + 2];
-      // no point of this lane changes while dist^2(pick, its box) >= (its largest running distance) (1 + 1e-5)
-      thr = empty_lane ? -1.f : __uint_as_float(bd) * 1.00001f;
-      if (lane == 0) {
-        slotA[wave] = make_float4(__uint_as_float(cand_d), __uint_as_float(cand_k), __uint_as_float(cand_m2), cand_x);
-        slotB[wave] = make_float2(cand_y, cand_z);
-      }
-    }
-#ifdef PASNL_TUNING
-    if (blockIdx.x == 0 && lane == 0) {
-      if (touched) atomicAdd(&fps_dbg[2], 1ull);
-      if (wave == 1) { atomicAdd(&fps_dbg[3], 1ull); atomicAdd(&fps_dbg[4], (unsigned long long)(clock64() - t_round)); }
-    }
-    const long long t_merge = clock64();
-#endif
-    __syncthreads();  // every wave's candidate is in its slot (untouched waves: as they left it)
-    uint32_t* bc = bcast + parity * 32;
-    if (wave == 0) {
-      // ---- merge, by ONE wave (the others wait: sixteen waves running this uniform code would queue four deep on every SIMD):
-      // up to K picks out of the WAVES candidates (lanes 0 .. WAVES-1), and for each pick the waves whose box it can reach
-      const float4 sa = lane < WAVES ? slotA[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float2 sb = lane < WAVES ? slotB[lane] : make_float2(0.f, 0.f);
-      int di = lane < WAVES ? (int)__float_as_uint(sa.x) : -1;
-      const uint32_t ki = __float_as_uint(sa.y);
-      const float wthr = __uint_as_float(__float_as_uint(sa.x)) * 1.00001f;  // wave w's largest running distance, inflated
-      uint32_t m2max = 0u;
-      int npn = 0;
-      float cx_[K], cy_[K], cz_[K];
-#pragma unroll
-      for (int s = 0; s < K; ++s) {
-        if (s > 0 && (npn < s || j + npn >= m)) break;  // an earlier candidate failed, or enough picks
-        const int gmax = __builtin_amdgcn_readlane(row_max_i32_to_lane15(di), 15);
-        if (s > 0 && (gmax <= 0 || (uint32_t)gmax <= m2max)) break;  // (i), (ii)
-        unsigned long long wt = __ballot(di == gmax) & 0xffffull;
-        int wl = (int)__builtin_ctzll(wt);
-        uint32_t gkey = (uint32_t)__builtin_amdgcn_readlane((int)ki, wl);
-        if (__builtin_popcountll(wt) > 1) {
-          wt &= wt - 1;
-          while (wt) {
-            const int l = (int)__builtin_ctzll(wt);
-            wt &= wt - 1;
-            const uint32_t kk = (uint32_t)__builtin_amdgcn_readlane((int)ki, l);
-            if (kk > gkey) { gkey = kk; wl = l; }
-          }
-        }
-        const float bx = readlane_f(sa.w, wl), by = readlane_f(sb.x, wl), bz = readlane_f(sb.y, wl);
-        if (s > 0) {  // (iii): the earlier picks of this round leave this candidate's distance as it is
-          bool keep = true;
-#pragma unroll
-          for (int t = 0; t < K; ++t)
-            if (t < s) {
-              const float dx = bx - cx_[t], dy = by - cy_[t], dz = bz - cz_[t];
-              const float dd = (dx * dx + dy * dy) + dz * dz;
-              keep = keep && !(dd < __uint_as_float((uint32_t)gmax));
-            }
-          if (!keep) break;
-        }
-        cx_[s] = bx; cy_[s] = by; cz_[s] = bz;
-        // the waves this pick can reach: distance from the pick to wave w's box against wave w's largest running distance
-        const float ex = fmaxf(fmaxf(mbl[0] - bx, bx - mbh[0]), 0.f), ey = fmaxf(fmaxf(mbl[1] - by, by - mbh[1]), 0.f),
-                    ez = fmaxf(fmaxf(mbl[2] - bz, bz - mbh[2]), 0.f);
-        const float lbw = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
-        const uint32_t reach = (uint32_t)(__ballot(lane < WAVES && lbw < wthr) & 0xffffull);
-        if (lane == 0) {
-          picks[j + s] = (int)(~gkey & 0x3fffffu);
-          bc[1 + s * 4] = __float_as_uint(bx); bc[2 + s * 4] = __float_as_uint(by); bc[3 + s * 4] = __float_as_uint(bz);
-          bc[4 + s * 4] = reach;
-        }
-        m2max = max(m2max, (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(sa.z), wl));
-        di = lane == wl ? -1 : di;
-        npn = s + 1;
-      }
-      if (lane == 0) bc[0] = (uint32_t)npn;
-#ifdef PASNL_TUNING
-      if (blockIdx.x == 0 && lane == 0) atomicAdd(&fps_dbg[5], (unsigned long long)(clock64() - t_merge));
-#endif
-    }
-    __syncthreads();  // the round's picks are published
-    np = __builtin_amdgcn_readfirstlane((int)bc[0]);  // wave-uniform by construction: keep it (and the picks) in scalar registers
-#pragma unroll
-    for (int s = 0; s < K; ++s)
-      if (s < np) {
-        qx[s] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)bc[1 + s * 4]));
-        qy[s] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)bc[2 + s * 4]));
-        qz[s] = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)bc[3 + s * 4]));
-        qmask[s] = (uint32_t)__builtin_amdgcn_readfirstlane((int)bc[4 + s * 4]);
-      }
-    parity ^= 1;
-    j += np;
-#ifdef PASNL_TUNING
-    if (blockIdx.x == 0 && lane == 0 && wave == 1) { atomicAdd(&fps_dbg[6], (unsigned long long)(clock64() - t_round)); atomicAdd(&fps_dbg[7], (unsigned long long)np); }
-#endif
-  }
-  __syncthreads();
-  int* out = idx + (size_t)blockIdx.x * m;
-  for (int jj = tid; jj < m; jj += T) out[jj] = picks[jj];
-  fps_emit_xyz<T>(xyz + (size_t)blockIdx.x * n * 3, picks, m, out_xyz ? out_xyz + (size_t)blockIdx.x * m * 3 : nullptr, tid);
-}
-
-template <int WAVES, int NB, int K>
-static int fps_multi_launch(int b, int n, int m, const float* xyz, int* idx, hipStream_t st, float* oxyz = nullptr) {
-  size_t lds = (size_t)n * 12 + (size_t)((n + 1) & ~1) * 2;
-  lds = (lds + 15) & ~(size_t)15;
-  const size_t after = (size_t)2 * 16 * 16 + 2 * 16 * 8 + 16 * 6 * 4 + 2 * 32 * 4 + (size_t)m * 4;
-  lds += (size_t)4096 * 4 > after ? (size_t)4096 * 4 : after;
-  if (lds > 160 * 1024 - 1024 || n > 65535) return PASNL_EUNSUPPORTED;
-  auto kern = fps_multi_kernel<WAVES, NB, K>;
-  if (lds > 48 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return PASNL_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3(b), dim3(WAVES * 64), lds, st, n, m, xyz, idx, oxyz);
-  return pasnl_launch_status();
-}
-
-#endif  // PASNL_TUNING
 
 // ---------------------------------------------------------------------------------------------
 // gather_point / grad

@@ -6,6 +6,8 @@ exchange is one all-gather of the per-shard logits per forward (cls: (B/W,40) fp
 fully connected xGMI fabric a direct all-gather, latency- not bandwidth-bound.  One process per GPU; backend
 "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -52,3 +54,44 @@ def sharded_forward(forward, clouds, width):
     lo, hi = shard_range(rank, world, clouds.shape[0])
     local = forward(clouds[lo:hi])
     return gather_ragged(local, clouds.shape[0], width)
+
+
+def parse_cpulist(text):
+    """'0-3,8,10-11' (sysfs cpulist syntax) -> sorted list of CPU numbers."""
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return sorted(cpus)
+
+
+def gpu_numa_node(device_index, sysfs="/sys"):
+    """NUMA node of the host bridge a HIP device hangs off (its PCI function's sysfs `numa_node`), or None."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(os.path.join(sysfs, "bus", "pci", "devices", bdf, "numa_node")).read())
+        return node if node >= 0 else None
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
+def bind_to_gpu_numa(device_index, sysfs="/sys"):
+    """One process per GPU: pin this rank's host threads to the CPUs of its GPU's NUMA node, so that the launch thread, the
+    RCCL proxy thread and their queues do not cross the socket interconnect (eight ranks on a two-socket host otherwise
+    share whatever cores the scheduler picks).  Returns (node, number of CPUs bound) or (None, 0) when the topology is not
+    exposed (containers without sysfs NUMA files): the rank then keeps its inherited affinity."""
+    node = gpu_numa_node(device_index, sysfs)
+    if node is None:
+        return None, 0
+    try:
+        cpus = parse_cpulist(open(os.path.join(sysfs, "devices", "system", "node", f"node{node}", "cpulist")).read())
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return node, 0
+        os.sched_setaffinity(0, allowed)
+        return node, len(allowed)
+    except OSError:
+        return node, 0

@@ -126,6 +126,20 @@ def test_rccl_path_with_one_rank():
 
 
 @pytest.mark.gpu
+def test_rccl_path_sem_seg_res_gather_is_asynchronous():
+    """configs[4] on the multi-rank path with one rank: the per-step all-gather moves the (8, 10240 x 20) segmentation logits
+    (6.5 MB per rank, not the 10 KB of the classifier) behind the replayed graph, and the host only ENQUEUES a step: issuing
+    the steps takes a fraction of the time the GPU needs for them, so there is no host synchronisation inside a step."""
+    p = _bench("--gpus", "1", "--force-dist", "--model", "sem_seg_res", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert cfg["rccl_ranks"] == 1 and cfg["gathered_rows_match_local"] is True and cfg["outputs_agree"] is True
+    assert cfg["global_batch"] == 8 and "sem_seg_res" in line["metric"]
+    assert cfg["enqueue_ms_per_step"] < 0.5 * line["ms_per_step"], (cfg["enqueue_ms_per_step"], line["ms_per_step"])
+
+
+@pytest.mark.gpu
 def test_two_ranks_over_rccl():
     """Two ranks on two GPUs (skipped on a 1-GPU box): n_gpus, RCCL world size, all-reduce over both ranks, every rank's
     rows of the gathered logits equal its own logits, throughput counts both shards."""

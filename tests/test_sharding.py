@@ -60,3 +60,16 @@ def test_shard_range_partitions():
             assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_parse_cpulist_and_numa_binding(tmp_path):
+    """The launcher pins a rank to its GPU's NUMA node: cpulist parsing, and a missing topology leaves the affinity alone."""
+    import os
+
+    from pointasnl_amd import sharding
+
+    assert sharding.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert sharding.parse_cpulist("") == []
+    before = os.sched_getaffinity(0)
+    assert sharding.bind_to_gpu_numa(0, sysfs=str(tmp_path)) == (None, 0)  # no sysfs topology (and no GPU here)
+    assert os.sched_getaffinity(0) == before
