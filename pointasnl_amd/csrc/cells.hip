@@ -2185,6 +2185,121 @@ static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const floa
   return pasnl_launch_status();
 }
 
+// =============================================================================================
+// pasnl_sa_cell for the 16-channel first layer of pointasnl_sem_seg_res (mlp [16, 16, 32] on xyz-only rows, k = 32:
+// pointasnl_sem_seg_res.py:32): the same four products on v_mfma_f32_16x16x4_f32, whose 16-row tiles a 16-channel layer
+// fills -- on the 32x32x2 kernel above half of every conv0 / matmul tile and three quarters of conv1 multiply zero
+// padding, and the padded 32-channel output doubles the bytes written.  34 MFMAs of 32 cycles per group instead of 40 of
+// 64, 2 KiB stored per group instead of 4.
+//   A tile of the 16x16x4 MFMA: lane l = (n = l & 15, q = l >> 4) holds A[n][k = q], B[k = q][n], D[4 q + r][n] in
+//   register r -- so a D tile IS the next product's A (or B) operand when that product's k index at step s, lane group q
+//   is defined as 4 q + s (the chaining trick of the big kernel, one size down):
+//     H1^T[c][p]   : A = W0[col][c] (regs)  B = X[p][col] (regs)   3 steps: cols [dx dy dz x | y z fx fy | fz 1 0 0]
+//     G   [p][j]   : A = [dx dy dz 1][p]    B = [Ww ; bw][j]       1 step per 16 columns (tile jt holds columns 2 n + jt)
+//     H2  [p][c2]  : A = H1^T regs          B = W1[c][c2] (regs)   4 steps
+//     M   [c2][j]  : A = H2 regs            B = G regs             4 steps per row tile
+//   The weights are 3 + 2 + 4 registers per lane for the whole kernel (no LDS at all); a group is two row tiles of 16
+//   neighbours; the skip maxima are three 16-lane DPP reductions (lane group q owns columns q, 4 + q, 8 + q -- its own
+//   conv0 operands); a row of M leaves as 8-byte stores that cover 128 contiguous bytes per lane group.
+// =============================================================================================
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void sa_cell16_kernel(long groups, SaGatherSrc src, const float* __restrict__ w0,
+                                                           const float* __restrict__ b0, const float* __restrict__ w1,
+                                                           const float* __restrict__ b1, const float* __restrict__ ww,
+                                                           const float* __restrict__ bw, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+  const bool q0 = q == 0, q1 = q == 1, q2 = q == 2;
+  auto pick = [&](float a, float b, float c, float d) { return q0 ? a : (q1 ? b : (q2 ? c : d)); };
+  // ---- the weights, once per wave.  conv0: internal column 4 s + q of [xyz - c | xyz | feature | 1 | 0 | 0] -> channel n
+  float a0[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int col = 4 * s + q;
+    a0[s] = col < 9 ? w0[col * 16 + n] : (col == 9 ? b0[n] : 0.f);
+  }
+  float wn[2];  // weight net: row q of [Ww ; bw], column 2 n + jt
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) wn[jt] = q < 3 ? ww[q * 32 + 2 * n + jt] : bw[2 * n + jt];
+  float w1r[4];  // conv1: input channel 4 q + s -> output channel n
+#pragma unroll
+  for (int s = 0; s < 4; ++s) w1r[s] = w1[(4 * q + s) * 16 + n];
+  const float b1n = b1[n];
+
+  const int m = src.m;
+  const uint32_t first = blockIdx.x * NW + (threadIdx.x >> 6), stride = gridDim.x * NW;  // groups < 2^31 (sa_cell_entry)
+  for (uint32_t g = first; g < (uint32_t)groups; g += stride) {
+    const uint32_t bi = g / (uint32_t)m;
+    const int* gi = src.idx + (size_t)g * 32;
+    const int i0 = gi[n], i1 = gi[16 + n];  // the rows of the two tiles this lane stands for
+    const float* cen = src.new_xyz + (size_t)g * 3;
+    const float cx = cen[0], cy = cen[1], cz = cen[2];
+    const float* base = src.xyz + (size_t)bi * src.n * 3;
+    const float* fbase = src.feature + (size_t)bi * src.n * 3;
+    const float* pr[2] = {base + (size_t)i0 * 3, base + (size_t)i1 * 3};
+    const float* fr[2] = {fbase + (size_t)i0 * 3, fbase + (size_t)i1 * 3};
+    f32x4 M[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float sk[3] = {-INFINITY, -INFINITY, -INFINITY};  // running maxima of columns q, 4 + q, 8 + q over the group's rows
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float px = pr[t][0], py = pr[t][1], pz = pr[t][2];
+      const float fx = fr[t][0], fy = fr[t][1], fz = fr[t][2];
+      const float dx = px - cx, dy = py - cy, dz = pz - cz;
+      // this lane's operand of the three conv0 steps = columns q, 4 + q, 8 + q of its row
+      const float x0 = pick(dx, dy, dz, px), x1 = pick(py, pz, fx, fy), x2 = pick(fz, 1.f, 0.f, 0.f);
+      sk[0] = vmaxf(sk[0], x0); sk[1] = vmaxf(sk[1], x1); sk[2] = vmaxf(sk[2], x2);
+      f32x4 H1 = {0.f, 0.f, 0.f, 0.f};
+      H1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], x0, H1, 0, 0, 0);
+      H1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1], x1, H1, 0, 0, 0);
+      H1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[2], x2, H1, 0, 0, 0);
+      // weight net on the centred coordinates (+ bias through the constant 1): rows x columns 2 n + jt
+      const float gx = q < 3 ? x0 : 1.f;
+      f32x4 G[2];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        G[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        G[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gx, wn[jt], G[jt], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) G[jt][r] = vmaxf(G[jt][r], 0.f);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H1[r] = vmaxf(H1[r], 0.f);  // (the conv0 bias came with the MFMA)
+      f32x4 H2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) H2 = __builtin_amdgcn_mfma_f32_16x16x4f32(H1[s], w1r[s], H2, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) H2[r] = fmaxf(H2[r] + b1n, 0.f);
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) M[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(H2[s], G[jt][s], M[jt], 0, 0, 0);
+    }
+    // M[jt][r] = channel 4 q + r, column 2 n + jt -> out[g][c * 32 + j]: lane group q stores 128 contiguous bytes per channel
+    float* o = out + (size_t)g * 16 * 32 + (size_t)(4 * q) * 32 + 2 * n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<float2*>(o + r * 32) = make_float2(M[0][r], M[1][r]);
+    // skip maxima: reference column c = internal column c (c < 9); lane group q holds columns q, 4 + q, 8 + q (all-reduced)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) sk[s] = row16_max(sk[s]);
+    if (n == 15) {
+      float* so = src.skip_max + (size_t)g * 9;
+      so[q] = sk[0];
+      so[4 + q] = sk[1];
+      if (q == 0) so[8] = sk[2];
+    }
+  }
+}
+
+static int sa_cell16_launch(long groups, SaGatherSrc src, const float* w0, const float* b0, const float* w1, const float* b1,
+                            const float* ww, const float* bw, float* out, hipStream_t st) {
+  constexpr int NW = 4;
+  // no LDS, ~64 registers: 8 waves per SIMD hide the two dependent round trips (indices, rows) of a group; the grid is
+  // sized to fill the chip a few times over and strides over the groups
+  const long wgs = (groups + NW - 1) / NW, cap = 256L * 8 * 2;
+  hipLaunchKernelGGL(sa_cell16_kernel<NW>, dim3((unsigned)(wgs < cap ? wgs : cap)), dim3(NW * 64), 0, st, groups, src, w0, b0, w1,
+                     b1, ww, bw, out);
+  return pasnl_launch_status();
+}
+
 // Waves per workgroup: two waves per SIMD (8 per workgroup, one LDS copy of the weights) where 256 registers per wave
 // suffice (c1 <= 64; 201 vs 240 us at cls layer1, 44 vs 59 us at ScanNet layer2 when measured); the 128-channel cell
 // needs ~350 registers (at 8 waves it spilled: 3 % faster, 2.4x the HBM bytes) and runs one wave per SIMD.
@@ -2234,6 +2349,10 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   // the row's last chunk: live MFMA steps (0 = the width is a multiple of 32); see TAIL8
   const int wi = 8 + c, rem = wi & 31;
   const bool tail8 = rem != 0 && (vec ? rem : (rem + 1) >> 1) <= 8;
+  if (c1 == 16 && c2 == 16) {  // the 16-channel first layer: xyz-only rows, 32 neighbours, centres from a table
+    PASNL_REQUIRE(c == 3 && k == 32 && new_xyz, PASNL_EUNSUPPORTED);
+    return sa_cell16_launch(groups, src, w0, b0, w1, b1, ww, bw, out, st);
+  }
   if (c1 == 32 && c2 == 32) return sa_cell_cfg<32, 32>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   if (c1 == 128 && c2 == 128) return sa_cell_cfg<128, 128>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);

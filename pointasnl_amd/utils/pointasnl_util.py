@@ -119,16 +119,20 @@ def sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn):
     return out
 
 
-def _sa_cell_weights(w_in, mlp, bn, weight_decay):
+SA_CELL16 = True  # the 16-channel first layer on its own 16x16x4 kernel (False: zero-padded on the 32-channel kernel, A/B)
+
+
+def _sa_cell_weights(w_in, mlp, bn, weight_decay, native16=False):
     """(w0, b0, w1, b1, ww, bw, c_kernel) for pasnl_sa_cell, whose two convolutions are c x c with c in {32, 64, 128}:
       * mlp = [c, c, out]: the layer's own conv0 / conv1;
-      * mlp = [16, 16, out] (pointasnl_sem_seg_res.py layer0): both zero-padded to 32 channels -- the padded channels are
+      * mlp = [16, 16, out] (pointasnl_sem_seg_res.py layer0): as they are where the 16-channel kernel applies (xyz-only rows,
+        32 neighbours, centres from a table: native16); otherwise zero-padded to 32 channels -- the padded channels are
         relu(0 + 0) = 0 and feed zero rows, so channels 0..15 are bit-identical to the unpadded arithmetic;
       * mlp = [c, out] (the *_2 residual layers: ONE convolution, pointasnl_util.py:264-269 with len(mlp) == 2): conv1 = the
         identity with zero bias -- relu(h * 1 + 0) = h exactly for h = relu(.) >= 0.
     The folded / padded tensors are cached in the store like every other folded weight."""
     st = tf_util.store()
-    key = st.path("sa_cell_weights")
+    key = st.path("sa_cell_weights16" if native16 else "sa_cell_weights")
     if key not in st._folded:
         c1 = mlp[0]
         with tf_util.variable_scope('conv0'):
@@ -140,7 +144,7 @@ def _sa_cell_weights(w_in, mlp, bn, weight_decay):
             w1, b1 = torch.eye(c1, dtype=torch.float32, device=w0.device), torch.zeros(c1, dtype=torch.float32, device=w0.device)
         with tf_util.variable_scope('weight_net'), tf_util.variable_scope('wconv0'):
             ww, bw = st.layer(3, 32, True, weight_decay)
-        ck = max(c1, 32)
+        ck = c1 if native16 else max(c1, 32)
         if ck != c1:
             pad = ck - c1
             w0 = torch.nn.functional.pad(w0, (0, pad))
@@ -159,7 +163,8 @@ def sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay
        output when c = 16),  skip (B,P,6+C)"""
     b, n, c = feature.shape
     _, p, k = idx.shape
-    w0, b0, w1, b1, ww, bw, ck = _sa_cell_weights(6 + c, mlp, bn, weight_decay)
+    native16 = SA_CELL16 and len(mlp) == 3 and mlp[0] == 16 and c == 3 and k == 32 and new_xyz is not None
+    w0, b0, w1, b1, ww, bw, ck = _sa_cell_weights(6 + c, mlp, bn, weight_decay, native16)
     xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
     out = torch.empty((b, p, ck, 32), dtype=torch.float32, device=xyz.device)
     skip = torch.empty((b, p, 6 + c), dtype=torch.float32, device=xyz.device)

@@ -205,6 +205,38 @@ def test_sa_cell_gather_fused(b, n, c, m, k, c1):
     np.testing.assert_allclose(got.cpu().numpy(), two.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
 
 
+@pytest.mark.parametrize("b,n,m", [(2, 1024, 1024), (3, 300, 77), (1, 64, 1), (8, 2048, 500)])
+def test_sa_cell_16_channels_native_kernel(b, n, m, monkeypatch):
+    """mlp [16, 16, 32] on xyz-only rows, 32 neighbours (pointasnl_sem_seg_res.py:32): the 16x16x4-MFMA kernel against the fp64
+    restatement, its skip maxima bit-equal to the gathered maximum, and the same function as the zero-padded 32-channel kernel."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    st = _store(b * 7 + m)
+    rng = np.random.default_rng(n + m)
+    xyz = clouds(15, b, n)
+    idx = rng.integers(0, n, (b, m, 32)).astype(np.int32)
+    new_xyz = clouds(16, b, m)
+    with st.scope("L"):
+        got, skip = U.sa_cell(dev(xyz), dev(xyz), dev(idx), dev(new_xyz), [16, 16, 32], False, None, None, True)
+    assert got.shape == (b, m, 16, 32) and got.is_contiguous()  # no padded channels behind the view
+    bi = np.arange(b)[:, None, None]
+    gx = xyz[bi, idx]
+    x = np.concatenate([gx - new_xyz[:, :, None, :], gx, gx], axis=-1)
+    np.testing.assert_array_equal(skip.cpu().numpy(), x.max(axis=2))
+    p = st.export_numpy()
+    x64 = x.astype(np.float64)
+    h = cells._layer(cells._layer(x64, p["L/conv0"], "relu"), p["L/conv1"], "relu")
+    wn = cells._layer(x64[..., :3], p["L/weight_net/wconv0"], "relu")
+    want = np.swapaxes(h, 2, 3) @ wn
+    scale = np.abs(want).max()
+    assert np.abs(got.cpu().numpy() - want).max() / scale < 1e-5
+    monkeypatch.setattr(U, "SA_CELL16", False)
+    with st.scope("L"):
+        padded, skip2 = U.sa_cell(dev(xyz), dev(xyz), dev(idx), dev(new_xyz), [16, 16, 32], False, None, None, True)
+    np.testing.assert_array_equal(skip.cpu().numpy(), skip2.cpu().numpy())
+    np.testing.assert_allclose(got.cpu().numpy(), padded.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
+
+
 def test_sa_cell_unaligned_weights_take_the_scalar_staging_path():
     """The C-ABI takes any float pointers: weights that are not 16-byte aligned are staged with dword copies and give
     bit-identical results."""
