@@ -2300,6 +2300,173 @@ static int sa_cell16_launch(long groups, SaGatherSrc src, const float* w0, const
   return pasnl_launch_status();
 }
 
+// =============================================================================================
+// pasnl_sa_cell for the WIDE layers (c1 = c2 = 256 or 512: pointasnl_sem_seg.py:34 layer4, pointasnl_sem_seg_res.py:46-51
+// layer3_2 / 4_1 / 4_2): their weights (262 x 256 + 256 x 256 floats and up) do not fit the LDS, and they have few groups
+// (320 .. 640), so the persistent one-wave-per-group kernel above has nothing to amortise a weight copy over.  Here ONE
+// WORKGROUP owns one group and its c / 32 waves each own a 32-channel block of both convolutions:
+//   1. the group's 32 rows [xyz - centre | xyz | 1 | 0 | feature] are gathered into LDS once (Xs, odd row pitch);
+//      the skip maxima are column maxima of that tile;
+//   2. conv0: wave v accumulates H1^T block v (32 channels x 32 rows): A = W0 rows straight from global memory (L2: every
+//      workgroup streams the same 270 .. 1 060 KiB), B = X from LDS; ReLU; the block goes to LDS as H1[row][channel];
+//   3. conv1 (when the layer has one): H2 block v (32 rows x 32 channels) from H1 (LDS) and W1 (global); bias, ReLU;
+//      a layer with a single convolution (mlp = [c, c]) reads its H2 block back from H1 instead -- no identity product;
+//   4. G = relu(X[:, 0:3] Ww + bw) per wave (3 MFMA steps), M block v = H2^T G, stored as in the kernel above.
+//   v_mfma_f32_32x32x2_f32 throughout, D tiles chained as operands exactly as above (kappa).  k = 32 (one tile per group).
+// =============================================================================================
+template <int C, bool CONV1>
+__global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGatherSrc src, const float* __restrict__ w0,
+                                                                  const float* __restrict__ b0, const float* __restrict__ w1,
+                                                                  const float* __restrict__ b1, const float* __restrict__ ww,
+                                                                  const float* __restrict__ bw, float* __restrict__ out) {
+  constexpr int NW = C / 32, T = NW * 64, HP = C + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int cf = w - 6, wi = 8 + cf;        // internal width (a multiple of 8: cf % 4 == 0 and the launcher asks for cf % 8 == 0)
+  const int xp = wi + 1;                    // odd row pitch: conflict-free column-pair reads by 32 rows
+  float* Xs = reinterpret_cast<float*>(smem);          // [32][xp]
+  float* H1s = Xs + 32 * xp;                           // [32][HP]
+  int* rows = reinterpret_cast<int*>(H1s + 32 * HP);   // [32] neighbour indices of the group
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ql = lane & 31;
+  const int g = blockIdx.x;
+  const int bi = g / src.m;
+  if (tid < 32) rows[tid] = src.idx[(size_t)g * 32 + tid];
+  __syncthreads();
+  // ---- 1. gather
+  {
+    const float* fb = src.feature + (size_t)bi * src.n * cf;
+    const int q4 = cf >> 2;
+    for (int i = tid; i < 32 * q4; i += T) {
+      const int r = i / q4, q = i - r * q4;
+      const float4 v = reinterpret_cast<const float4*>(fb + (size_t)rows[r] * cf)[q];
+      float* d = Xs + r * xp + 8 + 4 * q;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if (tid < 32) {
+      const float* pp = src.xyz + ((size_t)bi * src.n + rows[tid]) * 3;
+      const float* cc = src.new_xyz + (size_t)g * 3;
+      const float px = pp[0], py = pp[1], pz = pp[2];
+      float* d = Xs + tid * xp;
+      d[0] = px - cc[0]; d[1] = py - cc[1]; d[2] = pz - cc[2];
+      d[3] = px; d[4] = py; d[5] = pz; d[6] = 1.f; d[7] = 0.f;
+    }
+  }
+  __syncthreads();
+  // skip maxima (pointasnl_util.py:258): reference column c = internal column c (c < 6) or c + 2
+  for (int c = tid; c < w; c += T) {
+    const float* col = Xs + (c < 6 ? c : c + 2);
+    float mx = col[0];
+#pragma unroll 8
+    for (int r = 1; r < 32; ++r) mx = fmaxf(mx, col[r * xp]);
+    src.skip_max[(size_t)g * w + c] = mx;
+  }
+  // ---- 2. conv0: H1^T block `wave`.  Step s contracts internal columns 2 s (lanes 0..31) and 2 s + 1 (lanes 32..63);
+  // internal rows of W0: 0..5 = w0 rows 0..5, 6 = b0 (the bias rides on the constant-1 column), 7 = zero, 8.. = w0 rows 6..
+  const int ch = wave * 32 + ql;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  {
+    const float* xrow = Xs + ql * xp + h;
+    // the first four steps (columns 0..7)
+    const float a3 = h ? 0.f : b0[ch];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(size_t)(2 * s + h) * C + ch], xrow[2 * s], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, xrow[6], acc, 0, 0, 0);
+    // the features: w0 row 2 s + h - 2, in batches of BT steps, the next batch's operands requested while this one multiplies
+    constexpr int BT = 8;   // (16 measured slower: 139 vs 126 us at 320 groups of 512 channels)
+    const float* wp = w0 + (size_t)(6 + h) * C + ch;  // w0 row of internal column 8 + h
+    const int nsteps = cf >> 1;                        // a multiple of BT (cf % 16 == 0)
+    float wa[2][BT], xb[2][BT];
+#pragma unroll
+    for (int u = 0; u < BT; ++u) { wa[0][u] = wp[(size_t)(2 * u) * C]; xb[0][u] = xrow[8 + 2 * u]; }
+    for (int s0 = 0; s0 < nsteps; s0 += 2 * BT) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int sb = s0 + half * BT;
+        if (sb < nsteps) {
+          const int sn = min(sb + BT, nsteps - BT);  // the batch after this one (a dummy re-read at the end)
+#pragma unroll
+          for (int u = 0; u < BT; ++u) { wa[half ^ 1][u] = wp[(size_t)(2 * (sn + u)) * C]; xb[half ^ 1][u] = xrow[8 + 2 * (sn + u)]; }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < BT; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[half][u], xb[half][u], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  // ReLU; D[m = channel wave*32 + kappa(r,h)][n = row ql] -> H1s[row][channel]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) H1s[ql * HP + wave * 32 + kappa(r, h)] = fmaxf(acc[r], 0.f);
+  __syncthreads();
+  // ---- 3. conv1 (or the block of H1 itself): H2[m = row kappa(t,h)][n = channel ch]
+  f32x16 H2;
+  if constexpr (CONV1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) H2[r] = 0.f;
+    constexpr int BT = 8, NS = C / 2;
+    const float* hrow = H1s + ql * HP + h;
+    const float* wp = w1 + (size_t)h * C + ch;
+    float wa[2][BT], xb[2][BT];
+#pragma unroll
+    for (int u = 0; u < BT; ++u) { wa[0][u] = wp[(size_t)(2 * u) * C]; xb[0][u] = hrow[2 * u]; }
+    for (int s0 = 0; s0 < NS; s0 += 2 * BT) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int sb = s0 + half * BT;
+        const int sn = min(sb + BT, NS - BT);
+#pragma unroll
+        for (int u = 0; u < BT; ++u) { wa[half ^ 1][u] = wp[(size_t)(2 * (sn + u)) * C]; xb[half ^ 1][u] = hrow[2 * (sn + u)]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < BT; ++u) H2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[half][u], wa[half][u], H2, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const float bb = b1[ch];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) H2[r] = fmaxf(H2[r] + bb, 0.f);
+  } else {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) H2[t] = H1s[kappa(t, h) * HP + ch];
+  }
+  // ---- 4. weight net on the centred coordinates: G[m = row kappa][n = j]; columns 0..3 = dx dy dz x (x is no input: zero row)
+  f32x16 G;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) G[r] = 0.f;
+  {
+    const float* xrow = Xs + ql * xp + h;
+    const float b0w = ww[h * 32 + ql], b1w = h ? 0.f : ww[2 * 32 + ql];
+    G = __builtin_amdgcn_mfma_f32_32x32x2f32(xrow[0], b0w, G, 0, 0, 0);
+    G = __builtin_amdgcn_mfma_f32_32x32x2f32(xrow[2], b1w, G, 0, 0, 0);
+    const float bj = bw[ql];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[r] = fmaxf(G[r] + bj, 0.f);
+  }
+  f32x16 M;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) M[r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) M = __builtin_amdgcn_mfma_f32_32x32x2f32(H2[t], G[t], M, 0, 0, 0);
+  float* o = out + (size_t)g * C * 32;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[(size_t)(wave * 32 + kappa(r, h)) * 32 + ql] = M[r];
+}
+
+template <int C, bool CONV1>
+static int sa_cell_wide_launch(long groups, int w, SaGatherSrc src, const float* w0, const float* b0, const float* w1,
+                               const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
+  const int wi = 8 + (w - 6);
+  const size_t lds = ((size_t)32 * (wi + 1) + (size_t)32 * (C + 1) + 32) * sizeof(float);
+  if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
+  auto kern = sa_cell_wide_kernel<C, CONV1>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(C / 32 * 64), lds, st, w, src, w0, b0, w1, b1, ww, bw, out);
+  return pasnl_launch_status();
+}
+
 // Waves per workgroup: two waves per SIMD (8 per workgroup, one LDS copy of the weights) where 256 registers per wave
 // suffice (c1 <= 64; 201 vs 240 us at cls layer1, 44 vs 59 us at ScanNet layer2 when measured); the 128-channel cell
 // needs ~350 registers (at 8 waves it spilled: 3 % faster, 2.4x the HBM bytes) and runs one wave per SIMD.
@@ -2336,7 +2503,9 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   const long groups = (long)b * m;
   if (groups == 0) return PASNL_OK;
   PASNL_REQUIRE(groups < (1L << 31), PASNL_EUNSUPPORTED);
-  PASNL_REQUIRE(xyz && feature && idx && w0 && b0 && w1 && b1 && ww && bw && out && skip_max, PASNL_ENULL);
+  PASNL_REQUIRE(xyz && feature && idx && w0 && b0 && ww && bw && out && skip_max, PASNL_ENULL);
+  // w1 == NULL: the layer has ONE convolution (mlp = [c, c]: the *_2 layers of pointasnl_sem_seg_res.py) -- the wide kernel only
+  PASNL_REQUIRE((w1 && b1) || c1 >= 256, PASNL_ENULL);
   // new_xyz == NULL: the centre of a group is its neighbour 0.  The kernel's centre prefetch stays unconditional and is
   // pointed at xyz, whose b*n*3 floats cover the b*m*3 it touches when m <= n
   PASNL_REQUIRE(new_xyz || m <= n, PASNL_EUNSUPPORTED);
@@ -2349,6 +2518,14 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   // the row's last chunk: live MFMA steps (0 = the width is a multiple of 32); see TAIL8
   const int wi = 8 + c, rem = wi & 31;
   const bool tail8 = rem != 0 && (vec ? rem : (rem + 1) >> 1) <= 8;
+  if ((c1 == 256 && c2 == 256) || (c1 == 512 && c2 == 512)) {  // the wide layers: one workgroup per group, weights from L2
+    PASNL_REQUIRE(k == 32 && c % 16 == 0 && new_xyz && reinterpret_cast<uintptr_t>(feature) % 16 == 0, PASNL_EUNSUPPORTED);
+    if (c1 == 256)
+      return w1 ? sa_cell_wide_launch<256, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st)
+                : sa_cell_wide_launch<256, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
+    return w1 ? sa_cell_wide_launch<512, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st)
+              : sa_cell_wide_launch<512, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  }
   if (c1 == 16 && c2 == 16) {  // the 16-channel first layer: xyz-only rows, 32 neighbours, centres from a table
     PASNL_REQUIRE(c == 3 && k == 32 && new_xyz, PASNL_EUNSUPPORTED);
     return sa_cell16_launch(groups, src, w0, b0, w1, b1, ww, bw, out, st);

@@ -790,7 +790,11 @@ static int fps_dispatch(int b, int n, int m, const float* xyz, int* idx, float* 
   if (n <= 128) return fps_launch<1, 2>(b, n, m, xyz, idx, st, oxyz);
   if (n <= 256) return fps_launch<1, 4>(b, n, m, xyz, idx, st, oxyz);
   if (n <= 512) return fps_launch<1, 8>(b, n, m, xyz, idx, st, oxyz);
-  if (n <= 1024) return fps_launch<4, 4>(b, n, m, xyz, idx, st, oxyz);   // measured: (4,4) 192 us vs (1,16) 241 us at B=64, m=512
+  // 513..1024 points.  Up to ~2 clouds per CU the four-wave workgroup wins (the round is a latency chain and four waves share
+  // its arithmetic: 199 vs 246 us at B = 64, 203 vs 250 at B = 256, 1024 -> 512); beyond that the CUs are full and ONE wave
+  // per cloud -- 16 points per lane, no barrier, no LDS hop between waves -- is cheaper per cloud: 269 vs 318 us at B = 1024,
+  // 387 vs 524 at B = 2048 (tools/fps_batch_sweep.py, profiles/r04_g_fps_batch_sweep.txt)
+  if (n <= 1024) return b > 640 ? fps_launch<1, 16>(b, n, m, xyz, idx, st, oxyz) : fps_launch<4, 4>(b, n, m, xyz, idx, st, oxyz);
   if (n <= 2048) return fps_launch<4, 8>(b, n, m, xyz, idx, st, oxyz);   // measured (tools/fps_cfg_sweep.py): 146 vs 207 us for (2,16) at 8x1280->320, 231 vs 329 us at 16x2048->512
   if (!tune_env("PASNL_FPS_NOPRUNE")) {
     // pruned rounds (fps_pruned_kernel): the unpruned kernels below stay as the A/B reference

@@ -86,6 +86,7 @@ def sa_group(xyz, feature, idx, new_xyz):
 SA_TAIL_MIN_ROWS = 2048
 SA_TAIL_FUSED = True     # skip conv + back-projection + adds + aggregation in one kernel (pasnl_sa_tail); False = op by op
 SA_CELL_GATHER = True    # grouping fused into the local cell (pasnl_sa_cell); False = pasnl_sa_group + pasnl_sa_local_cell
+SA_CELL_WIDE = True      # the 256- / 512-channel layers on pasnl_sa_cell too (False: pasnl_sa_group + the vendor chain, A/B)
 LOCAL_CELL_FUSED = True  # False = the reference's op-by-op chain on the vendor BLAS (kept for A/B and as fallback)
 
 
@@ -94,9 +95,10 @@ def _local_cell_supported(w, mlp, nsample):
     PASNL_EUNSUPPORTED beyond them, which PointASNLSetAbstraction catches and answers with the next path down."""
     if not LOCAL_CELL_FUSED or nsample % 32:
         return False
+    wide = (256, 512) if SA_CELL_WIDE else ()  # one workgroup per group, weights streamed from L2 (sa_cell_wide_kernel)
     if len(mlp) == 3:  # conv0 -> conv1 -> (weight net, matmul) -> after_conv
-        return mlp[0] == mlp[1] and mlp[0] in (16, 32, 64, 128)
-    return len(mlp) == 2 and mlp[0] in (32, 64, 128)  # one convolution only (the *_2 layers of pointasnl_sem_seg_res.py)
+        return mlp[0] == mlp[1] and mlp[0] in (16, 32, 64, 128) + wide
+    return len(mlp) == 2 and mlp[0] in (32, 64, 128) + wide  # one convolution only (the *_2 layers of pointasnl_sem_seg_res.py)
 
 
 def sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn):
@@ -140,6 +142,8 @@ def _sa_cell_weights(w_in, mlp, bn, weight_decay, native16=False):
         if len(mlp) == 3:
             with tf_util.variable_scope('conv1'):
                 w1, b1 = st.layer(c1, mlp[1], bn, weight_decay)
+        elif c1 >= 256:
+            w1, b1 = None, None  # the wide kernel takes "no conv1" as such (no 256 x 256 identity product)
         else:
             w1, b1 = torch.eye(c1, dtype=torch.float32, device=w0.device), torch.zeros(c1, dtype=torch.float32, device=w0.device)
         with tf_util.variable_scope('weight_net'), tf_util.variable_scope('wconv0'):
@@ -151,7 +155,7 @@ def _sa_cell_weights(w_in, mlp, bn, weight_decay, native16=False):
             b0 = torch.nn.functional.pad(b0, (0, pad))
             w1 = torch.nn.functional.pad(w1, (0, pad, 0, pad))
             b1 = torch.nn.functional.pad(b1, (0, pad))
-        st._folded[key] = tuple(t.contiguous() for t in (w0, b0, w1, b1, ww, bw)) + (ck,)
+        st._folded[key] = tuple(None if t is None else t.contiguous() for t in (w0, b0, w1, b1, ww, bw)) + (ck,)
     return st._folded[key]
 
 

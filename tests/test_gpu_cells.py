@@ -237,6 +237,38 @@ def test_sa_cell_16_channels_native_kernel(b, n, m, monkeypatch):
     np.testing.assert_allclose(got.cpu().numpy(), padded.cpu().numpy(), rtol=1e-5, atol=1e-6 * scale)
 
 
+@pytest.mark.parametrize("b,n,c,m,c1,conv1", [(2, 300, 256, 40, 256, True), (1, 128, 256, 33, 256, False), (2, 96, 512, 20, 512, False),
+                                               (1, 64, 128, 7, 256, True), (1, 80, 512, 3, 512, True)])
+def test_sa_cell_wide_layers(b, n, c, m, c1, conv1):
+    """The 256- / 512-channel layers (pointasnl_sem_seg.py:34, pointasnl_sem_seg_res.py:46-51) on pasnl_sa_cell: one workgroup per
+    group, weights from L2; with conv1 (mlp [c, c, out]) and without (mlp [c, c]: the *_2 layers).  fp64 restatement to 1e-5,
+    skip maxima bit-equal."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    st = _store(b * 13 + c1 + m)
+    rng = np.random.default_rng(n + c + m)
+    xyz = clouds(25, b, n)
+    feat = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, 32)).astype(np.int32)
+    new_xyz = clouds(26, b, m)
+    mlp = [c1, c1, 2 * c1] if conv1 else [c1, c1]
+    with st.scope("L"):
+        got, skip = U.sa_cell(dev(xyz), dev(feat), dev(idx), dev(new_xyz), mlp, False, None, None, True)
+    assert got.shape == (b, m, c1, 32)
+    bi = np.arange(b)[:, None, None]
+    gx = xyz[bi, idx]
+    x = np.concatenate([gx - new_xyz[:, :, None, :], gx, feat[bi, idx]], axis=-1)
+    np.testing.assert_array_equal(skip.cpu().numpy(), x.max(axis=2))
+    p = st.export_numpy()
+    x64 = x.astype(np.float64)
+    hcell = cells._layer(x64, p["L/conv0"], "relu")
+    if conv1:
+        hcell = cells._layer(hcell, p["L/conv1"], "relu")
+    wn = cells._layer(x64[..., :3], p["L/weight_net/wconv0"], "relu")
+    want = np.swapaxes(hcell, 2, 3) @ wn
+    assert np.abs(got.cpu().numpy() - want).max() / np.abs(want).max() < 1e-5
+
+
 def test_sa_cell_unaligned_weights_take_the_scalar_staging_path():
     """The C-ABI takes any float pointers: weights that are not 16-byte aligned are staged with dword copies and give
     bit-identical results."""

@@ -90,6 +90,16 @@ def test_gather_point_and_grad(P):
     np.testing.assert_array_equal(x.grad.cpu().numpy(), O.gather_point_grad(xyz, idx, g))
 
 
+@pytest.mark.parametrize("kind", ["ball", "lattice"])
+def test_fps_many_clouds_take_the_one_wave_kernel(P, kind):
+    """More than 640 clouds of 513..1024 points are sampled by one wave per cloud (16 points per lane): the same picks, ties
+    included (the lattice clouds are full of equal distances)."""
+    xyz = clouds(77, 704, 1000, kind)
+    want = O.farthest_point_sample(300, xyz)
+    got = P.tf_sampling.farthest_point_sample(300, dev(xyz)).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("b,n,m,ns,r,kind", [
     (32, 512, 128, 64, 0.1, "cube"),      # the reference's own micro-bench shape (tf_grouping.py:78-88)
     (4, 1024, 512, 32, 0.2, "ball"),
