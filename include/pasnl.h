@@ -216,7 +216,11 @@ int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, const float* x
  * (L2-resident), so the (b,m,k,6+c) grouped tensor never exists in HBM.  Also returns the skip connection's
  * reduce_max over the k neighbours: skip_max (b,m,6+c) -- bit-equal to pasnl_sa_group's.
  * out (b*m, c2*32) as pasnl_sa_local_cell.  Replaces two tf.gather_nd, two concats, a subtraction, a reduce_max,
- * three conv2d, a transpose and a batched matmul of the reference graph.  Same shape limits as above.
+ * three conv2d, a transpose and a batched matmul of the reference graph.  Shape limits as above for c1 = c2 in {32, 64, 128}; also
+ *   c1 = c2 = 16 (pointasnl_sem_seg_res.py:32: xyz-only rows c = 3, k = 32, new_xyz given): a 16x16x4-MFMA kernel, no padding;
+ *   c1 = c2 in {256, 512} (pointasnl_sem_seg.py:34, pointasnl_sem_seg_res.py:46-51: k = 32, c % 16 == 0, feature 16-byte aligned,
+ *   new_xyz given): one workgroup per group, weights streamed from L2; there w1 = b1 = NULL means the layer has a single
+ *   convolution (mlp = [c, c]) and H2 = H1.
  * new_xyz == NULL: the centre of group (b,j) is its own neighbour 0, xyz[b, idx[b,j,0]] -- AdaptiveSampling with
  * as_neighbor == 0 (pointasnl_util.py:161-163), taken from the tile the kernel gathers anyway, so that the launch does not
  * wait for pasnl_take_neighbor0 (needs m <= n, else PASNL_EUNSUPPORTED). */
