@@ -37,13 +37,24 @@ struct KtFrame {  // one activation of divideTree
 
 __device__ __forceinline__ size_t kt_align(size_t x) { return (x + 15) & ~(size_t)15; }
 static inline size_t kt_align_h(size_t x) { return (x + 15) & ~(size_t)15; }
-// workspace of one cloud: [flag, root, nodes used, depth] | vind[n] | nodes[2n] | build frames[KT_DEPTH]
-static inline size_t kt_cloud_bytes(int n) {
-  return kt_align_h(16) + kt_align_h((size_t)n * 4) + kt_align_h((size_t)2 * n * sizeof(KtNode)) + kt_align_h((size_t)KT_DEPTH * sizeof(KtFrame));
+struct KtWork {  // an inner node waiting for its split (parallel build): the activation's arguments
+  int node;
+  unsigned left, right;
+  float box[6];
+};
+constexpr int KTB_WAVES = 16;          // waves of the parallel build's workgroup (one workgroup per cloud)
+constexpr int KTB_NMAX = 10240;        // points per cloud it holds in LDS (vind + the cut coordinate + a scratch slice)
+static inline int kt_queue_cap(int n) { return n / (KT_LEAF + 1) + 2; }  // inner nodes of one level: more than KT_LEAF points each
+// workspace of one cloud: [flag, root, nodes used, depth] | vind[n] | nodes[2n] | build frames[KT_DEPTH] | 2 level queues |
+// recs[n]: {x, y, z, index} of vind[i] -- the points in LEAF ORDER, so that a leaf's scan is one contiguous read
+static inline size_t kt_recs_offset(int n) {
+  return kt_align_h(16) + kt_align_h((size_t)n * 4) + kt_align_h((size_t)2 * n * sizeof(KtNode)) + kt_align_h((size_t)KT_DEPTH * sizeof(KtFrame)) +
+         2 * kt_align_h((size_t)kt_queue_cap(n) * sizeof(KtWork));
 }
+static inline size_t kt_cloud_bytes(int n) { return kt_recs_offset(n) + kt_align_h((size_t)n * 16); }
 
 __global__ __launch_bounds__(64) void knn_tree_build_kernel(int n, const float* __restrict__ pts_all, char* __restrict__ ws_all,
-                                                           size_t stride) {
+                                                           size_t stride, size_t recs_off) {
   if (threadIdx.x != 0) return;
   const float* pts = pts_all + (size_t)blockIdx.x * n * 3;
   char* ws = ws_all + (size_t)blockIdx.x * stride;
@@ -186,38 +197,281 @@ __global__ __launch_bounds__(64) void knn_tree_build_kernel(int n, const float* 
 
   KtFrame& out = st[1];
   for (int i = 0; i < 6; ++i) out.bbox[i] = st[0].bbox[i];
+  {
+    float4* recs = reinterpret_cast<float4*>(ws + recs_off);
+    for (int i = 0; i < n; ++i) recs[i] = make_float4(get(vind[i], 0), get(vind[i], 1), get(vind[i], 2), __int_as_float((int)vind[i]));
+  }
   hdr[1] = st[0].node;
   hdr[2] = nnodes;
   hdr[3] = maxdepth;
 }
 
-struct KtSearchFrame {
-  int node, other, feat, state;
-  float mindistsq, cut, dst;
-};
+// ---------------------------------------------------------------------------------------------------------------------
+// The same tree, built by a WORKGROUP per cloud (n <= KTB_NMAX).  What makes the serial build slow is not its arithmetic
+// but that one lane walks a chain of dependent global loads (60 ms for 16 clouds of 8192 points); what makes it look
+// inherently serial is planeSplit's in-place Hoare partition.  Both yield:
+//   * the activations of one tree LEVEL are independent (disjoint slices of vind): a wave per node, level by level, the
+//     nodes of the next level queued in the workspace (breadth first instead of the reference's recursion -- the node
+//     NUMBERS differ, the tree does not, and the search follows child pointers);
+//   * computeMinMax is a min / max reduction (exact in any order);
+//   * planeSplit (nanoflann.hpp:1016-1043) ends in a state that depends only on which elements satisfy the predicate:
+//     with c of them, the i-th violator among the first c positions (ascending) has been swapped with the i-th satisfier
+//     among the rest (DESCENDING), nothing else has moved, and the pointers meet at c (the `right &&` guard only ever stops
+//     a scan that has nothing left to swap).  Ranks by ballot + prefix popcount, positions through a scratch slice, swaps in
+//     parallel -- the same permutation as the loop, element for element (checked against a transcription of the loop on
+//     200 000 random slices with ties, tests/test_knn_tree_partition.py, and against the serial build on the GPU);
+//   * the tight box a child returns is the bounding box of its points, so divlow / divhigh (:956-957) are the maximum of
+//     the left part / the minimum of the right part along the cut dimension -- two more reductions, no second traversal.
+// The cut coordinate of a node's points sits in LDS next to vind and is permuted with it; the other coordinates are read
+// from global memory (L2) for the candidate dimensions of middleSplit_ only.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ktb_wave_sync() {  // LDS operations of a wave execute in order; keep the compiler from moving them
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-template <typename IdxT>
-__global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k, const float* __restrict__ pts_all,
-                                                            const float* __restrict__ queries, const char* __restrict__ ws_all,
-                                                            size_t stride, float* __restrict__ rdist_all, int* __restrict__ ridx_all,
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int n, const float* __restrict__ pts_all,
+                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned* vind = reinterpret_cast<unsigned*>(smem);                       // [n]
+  float* vals = reinterpret_cast<float*>(vind + n);                          // [n] cut coordinate of vind[i] (current node)
+  unsigned short* sc = reinterpret_cast<unsigned short*>(vals + n);          // [n] positions of misplaced elements
+  float* part = reinterpret_cast<float*>(sc + ((n + 1) & ~1));               // [KTB_WAVES][6] root-box partials
+  int* ctr = reinterpret_cast<int*>(part + KTB_WAVES * 6);                   // [0], [1]: queue lengths; [2]: nodes used; [3]: flag
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* pts = pts_all + (size_t)blockIdx.x * n * 3;
+  char* ws = ws_all + (size_t)blockIdx.x * stride;
+  int* hdr = reinterpret_cast<int*>(ws);
+  unsigned* gvind = reinterpret_cast<unsigned*>(ws + kt_align(16));
+  KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(16) + kt_align((size_t)n * 4));
+  KtFrame* fr = reinterpret_cast<KtFrame*>(ws + kt_align(16) + kt_align((size_t)n * 4) + kt_align((size_t)2 * n * sizeof(KtNode)));
+  const int qcap = n / (KT_LEAF + 1) + 2;
+  KtWork* queue[2];
+  queue[0] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(fr) + kt_align((size_t)KT_DEPTH * sizeof(KtFrame)));
+  queue[1] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(queue[0]) + kt_align((size_t)qcap * sizeof(KtWork)));
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));  // lanes below this one
+
+  // init_vind (:1318), computeBoundingBox (:1321-1346)
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = tid; i < n; i += KTB_WAVES * 64) {
+    vind[i] = (unsigned)i;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float v = pts[(size_t)i * 3 + d];
+      lo[d] = v < lo[d] ? v : lo[d];
+      hi[d] = v > hi[d] ? v : hi[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { lo[d] = wave_min_f32(lo[d]); hi[d] = wave_max_f32(hi[d]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { part[wave * 6 + 2 * d] = lo[d]; part[wave * 6 + 2 * d + 1] = hi[d]; }
+  }
+  if (tid < 4) ctr[tid] = 0;
+  __syncthreads();
+  float root[6];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float l = part[2 * d], h = part[2 * d + 1];
+    for (int w = 1; w < KTB_WAVES; ++w) { l = fminf(l, part[w * 6 + 2 * d]); h = fmaxf(h, part[w * 6 + 2 * d + 1]); }
+    root[2 * d] = l; root[2 * d + 1] = h;
+  }
+  if (tid == 0) {
+    ctr[2] = 1;  // node 0 = the root
+    if (n <= KT_LEAF) {
+      nodes[0].child1 = nodes[0].child2 = -1; nodes[0].a = 0; nodes[0].divlow = __int_as_float(n); nodes[0].divhigh = 0.f;
+    } else {
+      KtWork w0; w0.node = 0; w0.left = 0; w0.right = (unsigned)n;
+      for (int i = 0; i < 6; ++i) w0.box[i] = root[i];
+      queue[0][0] = w0;
+      ctr[0] = 1;
+    }
+    for (int i = 0; i < 6; ++i) fr[1].bbox[i] = root[i];  // root_bbox after divideTree = the tight box of all points (what the search reads)
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  int cur = 0, level = 0;
+  for (;;) {
+    const int nq = ctr[cur];
+    if (nq == 0) break;
+    if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }  // deeper than the search's stack: flagged, not built
+    for (int e = wave; e < nq; e += KTB_WAVES) {
+      KtWork wk;  // the same address in every lane; written by another wave one level ago: plain vector loads, never the scalar cache
+      {
+        const volatile KtWork* qe = queue[cur] + e;
+        wk.node = qe->node; wk.left = qe->left; wk.right = qe->right;
+        for (int i = 0; i < 6; ++i) wk.box[i] = qe->box[i];
+      }
+      const unsigned left = wk.left, right = wk.right, count = right - left;
+      // ---- middleSplit_ (:966-1005)
+      const float EPS = 0.00001f;
+      float max_span = wk.box[1] - wk.box[0];
+      for (int d = 1; d < 3; ++d) {
+        const float span = wk.box[2 * d + 1] - wk.box[2 * d];
+        if (span > max_span) max_span = span;
+      }
+      float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
+      int cutfeat = 0;
+      for (int d = 0; d < 3; ++d) {
+        const float span = wk.box[2 * d + 1] - wk.box[2 * d];
+        if (span > (1 - EPS) * max_span) {
+          float mn = INFINITY, mx = -INFINITY;  // computeMinMax (:898-907)
+          for (unsigned p = lane; p < count; p += 64) {
+            const float v = pts[(size_t)vind[left + p] * 3 + d];
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+          }
+          mn = wave_min_f32(mn); mx = wave_max_f32(mx);
+          const float spread = mx - mn;
+          if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn; mx_c = mx; }
+        }
+      }
+      const float split_val = (wk.box[2 * cutfeat] + wk.box[2 * cutfeat + 1]) / 2;
+      float cutval;  // (the second computeMinMax of the reference, on cutfeat, returns mn_c / mx_c again)
+      if (split_val < mn_c) cutval = mn_c;
+      else if (split_val > mx_c) cutval = mx_c;
+      else cutval = split_val;
+      for (unsigned p = lane; p < count; p += 64) vals[left + p] = pts[(size_t)vind[left + p] * 3 + cutfeat];
+      ktb_wave_sync();
+      // ---- planeSplit (:1016-1043): two passes, each the parallel form of the Hoare loop (header)
+      unsigned lim[2];
+      unsigned lo_p = 0;
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        auto pred = [&](float v) { return pass == 0 ? v < cutval : v <= cutval; };
+        unsigned cnt = 0;
+        for (unsigned p0 = lo_p; p0 < count; p0 += 64) {
+          const unsigned p = p0 + lane;
+          cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p < count && pred(vals[left + p])));
+        }
+        const unsigned mid = lo_p + cnt;  // where the pointers meet
+        unsigned nl = 0, nr = 0;
+        for (unsigned p0 = lo_p; p0 < mid; p0 += 64) {  // violators among the first cnt positions, ascending
+          const unsigned p = p0 + lane;
+          const bool mis = p < mid && !pred(vals[left + p]);
+          const unsigned long long mk = __builtin_amdgcn_ballot_w64(mis);
+          if (mis) sc[left + lo_p + nl + (unsigned)__builtin_popcountll(mk & lt_mask)] = (unsigned short)p;
+          nl += (unsigned)__builtin_popcountll(mk);
+        }
+        for (unsigned q0 = 0; mid + q0 < count; q0 += 64) {  // satisfiers among the rest, descending
+          const unsigned q = q0 + lane;
+          const bool in = mid + q < count;
+          const unsigned p = count - 1 - (in ? q : 0);
+          const bool mis = in && pred(vals[left + p]);
+          const unsigned long long mk = __builtin_amdgcn_ballot_w64(mis);
+          if (mis) sc[right - 1 - (nr + (unsigned)__builtin_popcountll(mk & lt_mask))] = (unsigned short)p;
+          nr += (unsigned)__builtin_popcountll(mk);
+        }
+        ktb_wave_sync();
+        for (unsigned i = lane; i < nl; i += 64) {  // nl == nr
+          const unsigned a = left + sc[left + lo_p + i], b = left + sc[right - 1 - i];
+          const unsigned ta = vind[a], tb = vind[b];
+          const float va = vals[a], vb = vals[b];
+          vind[a] = tb; vind[b] = ta;
+          vals[a] = vb; vals[b] = va;
+        }
+        ktb_wave_sync();
+        lim[pass] = mid;
+        lo_p = mid;
+      }
+      unsigned index;
+      if (lim[0] > count / 2) index = lim[0];
+      else if (lim[1] < count / 2) index = lim[1];
+      else index = count / 2;
+      // ---- the children's tight boxes along cutfeat: divlow = max of the left part, divhigh = min of the right part (:956-957)
+      float dl = -INFINITY, dh = INFINITY;
+      for (unsigned p = lane; p < count; p += 64) {
+        const float v = vals[left + p];
+        if (p < index) dl = v > dl ? v : dl;
+        else dh = v < dh ? v : dh;
+      }
+      dl = wave_max_f32(dl); dh = wave_min_f32(dh);
+      if (lane == 0) {
+        int child[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned cl = c == 0 ? left : left + index, cr = c == 0 ? left + index : right;
+          const int id = atomicAdd(&ctr[2], 1);
+          child[c] = id;
+          if (cr - cl <= (unsigned)KT_LEAF) {  // leaf (:921-936)
+            nodes[id].child1 = nodes[id].child2 = -1;
+            nodes[id].a = (int)cl;
+            nodes[id].divlow = __int_as_float((int)cr);
+            nodes[id].divhigh = 0.f;
+          } else {
+            KtWork w;
+            w.node = id; w.left = cl; w.right = cr;
+            for (int i = 0; i < 6; ++i) w.box[i] = wk.box[i];
+            if (c == 0) w.box[2 * cutfeat + 1] = cutval;  // left child: high = cutval (:946-947); right child: low = cutval (:951-952)
+            else w.box[2 * cutfeat] = cutval;
+            queue[cur ^ 1][atomicAdd(&ctr[cur ^ 1], 1)] = w;
+          }
+        }
+        KtNode nd;
+        nd.child1 = child[0]; nd.child2 = child[1]; nd.a = cutfeat; nd.divlow = dl; nd.divhigh = dh;
+        nodes[wk.node] = nd;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) ctr[cur] = 0;
+    cur ^= 1;
+    ++level;
+    __syncthreads();
+  }
+  __syncthreads();
+  float4* recs = reinterpret_cast<float4*>(ws + recs_off);
+  for (int i = tid; i < n; i += KTB_WAVES * 64) {
+    const unsigned v = vind[i];
+    gvind[i] = v;
+    recs[i] = make_float4(pts[(size_t)v * 3], pts[(size_t)v * 3 + 1], pts[(size_t)v * 3 + 2], __int_as_float((int)v));
+  }
+  if (tid == 0) { hdr[0] = ctr[3]; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The search: one lane per query, nanoflann's searchLevel (:1351-1410) with an explicit stack.  Everything a step waits for
+// is kept close: the result set and the stack live in LDS (slot-major / lane-minor), a leaf's points arrive as ONE burst of
+// independent 16-byte reads from the leaf-ordered records the build left behind, and a frame is three words:
+//   word 0 = other child | feat << 28 | state << 30,  word 1 = mindistsq,  word 2 = cut (state 1) or the saved dists[feat] (state 2).
+// RS_LDS = false (k > 64): the result set in the caller's workspace.  Frames beyond KT_LDS_DEPTH (pathological trees) go to
+// a per-lane array in scratch memory.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int KT_LDS_DEPTH = 32;
+
+template <typename IdxT, bool RS_LDS>
+__global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k, const float* __restrict__ queries,
+                                                            const char* __restrict__ ws_all, size_t stride, size_t recs_off,
+                                                            float* __restrict__ rdist_all, int* __restrict__ ridx_all,
                                                             IdxT* __restrict__ out, int* __restrict__ flag) {
   const int j = blockIdx.x * 64 + threadIdx.x;
   if (j >= m) return;
   const int bi = blockIdx.y;
-  const float* pts = pts_all + (size_t)bi * n * 3;
   const char* ws = ws_all + (size_t)bi * stride;
   const int* hdr = reinterpret_cast<const int*>(ws);
   if (hdr[0] != 0) { if (j == 0) atomicExch(flag, 1); return; }
-  const unsigned* vind = reinterpret_cast<const unsigned*>(ws + kt_align(16));
   const KtNode* nodes = reinterpret_cast<const KtNode*>(ws + kt_align(16) + kt_align((size_t)n * 4));
   const KtFrame* bst = reinterpret_cast<const KtFrame*>(ws + kt_align(16) + kt_align((size_t)n * 4) + kt_align((size_t)2 * n * sizeof(KtNode)));
+  const float4* recs = reinterpret_cast<const float4*>(ws + recs_off);
   const float* rootbox = bst[1].bbox;
   const float* qp = queries + ((size_t)bi * m + j) * 3;
   const float vec[3] = {qp[0], qp[1], qp[2]};
-  float* rd = rdist_all + ((size_t)bi * m + j) * k;   // KNNResultSet: dists / indices, sorted, `count` valid entries
-  int* ri = ridx_all + ((size_t)bi * m + j) * k;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // the stack: [KT_LDS_DEPTH][3 words][64 lanes]
+  uint32_t* stk = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
+  uint32_t deep[RS_LDS ? (KT_DEPTH - KT_LDS_DEPTH) * 3 : (KT_DEPTH - KT_LDS_DEPTH) * 3];  // frames past the LDS part (never touched by sane trees)
+  auto fw = [&](int level, int word) -> uint32_t& {
+    return level < KT_LDS_DEPTH ? stk[(level * 3 + word) * 64] : deep[(level - KT_LDS_DEPTH) * 3 + word];
+  };
+  // KNNResultSet: dists / indices, sorted, `count` valid entries; entry p of this lane at [p * RS]
+  constexpr int RS = RS_LDS ? 64 : 1;
+  float* rd = RS_LDS ? reinterpret_cast<float*>(smem) + KT_LDS_DEPTH * 3 * 64 + threadIdx.x : rdist_all + ((size_t)bi * m + j) * k;
+  int* ri = RS_LDS ? reinterpret_cast<int*>(smem) + KT_LDS_DEPTH * 3 * 64 + (size_t)k * 64 + threadIdx.x : ridx_all + ((size_t)bi * m + j) * k;
   int count = 0;
-  rd[k - 1] = 3.402823466e+38f;  // init(): dists[capacity-1] = max (:91-92)
+  rd[(k - 1) * RS] = 3.402823466e+38f;  // init(): dists[capacity-1] = max (:91-92)
   // computeInitialDistances (:1045-1061)
   float dists[3] = {0.f, 0.f, 0.f};
   float distsq = 0.f;
@@ -226,69 +480,86 @@ __global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k
     if (vec[d] > rootbox[2 * d + 1]) { dists[d] = (vec[d] - rootbox[2 * d + 1]) * (vec[d] - rootbox[2 * d + 1]); distsq += dists[d]; }
   }
   const float epsError = 1.f;  // 1 + SearchParams(10).eps, eps = 0
-  KtSearchFrame st[KT_DEPTH];
-  int sp = 0;
-  st[0].node = hdr[1]; st[0].mindistsq = distsq; st[0].state = 0;
-  while (sp >= 0) {
-    KtSearchFrame& f = st[sp];
-    const KtNode nd = nodes[f.node];
-    if (f.state == 0) {
+  int node = hdr[1];
+  float mindistsq = distsq;  // of the activation that is running
+  int sp = 0;                // frames below it
+  for (;;) {
+    // ---- descend from `node` to a leaf, pushing an inner node's frame (state 1: near child running) on the way
+    for (;;) {
+      const KtNode nd = nodes[node];
       if (nd.child1 < 0) {  // leaf (:1355-1369): the worst distance is read ONCE, before the scan
-        const float worst = rd[k - 1];
+        const float worst = rd[(k - 1) * RS];
         const int left = nd.a, right = __float_as_int(nd.divlow);
-        for (int i = left; i < right; ++i) {
-          const unsigned index = vind[i];
-          // L2_Adaptor::evalMetric, dim 3: only the tail loop runs (:343-346): result += diff * diff, diff = query - point
-          float dist = 0.f;
-          for (int d = 0; d < 3; ++d) {
-            const float diff = vec[d] - pts[(size_t)index * 3 + d];
-            dist += diff * diff;
-          }
-          if (dist < worst) {  // KNNResultSet::addPoint (:115-134): behind the entries of equal distance
-            int p;
-            for (p = count; p > 0; --p) {
-              if (rd[p - 1] > dist) {
-                if (p < k) { rd[p] = rd[p - 1]; ri[p] = ri[p - 1]; }
-              } else break;
+        float4 rec[KT_LEAF];
+#pragma unroll
+        for (int i = 0; i < KT_LEAF; ++i) rec[i] = recs[min(left + i, n - 1)];  // one burst: the scan below waits once
+#pragma unroll
+        for (int i = 0; i < KT_LEAF; ++i) {
+          if (left + i < right) {
+            // L2_Adaptor::evalMetric, dim 3: only the tail loop runs (:343-346): result += diff * diff, diff = query - point
+            float dist = 0.f;
+            { const float diff = vec[0] - rec[i].x; dist += diff * diff; }
+            { const float diff = vec[1] - rec[i].y; dist += diff * diff; }
+            { const float diff = vec[2] - rec[i].z; dist += diff * diff; }
+            if (dist < worst) {  // KNNResultSet::addPoint (:115-134): behind the entries of equal distance
+              int p;
+              for (p = count; p > 0; --p) {
+                const float prev = rd[(p - 1) * RS];
+                if (prev > dist) {
+                  if (p < k) { rd[p * RS] = prev; ri[p * RS] = ri[(p - 1) * RS]; }
+                } else break;
+              }
+              if (p < k) { rd[p * RS] = dist; ri[p * RS] = __float_as_int(rec[i].w); }
+              if (count < k) ++count;
             }
-            if (p < k) { rd[p] = dist; ri[p] = (int)index; }
-            if (count < k) ++count;
           }
         }
-        --sp;
-        continue;
+        break;
       }
       const int idx = nd.a;
-      const float val = vec[idx];
+      const float val = idx == 0 ? vec[0] : (idx == 1 ? vec[1] : vec[2]);
       const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
-      int best;
-      if ((diff1 + diff2) < 0) { best = nd.child1; f.other = nd.child2; f.cut = (val - nd.divhigh) * (val - nd.divhigh); }
-      else { best = nd.child2; f.other = nd.child1; f.cut = (val - nd.divlow) * (val - nd.divlow); }
-      f.feat = idx;
-      f.state = 1;
+      int best, other;
+      float cut;
+      if ((diff1 + diff2) < 0) { best = nd.child1; other = nd.child2; cut = (val - nd.divhigh) * (val - nd.divhigh); }
+      else { best = nd.child2; other = nd.child1; cut = (val - nd.divlow) * (val - nd.divlow); }
       if (sp + 1 >= KT_DEPTH) { atomicExch(flag, 1); return; }
-      st[sp + 1].node = best; st[sp + 1].mindistsq = f.mindistsq; st[sp + 1].state = 0;
+      fw(sp, 0) = (uint32_t)other | ((uint32_t)idx << 28) | (1u << 30);
+      fw(sp, 1) = __float_as_uint(mindistsq);
+      fw(sp, 2) = __float_as_uint(cut);
       ++sp;
-    } else if (f.state == 1) {  // the near child is done (:1397-1405)
-      const float dst = f.feat == 0 ? dists[0] : (f.feat == 1 ? dists[1] : dists[2]);
-      const float mind = f.mindistsq + f.cut - dst;
-      f.dst = dst;
-      if (f.feat == 0) dists[0] = f.cut; else if (f.feat == 1) dists[1] = f.cut; else dists[2] = f.cut;
-      if (mind * epsError <= rd[k - 1]) {
-        f.state = 2;
-        st[sp + 1].node = f.other; st[sp + 1].mindistsq = mind; st[sp + 1].state = 0;
-        ++sp;
-      } else {
-        if (f.feat == 0) dists[0] = dst; else if (f.feat == 1) dists[1] = dst; else dists[2] = dst;
+      node = best;  // (the near child inherits mindistsq, :1396)
+    }
+    // ---- return: pop frames until one still has its far child to run
+    bool descend = false;
+    while (sp > 0) {
+      const uint32_t w0 = fw(sp - 1, 0);
+      const int feat = (int)((w0 >> 28) & 3u);
+      if ((w0 >> 30) == 1u) {  // the near child is done (:1397-1405)
+        const float fmind = __uint_as_float(fw(sp - 1, 1)), cut = __uint_as_float(fw(sp - 1, 2));
+        const float dst = feat == 0 ? dists[0] : (feat == 1 ? dists[1] : dists[2]);
+        const float mind = fmind + cut - dst;
+        if (feat == 0) dists[0] = cut; else if (feat == 1) dists[1] = cut; else dists[2] = cut;
+        if (mind * epsError <= rd[(k - 1) * RS]) {
+          fw(sp - 1, 0) = (w0 & 0x3FFFFFFFu) | (2u << 30);
+          fw(sp - 1, 2) = __float_as_uint(dst);
+          node = (int)(w0 & 0x0FFFFFFFu);
+          mindistsq = mind;
+          descend = true;
+          break;
+        }
+        if (feat == 0) dists[0] = dst; else if (feat == 1) dists[1] = dst; else dists[2] = dst;
+        --sp;
+      } else {  // the far child is done: dists[idx] = dst (:1404)
+        const float dst = __uint_as_float(fw(sp - 1, 2));
+        if (feat == 0) dists[0] = dst; else if (feat == 1) dists[1] = dst; else dists[2] = dst;
         --sp;
       }
-    } else {
-      if (f.feat == 0) dists[0] = f.dst; else if (f.feat == 1) dists[1] = f.dst; else dists[2] = f.dst;
-      --sp;
     }
+    if (!descend) break;
   }
   IdxT* o = out + ((size_t)bi * m + j) * k;
-  for (int s = 0; s < k; ++s) o[s] = (IdxT)ri[s];
+  for (int s = 0; s < k; ++s) o[s] = (IdxT)ri[s * RS];
 }
 
 }  // namespace pasnl
@@ -316,13 +587,31 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
   const size_t stride = kt_cloud_bytes(n);
   float* rdist = reinterpret_cast<float*>(clouds + (size_t)b * stride);
   int* ridx = reinterpret_cast<int*>(reinterpret_cast<char*>(rdist) + kt_align_h((size_t)b * m * k * 4));
-  hipLaunchKernelGGL(knn_tree_build_kernel, dim3(b), dim3(64), 0, st, n, support, clouds, stride);
+  const bool serial = n > KTB_NMAX || tune_env("PASNL_KNN_TREE_SERIAL") != nullptr;  // (tuning build: the checker of the parallel build)
+  const size_t recs_off = kt_recs_offset(n);
+  if (serial) {
+    hipLaunchKernelGGL(knn_tree_build_kernel, dim3(b), dim3(64), 0, st, n, support, clouds, stride, recs_off);
+  } else {
+    const size_t lds = (size_t)n * 8 + (size_t)((n + 1) & ~1) * 2 + (KTB_WAVES * 6 + 4) * 4;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_tree_build_par_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return PASNL_ELAUNCH;
+    hipLaunchKernelGGL(knn_tree_build_par_kernel, dim3(b), dim3(KTB_WAVES * 64), lds, st, n, support, clouds, stride, recs_off);
+  }
   dim3 grid((m + 63) / 64, b);
-  if (idx_is_i64)
-    hipLaunchKernelGGL((knn_tree_search_kernel<long long>), grid, dim3(64), 0, st, n, m, k, support, queries, clouds, stride, rdist,
-                       ridx, static_cast<long long*>(idx), flag);
-  else
-    hipLaunchKernelGGL((knn_tree_search_kernel<int>), grid, dim3(64), 0, st, n, m, k, support, queries, clouds, stride, rdist, ridx,
-                       static_cast<int*>(idx), flag);
+  const bool rs_lds = k <= 64;
+  const size_t lds = (size_t)KT_LDS_DEPTH * 3 * 64 * 4 + (rs_lds ? (size_t)k * 64 * 8 : 0);
+#define PASNL_KT_SEARCH(T, L)                                                                                                     \
+  {                                                                                                                               \
+    auto kern = knn_tree_search_kernel<T, L>;                                                                                     \
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                               (int)lds) != hipSuccess)                                                           \
+      return PASNL_ELAUNCH;                                                                                                       \
+    hipLaunchKernelGGL(kern, grid, dim3(64), lds, st, n, m, k, queries, clouds, stride, recs_off, rdist, ridx, static_cast<T*>(idx), \
+                       flag);                                                                                                     \
+  }
+  if (idx_is_i64) { if (rs_lds) PASNL_KT_SEARCH(long long, true) else PASNL_KT_SEARCH(long long, false) }
+  else { if (rs_lds) PASNL_KT_SEARCH(int, true) else PASNL_KT_SEARCH(int, false) }
+#undef PASNL_KT_SEARCH
   return pasnl_launch_status();
 }

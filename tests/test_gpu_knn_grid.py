@@ -143,3 +143,28 @@ def test_knn_nanoflann_matches_live_reference_when_built():
     want = ref.knn_batch(sup, qry, 24)
     got = P.nearest_neighbors.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), 24, tie_order="nanoflann")
     np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("n,m,k,kind", [(8192, 300, 32, "lattice"), (10240, 200, 16, "dup"), (37, 20, 8, "lattice"), (11, 5, 3, "lattice"),
+                                        (10, 4, 3, "lattice"), (5000, 256, 32, "plane"), (12000, 64, 8, "lattice")])
+def test_knn_nanoflann_parallel_build_matches_live_reference(n, m, k, kind):
+    """The workgroup-per-cloud build (n <= 10240; csrc/knn_tree.hip knn_tree_build_par_kernel) and the one-lane build behind it
+    (n = 12000) against the reference library itself, on clouds made of ties: lattices, duplicated points, a flat cloud."""
+    from oracle import ref
+    if not ref.available("libref_knn.so"):
+        pytest.skip("oracle/_ref/libref_knn.so not built here")
+    rng = np.random.default_rng(n + m)
+    sup = rng.random((3, n, 3))
+    if kind == "lattice":
+        sup = np.round(sup * 10) / 10
+    elif kind == "dup":
+        sup[:, n // 2:] = sup[:, : n - n // 2]  # every point twice
+        sup = np.round(sup * 64) / 64
+    elif kind == "plane":
+        sup[..., 2] = 0.5
+        sup = np.round(sup * 40) / 40
+    sup = sup.astype(np.float32)
+    qry = np.concatenate([sup[:, : m // 2], rng.random((3, m - m // 2, 3)).astype(np.float32)], axis=1)
+    want = ref.knn_batch(sup, qry, k)
+    got = P.nearest_neighbors.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), k, tie_order="nanoflann")
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
