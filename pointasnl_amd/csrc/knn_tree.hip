@@ -9,9 +9,13 @@
 // bit for bit, for data with ties, by re-doing what nanoflann does -- the same tree (divideTree / middleSplit_ / planeSplit,
 // nanoflann.hpp:916-1043, re-stated here with explicit stacks; every float expression in the reference's association, no
 // contraction) and the same search (searchLevel :1351-1410, near child first) -- on the GPU:
-//   * knn_tree_build_kernel: ONE lane per cloud builds the tree serially into a caller workspace (the build is inherently a
-//     sequence of in-place partitions; an optional exactness mode, not a fast path);
-//   * knn_tree_search_kernel: one lane per query walks it with nanoflann's result-set insertion.
+//   * knn_tree_build_par_kernel (n <= 10240): a workgroup per cloud builds the tree level by level, a wave per node, with
+//     planeSplit's Hoare loop in closed form; knn_tree_build_kernel: the literal one-lane restatement (larger clouds, and the
+//     checker of the parallel build in the tuning build);
+//   * knn_tree_search_kernel: one lane per query walks it as a flat state machine, the result set as the k smallest
+//     (distance, arrival) keys in LDS, sorted once at the end.
+//   16 clouds of 8192 points, 1024 queries, k = 32: 60.2 ms (round 3: one lane per cloud) -> 1.1 ms; the canonical-order
+//   kernels take 62 us -- an exactness mode that is usable, not a fast path.
 // Trees or searches deeper than KT_DEPTH levels (pathological, exponentially clustered data) raise a flag in the workspace,
 // which the Python wrapper turns into PasnlUnsupported.
 #include "common.hpp"
@@ -433,22 +437,31 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The search: one lane per query, nanoflann's searchLevel (:1351-1410) with an explicit stack.  Everything a step waits for
-// is kept close: the result set and the stack live in LDS (slot-major / lane-minor), a leaf's points arrive as ONE burst of
-// independent 16-byte reads from the leaf-ordered records the build left behind, and a frame is three words:
-//   word 0 = other child | feat << 28 | state << 30,  word 1 = mindistsq,  word 2 = cut (state 1) or the saved dists[feat] (state 2).
-// RS_LDS = false (k > 64): the result set in the caller's workspace.  Frames beyond KT_LDS_DEPTH (pathological trees) go to
-// a per-lane array in scratch memory.
+// The search: one lane per query, nanoflann's searchLevel (:1351-1410) as a FLAT state machine.  Sixty-four lanes walk
+// sixty-four different paths; written as the recursion reads (descend loop, leaf loop with an insertion loop inside, return
+// loop) a wave executes every nested loop for its slowest lane while the others wait (measured: 2.6 ms for 512 queries per
+// cloud).  Here every lane performs bounded micro-steps per iteration -- examine one leaf candidate, pop one frame, visit one
+// node -- so an iteration costs the sum of three short code paths and all lanes advance.
+//   * The result set is nanoflann's KNNResultSet (:67-135) in another representation: the k smallest (distance, arrival)
+//     keys seen so far, UNSORTED, plus the largest of them.  addPoint's sorted insertion "behind the entries of equal
+//     distance" keeps exactly those k keys in that order, and a candidate enters iff its distance is below the current
+//     k-th (the reference tests the value it read at the leaf's entry, then its insertion drops what the fresh value would
+//     have refused).  The new entry takes the slot of the old maximum; the new maximum is found per group of eight slots
+//     (independent LDS reads; only the group that changed is rescanned) where the reference's shifting loop is a chain of
+//     dependent ones.  The set is sorted once, at the end, by (distance, arrival).
+//   * Result set and stack live in LDS (slot-major / lane-minor); every global read (the node a lane descends to, a leaf's
+//     records in leaf order as the build left them) is requested one iteration before it is used.  A frame is three words:
+//     word 0 = other child | feat << 28 | state << 30,  word 1 = mindistsq,  word 2 = cut (state 1) / the saved dists[feat] (2).
+//   k <= 64 and n <= 65535 (16-bit arrival numbers and indices); frames beyond KT_LDS_DEPTH (pathological trees) in scratch.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int KT_LDS_DEPTH = 32;
+constexpr float KT_FLT_MAX = 3.402823466e+38f;
 
-template <typename IdxT, bool RS_LDS>
+template <typename IdxT>
 __global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k, const float* __restrict__ queries,
                                                             const char* __restrict__ ws_all, size_t stride, size_t recs_off,
-                                                            float* __restrict__ rdist_all, int* __restrict__ ridx_all,
                                                             IdxT* __restrict__ out, int* __restrict__ flag) {
   const int j = blockIdx.x * 64 + threadIdx.x;
-  if (j >= m) return;
   const int bi = blockIdx.y;
   const char* ws = ws_all + (size_t)bi * stride;
   const int* hdr = reinterpret_cast<const int*>(ws);
@@ -457,21 +470,25 @@ __global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k
   const KtFrame* bst = reinterpret_cast<const KtFrame*>(ws + kt_align(16) + kt_align((size_t)n * 4) + kt_align((size_t)2 * n * sizeof(KtNode)));
   const float4* recs = reinterpret_cast<const float4*>(ws + recs_off);
   const float* rootbox = bst[1].bbox;
-  const float* qp = queries + ((size_t)bi * m + j) * 3;
+  const bool live = j < m;
+  const float* qp = queries + ((size_t)bi * m + (live ? j : 0)) * 3;
   const float vec[3] = {qp[0], qp[1], qp[2]};
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // the stack: [KT_LDS_DEPTH][3 words][64 lanes]
-  uint32_t* stk = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;
-  uint32_t deep[RS_LDS ? (KT_DEPTH - KT_LDS_DEPTH) * 3 : (KT_DEPTH - KT_LDS_DEPTH) * 3];  // frames past the LDS part (never touched by sane trees)
-  auto fw = [&](int level, int word) -> uint32_t& {
-    return level < KT_LDS_DEPTH ? stk[(level * 3 + word) * 64] : deep[(level - KT_LDS_DEPTH) * 3 + word];
+  uint32_t* stk = reinterpret_cast<uint32_t*>(smem) + threadIdx.x;                       // [KT_LDS_DEPTH][3][64]
+  const int kp = (k + 7) & ~7;
+  float* rd = reinterpret_cast<float*>(smem) + KT_LDS_DEPTH * 3 * 64 + threadIdx.x;      // [kp][64] distances
+  uint32_t* rk = reinterpret_cast<uint32_t*>(rd) + (size_t)kp * 64;                      // [kp][64] arrival << 16 | index
+  for (int s0 = k; s0 < kp; ++s0) { rd[s0 * 64] = 0.f; rk[s0 * 64] = 0u; }                // padding: key 0 never is the maximum
+  uint32_t deep[(KT_DEPTH - KT_LDS_DEPTH) * 3];  // frames past the LDS part (never touched by sane trees)
+  // (two address spaces: a reference that may point to either would turn every stack access into a flat load)
+  auto frd = [&](int level, int word) -> uint32_t {
+    if (level < KT_LDS_DEPTH) return stk[(level * 3 + word) * 64];
+    return deep[(level - KT_LDS_DEPTH) * 3 + word];
   };
-  // KNNResultSet: dists / indices, sorted, `count` valid entries; entry p of this lane at [p * RS]
-  constexpr int RS = RS_LDS ? 64 : 1;
-  float* rd = RS_LDS ? reinterpret_cast<float*>(smem) + KT_LDS_DEPTH * 3 * 64 + threadIdx.x : rdist_all + ((size_t)bi * m + j) * k;
-  int* ri = RS_LDS ? reinterpret_cast<int*>(smem) + KT_LDS_DEPTH * 3 * 64 + (size_t)k * 64 + threadIdx.x : ridx_all + ((size_t)bi * m + j) * k;
-  int count = 0;
-  rd[(k - 1) * RS] = 3.402823466e+38f;  // init(): dists[capacity-1] = max (:91-92)
+  auto fwr = [&](int level, int word, uint32_t v) {
+    if (level < KT_LDS_DEPTH) stk[(level * 3 + word) * 64] = v;
+    else deep[(level - KT_LDS_DEPTH) * 3 + word] = v;
+  };
   // computeInitialDistances (:1045-1061)
   float dists[3] = {0.f, 0.f, 0.f};
   float distsq = 0.f;
@@ -480,86 +497,146 @@ __global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k
     if (vec[d] > rootbox[2 * d + 1]) { dists[d] = (vec[d] - rootbox[2 * d + 1]) * (vec[d] - rootbox[2 * d + 1]); distsq += dists[d]; }
   }
   const float epsError = 1.f;  // 1 + SearchParams(10).eps, eps = 0
+  enum { NODE = 0, LEAF = 1, POP = 2, DONE = 3 };
+  int mode = live ? NODE : DONE;
   int node = hdr[1];
-  float mindistsq = distsq;  // of the activation that is running
-  int sp = 0;                // frames below it
-  for (;;) {
-    // ---- descend from `node` to a leaf, pushing an inner node's frame (state 1: near child running) on the way
-    for (;;) {
-      const KtNode nd = nodes[node];
-      if (nd.child1 < 0) {  // leaf (:1355-1369): the worst distance is read ONCE, before the scan
-        const float worst = rd[(k - 1) * RS];
-        const int left = nd.a, right = __float_as_int(nd.divlow);
-        float4 rec[KT_LEAF];
+  float mindistsq = distsq;      // of the activation that is running
+  int sp = 0;                    // frames below it
+  int count = 0, maxpos = 0;     // entries in the set; the slot of its largest (distance, arrival) once it is full
+  uint32_t arrivals = 0;         // candidates that entered so far
+  float worst = KT_FLT_MAX;      // the k-th distance: dists[capacity - 1] = max until the set is full (:91-92)
+  int li = 0, lend = 0;          // leaf cursor
+  float4 rec = make_float4(0.f, 0.f, 0.f, 0.f);  // the candidate at li (requested one step ahead)
+  bool overflow = false, filled = false;
+  unsigned long long gmax[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};  // per group of eight slots: its largest key ...
+  int gpos[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                        // ... and that key's slot
+  KtNode ndc = nodes[node];      // the node a descending lane is at (requested when the step that chose it ended)
+  // One iteration: a candidate for the lanes inside a leaf, then one frame for the lanes that are returning (a lane that has
+  // just finished its leaf among them), then one node for the lanes that are descending (a lane whose pop has just sent it
+  // into a far child among them): the transitions leaf -> return -> descend cost no extra iteration.
+  while (__any(mode != DONE)) {
+    if (mode == LEAF) {
+      const float4 c = rec;
+      rec = recs[min(li + 1, n - 1)];  // the next candidate, whatever happens to this one
+      // L2_Adaptor::evalMetric, dim 3: only the tail loop runs (:343-346): result += diff * diff, diff = query - point
+      float dist = 0.f;
+      { const float diff = vec[0] - c.x; dist += diff * diff; }
+      { const float diff = vec[1] - c.y; dist += diff * diff; }
+      { const float diff = vec[2] - c.z; dist += diff * diff; }
+      if (dist < worst) {  // KNNResultSet::addPoint (:115-134), see the header
+        const int slot = count < k ? count : maxpos;
+        rd[slot * 64] = dist;
+        rk[slot * 64] = (arrivals << 16) | (uint32_t)__float_as_int(c.w);
+        ++arrivals;
+        if (count < k) ++count;
+        if (count == k) {
+          // the largest (distance, arrival) of the full set, kept per group of eight slots (registers): the new entry took the
+          // place of the old maximum, so only THAT group has changed (the first time the set is full every group is scanned)
+          const int g_lo = filled ? (slot >> 3) : 0, g_hi = filled ? (slot >> 3) + 1 : (kp >> 3);
+          for (int g = g_lo; g < g_hi; ++g) {
+            uint32_t dk[8], ak[8];
 #pragma unroll
-        for (int i = 0; i < KT_LEAF; ++i) rec[i] = recs[min(left + i, n - 1)];  // one burst: the scan below waits once
+            for (int u = 0; u < 8; ++u) { dk[u] = __float_as_uint(rd[(g * 8 + u) * 64]); ak[u] = rk[(g * 8 + u) * 64]; }
+            unsigned long long big = 0ull;
+            int bp = 0;
 #pragma unroll
-        for (int i = 0; i < KT_LEAF; ++i) {
-          if (left + i < right) {
-            // L2_Adaptor::evalMetric, dim 3: only the tail loop runs (:343-346): result += diff * diff, diff = query - point
-            float dist = 0.f;
-            { const float diff = vec[0] - rec[i].x; dist += diff * diff; }
-            { const float diff = vec[1] - rec[i].y; dist += diff * diff; }
-            { const float diff = vec[2] - rec[i].z; dist += diff * diff; }
-            if (dist < worst) {  // KNNResultSet::addPoint (:115-134): behind the entries of equal distance
-              int p;
-              for (p = count; p > 0; --p) {
-                const float prev = rd[(p - 1) * RS];
-                if (prev > dist) {
-                  if (p < k) { rd[p * RS] = prev; ri[p * RS] = ri[(p - 1) * RS]; }
-                } else break;
-              }
-              if (p < k) { rd[p * RS] = dist; ri[p * RS] = __float_as_int(rec[i].w); }
-              if (count < k) ++count;
+            for (int u = 0; u < 8; ++u) {
+              const unsigned long long key = ((unsigned long long)dk[u] << 32) | ak[u];
+              if (key >= big) { big = key; bp = g * 8 + u; }
             }
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+              if (t == g) { gmax[t] = big; gpos[t] = bp; }
           }
+          filled = true;
+          unsigned long long big = gmax[0];
+          int bp = gpos[0];
+#pragma unroll
+          for (int t = 1; t < 8; ++t)
+            if (gmax[t] >= big) { big = gmax[t]; bp = gpos[t]; }
+          maxpos = bp;
+          worst = __uint_as_float((uint32_t)(big >> 32));
         }
-        break;
       }
-      const int idx = nd.a;
-      const float val = idx == 0 ? vec[0] : (idx == 1 ? vec[1] : vec[2]);
-      const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
-      int best, other;
-      float cut;
-      if ((diff1 + diff2) < 0) { best = nd.child1; other = nd.child2; cut = (val - nd.divhigh) * (val - nd.divhigh); }
-      else { best = nd.child2; other = nd.child1; cut = (val - nd.divlow) * (val - nd.divlow); }
-      if (sp + 1 >= KT_DEPTH) { atomicExch(flag, 1); return; }
-      fw(sp, 0) = (uint32_t)other | ((uint32_t)idx << 28) | (1u << 30);
-      fw(sp, 1) = __float_as_uint(mindistsq);
-      fw(sp, 2) = __float_as_uint(cut);
-      ++sp;
-      node = best;  // (the near child inherits mindistsq, :1396)
+      ++li;
+      if (li >= lend) mode = POP;
     }
-    // ---- return: pop frames until one still has its far child to run
-    bool descend = false;
-    while (sp > 0) {
-      const uint32_t w0 = fw(sp - 1, 0);
-      const int feat = (int)((w0 >> 28) & 3u);
-      if ((w0 >> 30) == 1u) {  // the near child is done (:1397-1405)
-        const float fmind = __uint_as_float(fw(sp - 1, 1)), cut = __uint_as_float(fw(sp - 1, 2));
-        const float dst = feat == 0 ? dists[0] : (feat == 1 ? dists[1] : dists[2]);
-        const float mind = fmind + cut - dst;
-        if (feat == 0) dists[0] = cut; else if (feat == 1) dists[1] = cut; else dists[2] = cut;
-        if (mind * epsError <= rd[(k - 1) * RS]) {
-          fw(sp - 1, 0) = (w0 & 0x3FFFFFFFu) | (2u << 30);
-          fw(sp - 1, 2) = __float_as_uint(dst);
-          node = (int)(w0 & 0x0FFFFFFFu);
-          mindistsq = mind;
-          descend = true;
-          break;
+    if (mode == POP) {
+      if (sp == 0) mode = DONE;
+      else {
+        const uint32_t w0 = frd(sp - 1, 0);
+        const int feat = (int)((w0 >> 28) & 3u);
+        if ((w0 >> 30) == 1u) {  // the near child is done (:1397-1405)
+          const float fmind = __uint_as_float(frd(sp - 1, 1)), cut = __uint_as_float(frd(sp - 1, 2));
+          const float dst = feat == 0 ? dists[0] : (feat == 1 ? dists[1] : dists[2]);
+          const float mind = fmind + cut - dst;
+          if (mind * epsError <= worst) {
+            if (feat == 0) dists[0] = cut; else if (feat == 1) dists[1] = cut; else dists[2] = cut;
+            fwr(sp - 1, 0, (w0 & 0x3FFFFFFFu) | (2u << 30));
+            fwr(sp - 1, 2, __float_as_uint(dst));
+            node = (int)(w0 & 0x0FFFFFFFu);
+            ndc = nodes[node];
+            mindistsq = mind;
+            mode = NODE;
+          } else {
+            --sp;  // (dists[idx] = cut; ... dists[idx] = dst: unchanged)
+          }
+        } else {  // the far child is done: dists[idx] = dst (:1404)
+          const float dst = __uint_as_float(frd(sp - 1, 2));
+          if (feat == 0) dists[0] = dst; else if (feat == 1) dists[1] = dst; else dists[2] = dst;
+          --sp;
         }
-        if (feat == 0) dists[0] = dst; else if (feat == 1) dists[1] = dst; else dists[2] = dst;
-        --sp;
-      } else {  // the far child is done: dists[idx] = dst (:1404)
-        const float dst = __uint_as_float(fw(sp - 1, 2));
-        if (feat == 0) dists[0] = dst; else if (feat == 1) dists[1] = dst; else dists[2] = dst;
-        --sp;
       }
     }
-    if (!descend) break;
+    if (mode == NODE) {
+      const KtNode nd = ndc;
+      if (nd.child1 < 0) {  // leaf (:1355-1369)
+        li = nd.a;
+        lend = __float_as_int(nd.divlow);
+        rec = recs[li];
+        mode = li < lend ? LEAF : POP;
+      } else {
+        const int idx = nd.a;
+        const float val = idx == 0 ? vec[0] : (idx == 1 ? vec[1] : vec[2]);
+        const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+        int best, other;
+        float cut;
+        if ((diff1 + diff2) < 0) { best = nd.child1; other = nd.child2; cut = (val - nd.divhigh) * (val - nd.divhigh); }
+        else { best = nd.child2; other = nd.child1; cut = (val - nd.divlow) * (val - nd.divlow); }
+        if (sp + 1 >= KT_DEPTH) { overflow = true; mode = DONE; }
+        else {
+          fwr(sp, 0, (uint32_t)other | ((uint32_t)idx << 28) | (1u << 30));
+          fwr(sp, 1, __float_as_uint(mindistsq));
+          fwr(sp, 2, __float_as_uint(cut));
+          ++sp;
+          node = best;  // (the near child inherits mindistsq, :1396)
+          ndc = nodes[best];
+        }
+      }
+    }
   }
+  if (overflow) atomicExch(flag, 1);
+  if (!live) return;
+  // the set in the reference's order: ascending (distance, arrival).  k <= n: the set is full.
   IdxT* o = out + ((size_t)bi * m + j) * k;
-  for (int s = 0; s < k; ++s) o[s] = (IdxT)ri[s * RS];
+  for (int s0 = k; s0 < kp; ++s0) { rd[s0 * 64] = __uint_as_float(0xFFFFFFFFu); rk[s0 * 64] = 0xFFFFFFFFu; }  // padding: never the minimum
+  for (int r = 0; r < k; ++r) {
+    unsigned long long best = ~0ull;
+    int bp = 0;
+    for (int s0 = 0; s0 < kp; s0 += 8) {
+      uint32_t dk[8], ak[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { dk[u] = __float_as_uint(rd[(s0 + u) * 64]); ak[u] = rk[(s0 + u) * 64]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const unsigned long long key = ((unsigned long long)dk[u] << 32) | ak[u];
+        if (key < best) { best = key; bp = s0 + u; }
+      }
+    }
+    o[r] = (IdxT)(uint32_t)(best & 0xFFFFu);
+    rd[bp * 64] = __uint_as_float(0xFFFFFFFFu);  // taken (no distance has these bits: not even NaN keys compare below ~0)
+    rk[bp * 64] = 0xFFFFFFFFu;
+  }
 }
 
 }  // namespace pasnl
@@ -568,7 +645,7 @@ using namespace pasnl;
 
 extern "C" size_t pasnl_knn_tree_workspace_bytes(int b, int n, int m, int k) {
   if (b <= 0 || n <= 0 || m <= 0 || k <= 0) return 0;
-  return 256 + (size_t)b * kt_cloud_bytes(n) + kt_align_h((size_t)b * m * k * 4) * 2;
+  return 256 + (size_t)b * kt_cloud_bytes(n);  // (the search keeps its result sets in LDS)
 }
 
 extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
@@ -578,6 +655,7 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
   if (b == 0 || m == 0) return PASNL_OK;
   PASNL_REQUIRE(support && queries && idx && workspace, PASNL_ENULL);
   PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE(k <= 64 && n <= 65535, PASNL_EUNSUPPORTED);  // the search's result set: 16-bit arrival numbers / indices, k slots of LDS per lane
   PASNL_REQUIRE(workspace_bytes >= pasnl_knn_tree_workspace_bytes(b, n, m, k), PASNL_EWORKSPACE);
   hipStream_t st = pasnl_hip_stream(stream);
   char* base = static_cast<char*>(workspace);
@@ -585,8 +663,6 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
   if (hipMemsetAsync(flag, 0, 256, st) != hipSuccess) return PASNL_ELAUNCH;
   char* clouds = base + 256;
   const size_t stride = kt_cloud_bytes(n);
-  float* rdist = reinterpret_cast<float*>(clouds + (size_t)b * stride);
-  int* ridx = reinterpret_cast<int*>(reinterpret_cast<char*>(rdist) + kt_align_h((size_t)b * m * k * 4));
   const bool serial = n > KTB_NMAX || tune_env("PASNL_KNN_TREE_SERIAL") != nullptr;  // (tuning build: the checker of the parallel build)
   const size_t recs_off = kt_recs_offset(n);
   if (serial) {
@@ -599,19 +675,16 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
     hipLaunchKernelGGL(knn_tree_build_par_kernel, dim3(b), dim3(KTB_WAVES * 64), lds, st, n, support, clouds, stride, recs_off);
   }
   dim3 grid((m + 63) / 64, b);
-  const bool rs_lds = k <= 64;
-  const size_t lds = (size_t)KT_LDS_DEPTH * 3 * 64 * 4 + (rs_lds ? (size_t)k * 64 * 8 : 0);
-#define PASNL_KT_SEARCH(T, L)                                                                                                     \
+  const size_t lds = (size_t)KT_LDS_DEPTH * 3 * 64 * 4 + (size_t)((k + 7) & ~7) * 64 * 8;
+#define PASNL_KT_SEARCH(T)                                                                                                        \
   {                                                                                                                               \
-    auto kern = knn_tree_search_kernel<T, L>;                                                                                     \
+    auto kern = knn_tree_search_kernel<T>;                                                                                        \
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                                (int)lds) != hipSuccess)                                                           \
       return PASNL_ELAUNCH;                                                                                                       \
-    hipLaunchKernelGGL(kern, grid, dim3(64), lds, st, n, m, k, queries, clouds, stride, recs_off, rdist, ridx, static_cast<T*>(idx), \
-                       flag);                                                                                                     \
+    hipLaunchKernelGGL(kern, grid, dim3(64), lds, st, n, m, k, queries, clouds, stride, recs_off, static_cast<T*>(idx), flag);      \
   }
-  if (idx_is_i64) { if (rs_lds) PASNL_KT_SEARCH(long long, true) else PASNL_KT_SEARCH(long long, false) }
-  else { if (rs_lds) PASNL_KT_SEARCH(int, true) else PASNL_KT_SEARCH(int, false) }
+  if (idx_is_i64) PASNL_KT_SEARCH(long long) else PASNL_KT_SEARCH(int)
 #undef PASNL_KT_SEARCH
   return pasnl_launch_status();
 }
