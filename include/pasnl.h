@@ -143,8 +143,10 @@ int pasnl_knn_batch_ws(int b, int n, int m, int k, const float* support, const f
  * which of several tied candidates is the K-th): nanoflann keeps candidates of equal distance in the order its KD-tree visits
  * them (nanoflann.hpp:115-134, :1351-1410; tree: divideTree / middleSplit_ / planeSplit :916-1043, leaf size 10,
  * knn_.cxx:83).  Replaces cpp_knn_batch knn_.cxx:72-101 bit for bit, ties included, by rebuilding that tree and that search on
- * the GPU -- an optional exactness mode (one lane builds a cloud's tree), not a fast path; pasnl_knn_batch returns the
- * canonical (distance, index) order, identical whenever distances are distinct.  k <= n.  workspace:
+ * the GPU -- an exactness mode (a workgroup per cloud builds the tree level by level, a lane per query searches it: about
+ * 1 ms for 16 clouds of 8192 points where the canonical kernels take 0.06), not a fast path; pasnl_knn_batch returns the
+ * canonical (distance, index) order, identical whenever distances are distinct.  k <= n, k <= 64, n <= 65535
+ * (else PASNL_EUNSUPPORTED).  workspace:
  * pasnl_knn_tree_workspace_bytes(b, n, m, k) bytes; its first int32 is non-zero afterwards if a tree or a search was deeper
  * than 96 levels (pathological clustering: the result is then not valid). */
 size_t pasnl_knn_tree_workspace_bytes(int b, int n, int m, int k);
