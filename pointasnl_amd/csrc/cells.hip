@@ -929,7 +929,9 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   float px = 0.f, py = 0.f, pz = 0.f;   // the tile's neighbour coordinates (one row per lane pair)
   float nf0 = 0.f, nf1 = 0.f;           // centre0 outputs: neighbour 0's feature row, in flight during a group's first tile
   float f3x = 0.f, f3y = 0.f, f3z = 0.f;  // XYZ3: the tile row's three features (one 12-byte load instead of clamped dword loads)
-  const float* frow = src.feature;       // and its feature row
+  unsigned frow_off = 0;                 // and its feature row: element offset into src.feature (one register, not a 64-bit
+  const float* const fbase_ = src.feature;  // pointer per lane; a tensor of < 2^32 floats: sa_cell_entry checks)
+#define frow (fbase_ + frow_off)
   // operands [u0, u1) of chunk ch (VEC: whole 16-byte groups); the loops unroll, u0 / u1 are constants at every call
   auto load_part = [&](int ch, int u0, int u1) {
     if constexpr ((PASNL_SA_ABLATE & 2) != 0) {
@@ -973,7 +975,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
   auto request_rows = [&](long bc, int i) {
     const float* pp = src.xyz + ((size_t)bc * src.n + i) * 3;
     px = pp[0]; py = pp[1]; pz = pp[2];
-    frow = src.feature + ((size_t)bc * src.n + i) * (size_t)cf;
+    frow_off = (unsigned)(((size_t)bc * src.n + i) * (size_t)cf);
     if constexpr (XYZ3) {
       f3x = frow[0]; f3y = frow[1]; f3z = frow[2];
     } else {
@@ -1286,6 +1288,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 #endif
 }
 
+#undef frow
 #ifdef PASNL_SA_CELL_PROBE
 }  // namespace pasnl
 // [prologue, start wait, conv0 (incl. chunk wait), chunk wait, conv1 + matmul, epilogue, tiles, wave total, waves,
@@ -2474,14 +2477,17 @@ template <int C1, int C2>
 static int sa_cell_cfg(bool vec, bool tail8, long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0,
                        const float* w1, const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
   constexpr int NW = C1 >= 128 ? 4 : 8;
+  // NG: the 64-channel forms no model uses (no 8-step tail, or scalar loads of a row that is not xyz-only) need more than the
+  // 256 registers two waves per SIMD leave each -- they ran with 150-300 bytes of spills; one wave per SIMD instead
+  constexpr int NG = C1 >= 64 ? 4 : 8;
   if (vec) return tail8 ? sa_cell_launch<C1, C2, NW, true, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
-                        : sa_cell_launch<C1, C2, NW, true, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+                        : sa_cell_launch<C1, C2, NG, true, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   if constexpr (C1 <= 64) {
     if (w == 9 && tail8 && k == 32)  // the xyz-only first layer of every model: rows [xyz - c | xyz | xyz-as-feature]
       return sa_cell_launch<C1, C2, NW, false, true, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   }
-  return tail8 ? sa_cell_launch<C1, C2, NW, false, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
-               : sa_cell_launch<C1, C2, NW, false, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  return tail8 ? sa_cell_launch<C1, C2, NG, false, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
+               : sa_cell_launch<C1, C2, NG, false, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
 }
 
 extern "C" int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, const float* x, const float* w0, const float* b0,
@@ -2503,6 +2509,7 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   const long groups = (long)b * m;
   if (groups == 0) return PASNL_OK;
   PASNL_REQUIRE(groups < (1L << 31), PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE((long)b * n * c < (1L << 32), PASNL_EUNSUPPORTED);  // feature rows are addressed by 32-bit element offsets
   PASNL_REQUIRE(xyz && feature && idx && w0 && b0 && ww && bw && out && skip_max, PASNL_ENULL);
   // w1 == NULL: the layer has ONE convolution (mlp = [c, c]: the *_2 layers of pointasnl_sem_seg_res.py) -- the wide kernel only
   PASNL_REQUIRE((w1 && b1) || c1 >= 256, PASNL_ENULL);
