@@ -190,9 +190,9 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a) { lo[a] = wave_min_f32(lo[a]); hi[a] = wave_max_f32(hi[a]); }
-  if (lane == 0) {
+  if (lane == 0) {  // [6][BG_WAVES]: the minima, and the maxima NEGATED (one kind of reduction below; negation is exact)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { red[wave * 6 + a] = lo[a]; red[wave * 6 + 3 + a] = hi[a]; }
+    for (int a = 0; a < 3; ++a) { red[a * BG_WAVES + wave] = lo[a]; red[(3 + a) * BG_WAVES + wave] = -hi[a]; }
   }
   for (int c = tid; c < BG_NC; c += BG_THREADS) ccount[c] = 0;
   __syncthreads();
@@ -204,12 +204,17 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
       if (k < n) { px[i] = raw[k * 3]; py[i] = raw[k * 3 + 1]; pz[i] = raw[k * 3 + 2]; }  // stride 3 dwords: conflict-free
     }
   }
+  {
+    // the 48 partials in lanes 0..47 (axis-major, one wave's value per lane): three DPP steps reduce every group of eight lanes
+    // into its last lane, six readlanes put the box into SGPRs (48 LDS reads and 42 min / max per thread before)
+    static_assert(BG_WAVES == 8, "the groups of the reduction are eight lanes wide");
+    float v = lane < 6 * BG_WAVES ? red[lane] : INFINITY;
+    const float inf = INFINITY;
+#define PASNL_BG_MIN8(CTRL) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(inf), __float_as_int(v), CTRL, 0xf, 0xf, false)));
+    PASNL_BG_MIN8(DPP_ROW_SHR1) PASNL_BG_MIN8(DPP_ROW_SHR2) PASNL_BG_MIN8(DPP_ROW_SHR4)
+#undef PASNL_BG_MIN8
 #pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float l = red[a], h = red[3 + a];
-#pragma unroll
-    for (int w = 1; w < BG_WAVES; ++w) { l = fminf(l, red[w * 6 + a]); h = fmaxf(h, red[w * 6 + 3 + a]); }
-    lo[a] = bg_uni(l); hi[a] = bg_uni(h);
+    for (int a = 0; a < 3; ++a) { lo[a] = readlane_f(v, a * 8 + 7); hi[a] = -readlane_f(v, (3 + a) * 8 + 7); }
   }
   // ---- B. grid geometry (identical in every thread)
   const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
