@@ -2328,7 +2328,7 @@ __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGath
   const int xp = wi + 1;                    // odd row pitch: conflict-free column-pair reads by 32 rows
   float* Xs = reinterpret_cast<float*>(smem);          // [32][xp]
   float* H1s = Xs + 32 * xp;                           // [32][HP]
-  int* rows = reinterpret_cast<int*>(H1s + 32 * HP);   // [32] neighbour indices of the group
+  int* rows = reinterpret_cast<int*>(CONV1 ? H1s + 32 * HP : H1s);  // [32] neighbour indices of the group (no H1 tile without conv1)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, ql = lane & 31;
   const int g = blockIdx.x;
   const int bi = g / src.m;
@@ -2364,6 +2364,11 @@ __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGath
   }
   // ---- 2. conv0: H1^T block `wave`.  Step s contracts internal columns 2 s (lanes 0..31) and 2 s + 1 (lanes 32..63);
   // internal rows of W0: 0..5 = w0 rows 0..5, 6 = b0 (the bias rides on the constant-1 column), 7 = zero, 8.. = w0 rows 6..
+  // With conv1 the block is wanted as H1^T (channels x rows: the weights are the A operand); WITHOUT it the block IS H2 and
+  // is wanted as rows x channels -- the same products with the operands swapped, no exchange through LDS, no barrier.
+  auto mm = [](float wv, float xv, f32x16 d) {
+    return CONV1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(wv, xv, d, 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(xv, wv, d, 0, 0, 0);
+  };
   const int ch = wave * 32 + ql;
   f32x16 acc;
 #pragma unroll
@@ -2373,44 +2378,49 @@ __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGath
     // the first four steps (columns 0..7)
     const float a3 = h ? 0.f : b0[ch];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w0[(size_t)(2 * s + h) * C + ch], xrow[2 * s], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, xrow[6], acc, 0, 0, 0);
-    // the features: w0 row 2 s + h - 2, in batches of BT steps, the next batch's operands requested while this one multiplies
+    for (int s = 0; s < 3; ++s) acc = mm(w0[(size_t)(2 * s + h) * C + ch], xrow[2 * s], acc);
+    acc = mm(a3, xrow[6], acc);
+    // the features: w0 row 2 s + h - 2, in batches of BT steps; the operands of the batch after the NEXT one are requested
+    // while this one multiplies (three register sets: a weight row is a round trip to L2 of about two batches of MFMAs when
+    // four waves share the matrix pipe)
     constexpr int BT = 8;   // (16 measured slower: 139 vs 126 us at 320 groups of 512 channels)
     const float* wp = w0 + (size_t)(6 + h) * C + ch;  // w0 row of internal column 8 + h
-    const int nsteps = cf >> 1;                        // a multiple of BT (cf % 16 == 0)
-    float wa[2][BT], xb[2][BT];
+    const int nsteps = cf >> 1;                        // a multiple of BT (cf % 16 == 0), >= 2 BT
+    float wa[3][BT], xb[3][BT];
 #pragma unroll
-    for (int u = 0; u < BT; ++u) { wa[0][u] = wp[(size_t)(2 * u) * C]; xb[0][u] = xrow[8 + 2 * u]; }
-    for (int s0 = 0; s0 < nsteps; s0 += 2 * BT) {
+    for (int u = 0; u < BT; ++u) {
+      wa[0][u] = wp[(size_t)(2 * u) * C]; xb[0][u] = xrow[8 + 2 * u];
+      wa[1][u] = wp[(size_t)(2 * (BT + u)) * C]; xb[1][u] = xrow[8 + 2 * (BT + u)];
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += 3 * BT) {
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int sb = s0 + half * BT;
+      for (int third = 0; third < 3; ++third) {
+        const int sb = s0 + third * BT;
         if (sb < nsteps) {
-          const int sn = min(sb + BT, nsteps - BT);  // the batch after this one (a dummy re-read at the end)
+          const int sn = min(sb + 2 * BT, nsteps - BT);  // two batches ahead (a dummy re-read at the end)
 #pragma unroll
-          for (int u = 0; u < BT; ++u) { wa[half ^ 1][u] = wp[(size_t)(2 * (sn + u)) * C]; xb[half ^ 1][u] = xrow[8 + 2 * (sn + u)]; }
+          for (int u = 0; u < BT; ++u) { wa[(third + 2) % 3][u] = wp[(size_t)(2 * (sn + u)) * C]; xb[(third + 2) % 3][u] = xrow[8 + 2 * (sn + u)]; }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int u = 0; u < BT; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[half][u], xb[half][u], acc, 0, 0, 0);
+          for (int u = 0; u < BT; ++u) acc = mm(wa[third][u], xb[third][u], acc);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
   }
-  // ReLU; D[m = channel wave*32 + kappa(r,h)][n = row ql] -> H1s[row][channel]
-#pragma unroll
-  for (int r = 0; r < 16; ++r) H1s[ql * HP + wave * 32 + kappa(r, h)] = fmaxf(acc[r], 0.f);
-  __syncthreads();
   // ---- 3. conv1 (or the block of H1 itself): H2[m = row kappa(t,h)][n = channel ch]
   f32x16 H2;
   if constexpr (CONV1) {
+    // ReLU; D[m = channel wave*32 + kappa(r,h)][n = row ql] -> H1s[row][channel]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) H1s[ql * HP + wave * 32 + kappa(r, h)] = fmaxf(acc[r], 0.f);
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < 16; ++r) H2[r] = 0.f;
     constexpr int BT = 8, NS = C / 2;
     const float* hrow = H1s + ql * HP + h;
     const float* wp = w1 + (size_t)h * C + ch;
-    float wa[2][BT], xb[2][BT];
+    float wa[2][BT], xb[2][BT];  // (two register sets: a third, as in conv0, gained nothing here -- H1 comes from LDS)
 #pragma unroll
     for (int u = 0; u < BT; ++u) { wa[0][u] = wp[(size_t)(2 * u) * C]; xb[0][u] = hrow[2 * u]; }
     for (int s0 = 0; s0 < NS; s0 += 2 * BT) {
@@ -2431,7 +2441,7 @@ __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGath
     for (int r = 0; r < 16; ++r) H2[r] = fmaxf(H2[r] + bb, 0.f);
   } else {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) H2[t] = H1s[kappa(t, h) * HP + ch];
+    for (int t = 0; t < 16; ++t) H2[t] = fmaxf(acc[t], 0.f);  // D[m = row kappa(t,h)][n = channel ch]
   }
   // ---- 4. weight net on the centred coordinates: G[m = row kappa][n = j]; columns 0..3 = dx dy dz x (x is no input: zero row)
   f32x16 G;
@@ -2460,7 +2470,7 @@ template <int C, bool CONV1>
 static int sa_cell_wide_launch(long groups, int w, SaGatherSrc src, const float* w0, const float* b0, const float* w1,
                                const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
   const int wi = 8 + (w - 6);
-  const size_t lds = ((size_t)32 * (wi + 1) + (size_t)32 * (C + 1) + 32) * sizeof(float);
+  const size_t lds = ((size_t)32 * (wi + 1) + (CONV1 ? (size_t)32 * (C + 1) : 0) + 32) * sizeof(float);
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
   auto kern = sa_cell_wide_kernel<C, CONV1>;
   if (lds > 48 * 1024 &&
