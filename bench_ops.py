@@ -126,6 +126,9 @@ def main():
     if want("interp"):
         x1, x2 = cloud(16, 8192), cloud(16, 1024)
         rows += timeit(lambda: P.tf_interpolate.three_nn(x1, x2), "three_nn scannet-fa4 B=16")
+        for (b, n, m, name) in [(8, 10240, 1280, "kitti-fa4"), (8, 1280, 320, "kitti-fa3"), (16, 1024, 256, "scannet-fa3"), (16, 256, 64, "scannet-fa2")]:
+            y1, y2 = cloud(b, n), cloud(b, m)
+            rows += timeit(lambda: P.tf_interpolate.three_nn(y1, y2), f"three_nn {name} B={b}")
         d, i = P.tf_interpolate.three_nn(x1, x2)
         w = P.tf_interpolate.three_weights(d)
         pts = torch.rand((16, 1024, 128), device="cuda")

@@ -6,51 +6,84 @@
 
 namespace pasnl {
 
-constexpr int NN_TILE = 2048;  // known points per LDS tile, 16 B each (x,y,z,pad) = 32 KiB
+// 64 unknown points per workgroup, one per lane; the workgroup's four waves each scan a contiguous quarter of the known cloud
+// and the quarters' triples are merged in index order, so the result is the sequential scan's: the 3-deep cascade keeps
+// strict '<' and equal distances keep the lower index (tf_interpolate.cpp:74-90).  The known points are wave-uniform: they
+// arrive by scalar loads (12 dwords = 4 points per request) and feed the vector ALU as scalar operands -- no LDS, no barrier
+// in the scan.  The cascade is branch-free (3 compares + 10 selects per pair): with 64 lanes some lane's top three changes at
+// most steps (3/k per lane), so a skip test would rarely skip.  NaN distances fail every compare, as in the reference.
+constexpr int NN_SPLIT = 4;
 
-// One unknown point per lane; the known cloud streams through LDS as float4 and every lane reads the
-// same element (LDS broadcast, one b128 read per pair).  The 3-deep cascade keeps strict '<' so equal
-// distances keep the lower index (tf_interpolate.cpp:74-90).
-__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float* __restrict__ xyz1,
-                                                      const float* __restrict__ xyz2, float* __restrict__ dist,
-                                                      int* __restrict__ idx) {
-  __shared__ float4 known[NN_TILE];
+#define PASNL_NN_STEP(d_, k_)                                   \
+  {                                                             \
+    const float d = (d_);                                       \
+    const int kk = (k_);                                        \
+    const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;           \
+    b3 = c2 ? b2 : (c3 ? d : b3);                               \
+    i3 = c2 ? i2 : (c3 ? kk : i3);                              \
+    b2 = c1 ? b1 : (c2 ? d : b2);                               \
+    i2 = c1 ? i1 : (c2 ? kk : i2);                              \
+    b1 = c1 ? d : b1;                                           \
+    i1 = c1 ? kk : i1;                                          \
+  }
+
+__global__ __launch_bounds__(64 * NN_SPLIT) void three_nn_kernel(int n, int m, const float* __restrict__ xyz1,
+                                                                const float* __restrict__ xyz2, float* __restrict__ dist,
+                                                                int* __restrict__ idx) {
+  __shared__ float mb[NN_SPLIT - 1][3][64];
+  __shared__ int mi[NN_SPLIT - 1][3][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bi = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * 64 + lane;
   const bool ok = j < n;
   const float* u = xyz1 + ((size_t)bi * n + (ok ? j : 0)) * 3;
   const float x1 = u[0], y1 = u[1], z1 = u[2];
-  const float* kc = xyz2 + (size_t)bi * m * 3;
+  const float* __restrict__ kc = xyz2 + (size_t)bi * m * 3;
+  const int per = ((m + NN_SPLIT - 1) / NN_SPLIT + 3) & ~3;  // a multiple of 4: only the cloud's end has a ragged tail
+  const int lo = min(m, wave * per), hi = min(m, lo + per);
 
   float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;  // the reference's 1e40 doubles == +inf as float
   int i1 = 0, i2 = 0, i3 = 0;
-  for (int base = 0; base < m; base += NN_TILE) {
-    int tcnt = min(NN_TILE, m - base);
-    __syncthreads();
-    for (int p = threadIdx.x; p < tcnt; p += 256) {
-      const float* s = kc + (size_t)(base + p) * 3;
-      known[p] = make_float4(s[0], s[1], s[2], 0.f);
-    }
-    __syncthreads();
-    for (int p = 0; p < tcnt; ++p) {
-      float4 q = known[p];
-      float d = dist2(q.x, q.y, q.z, x1, y1, z1);
-      int k = base + p;
-      if (d < b1) {
-        b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k;
-      } else if (d < b2) {
-        b3 = b2; i3 = i2; b2 = d; i2 = k;
-      } else if (d < b3) {
-        b3 = d; i3 = k;
-      }
+  int p = lo;
+  if (p + 4 <= hi) {  // the next four points are requested before the current four are used
+    float c[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) c[t] = kc[(size_t)p * 3 + t];
+    for (; p + 4 <= hi; p += 4) {
+      const int pn = p + 8 <= hi ? p + 4 : p;
+      const float* __restrict__ s = kc + (size_t)pn * 3;
+      float nx[12];
+#pragma unroll
+      for (int t = 0; t < 12; ++t) nx[t] = s[t];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) PASNL_NN_STEP(dist2(c[3 * t], c[3 * t + 1], c[3 * t + 2], x1, y1, z1), p + t)
+#pragma unroll
+      for (int t = 0; t < 12; ++t) c[t] = nx[t];
     }
   }
-  if (ok) {
-    size_t o = ((size_t)bi * n + j) * 3;
-    dist[o] = b1; dist[o + 1] = b2; dist[o + 2] = b3;
-    idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+  for (; p < hi; ++p) {
+    const float* __restrict__ s = kc + (size_t)p * 3;
+    PASNL_NN_STEP(dist2(s[0], s[1], s[2], x1, y1, z1), p)
+  }
+  if (wave > 0) {
+    mb[wave - 1][0][lane] = b1; mb[wave - 1][1][lane] = b2; mb[wave - 1][2][lane] = b3;
+    mi[wave - 1][0][lane] = i1; mi[wave - 1][1][lane] = i2; mi[wave - 1][2][lane] = i3;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // later quarters hold higher indices: inserting their (ascending) triples with strict '<' is the sequential scan
+#pragma unroll
+    for (int w = 0; w < NN_SPLIT - 1; ++w)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) PASNL_NN_STEP(mb[w][t][lane], mi[w][t][lane])
+    if (ok) {
+      const size_t o = ((size_t)bi * n + j) * 3;
+      dist[o] = b1; dist[o + 1] = b2; dist[o + 2] = b3;
+      idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+    }
   }
 }
+#undef PASNL_NN_STEP
 
 // out[row, l] = (p[i1,l]*w1 + p[i2,l]*w2) + p[i3,l]*w3 ; one thread per VEC channels of one output row.
 template <int VEC>
@@ -131,7 +164,7 @@ extern "C" int pasnl_three_nn(int b, int n, int m, const float* xyz1, const floa
   if (b == 0 || n == 0) return PASNL_OK;
   PASNL_REQUIRE(xyz1 && dist && idx && (m == 0 || xyz2), PASNL_ENULL);
   PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
-  hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 0, pasnl_hip_stream(stream), n, m, xyz1, xyz2, dist,
+  hipLaunchKernelGGL(three_nn_kernel, dim3((n + 63) / 64, b), dim3(64 * NN_SPLIT), 0, pasnl_hip_stream(stream), n, m, xyz1, xyz2, dist,
                      idx);
   return pasnl_launch_status();
 }

@@ -255,6 +255,34 @@ def test_three_nn(P, b, n, m, kind):
     np.testing.assert_array_equal(d.cpu().numpy(), wd)
 
 
+@pytest.mark.parametrize("n,m", [(70, 1), (70, 2), (70, 3), (70, 5), (130, 17), (64, 18), (200, 16), (33, 1281), (257, 4095)])
+def test_three_nn_ragged_quarters_and_ties(P, n, m):
+    """The four waves of a workgroup scan quarters of the known cloud (rounded up to 4 points) and merge: every split raggedness,
+    fewer known points than neighbours asked for (+inf / index 0 like the reference), and equal distances on either side of a
+    quarter boundary (every known point duplicated 4x at shuffled positions: the lower index has to win), plus inf / nan
+    coordinates (a nan distance fails every compare: skipped)."""
+    rng = np.random.default_rng(n * 7 + m)
+    base = rng.random((2, max(1, (m + 3) // 4), 3), dtype=np.float32)
+    x2 = np.concatenate([base] * 4, axis=1)[:, :m]
+    x2 = np.stack([x2[c][rng.permutation(m)] for c in range(2)])
+    x1 = rng.random((2, n, 3), dtype=np.float32)
+    x1[:, : min(n, m)] = x2[:, : min(n, m)]  # zero distances too
+    for a, b in ((x1, x2),):
+        wd, wi = O.three_nn(a, b)
+        d, i = P.tf_interpolate.three_nn(dev(a), dev(b))
+        np.testing.assert_array_equal(i.cpu().numpy(), wi)
+        np.testing.assert_array_equal(d.cpu().numpy(), wd)
+    if m >= 5:
+        x2b = x2.copy()
+        x2b[0, 1, 0] = np.inf
+        x2b[1, m - 1, 2] = np.nan
+        x2b[1, 0, 1] = -np.inf
+        wd, wi = O.three_nn(x1, x2b)
+        d, i = P.tf_interpolate.three_nn(dev(x1), dev(x2b))
+        np.testing.assert_array_equal(i.cpu().numpy(), wi)
+        np.testing.assert_array_equal(d.cpu().numpy(), wd)
+
+
 @pytest.mark.parametrize("b,m,c,n", [(32, 128, 64, 512), (2, 1024, 128, 8192), (2, 64, 512, 256), (2, 50, 7, 33)])
 def test_three_interpolate_and_grad(P, b, m, c, n):
     rng = np.random.default_rng(m)
