@@ -295,8 +295,13 @@ __global__ __launch_bounds__(SPLIT * 64) void nl_attention_mfma_kernel(int p, in
 //   its own round trips, which more waves per SIMD do not do for it (equal-length phases).
 //   LDS only for the final merge of the SPLIT partial results.
 // =============================================================================================
+// cb = 64: capped at 256 registers (two waves per SIMD; uncapped the compiler takes 210 + 48 accumulation registers = one wave):
+// cls layer 2 19.2 -> 17.6 us.  cb = 32 is left alone: four waves per SIMD without accumulation registers, block addresses by
+// scalar base + constant offsets (-60 vector instructions per block) and v_permlane32_swap instead of the two LDS shuffles each
+// measured SLOWER on the long key loops (scannet 198 -> 207 / 212 / 203 us, all three 231; profiles/r04_q_nl_ab.txt) -- the loop
+// is bound by its own chain of round trips, not by issue: fewer instructions between the loads lengthen the measured VMEM latency
 template <int CB, int SPLIT>
-__global__ __launch_bounds__(SPLIT * 64) void nl_attention_direct_kernel(int p, int n, float qscale,
+__global__ __launch_bounds__(SPLIT * 64, CB == 64 ? 2 : 1) void nl_attention_direct_kernel(int p, int n, float qscale,
                                                                        const float* __restrict__ q,
                                                                        const float* __restrict__ kv,
                                                                        float* __restrict__ out) {

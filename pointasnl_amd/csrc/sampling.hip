@@ -434,6 +434,10 @@ __global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, co
   int* picks = hist + 64;                                                         // ... and [m] picks
   __shared__ float red[6][WAVES];
   __shared__ int wsum[WAVES];
+#if defined(PASNL_TUNING) && PASNL_FPS_ABL == 0
+  __shared__ int dbg_act[3][4];
+  if (threadIdx.x < 12) (&dbg_act[0][0])[threadIdx.x] = 0;
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* cloud = xyz + (size_t)blockIdx.x * n * 3;
@@ -541,7 +545,10 @@ __global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, co
                 ez = fmaxf(fmaxf(blo[2] - z1, z1 - bhi[2]), 0.f);
     const float lb = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
 #if defined(PASNL_TUNING) && PASNL_FPS_ABL == 0
-    if (lane == 0 && (blockIdx.x & 3) == 0) { atomicAdd(&fps_dbg[1], 1ull); if (__ballot(lb < thr) != 0ull) atomicAdd(&fps_dbg[0], 1ull); }
+    if ((blockIdx.x & 3) == 0) {
+      const bool act = __ballot(lb < thr) != 0ull;
+      if (lane == 0) { atomicAdd(&fps_dbg[1], 1ull); if (act) { atomicAdd(&fps_dbg[0], 1ull); atomicAdd(&dbg_act[j % 3][wave & 3], 1); } }
+    }
 #endif
     if ((PASNL_FPS_ABL == 2 || __ballot(lb < thr) != 0ull) && PASNL_FPS_ABL != 1) {  // wave-uniform
 #pragma unroll
@@ -590,6 +597,13 @@ __global__ __launch_bounds__(WAVES * 64) void fps_pruned_kernel(int n, int m, co
     if (lane == 0) slot[wave] = make_float2(__uint_as_float(cand_d), __uint_as_float(cand_k));
     __syncthreads();
     const float2 sv = lane < WAVES ? slot[lane] : make_float2(0.f, 0.f);
+#if defined(PASNL_TUNING) && PASNL_FPS_ABL == 0
+    if (tid == 0 && (blockIdx.x & 3) == 0) {  // rounds by the number of active waves on the busiest SIMD (waves w, w+4, .. share one)
+      const int mxa = max(max(dbg_act[j % 3][0], dbg_act[j % 3][1]), max(dbg_act[j % 3][2], dbg_act[j % 3][3]));
+      atomicAdd(&fps_dbg[2 + min(mxa, 4)], 1ull);
+      for (int q = 0; q < 4; ++q) dbg_act[(j + 2) % 3][q] = 0;
+    }
+#endif
     const int di = (int)__float_as_uint(sv.x);
     const uint32_t ki = __float_as_uint(sv.y);
     const int gmax = __builtin_amdgcn_readlane(row_max_i32_to_lane15(di), 15);

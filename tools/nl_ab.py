@@ -1,0 +1,25 @@
+"""A/B of nl_attention_direct variants: one library per combination of compile-time switches (csrc/libpasnl_hip_nl<LB><ADDR><SWAP>.so,
+built by hand: -DPASNL_NL_LB/ADDR/SWAP), the four model shapes each."""
+import glob, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if len(sys.argv) > 1:
+    sys.path.insert(0, ROOT)
+    import numpy as np, torch
+    from pointasnl_amd import _hip
+    _hip.LIB_PATH = sys.argv[1]
+    from pointasnl_amd.utils import pointasnl_util as U
+    out = []
+    for (b, p, n, cb, name) in [(64, 512, 1024, 32, "cls-L1"), (64, 128, 512, 64, "cls-L2"), (16, 1024, 8192, 32, "scannet-L1"), (8, 1280, 10240, 32, "kitti-L1_1")]:
+        q = torch.randn((b, p, cb), device="cuda"); kv = torch.randn((b, n, 2 * cb), device="cuda")
+        for _ in range(3): U.nl_attention(q, kv, variant=2)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(20):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); U.nl_attention(q, kv, variant=2); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        out.append(f"{name} {np.median(ts):7.1f}")
+    print(os.path.basename(sys.argv[1]), " | ".join(out), flush=True)
+else:
+    for lib in sorted(glob.glob(os.path.join(ROOT, "pointasnl_amd/csrc/libpasnl_hip_nl*.so"))):
+        subprocess.run([sys.executable, __file__, lib])
