@@ -4,7 +4,7 @@
 import torch
 from pointasnl_amd.utils import tf_util
 from pointasnl_amd.utils.pointasnl_util import (PointASNLSetAbstraction, PointASNLDecodingLayer, get_repulsion_loss, Forked,
-                                                sa_search, knn_query, neighbor0_xyz)
+                                                sa_search, sa_search_split, knn_query, neighbor0_xyz)
 from pointasnl_amd.tf_interpolate import three_nn
 
 
@@ -40,7 +40,7 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
 
     def level1(xyz1):  # l1_xyz final
         knn[1] = Forked(lambda: knn_query(32, xyz1, xyz1), slot=1)
-        srch[2] = Forked(lambda: sa_search(xyz1, None, num_points[1], 32, knn_all=knn[1]), slot=0)
+        srch[2] = sa_search_split(xyz1, num_points[1], 32, knn[1], slot=0)  # sampler alone on its side stream; rows joined at use
 
     def level2(xyz2):  # l2_xyz final: everything below it depends on coordinates only
         def chain():

@@ -476,8 +476,20 @@ class Forked:
         return self.value
 
 
+class Deferred:
+    """.get() like Forked: a value put together from forked pieces on the CONSUMER's stream, once (later consumers reuse it)."""
+
+    def __init__(self, fn):
+        self._fn, self._have, self.value = fn, False, None
+
+    def get(self):
+        if not self._have:
+            self.value, self._have, self._fn = self._fn(), True, None
+        return self.value
+
+
 def _resolved(x):
-    return x.get() if isinstance(x, Forked) else x
+    return x.get() if isinstance(x, (Forked, Deferred)) else x
 
 
 def neighbor0_xyz(xyz, idx):
@@ -527,6 +539,25 @@ def sa_search(xyz, feature, npoint, nsample, use_knn=True, radius=None, knn_all=
     else:
         idx, _ = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
     return new_xyz, None, idx
+
+
+def sa_search_split(xyz, npoint, nsample, knn_all, slot=0):
+    """sa_search(xyz, None, npoint, nsample, knn_all=knn_all) with ONLY the sampler on a side stream: the neighbour lists (rows
+    of the self-kNN `knn_all`, tensor or Forked) are gathered where the result is consumed.  A fork that waits for another
+    fork inside it -- Forked(lambda: sa_search(.., knn_all=<Forked>)): the sampler's branch joins the kNN's branch before it
+    returns to the forward -- made the HIP-graph executor place the sampler BEHIND the kernels of the layer it was meant to
+    run beside (sem_seg_res: layer 1's 1-ms sampler started after layer 0's cell instead of at t = 0; serial forward 3.38 ->
+    2.96 ms with the branches kept apart, profiles/r04_q_fork_variants.txt).  -> Deferred of (new_xyz, None, idx)"""
+    fp = Forked(lambda: tf_sampling.farthest_point_sample_gather(npoint, xyz), slot=slot)
+
+    def join():
+        fps_idx, new_xyz = fp.get()
+        k_all = _resolved(knn_all)
+        idx = _gather_index_rows(k_all, fps_idx)
+        if k_all.shape[2] != nsample:
+            idx = idx[:, :, :nsample].contiguous()
+        return new_xyz, None, idx
+    return Deferred(join)
 
 
 def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_decay, weight_decay, scope, bn=True,
