@@ -45,3 +45,23 @@ def test_forked_forward_is_bit_identical_to_single_stream(model, bsz, n, monkeyp
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(gout, ref), f"graph replay {i}"
+
+
+def test_split_search_equals_plain_search():
+    """sa_search_split (the sampler alone on a side stream, neighbour rows joined at use, one gather for every consumer) returns
+    what sa_search returns on the same coordinates, with the self-kNN given as a tensor, as a Forked, or wider than nsample."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    x = torch.from_numpy(B.synth_clouds(9, 3, 4096)).cuda()
+    k_all = U.knn_query(32, x, x)
+    ref = U.sa_search(x, None, 512, 32, knn_all=k_all)
+    for knn_all in (k_all, U.Forked(lambda: U.knn_query(32, x, x), slot=1)):
+        d = U.sa_search_split(x, 512, 32, knn_all, slot=0)
+        got = d.get()
+        assert d.get() is got  # joined once
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], ref[0]) and got[1] is None and torch.equal(got[2], ref[2])
+    got16 = U.sa_search_split(x, 512, 16, k_all).get()
+    ref16 = U.sa_search(x, None, 512, 16, knn_all=k_all)
+    torch.cuda.synchronize()
+    assert torch.equal(got16[2], ref16[2]) and got16[2].shape[-1] == 16
