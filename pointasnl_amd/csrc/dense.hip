@@ -257,9 +257,10 @@ extern "C" int pasnl_dense_rows(int rows, int kdim, int n, const float* x, const
 // library does not split K for these (40-53 TF, and 3.9 TF on (4096,384,256)); this kernel does:
 //   * a workgroup (4 waves) owns one 128 x 128 output tile and one K slice; a wave owns 64 x 64 of it as 2 x 2
 //     v_mfma_f32_32x32x2_f32 accumulators;
-//   * chunks of 16 contraction indices go through LDS, double-buffered: A rows as they are (k contiguous: 64-byte runs per
+//   * chunks of 32 contraction indices (16: one chunk of loads in flight did not cover the A stream's HBM latency -- 40-54 TF)
+//     go through LDS, double-buffered: A rows as they are (k contiguous: 64-byte runs per
 //     row from global), W TRANSPOSED on the way in (a thread loads 8 words of one column, 256-byte runs per wave, and
-//     writes two 16-byte pieces of Ws[col][k]); both tiles have rows of 20 floats, so the 16-byte operand reads of 16
+//     writes 16-byte pieces of Ws[col][k]); both tiles have rows of KC + 4 floats, so the 16-byte operand reads of 16
 //     lanes hit 16 different bank quads;
 //   * MFMA step t of a group of 8 indices contracts k0+t and k0+4+t (any pairing is legal as long as A and B agree), so a
 //     lane's operand for four steps is ONE ds_read_b128;
@@ -269,12 +270,16 @@ extern "C" int pasnl_dense_rows(int rows, int kdim, int n, const float* x, const
 // ---------------------------------------------------------------------------------------------
 namespace pasnl {
 
-constexpr int SK_BM = 128, SK_BN = 128, SK_KC = 16, SK_LD = 20;
+constexpr int SK_BM = 128, SK_BN = 128;
+// SK_KC contraction indices per chunk (32; 16 when K is only a multiple of 16); tile rows of KC + 4 floats: 16-byte reads of 16
+// lanes hit 16 bank quads; a thread moves SK_H = KC / 2 indices of one A row and of one W column per chunk
 
+template <int SK_KC>
 __global__ __launch_bounds__(256) void dense_splitk_kernel(int M, int K, int N, int lda, int kslice, int ksplit,
                                                           const float* __restrict__ A, const float* __restrict__ W,
                                                           const float* __restrict__ bias, int relu, float* __restrict__ out,
                                                           float* __restrict__ part) {
+  constexpr int SK_LD = SK_KC + 4, SK_H = SK_KC / 2;
   __shared__ __attribute__((aligned(16))) float As[2][SK_BM * SK_LD];
   __shared__ __attribute__((aligned(16))) float Ws[2][SK_BN * SK_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l32 = lane & 31;
@@ -283,24 +288,25 @@ __global__ __launch_bounds__(256) void dense_splitk_kernel(int M, int K, int N, 
   const int kbeg = ks * kslice, kend = min(kbeg + kslice, K);
   const int nchunks = (kend - kbeg) / SK_KC;
 
-  // global -> registers: A: thread t takes row t/2, 8 contraction indices (two float4); W: column t%128, 8 indices
-  const int arow = tid >> 1, akq = (tid & 1) * 8;
+  // global -> registers: A: thread t takes row t/2, KC/2 contraction indices (KC/8 float4); W: column t%128, KC/2 indices
+  const int arow = tid >> 1, akq = (tid & 1) * SK_H;
   const float* ap = A + (size_t)min(m0 + arow, M - 1) * lda + kbeg + akq;
-  const int wcol = tid & 127, wkh = (tid >> 7) * 8;
+  const int wcol = tid & 127, wkh = (tid >> 7) * SK_H;
   const float* wp = W + (size_t)(kbeg + wkh) * N + min(n0 + wcol, N - 1);
-  float4 ra0, ra1;
-  float rw[8];
+  float4 ra[SK_H / 4];
+  float rw[SK_H];
   auto gload = [&](int c) {
-    ra0 = *reinterpret_cast<const float4*>(ap + c * SK_KC);
-    ra1 = *reinterpret_cast<const float4*>(ap + c * SK_KC + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rw[j] = wp[(size_t)(c * SK_KC + j) * N];
+    for (int j = 0; j < SK_H / 4; ++j) ra[j] = *reinterpret_cast<const float4*>(ap + c * SK_KC + 4 * j);
+#pragma unroll
+    for (int j = 0; j < SK_H; ++j) rw[j] = wp[(size_t)(c * SK_KC + j) * N];
   };
   auto lstore = [&](int buf) {
-    *reinterpret_cast<float4*>(&As[buf][arow * SK_LD + akq]) = ra0;
-    *reinterpret_cast<float4*>(&As[buf][arow * SK_LD + akq + 4]) = ra1;
-    *reinterpret_cast<float4*>(&Ws[buf][wcol * SK_LD + wkh]) = make_float4(rw[0], rw[1], rw[2], rw[3]);
-    *reinterpret_cast<float4*>(&Ws[buf][wcol * SK_LD + wkh + 4]) = make_float4(rw[4], rw[5], rw[6], rw[7]);
+#pragma unroll
+    for (int j = 0; j < SK_H / 4; ++j) {
+      *reinterpret_cast<float4*>(&As[buf][arow * SK_LD + akq + 4 * j]) = ra[j];
+      *reinterpret_cast<float4*>(&Ws[buf][wcol * SK_LD + wkh + 4 * j]) = make_float4(rw[4 * j], rw[4 * j + 1], rw[4 * j + 2], rw[4 * j + 3]);
+    }
   };
 
   f32x16 acc[2][2];
@@ -322,22 +328,19 @@ __global__ __launch_bounds__(256) void dense_splitk_kernel(int M, int K, int N, 
     const float* as = &As[buf][(wm * 64 + l32) * SK_LD + 4 * h];
     const float* ws = &Ws[buf][(wn * 64 + l32) * SK_LD + 4 * h];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < SK_KC / 8; ++g) {
       float4 a[2], b[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         a[i] = *reinterpret_cast<const float4*>(as + i * 32 * SK_LD + g * 8);
         b[i] = *reinterpret_cast<const float4*>(ws + i * 32 * SK_LD + g * 8);
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-        }
+      // the four accumulators in turn inside every contraction step: no product waits for the one issued just before it
+#define PASNL_SK_STEP(f)                                                                              \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)          \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].f, b[j].f, acc[i][j], 0, 0, 0);
+      PASNL_SK_STEP(x) PASNL_SK_STEP(y) PASNL_SK_STEP(z) PASNL_SK_STEP(w)
+#undef PASNL_SK_STEP
     }
     if (c + 1 < nchunks) lstore(buf ^ 1);  // the other buffer: its readers finished before the barrier that opened this chunk
     __syncthreads();
@@ -406,10 +409,13 @@ struct SplitKPlan {
 
 static SplitKPlan splitk_plan(int M, int K, int N) {
   SplitKPlan p;
+  const int SK_KC = K % 32 == 0 ? 32 : 16;
   p.mt = (M + SK_BM - 1) / SK_BM;
   p.nt = (N + SK_BN - 1) / SK_BN;
   const int tiles = p.mt * p.nt;
-  int want = (256 + tiles - 1) / tiles;  // ~1 workgroup per CU: a slice is long enough to amortise prologue, partial tile and reduce
+  // at most one workgroup per CU: a slice is long enough to amortise prologue, partial tile and reduce.  Rounded DOWN: 13
+  // slices x 20 tiles = 260 workgroups put two on four of the 256 CUs and the launch took twice one workgroup's time
+  int want = 256 / tiles;
   const int most = K / 64 > 0 ? K / 64 : 1;  // slices of at least 64 contraction indices
   if (want > most) want = most;
   if (want < 1) want = 1;
@@ -431,7 +437,7 @@ extern "C" int pasnl_dense_splitk(int rows, int kdim, int n, int lda, const floa
   PASNL_REQUIRE(rows >= 0 && kdim > 0 && n > 0 && lda >= kdim, PASNL_EINVAL);
   if (rows == 0) return PASNL_OK;
   PASNL_REQUIRE(x && w && bias && out, PASNL_ENULL);
-  PASNL_REQUIRE(kdim % SK_KC == 0 && lda % 4 == 0 && n % 4 == 0, PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE(kdim % 16 == 0 && lda % 4 == 0 && n % 4 == 0, PASNL_EUNSUPPORTED);
   PASNL_REQUIRE((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(bias)) % 16 == 0,
                 PASNL_EUNSUPPORTED);
   const SplitKPlan p = splitk_plan(rows, kdim, n);
@@ -439,8 +445,12 @@ extern "C" int pasnl_dense_splitk(int rows, int kdim, int n, int lda, const floa
   PASNL_REQUIRE(p.bytes == 0 || (workspace && workspace_bytes >= p.bytes), PASNL_EWORKSPACE);
   hipStream_t st = pasnl_hip_stream(stream);
   float* part = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(dense_splitk_kernel, dim3(p.nt, p.mt, p.ksplit), dim3(256), 0, st, rows, kdim, n, lda, p.kslice, p.ksplit, x,
-                     w, bias, relu, out, part);
+  if (kdim % 32 == 0)
+    hipLaunchKernelGGL(dense_splitk_kernel<32>, dim3(p.nt, p.mt, p.ksplit), dim3(256), 0, st, rows, kdim, n, lda, p.kslice,
+                       p.ksplit, x, w, bias, relu, out, part);
+  else
+    hipLaunchKernelGGL(dense_splitk_kernel<16>, dim3(p.nt, p.mt, p.ksplit), dim3(256), 0, st, rows, kdim, n, lda, p.kslice,
+                       p.ksplit, x, w, bias, relu, out, part);
   if (p.ksplit > 1) {
     const long total = (long)rows * (n / 4);
     long g = (total + 255) / 256;

@@ -201,7 +201,7 @@ def _dense_rows_workspace(nbytes, device):
 
 # Thin products with a long contraction on pasnl_dense_splitk -- only where it was measured to beat the vendor library WITH its
 # transposed-weights trick (tools/splitk_probe.py): one column block of tiles, thousands of rows, K >= 4096, e.g. sem_seg_res's
-# (2560, 4096, 128): 62 -> 51 us.  Everywhere else the vendor kernels are as fast or faster (EXPERIMENTS.md).
+# (2560, 4096, 128): 62 -> 44 us (at most ONE workgroup per CU: 13 slices x 20 tiles had been 260).  Everywhere else the vendor kernels are as fast or faster (EXPERIMENTS.md).
 DENSE_SPLITK = True
 SPLITK_MIN_K = 4096
 SPLITK_MAX_N = 128
