@@ -487,6 +487,7 @@ def protocol_only(args, rank, world):
 # one configuration: inputs, capture, timed replays, agreement with the eager forward, per-kernel pass
 # ---------------------------------------------------------------------------------------------------------------
 _FORWARD_STREAM = None
+SPLIT_PREFIX = os.environ.get('PASNL_BENCH_SPLIT_PREFIX', '1') != '0'  # tuning switch: sem_seg_res prefix as two plain branches
 PREFETCH_SLOTS = tuple(int(v) for v in os.environ.get('PASNL_BENCH_PREFETCH_SLOTS', '3,4').split(','))  # side streams of the prefetch
 WORKLOADS = {
     1: dict(model="cls", AS=False, noise=0, batch=64, points=1024, name="configs[1]: ModelNet40 pointasnl_cls, 1024 pts"),
@@ -621,10 +622,19 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
             torch.cuda.synchronize()
 
             def body(cur, nxt):
-                fk = []
+                fk, late = [], []
 
                 def fork():  # sibling forks from the forward's own stream, each joined to it (a fork of a fork crashes
                     #          hipStreamEndCapture on ROCm 7.2)
+                    if res and SPLIT_PREFIX:
+                        # sem_seg_res: the sampler and the self-kNN each ALONE on a side branch, their join (the rows of the
+                        # sampled points + the hand-over copies) on the forward's stream once both are back -- a branch that
+                        # waits for another branch inside misleads the graph executor's placement (EXPERIMENTS.md, round 4)
+                        ff = pointasnl_util.Forked(lambda: tf_sampling.farthest_point_sample_gather(N // 8, xyz_of(xs[nxt])), slot=PREFETCH_SLOTS[0])
+                        kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt])), slot=PREFETCH_SLOTS[1])
+                        fk.extend([ff, kf])
+                        late.append((ff, kf))
+                        return
                     kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt])), slot=PREFETCH_SLOTS[1]) \
                         if res else None
 
@@ -640,6 +650,10 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
                 o = forward(xs[cur], search=as_search(xs[cur], S[cur]), before_head=None if fk else fork)
                 for f in fk:
                     f.get()  # join: the graph ends when everything has finished
+                for ff, kf in late:
+                    (fps_idx, new_xyz), k_all = ff.get(), kf.get()
+                    for dst, src in zip(S[nxt], [k_all, new_xyz, pointasnl_util._gather_index_rows(k_all, fps_idx)]):
+                        dst.copy_(src)
                 return o
 
             for cur in (0, 1):

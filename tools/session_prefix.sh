@@ -1,0 +1,6 @@
+#!/bin/bash
+O=gpurun_out/r04q; mkdir -p $O; export TMPDIR=/tmp
+run() { timeout 300 python bench.py --worker --model sem_seg_res --steps 20 --warmup 5 --no-cpu-baseline --no-others 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'prefetch ms', d['ms_per_step'], 'serial', d['config'].get('serial_ms_per_step'), 'agree', d['config'].get('outputs_agree'))"; }
+for v in 1 0 1 0; do PASNL_BENCH_SPLIT_PREFIX=$v run "split_prefix=$v"; done
