@@ -779,21 +779,9 @@ def ball_query_sweep(batches=(64, 256, 1024, 4096), iters=20):
         us = [e0.elapsed_time(e1) * 1e3 for _, _, e0, e1 in _hip.PROFILE]
         _hip.PROFILE = None
         med = float(np.median(us))
-        # the same launch as a train of 10 between ONE pair of events: an event pair around a single launch also times the
-        # dispatch of that launch (~6 us), which a 20-us kernel shows and rocprofv3's kernel duration does not contain
-        trains = []
-        for _ in range(5):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                P.tf_grouping.query_ball_point(0.2, 32, x, q)
-            e1.record()
-            torch.cuda.synchronize()
-            trains.append(e0.elapsed_time(e1) * 1e2)
-        train = float(np.median(trains))
         by, fl, _ = algorithmic("pasnl_query_ball_point", (b, 1024, 512, 32))
         traffic, src = measured_traffic("pasnl_query_ball_point", [b, 1024, 512, 32])
-        out.append({"B": b, "dims": [b, 1024, 512, 32], "radius": 0.2, "median_us": round(med, 2), "min_us": round(min(us), 2), "train_us": round(train, 2),
+        out.append({"B": b, "dims": [b, 1024, 512, 32], "radius": 0.2, "median_us": round(med, 2), "min_us": round(min(us), 2),
                     "alg_MB": round(by / 1e6, 2), "GB/s": round(by / med / 1e3, 1), "hbm_frac": round(by / med / 1e3 / HBM_PEAK_GBS, 4),
                     "traffic": traffic})
         sources.add(src)
@@ -1027,7 +1015,6 @@ def main():
         for e in sweep:
             config[f"ball_hbm_frac_b{e['B']}"] = e["hbm_frac"]
             config[f"ball_us_b{e['B']}"] = e["median_us"]
-            config[f"ball_train_us_b{e['B']}"] = e["train_us"]  # per launch in a train of 10 (no per-launch dispatch in the bracket)
     out = {
         "metric": "point-clouds/sec fwd (Bx1024 pts, ModelNet40 cls)" if args.model == "cls" else
                   f"point-clouds/sec fwd (Bx{res['N']} pts, pointasnl_{args.model})",
