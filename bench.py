@@ -706,7 +706,7 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
             last = step()
         enqueued = time.perf_counter() - t0  # host time to issue the K steps (replay + collective): no host sync inside a step
         torch.cuda.synchronize()
-        if os.environ.get("PASNL_BENCH_TRACE_ONLY"):  # profiling hook (tools/session_tl.sh): a kernel trace that ends with the timed
+        if os.environ.get("PASNL_BENCH_TRACE_ONLY"):  # profiling hook (tools/sessions/session_tl.sh): a kernel trace that ends with the timed
             sys.exit(0)                               # replays, not with the serial comparison and the eager per-kernel pass
         if multi:
             dist.barrier()

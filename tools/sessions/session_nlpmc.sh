@@ -1,5 +1,5 @@
 #!/bin/bash
-# counters of nl_attention_direct (one kernel, scannet shape), baseline library against the variant: bash tools/session_nlpmc.sh libA libB
+# counters of nl_attention_direct (one kernel, scannet shape), baseline library against the variant: bash tools/sessions/session_nlpmc.sh libA libB
 export TMPDIR=/tmp
 O=gpurun_out/r04q/nlpmc; rm -rf $O; mkdir -p $O
 for lib in "$@"; do
