@@ -645,7 +645,7 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
                     fk.append(pointasnl_util.Forked(run_prefix, slot=PREFETCH_SLOTS[0]))
                     if kf is not None:
                         fk.append(kf)
-                if spec.get("prefetch_at", "head") == "start":
+                if os.environ.get("PASNL_BENCH_PREFETCH_AT", spec.get("prefetch_at", "head")) == "start":  # (tuning switch)
                     fork()
                 o = forward(xs[cur], search=as_search(xs[cur], S[cur]), before_head=None if fk else fork)
                 for f in fk:
