@@ -22,6 +22,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr float LOG2E = 1.4426950408889634f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// A value combined across the two halves of the wave (lane l with lane l ^ 32): v_permlane32_swap_b32 with both operands the
+// same register leaves {value of lane l & 31, value of lane (l & 31) + 32} in every lane -- one vector instruction where
+// __shfl_xor(v, 32) is a ds_bpermute_b32 (an LDS round trip).  lo + hi in both halves: the same bits as own + other.
+__device__ __forceinline__ float half_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // row index held in register r of lane-half h of a 32x32 MFMA C/D tile
 __device__ __forceinline__ int kappa(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
@@ -444,6 +455,182 @@ __global__ __launch_bounds__(SPLIT * 64, CB == 64 ? 2 : 1) void nl_attention_dir
         *reinterpret_cast<float4*>(op + c * 32 + 8 * g + 4 * h) = v;
       }
   }
+}
+
+// =============================================================================================
+// Non-local attention, cb = 32, TWO query tiles per wave (64 queries per workgroup).  A key block's K and V registers feed two
+// independent score / output chains, so (a) every load serves twice the matrix work and (b) the wave has something for the
+// matrix pipe while it computes a softmax: the program order is
+//     S0 = K.Q0 | S1 = K.Q1 with softmax(S0) between its products | O0 += V.P0 with softmax(S1) between | O1 += V.P1
+// (sched_group_barrier: one product, then a few vector instructions), where the one-tile kernel above leaves the pipe idle
+// during its softmax unless another wave happens to be in a product phase.  Same arithmetic per tile as the kernel above (same
+// key blocks per wave, same merge order).  cls layer 1 64.6 -> 55 us, ScanNet layer 1 202 -> 178, KITTI layer 1_1 222 -> 200
+// (profiles/r04_q_nl_pair.txt); without its refills the loop runs 2-3 % faster: it is not waiting for memory.
+// =============================================================================================
+template <int SPLIT>
+__global__ __launch_bounds__(SPLIT * 64, 2) void nl_attention_pair_kernel(int p, int n, float qscale, const float* __restrict__ q,
+                                                                     const float* __restrict__ kv, float* __restrict__ out) {
+  constexpr int CB = 32, HC = 16;
+  constexpr int PARK = (CB / 2 + 2) * 64;  // floats a wave parks per tile for the merge
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, ql = lane & 31;
+  int bi = blockIdx.y, qt = blockIdx.x;  // XCD-aware mapping as in nl_attention_mfma_kernel
+  if ((gridDim.y & 7) == 0) {
+    const int id = blockIdx.y * gridDim.x + blockIdx.x, slot = id >> 3;
+    bi = (id & 7) + 8 * (slot / (int)gridDim.x);
+    qt = slot % (int)gridDim.x;
+  }
+  const int q0 = qt * 64;
+  const float* kvb = kv + (size_t)bi * n * 2 * CB;
+
+  float qreg[2][HC];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const float* qp = q + ((size_t)bi * p + min(q0 + 32 * u + ql, p - 1)) * CB + HC * h;
+#pragma unroll
+    for (int t = 0; t < HC; ++t) qreg[u][t] = qp[t] * qscale;
+  }
+  f32x16 O[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[u][r] = 0.f;
+  float mrun[2] = {-INFINITY, -INFINITY}, lrun[2] = {0.f, 0.f};
+
+  float kreg[HC], vreg[16];
+  // n is a multiple of the 32-key block here (the launcher's condition): no ragged block, so a block's rows are ONE lane
+  // pointer each for K and V plus compile-time offsets (V: rows kappa(t, h) - 14 around row 14, inside the load's 13-bit
+  // immediate), advanced by a uniform stride per block -- 4 address registers instead of 40
+  const float* kp = kvb + (size_t)(wave * NL_KB + ql) * 2 * CB + HC * h;
+  const float* vp = kvb + (size_t)(wave * NL_KB + 4 * h + 14) * 2 * CB + CB + ql;
+  auto load_k = [&]() {
+#pragma unroll
+    for (int g = 0; g < HC / 4; ++g) {
+      const float4 v = reinterpret_cast<const float4*>(kp)[g];
+      kreg[4 * g] = v.x; kreg[4 * g + 1] = v.y; kreg[4 * g + 2] = v.z; kreg[4 * g + 3] = v.w;
+    }
+  };
+  auto load_v = [&]() {
+#pragma unroll
+    for (int t = 0; t < 16; ++t) vreg[t] = vp[((t & 3) + 8 * (t >> 2) - 14) * 2 * CB];
+  };
+  // online softmax of one tile's 32 x 32 scores (this lane: 16 keys of one query; the other half-wave holds the other 16), cut
+  // into 16 pieces of a few vector instructions: piece i is issued right behind product i of the OTHER tile's chain and runs in
+  // its shadow (a 32x32x2 product occupies the matrix pipe for 64 cycles = 16 vector issue slots)
+  float tmx, mnew_, psum_;
+  auto softmax_piece = [&](f32x16& S, int u, float& alpha, int i) {
+    if (i == 0) {
+      tmx = fmaxf(fmaxf(S[0], S[1]), fmaxf(S[2], S[3]));
+    } else if (i < 4) {
+      tmx = fmaxf(tmx, fmaxf(fmaxf(S[4 * i], S[4 * i + 1]), fmaxf(S[4 * i + 2], S[4 * i + 3])));
+    } else if (i == 4) {
+      tmx = half_max(tmx);  // v_permlane32_swap: a vector instruction -- an LDS shuffle here would stall the pieces (and the
+                            // product) queued behind it for a round trip
+      mnew_ = fmaxf(mrun[u], tmx);
+      alpha = fast_exp2(mrun[u] - mnew_);
+      psum_ = 0.f;
+    } else if (i < 13) {  // pieces 5 .. 12: two probabilities each, summed in key order like the one-tile kernel
+      const int r = 2 * (i - 5);
+      S[r] = fast_exp2(S[r] - mnew_);
+      psum_ += S[r];
+      S[r + 1] = fast_exp2(S[r + 1] - mnew_);
+      psum_ += S[r + 1];
+    } else if (i == 13) {
+      psum_ = half_sum(psum_);
+      lrun[u] = lrun[u] * alpha + psum_;
+      mrun[u] = mnew_;
+    } else {  // pieces 14, 15: the running output rescaled
+#pragma unroll
+      for (int r = 8 * (i - 14); r < 8 * (i - 14) + 8; ++r) O[u][r] *= alpha;
+    }
+  };
+
+  const int first = wave * NL_KB;
+  constexpr size_t STRIDE = (size_t)SPLIT * NL_KB * 2 * CB;  // floats between a wave's consecutive key blocks
+  if (first < n) {
+    load_k();
+    __builtin_amdgcn_sched_barrier(0);
+    load_v();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int base = first; base < n; base += SPLIT * NL_KB) {
+    if (base + SPLIT * NL_KB < n) { kp += STRIDE; vp += STRIDE; }  // (uniform) the last refill of a wave re-reads its block
+    f32x16 S0, S1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { S0[r] = 0.f; S1[r] = 0.f; }
+    float alpha0, alpha1;
+#pragma unroll
+    for (int t = 0; t < HC; ++t) S0 = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[t], qreg[0][t], S0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S1's products with softmax(S0) in their shadow
+#pragma unroll
+    for (int t = 0; t < HC; ++t) {
+      S1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[t], qreg[1][t], S1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      softmax_piece(S0, 0, alpha0, t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#ifndef PASNL_NL_PAIR_NOLOAD  // (timing ablation: the loop without its refills)
+    load_k();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- O0 += V . P0 with softmax(S1) in its shadow
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      O[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[t], S0[t], O[0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      softmax_piece(S1, 1, alpha1, t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t) O[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[t], S1[t], O[1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef PASNL_NL_PAIR_NOLOAD
+    load_v();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  if constexpr (SPLIT > 1) {
+    float* park = reinterpret_cast<float*>(smem) + (size_t)wave * 2 * PARK;
+    if (wave > 0) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) park[u * PARK + r * 64 + lane] = O[u][r];
+        park[u * PARK + 16 * 64 + lane] = mrun[u];
+        park[u * PARK + 17 * 64 + lane] = lrun[u];
+      }
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll 1
+    for (int w = 1; w < SPLIT; ++w)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float* pw = reinterpret_cast<const float*>(smem) + (size_t)w * 2 * PARK + u * PARK;
+        const float mw = pw[16 * 64 + lane], lw = pw[17 * 64 + lane];
+        const float mnew = fmaxf(mrun[u], mw);  // a wave that saw no key block has m = -inf, l = 0, O = 0
+        const float a0 = mrun[u] == -INFINITY ? 0.f : fast_exp2(mrun[u] - mnew);
+        const float a1 = mw == -INFINITY ? 0.f : fast_exp2(mw - mnew);
+        lrun[u] = lrun[u] * a0 + lw * a1;
+        mrun[u] = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[u][r] = O[u][r] * a0 + pw[r * 64 + lane] * a1;
+      }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (q0 + 32 * u + ql < p) {
+      const float inv = 1.0f / lrun[u];
+      float* op = out + ((size_t)bi * p + q0 + 32 * u + ql) * CB;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(O[u][4 * g] * inv, O[u][4 * g + 1] * inv, O[u][4 * g + 2] * inv, O[u][4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + 8 * g + 4 * h) = v;
+      }
+    }
 }
 
 // =============================================================================================
@@ -1475,9 +1662,39 @@ static int nl_mfma_launch(int b, int p, int n, float qscale, const float* q, con
   return pasnl_launch_status();
 }
 
+template <int SPLIT>
+static int nl_pair_launch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, hipStream_t st) {
+  const size_t lds = (size_t)SPLIT * 2 * (32 / 2 + 2) * 64 * sizeof(float);
+  auto kern = nl_attention_pair_kernel<SPLIT>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3((p + 63) / 64, b), dim3(SPLIT * 64), lds, st, p, n, qscale, q, kv, out);
+  return pasnl_launch_status();
+}
+
 template <int CB>
 static int nl_mfma_dispatch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, bool staged,
                             hipStream_t st) {
+  if constexpr (CB == 32) {
+    // two query tiles per wave when there are pairs for at least half of the CUs (cls layer 1: 512, ScanNet layer 1: 256,
+    // KITTI layer 1_1: 160 -- 222 -> 200 us although 96 CUs stay empty) and no ragged key block
+    const long pairs = (long)b * ((p + 63) / 64);
+    const long blocks = (n + NL_KB - 1) / NL_KB;
+    const char* one = tune_env("PASNL_NL_PAIR");  // tuning only: "0" = never
+    const char* pm = tune_env("PASNL_NL_PAIR_MIN");  // tuning only
+    const long pair_min = pm && *pm ? atol(pm) : 128;
+    if (!staged && pairs >= pair_min && n % NL_KB == 0 && !(one && *one == '0')) {
+      int want = 1;
+      while (want < 8 && pairs * want < 2048 && want * 2 * 4 <= blocks) want *= 2;
+      const char* force = tune_env("PASNL_NL_SPLIT");
+      if (force && *force) want = atoi(force);
+      if (want >= 8) return nl_pair_launch<8>(b, p, n, qscale, q, kv, out, st);
+      if (want >= 4) return nl_pair_launch<4>(b, p, n, qscale, q, kv, out, st);
+      if (want >= 2) return nl_pair_launch<2>(b, p, n, qscale, q, kv, out, st);
+      return nl_pair_launch<1>(b, p, n, qscale, q, kv, out, st);
+    }
+  }
   // split the keys over enough waves to put ~4 on every SIMD (4096 waves; measured best on all reference shapes:
   // cls layer1 140 -> 82 us, cls layer2 128 -> 37 us, ScanNet layer1 1030 -> 279 us with the LDS-staged kernel), but
   // keep >= 4 key blocks per wave (cls layer2, 16 blocks: 19 us at 4 waves, 23 us at 8: the merge is not free) and

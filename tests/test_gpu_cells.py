@@ -40,6 +40,36 @@ def test_nl_attention(b, p, n, cb, variant):
     np.testing.assert_allclose(got, want64, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("b,p,n", [
+    (16, 512, 1024),   # cls layer 1 at a batch that reaches the two-tile kernel (128 pairs of tiles)
+    (3, 2800, 256),    # the last pair: a full tile and a tile of 16 queries
+    (2, 4100, 96),     # the last pair: 4 queries and an empty tile; 3 key blocks for up to 8 waves (waves without a block)
+    (130, 64, 32),     # one key block
+    (4, 2048, 8192),   # long key loop
+    (3, 2800, 250),    # a ragged key block: the dispatcher has to fall back to the one-tile kernel
+])
+def test_nl_attention_two_tiles_per_wave(b, p, n):
+    """cb = 32 with >= 128 pairs of 32-query tiles runs nl_attention_pair_kernel (two tiles per wave, softmax pieces in the
+    shadow of the other tile's products): the same 1e-5 contract, ragged query counts, waves that see no key block, and a key
+    that dominates late (the rescale path of both tiles)."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    cb = 32
+    rng = np.random.default_rng(p + n)
+    q = rng.standard_normal((b, p, cb)).astype(np.float32)
+    kv = rng.standard_normal((b, n, 2 * cb)).astype(np.float32)
+    kv[0, n - 3, :cb] = q[0, min(40, p - 1)] * 5.0   # a late spike for a query of the SECOND tile
+    kv[b - 1, n // 2, :cb] = q[b - 1, 1] * 5.0
+    sel = [0, b - 1] if b > 2 else list(range(b))    # the fp64 oracle on two clouds is enough (and keeps the test short)
+    got = U.nl_attention(dev(q), dev(kv), variant=2).cpu().numpy()
+    assert np.isfinite(got).all()
+    want = cells.nl_attention_core(q[sel].astype(np.float64), kv[sel].astype(np.float64), cb)
+    np.testing.assert_allclose(got[sel], want, rtol=1e-5, atol=1e-5)
+    # every cloud against the vector-FMA kernel (an independent implementation on the same inputs)
+    ref = U.nl_attention(dev(q), dev(kv), variant=1).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("b,p,n,cb", [(2, 128, 512, 64), (2, 45, 77, 32)])
 def test_nl_attention_lds_staged_kernel_still_agrees(b, p, n, cb):
     """cb <= 64 runs the kernel that takes its operands straight from global memory; the LDS-staged one (the only one
