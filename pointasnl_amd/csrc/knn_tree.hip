@@ -9,8 +9,8 @@
 // bit for bit, for data with ties, by re-doing what nanoflann does -- the same tree (divideTree / middleSplit_ / planeSplit,
 // nanoflann.hpp:916-1043, re-stated here with explicit stacks; every float expression in the reference's association, no
 // contraction) and the same search (searchLevel :1351-1410, near child first) -- on the GPU:
-//   * knn_tree_build_par_kernel (n <= 10240): a workgroup per cloud builds the tree level by level, a wave per node, with
-//     planeSplit's Hoare loop in closed form; knn_tree_build_kernel: the literal one-lane restatement (larger clouds, and the
+//   * knn_tree_build_lds_kernel (n <= 8192, the points in LDS) / knn_tree_build_par_kernel (n <= 10240, gathers): a workgroup
+//     per cloud builds the tree level by level, a wave per node, with planeSplit's Hoare loop in closed form; knn_tree_build_kernel: the literal one-lane restatement (larger clouds, and the
 //     checker of the parallel build in the tuning build);
 //   * knn_tree_search_kernel: one lane per query walks it as a flat state machine, the result set as the k smallest
 //     (distance, arrival) keys in LDS, sorted once at the end.
@@ -333,7 +333,10 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
           if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn; mx_c = mx; }
         }
       }
-      const float split_val = (wk.box[2 * cutfeat] + wk.box[2 * cutfeat + 1]) / 2;
+      // (selects, not wk.box[2 * cutfeat]: a dynamically indexed local array lives in scratch memory)
+      const float blo = cutfeat == 0 ? wk.box[0] : (cutfeat == 1 ? wk.box[2] : wk.box[4]);
+      const float bhi = cutfeat == 0 ? wk.box[1] : (cutfeat == 1 ? wk.box[3] : wk.box[5]);
+      const float split_val = (blo + bhi) / 2;
       float cutval;  // (the second computeMinMax of the reference, on cutfeat, returns mn_c / mx_c again)
       if (split_val < mn_c) cutval = mn_c;
       else if (split_val > mx_c) cutval = mx_c;
@@ -408,9 +411,9 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
           } else {
             KtWork w;
             w.node = id; w.left = cl; w.right = cr;
-            for (int i = 0; i < 6; ++i) w.box[i] = wk.box[i];
-            if (c == 0) w.box[2 * cutfeat + 1] = cutval;  // left child: high = cutval (:946-947); right child: low = cutval (:951-952)
-            else w.box[2 * cutfeat] = cutval;
+            // left child: high = cutval (:946-947); right child: low = cutval (:951-952)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : wk.box[i];
             queue[cur ^ 1][atomicAdd(&ctr[cur ^ 1], 1)] = w;
           }
         }
@@ -432,6 +435,219 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
     const unsigned v = vind[i];
     gvind[i] = v;
     recs[i] = make_float4(pts[(size_t)v * 3], pts[(size_t)v * 3 + 1], pts[(size_t)v * 3 + 2], __int_as_float((int)v));
+  }
+  if (tid == 0) { hdr[0] = ctr[3]; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; }
+}
+
+// The same build with the POINTS in LDS (n <= KTB_LDS_NMAX): records {x, y, z, index} that move with the index list, so every
+// pass over a node is a sequential LDS read.  In the kernel above a pass gathers pts[vind[i]] from global memory, one dependent
+// round trip per 64 points.  16 x 8192: 556 -> 485 us -- what remains is one wave's ~9 passes over a large node at the top
+// levels and ~3.5 us of fixed cost per node at the deep ones (EXPERIMENTS.md).
+constexpr int KTB_LDS_NMAX = 8192;  // 18 bytes per point: 147 KB of the 160 KB
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int n, const float* __restrict__ pts_all,
+                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* rec = reinterpret_cast<float4*>(smem);                             // [n] {x, y, z, index bits}: the points move with the index list
+  unsigned short* sc = reinterpret_cast<unsigned short*>(rec + n);           // [n] positions of misplaced elements
+  float* part = reinterpret_cast<float*>(sc + ((n + 1) & ~1));               // [KTB_WAVES][6] root-box partials
+  int* ctr = reinterpret_cast<int*>(part + KTB_WAVES * 6);                   // [0], [1]: queue lengths; [2]: nodes used; [3]: flag
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* pts = pts_all + (size_t)blockIdx.x * n * 3;
+  char* ws = ws_all + (size_t)blockIdx.x * stride;
+  int* hdr = reinterpret_cast<int*>(ws);
+  unsigned* gvind = reinterpret_cast<unsigned*>(ws + kt_align(16));
+  KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(16) + kt_align((size_t)n * 4));
+  KtFrame* fr = reinterpret_cast<KtFrame*>(ws + kt_align(16) + kt_align((size_t)n * 4) + kt_align((size_t)2 * n * sizeof(KtNode)));
+  const int qcap = n / (KT_LEAF + 1) + 2;
+  KtWork* queue[2];
+  queue[0] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(fr) + kt_align((size_t)KT_DEPTH * sizeof(KtFrame)));
+  queue[1] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(queue[0]) + kt_align((size_t)qcap * sizeof(KtWork)));
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));  // lanes below this one
+
+  // init_vind (:1318), computeBoundingBox (:1321-1346)
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = tid; i < n; i += KTB_WAVES * 64) {
+    const float c[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
+    rec[i] = make_float4(c[0], c[1], c[2], __int_as_float(i));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = c[d] < lo[d] ? c[d] : lo[d];
+      hi[d] = c[d] > hi[d] ? c[d] : hi[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { lo[d] = wave_min_f32(lo[d]); hi[d] = wave_max_f32(hi[d]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { part[wave * 6 + 2 * d] = lo[d]; part[wave * 6 + 2 * d + 1] = hi[d]; }
+  }
+  if (tid < 4) ctr[tid] = 0;
+  __syncthreads();
+  float root[6];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float l = part[2 * d], h = part[2 * d + 1];
+    for (int w = 1; w < KTB_WAVES; ++w) { l = fminf(l, part[w * 6 + 2 * d]); h = fmaxf(h, part[w * 6 + 2 * d + 1]); }
+    root[2 * d] = l; root[2 * d + 1] = h;
+  }
+  if (tid == 0) {
+    ctr[2] = 1;  // node 0 = the root
+    if (n <= KT_LEAF) {
+      nodes[0].child1 = nodes[0].child2 = -1; nodes[0].a = 0; nodes[0].divlow = __int_as_float(n); nodes[0].divhigh = 0.f;
+    } else {
+      KtWork w0; w0.node = 0; w0.left = 0; w0.right = (unsigned)n;
+      for (int i = 0; i < 6; ++i) w0.box[i] = root[i];
+      queue[0][0] = w0;
+      ctr[0] = 1;
+    }
+    for (int i = 0; i < 6; ++i) fr[1].bbox[i] = root[i];  // root_bbox after divideTree = the tight box of all points (what the search reads)
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  int cur = 0, level = 0;
+  for (;;) {
+    const int nq = ctr[cur];
+    if (nq == 0) break;
+    if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }  // deeper than the search's stack: flagged, not built
+    for (int e = wave; e < nq; e += KTB_WAVES) {
+      KtWork wk;  // the same address in every lane; written by another wave one level ago: plain vector loads, never the scalar cache
+      {
+        const volatile KtWork* qe = queue[cur] + e;
+        wk.node = qe->node; wk.left = qe->left; wk.right = qe->right;
+        for (int i = 0; i < 6; ++i) wk.box[i] = qe->box[i];
+      }
+      const unsigned left = wk.left, right = wk.right, count = right - left;
+      // ---- middleSplit_ (:966-1005)
+      const float EPS = 0.00001f;
+      float max_span = wk.box[1] - wk.box[0];
+      for (int d = 1; d < 3; ++d) {
+        const float span = wk.box[2 * d + 1] - wk.box[2 * d];
+        if (span > max_span) max_span = span;
+      }
+      // computeMinMax (:898-907) of all three dimensions in ONE pass over the node's records (a 16-byte LDS read per point);
+      // the reference evaluates only the dimensions whose span qualifies -- the selection below reads exactly those
+      float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (unsigned p = lane; p < count; p += 64) {
+        const float4 r = rec[left + p];
+        const float c[3] = {r.x, r.y, r.z};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          mn3[d] = c[d] < mn3[d] ? c[d] : mn3[d];
+          mx3[d] = c[d] > mx3[d] ? c[d] : mx3[d];
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { mn3[d] = wave_min_f32(mn3[d]); mx3[d] = wave_max_f32(mx3[d]); }
+      float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
+      int cutfeat = 0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const float span = wk.box[2 * d + 1] - wk.box[2 * d];
+        if (span > (1 - EPS) * max_span) {
+          const float spread = mx3[d] - mn3[d];
+          if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn3[d]; mx_c = mx3[d]; }
+        }
+      }
+      // (selects, not wk.box[2 * cutfeat]: a dynamically indexed local array lives in scratch memory)
+      const float blo = cutfeat == 0 ? wk.box[0] : (cutfeat == 1 ? wk.box[2] : wk.box[4]);
+      const float bhi = cutfeat == 0 ? wk.box[1] : (cutfeat == 1 ? wk.box[3] : wk.box[5]);
+      const float split_val = (blo + bhi) / 2;
+      float cutval;  // (the second computeMinMax of the reference, on cutfeat, returns mn_c / mx_c again)
+      if (split_val < mn_c) cutval = mn_c;
+      else if (split_val > mx_c) cutval = mx_c;
+      else cutval = split_val;
+      const float* cutc = reinterpret_cast<const float*>(rec) + cutfeat;  // cutc[4 i] = the cut coordinate of record i
+      // ---- planeSplit (:1016-1043): two passes, each the parallel form of the Hoare loop (header)
+      unsigned lim[2];
+      unsigned lo_p = 0;
+#pragma unroll 1
+      for (int pass = 0; pass < 2; ++pass) {
+        auto pred = [&](float v) { return pass == 0 ? v < cutval : v <= cutval; };
+        unsigned cnt = 0;
+        for (unsigned p0 = lo_p; p0 < count; p0 += 64) {
+          const unsigned p = p0 + lane;
+          cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p < count && pred(cutc[4 * (left + p)])));
+        }
+        const unsigned mid = lo_p + cnt;  // where the pointers meet
+        unsigned nl = 0, nr = 0;
+        for (unsigned p0 = lo_p; p0 < mid; p0 += 64) {  // violators among the first cnt positions, ascending
+          const unsigned p = p0 + lane;
+          const bool mis = p < mid && !pred(cutc[4 * (left + p)]);
+          const unsigned long long mk = __builtin_amdgcn_ballot_w64(mis);
+          if (mis) sc[left + lo_p + nl + (unsigned)__builtin_popcountll(mk & lt_mask)] = (unsigned short)p;
+          nl += (unsigned)__builtin_popcountll(mk);
+        }
+        for (unsigned q0 = 0; mid + q0 < count; q0 += 64) {  // satisfiers among the rest, descending
+          const unsigned q = q0 + lane;
+          const bool in = mid + q < count;
+          const unsigned p = count - 1 - (in ? q : 0);
+          const bool mis = in && pred(cutc[4 * (left + p)]);
+          const unsigned long long mk = __builtin_amdgcn_ballot_w64(mis);
+          if (mis) sc[right - 1 - (nr + (unsigned)__builtin_popcountll(mk & lt_mask))] = (unsigned short)p;
+          nr += (unsigned)__builtin_popcountll(mk);
+        }
+        ktb_wave_sync();
+        for (unsigned i = lane; i < nl; i += 64) {  // nl == nr
+          const unsigned a = left + sc[left + lo_p + i], b = left + sc[right - 1 - i];
+          const float4 ra = rec[a], rb = rec[b];
+          rec[a] = rb; rec[b] = ra;
+        }
+        ktb_wave_sync();
+        lim[pass] = mid;
+        lo_p = mid;
+      }
+      unsigned index;
+      if (lim[0] > count / 2) index = lim[0];
+      else if (lim[1] < count / 2) index = lim[1];
+      else index = count / 2;
+      // ---- the children's tight boxes along cutfeat: divlow = max of the left part, divhigh = min of the right part (:956-957)
+      float dl = -INFINITY, dh = INFINITY;
+      for (unsigned p = lane; p < count; p += 64) {
+        const float v = cutc[4 * (left + p)];
+        if (p < index) dl = v > dl ? v : dl;
+        else dh = v < dh ? v : dh;
+      }
+      dl = wave_max_f32(dl); dh = wave_min_f32(dh);
+      if (lane == 0) {
+        int child[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned cl = c == 0 ? left : left + index, cr = c == 0 ? left + index : right;
+          const int id = atomicAdd(&ctr[2], 1);
+          child[c] = id;
+          if (cr - cl <= (unsigned)KT_LEAF) {  // leaf (:921-936)
+            nodes[id].child1 = nodes[id].child2 = -1;
+            nodes[id].a = (int)cl;
+            nodes[id].divlow = __int_as_float((int)cr);
+            nodes[id].divhigh = 0.f;
+          } else {
+            KtWork w;
+            w.node = id; w.left = cl; w.right = cr;
+            // left child: high = cutval (:946-947); right child: low = cutval (:951-952)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : wk.box[i];
+            queue[cur ^ 1][atomicAdd(&ctr[cur ^ 1], 1)] = w;
+          }
+        }
+        KtNode nd;
+        nd.child1 = child[0]; nd.child2 = child[1]; nd.a = cutfeat; nd.divlow = dl; nd.divhigh = dh;
+        nodes[wk.node] = nd;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) ctr[cur] = 0;
+    cur ^= 1;
+    ++level;
+    __syncthreads();
+  }
+  __syncthreads();
+  float4* recs = reinterpret_cast<float4*>(ws + recs_off);
+  for (int i = tid; i < n; i += KTB_WAVES * 64) {  // the records are in leaf order already
+    const float4 r = rec[i];
+    gvind[i] = (unsigned)__float_as_int(r.w);
+    recs[i] = r;
   }
   if (tid == 0) { hdr[0] = ctr[3]; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; }
 }
@@ -667,6 +883,12 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
   const size_t recs_off = kt_recs_offset(n);
   if (serial) {
     hipLaunchKernelGGL(knn_tree_build_kernel, dim3(b), dim3(64), 0, st, n, support, clouds, stride, recs_off);
+  } else if (n <= KTB_LDS_NMAX && tune_env("PASNL_KNN_TREE_GATHER") == nullptr) {  // (tuning build: A/B against the gathering build)
+    const size_t lds = (size_t)n * 16 + (size_t)((n + 1) & ~1) * 2 + (KTB_WAVES * 6 + 4) * 4;
+    if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_tree_build_lds_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return PASNL_ELAUNCH;
+    hipLaunchKernelGGL(knn_tree_build_lds_kernel, dim3(b), dim3(KTB_WAVES * 64), lds, st, n, support, clouds, stride, recs_off);
   } else {
     const size_t lds = (size_t)n * 8 + (size_t)((n + 1) & ~1) * 2 + (KTB_WAVES * 6 + 4) * 4;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_tree_build_par_kernel),
