@@ -46,14 +46,20 @@ struct KtWork {  // an inner node waiting for its split (parallel build): the ac
   unsigned left, right;
   float box[6];
 };
+constexpr int KT_HDR = 32;   // header bytes: [flag, root, nodes used, depth, deep work items, the queue they are in, -, -]
+#define KT_NNODES(n) (2 * (n) + 32)  // node slots: the two-phase build hands every deep subtree its own id range (32 + 2 left ..)
+constexpr int KTD_MAXWORK = 16;   // subtrees handed to the second phase: the queue after KTD_TOP levels
+constexpr int KTD_TOP = 4;
 constexpr int KTB_WAVES = 16;          // waves of the parallel build's workgroup (one workgroup per cloud)
+constexpr int KTB_LDS_NMAX = 8192;     // points (of a cloud, of a subtree) whose 18-byte records + positions fit the LDS (147 KB)
+constexpr int KTB_LDS_NMAX_ = KTB_LDS_NMAX;
 constexpr int KTB_NMAX = 10240;        // points per cloud it holds in LDS (vind + the cut coordinate + a scratch slice)
 static inline int kt_queue_cap(int n) { return n / (KT_LEAF + 1) + 2; }  // inner nodes of one level: more than KT_LEAF points each
 // workspace of one cloud: [flag, root, nodes used, depth] | vind[n] | nodes[2n] | build frames[KT_DEPTH] | 2 level queues |
 // recs[n]: {x, y, z, index} of vind[i] -- the points in LEAF ORDER, so that a leaf's scan is one contiguous read
 static inline size_t kt_recs_offset(int n) {
-  return kt_align_h(16) + kt_align_h((size_t)n * 4) + kt_align_h((size_t)2 * n * sizeof(KtNode)) + kt_align_h((size_t)KT_DEPTH * sizeof(KtFrame)) +
-         2 * kt_align_h((size_t)kt_queue_cap(n) * sizeof(KtWork));
+  return kt_align_h(KT_HDR) + kt_align_h((size_t)n * 4) + kt_align_h((size_t)KT_NNODES(n) * sizeof(KtNode)) + kt_align_h((size_t)KT_DEPTH * sizeof(KtFrame)) +
+         2 * kt_align_h((size_t)kt_queue_cap(n) * sizeof(KtWork)) + 2 * kt_align_h((size_t)(kt_queue_cap(n) + 3 * KTD_MAXWORK) * sizeof(KtWork));
 }
 static inline size_t kt_cloud_bytes(int n) { return kt_recs_offset(n) + kt_align_h((size_t)n * 16); }
 
@@ -63,9 +69,9 @@ __global__ __launch_bounds__(64) void knn_tree_build_kernel(int n, const float* 
   const float* pts = pts_all + (size_t)blockIdx.x * n * 3;
   char* ws = ws_all + (size_t)blockIdx.x * stride;
   int* hdr = reinterpret_cast<int*>(ws);
-  unsigned* vind = reinterpret_cast<unsigned*>(ws + kt_align(16));
-  KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(16) + kt_align((size_t)n * 4));
-  KtFrame* st = reinterpret_cast<KtFrame*>(ws + kt_align(16) + kt_align((size_t)n * 4) + kt_align((size_t)2 * n * sizeof(KtNode)));
+  unsigned* vind = reinterpret_cast<unsigned*>(ws + kt_align(KT_HDR));
+  KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
+  KtFrame* st = reinterpret_cast<KtFrame*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4) + kt_align((size_t)KT_NNODES(n) * sizeof(KtNode)));
   hdr[0] = 0;
   for (int i = 0; i < n; ++i) vind[i] = (unsigned)i;                       // init_vind (:1318)
   auto get = [&](unsigned idx, int d) { return pts[(size_t)idx * 3 + d]; };  // dataset_get -> kdtree_get_pt
@@ -236,7 +242,7 @@ __device__ __forceinline__ void ktb_wave_sync() {  // LDS operations of a wave e
 }
 
 __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int n, const float* __restrict__ pts_all,
-                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off) {
+                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off, int stop_level) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* vind = reinterpret_cast<unsigned*>(smem);                       // [n]
   float* vals = reinterpret_cast<float*>(vind + n);                          // [n] cut coordinate of vind[i] (current node)
@@ -247,9 +253,9 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
   const float* pts = pts_all + (size_t)blockIdx.x * n * 3;
   char* ws = ws_all + (size_t)blockIdx.x * stride;
   int* hdr = reinterpret_cast<int*>(ws);
-  unsigned* gvind = reinterpret_cast<unsigned*>(ws + kt_align(16));
-  KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(16) + kt_align((size_t)n * 4));
-  KtFrame* fr = reinterpret_cast<KtFrame*>(ws + kt_align(16) + kt_align((size_t)n * 4) + kt_align((size_t)2 * n * sizeof(KtNode)));
+  unsigned* gvind = reinterpret_cast<unsigned*>(ws + kt_align(KT_HDR));
+  KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
+  KtFrame* fr = reinterpret_cast<KtFrame*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4) + kt_align((size_t)KT_NNODES(n) * sizeof(KtNode)));
   const int qcap = n / (KT_LEAF + 1) + 2;
   KtWork* queue[2];
   queue[0] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(fr) + kt_align((size_t)KT_DEPTH * sizeof(KtFrame)));
@@ -301,6 +307,21 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
   for (;;) {
     const int nq = ctr[cur];
     if (nq == 0) break;
+    if (stop_level > 0 && level >= stop_level) {
+      // hand the pending subtrees to knn_tree_build_deep_kernel (one workgroup each, records in LDS) -- unless one of them is
+      // too large for its LDS (a very lopsided tree): then this kernel finishes the tree itself
+      if (tid == 0) {
+        int big = 0;
+        for (int e = 0; e < nq; ++e) {
+          const volatile KtWork* qe = queue[cur] + e;
+          big |= (qe->right - qe->left) > (unsigned)KTB_LDS_NMAX_ ? 1 : 0;
+        }
+        ctr[3] |= big << 1;
+      }
+      __syncthreads();
+      if ((ctr[3] & 2) == 0) break;
+      stop_level = 0;
+    }
     if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }  // deeper than the search's stack: flagged, not built
     for (int e = wave; e < nq; e += KTB_WAVES) {
       KtWork wk;  // the same address in every lane; written by another wave one level ago: plain vector loads, never the scalar cache
@@ -436,16 +457,117 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
     gvind[i] = v;
     recs[i] = make_float4(pts[(size_t)v * 3], pts[(size_t)v * 3 + 1], pts[(size_t)v * 3 + 2], __int_as_float((int)v));
   }
-  if (tid == 0) { hdr[0] = ctr[3]; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; }
+  if (tid == 0) { hdr[0] = ctr[3] & 1; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; hdr[4] = (ctr[3] & 1) || stop_level == 0 ? 0 : ctr[cur]; hdr[5] = cur; }
 }
 
 // The same build with the POINTS in LDS (n <= KTB_LDS_NMAX): records {x, y, z, index} that move with the index list, so every
 // pass over a node is a sequential LDS read.  In the kernel above a pass gathers pts[vind[i]] from global memory, one dependent
 // round trip per 64 points.  16 x 8192: 556 -> 485 us -- what remains is one wave's ~9 passes over a large node at the top
 // levels and ~3.5 us of fixed cost per node at the deep ones (EXPERIMENTS.md).
-constexpr int KTB_LDS_NMAX = 8192;  // 18 bytes per point: 147 KB of the 160 KB
+// One inner node of the build with the points in LDS (middleSplit_ + planeSplit + the children's tight bounds), by one wave:
+// rec / sc positions `left .. right` are LDS positions.  -> cutfeat, cutval, index (the left child's size), divlow, divhigh
+struct KtSplit { int cutfeat; float cutval; unsigned index; float dl, dh; };
+__device__ __forceinline__ KtSplit ktb_split_node(float4* rec, unsigned short* sc, const KtWork& wk, const unsigned left,
+                                                  const unsigned right, const int lane, const unsigned long long lt_mask) {
+  const unsigned count = right - left;
+  // ---- middleSplit_ (:966-1005)
+  const float EPS = 0.00001f;
+  float max_span = wk.box[1] - wk.box[0];
+  for (int d = 1; d < 3; ++d) {
+    const float span = wk.box[2 * d + 1] - wk.box[2 * d];
+    if (span > max_span) max_span = span;
+  }
+  // computeMinMax (:898-907) of all three dimensions in ONE pass over the node's records (a 16-byte LDS read per point);
+  // the reference evaluates only the dimensions whose span qualifies -- the selection below reads exactly those
+  float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (unsigned p = lane; p < count; p += 64) {
+    const float4 r = rec[left + p];
+    const float c[3] = {r.x, r.y, r.z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn3[d] = c[d] < mn3[d] ? c[d] : mn3[d];
+      mx3[d] = c[d] > mx3[d] ? c[d] : mx3[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { mn3[d] = wave_min_f32(mn3[d]); mx3[d] = wave_max_f32(mx3[d]); }
+  float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
+  int cutfeat = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float span = wk.box[2 * d + 1] - wk.box[2 * d];
+    if (span > (1 - EPS) * max_span) {
+      const float spread = mx3[d] - mn3[d];
+      if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn3[d]; mx_c = mx3[d]; }
+    }
+  }
+  // (selects, not wk.box[2 * cutfeat]: a dynamically indexed local array lives in scratch memory)
+  const float blo = cutfeat == 0 ? wk.box[0] : (cutfeat == 1 ? wk.box[2] : wk.box[4]);
+  const float bhi = cutfeat == 0 ? wk.box[1] : (cutfeat == 1 ? wk.box[3] : wk.box[5]);
+  const float split_val = (blo + bhi) / 2;
+  float cutval;  // (the second computeMinMax of the reference, on cutfeat, returns mn_c / mx_c again)
+  if (split_val < mn_c) cutval = mn_c;
+  else if (split_val > mx_c) cutval = mx_c;
+  else cutval = split_val;
+  const float* cutc = reinterpret_cast<const float*>(rec) + cutfeat;  // cutc[4 i] = the cut coordinate of record i
+  // ---- planeSplit (:1016-1043): two passes, each the parallel form of the Hoare loop (header)
+  unsigned lim[2];
+  unsigned lo_p = 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    auto pred = [&](float v) { return pass == 0 ? v < cutval : v <= cutval; };
+    unsigned cnt = 0;
+    for (unsigned p0 = lo_p; p0 < count; p0 += 64) {
+      const unsigned p = p0 + lane;
+      cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p < count && pred(cutc[4 * (left + p)])));
+    }
+    const unsigned mid = lo_p + cnt;  // where the pointers meet
+    unsigned nl = 0, nr = 0;
+    for (unsigned p0 = lo_p; p0 < mid; p0 += 64) {  // violators among the first cnt positions, ascending
+      const unsigned p = p0 + lane;
+      const bool mis = p < mid && !pred(cutc[4 * (left + p)]);
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(mis);
+      if (mis) sc[left + lo_p + nl + (unsigned)__builtin_popcountll(mk & lt_mask)] = (unsigned short)p;
+      nl += (unsigned)__builtin_popcountll(mk);
+    }
+    for (unsigned q0 = 0; mid + q0 < count; q0 += 64) {  // satisfiers among the rest, descending
+      const unsigned q = q0 + lane;
+      const bool in = mid + q < count;
+      const unsigned p = count - 1 - (in ? q : 0);
+      const bool mis = in && pred(cutc[4 * (left + p)]);
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(mis);
+      if (mis) sc[right - 1 - (nr + (unsigned)__builtin_popcountll(mk & lt_mask))] = (unsigned short)p;
+      nr += (unsigned)__builtin_popcountll(mk);
+    }
+    ktb_wave_sync();
+    for (unsigned i = lane; i < nl; i += 64) {  // nl == nr
+      const unsigned a = left + sc[left + lo_p + i], b = left + sc[right - 1 - i];
+      const float4 ra = rec[a], rb = rec[b];
+      rec[a] = rb; rec[b] = ra;
+    }
+    ktb_wave_sync();
+    lim[pass] = mid;
+    lo_p = mid;
+  }
+  unsigned index;
+  if (lim[0] > count / 2) index = lim[0];
+  else if (lim[1] < count / 2) index = lim[1];
+  else index = count / 2;
+  // ---- the children's tight boxes along cutfeat: divlow = max of the left part, divhigh = min of the right part (:956-957)
+  float dl = -INFINITY, dh = INFINITY;
+  for (unsigned p = lane; p < count; p += 64) {
+    const float v = cutc[4 * (left + p)];
+    if (p < index) dl = v > dl ? v : dl;
+    else dh = v < dh ? v : dh;
+  }
+  dl = wave_max_f32(dl); dh = wave_min_f32(dh);
+  KtSplit r;
+  r.cutfeat = cutfeat; r.cutval = cutval; r.index = index; r.dl = dl; r.dh = dh;
+  return r;
+}
+
 __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int n, const float* __restrict__ pts_all,
-                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off) {
+                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off, int stop_level) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* rec = reinterpret_cast<float4*>(smem);                             // [n] {x, y, z, index bits}: the points move with the index list
   unsigned short* sc = reinterpret_cast<unsigned short*>(rec + n);           // [n] positions of misplaced elements
@@ -455,9 +577,9 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int 
   const float* pts = pts_all + (size_t)blockIdx.x * n * 3;
   char* ws = ws_all + (size_t)blockIdx.x * stride;
   int* hdr = reinterpret_cast<int*>(ws);
-  unsigned* gvind = reinterpret_cast<unsigned*>(ws + kt_align(16));
-  KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(16) + kt_align((size_t)n * 4));
-  KtFrame* fr = reinterpret_cast<KtFrame*>(ws + kt_align(16) + kt_align((size_t)n * 4) + kt_align((size_t)2 * n * sizeof(KtNode)));
+  unsigned* gvind = reinterpret_cast<unsigned*>(ws + kt_align(KT_HDR));
+  KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
+  KtFrame* fr = reinterpret_cast<KtFrame*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4) + kt_align((size_t)KT_NNODES(n) * sizeof(KtNode)));
   const int qcap = n / (KT_LEAF + 1) + 2;
   KtWork* queue[2];
   queue[0] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(fr) + kt_align((size_t)KT_DEPTH * sizeof(KtFrame)));
@@ -509,6 +631,7 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int 
   for (;;) {
     const int nq = ctr[cur];
     if (nq == 0) break;
+    if (stop_level > 0 && level >= stop_level) break;  // the pending subtrees go to knn_tree_build_deep_kernel, one workgroup each
     if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }  // deeper than the search's stack: flagged, not built
     for (int e = wave; e < nq; e += KTB_WAVES) {
       KtWork wk;  // the same address in every lane; written by another wave one level ago: plain vector loads, never the scalar cache
@@ -517,98 +640,11 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int 
         wk.node = qe->node; wk.left = qe->left; wk.right = qe->right;
         for (int i = 0; i < 6; ++i) wk.box[i] = qe->box[i];
       }
-      const unsigned left = wk.left, right = wk.right, count = right - left;
-      // ---- middleSplit_ (:966-1005)
-      const float EPS = 0.00001f;
-      float max_span = wk.box[1] - wk.box[0];
-      for (int d = 1; d < 3; ++d) {
-        const float span = wk.box[2 * d + 1] - wk.box[2 * d];
-        if (span > max_span) max_span = span;
-      }
-      // computeMinMax (:898-907) of all three dimensions in ONE pass over the node's records (a 16-byte LDS read per point);
-      // the reference evaluates only the dimensions whose span qualifies -- the selection below reads exactly those
-      float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY};
-      for (unsigned p = lane; p < count; p += 64) {
-        const float4 r = rec[left + p];
-        const float c[3] = {r.x, r.y, r.z};
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          mn3[d] = c[d] < mn3[d] ? c[d] : mn3[d];
-          mx3[d] = c[d] > mx3[d] ? c[d] : mx3[d];
-        }
-      }
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { mn3[d] = wave_min_f32(mn3[d]); mx3[d] = wave_max_f32(mx3[d]); }
-      float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
-      int cutfeat = 0;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        const float span = wk.box[2 * d + 1] - wk.box[2 * d];
-        if (span > (1 - EPS) * max_span) {
-          const float spread = mx3[d] - mn3[d];
-          if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn3[d]; mx_c = mx3[d]; }
-        }
-      }
-      // (selects, not wk.box[2 * cutfeat]: a dynamically indexed local array lives in scratch memory)
-      const float blo = cutfeat == 0 ? wk.box[0] : (cutfeat == 1 ? wk.box[2] : wk.box[4]);
-      const float bhi = cutfeat == 0 ? wk.box[1] : (cutfeat == 1 ? wk.box[3] : wk.box[5]);
-      const float split_val = (blo + bhi) / 2;
-      float cutval;  // (the second computeMinMax of the reference, on cutfeat, returns mn_c / mx_c again)
-      if (split_val < mn_c) cutval = mn_c;
-      else if (split_val > mx_c) cutval = mx_c;
-      else cutval = split_val;
-      const float* cutc = reinterpret_cast<const float*>(rec) + cutfeat;  // cutc[4 i] = the cut coordinate of record i
-      // ---- planeSplit (:1016-1043): two passes, each the parallel form of the Hoare loop (header)
-      unsigned lim[2];
-      unsigned lo_p = 0;
-#pragma unroll 1
-      for (int pass = 0; pass < 2; ++pass) {
-        auto pred = [&](float v) { return pass == 0 ? v < cutval : v <= cutval; };
-        unsigned cnt = 0;
-        for (unsigned p0 = lo_p; p0 < count; p0 += 64) {
-          const unsigned p = p0 + lane;
-          cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p < count && pred(cutc[4 * (left + p)])));
-        }
-        const unsigned mid = lo_p + cnt;  // where the pointers meet
-        unsigned nl = 0, nr = 0;
-        for (unsigned p0 = lo_p; p0 < mid; p0 += 64) {  // violators among the first cnt positions, ascending
-          const unsigned p = p0 + lane;
-          const bool mis = p < mid && !pred(cutc[4 * (left + p)]);
-          const unsigned long long mk = __builtin_amdgcn_ballot_w64(mis);
-          if (mis) sc[left + lo_p + nl + (unsigned)__builtin_popcountll(mk & lt_mask)] = (unsigned short)p;
-          nl += (unsigned)__builtin_popcountll(mk);
-        }
-        for (unsigned q0 = 0; mid + q0 < count; q0 += 64) {  // satisfiers among the rest, descending
-          const unsigned q = q0 + lane;
-          const bool in = mid + q < count;
-          const unsigned p = count - 1 - (in ? q : 0);
-          const bool mis = in && pred(cutc[4 * (left + p)]);
-          const unsigned long long mk = __builtin_amdgcn_ballot_w64(mis);
-          if (mis) sc[right - 1 - (nr + (unsigned)__builtin_popcountll(mk & lt_mask))] = (unsigned short)p;
-          nr += (unsigned)__builtin_popcountll(mk);
-        }
-        ktb_wave_sync();
-        for (unsigned i = lane; i < nl; i += 64) {  // nl == nr
-          const unsigned a = left + sc[left + lo_p + i], b = left + sc[right - 1 - i];
-          const float4 ra = rec[a], rb = rec[b];
-          rec[a] = rb; rec[b] = ra;
-        }
-        ktb_wave_sync();
-        lim[pass] = mid;
-        lo_p = mid;
-      }
-      unsigned index;
-      if (lim[0] > count / 2) index = lim[0];
-      else if (lim[1] < count / 2) index = lim[1];
-      else index = count / 2;
-      // ---- the children's tight boxes along cutfeat: divlow = max of the left part, divhigh = min of the right part (:956-957)
-      float dl = -INFINITY, dh = INFINITY;
-      for (unsigned p = lane; p < count; p += 64) {
-        const float v = cutc[4 * (left + p)];
-        if (p < index) dl = v > dl ? v : dl;
-        else dh = v < dh ? v : dh;
-      }
-      dl = wave_max_f32(dl); dh = wave_min_f32(dh);
+      const unsigned left = wk.left, right = wk.right;
+      const KtSplit sp_ = ktb_split_node(rec, sc, wk, left, right, lane, lt_mask);
+      const int cutfeat = sp_.cutfeat;
+      const float cutval = sp_.cutval, dl = sp_.dl, dh = sp_.dh;
+      const unsigned index = sp_.index;
       if (lane == 0) {
         int child[2];
 #pragma unroll
@@ -649,7 +685,116 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int 
     gvind[i] = (unsigned)__float_as_int(r.w);
     recs[i] = r;
   }
-  if (tid == 0) { hdr[0] = ctr[3]; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; }
+  if (tid == 0) { hdr[0] = ctr[3]; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; hdr[4] = ctr[3] ? 0 : ctr[cur]; hdr[5] = cur; }
+}
+
+// Second phase of the two-phase build: one workgroup per subtree the first phase left pending after KTD_TOP levels (<= 16 per
+// cloud).  The deep levels are thousands of small nodes with ~3.5 us of fixed cost each; one workgroup per cloud worked them off
+// 16 at a time on ONE CU -- here every subtree has its own workgroup (and CU), its records in LDS, its own node-id range
+// (32 + 2 left ..: a subtree of c points has < 2 c nodes) and its level queues in LDS (or, for a subtree too large for that --
+// then the only one of its size in the cloud -- in the workspace).
+constexpr int KTD_LDSQ_MAX = 6000;  // points of a subtree whose two level queues still fit in LDS behind its records
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_deep_kernel(int n, char* __restrict__ ws_all, size_t stride,
+                                                                            size_t recs_off) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  char* ws = ws_all + (size_t)blockIdx.y * stride;
+  int* hdr = reinterpret_cast<int*>(ws);
+  if ((int)blockIdx.x >= hdr[4]) return;
+  unsigned* gvind = reinterpret_cast<unsigned*>(ws + kt_align(KT_HDR));
+  KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
+  KtFrame* fr = reinterpret_cast<KtFrame*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4) + kt_align((size_t)KT_NNODES(n) * sizeof(KtNode)));
+  const int qcap = n / (KT_LEAF + 1) + 2;
+  KtWork* q1[2];
+  q1[0] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(fr) + kt_align((size_t)KT_DEPTH * sizeof(KtFrame)));
+  q1[1] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(q1[0]) + kt_align((size_t)qcap * sizeof(KtWork)));
+  KtWork* g2[2];
+  g2[0] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(q1[1]) + kt_align((size_t)qcap * sizeof(KtWork)));
+  g2[1] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(g2[0]) + kt_align((size_t)(qcap + 3 * KTD_MAXWORK) * sizeof(KtWork)));
+  float4* grecs = reinterpret_cast<float4*>(ws + recs_off);
+  const KtWork w0 = q1[hdr[5]][blockIdx.x];  // written by the previous kernel
+  const unsigned left0 = w0.left, count0 = w0.right - w0.left;
+
+  float4* rec = reinterpret_cast<float4*>(smem);                                  // [count0]
+  unsigned short* sc = reinterpret_cast<unsigned short*>(rec + count0);           // [count0]
+  char* after = smem + (((size_t)count0 * 18 + 15) & ~(size_t)15);
+  int* ctr = reinterpret_cast<int*>(after);                                       // [0], [1]: queue lengths; [2]: nodes used; [3]: flag
+  const int lq = (int)(count0 / (KT_LEAF + 1)) + 2;
+  const bool ldsq = count0 <= (unsigned)KTD_LDSQ_MAX;
+  KtWork* const qa = ldsq ? reinterpret_cast<KtWork*>(after + 16) : g2[0];  // (two named pointers: an indexed pair of pointers
+  KtWork* const qb = ldsq ? qa + lq : g2[1];                                //  into different address spaces would live in scratch)
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (unsigned i = tid; i < count0; i += KTB_WAVES * 64) rec[i] = grecs[left0 + i];
+  if (tid < 4) ctr[tid] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    KtWork w = w0;
+    w.left = 0; w.right = count0;
+    qa[0] = w;
+    ctr[0] = 1;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int idbase = 32 + 2 * (int)left0;
+  int cur = 0, level = KTD_TOP;  // (hdr[4] > 0: the first phase stopped exactly there)
+  for (;;) {
+    const int nq = ctr[cur];
+    if (nq == 0) break;
+    if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }
+    for (int e = wave; e < nq; e += KTB_WAVES) {
+      KtWork wk;
+      {
+        const volatile KtWork* qe = (cur ? qb : qa) + e;
+        wk.node = qe->node; wk.left = qe->left; wk.right = qe->right;
+        for (int i = 0; i < 6; ++i) wk.box[i] = qe->box[i];
+      }
+      const unsigned left = wk.left, right = wk.right;
+      const KtSplit sp_ = ktb_split_node(rec, sc, wk, left, right, lane, lt_mask);
+      const int cutfeat = sp_.cutfeat;
+      const float cutval = sp_.cutval;
+      const unsigned index = sp_.index;
+      if (lane == 0) {
+        int child[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned cl = c == 0 ? left : left + index, cr = c == 0 ? left + index : right;
+          const int id = idbase + atomicAdd(&ctr[2], 1);
+          child[c] = id;
+          if (cr - cl <= (unsigned)KT_LEAF) {  // leaf (:921-936): positions in the CLOUD's leaf order
+            nodes[id].child1 = nodes[id].child2 = -1;
+            nodes[id].a = (int)(left0 + cl);
+            nodes[id].divlow = __int_as_float((int)(left0 + cr));
+            nodes[id].divhigh = 0.f;
+          } else {
+            KtWork w;
+            w.node = id; w.left = cl; w.right = cr;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : wk.box[i];
+            (cur ? qa : qb)[atomicAdd(&ctr[cur ^ 1], 1)] = w;
+          }
+        }
+        KtNode nd;
+        nd.child1 = child[0]; nd.child2 = child[1]; nd.a = cutfeat; nd.divlow = sp_.dl; nd.divhigh = sp_.dh;
+        nodes[wk.node] = nd;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) ctr[cur] = 0;
+    cur ^= 1;
+    ++level;
+    __syncthreads();
+  }
+  __syncthreads();
+  for (unsigned i = tid; i < count0; i += KTB_WAVES * 64) {
+    const float4 r = rec[i];
+    gvind[left0 + i] = (unsigned)__float_as_int(r.w);
+    grecs[left0 + i] = r;
+  }
+  if (tid == 0) {
+    if (ctr[3]) atomicExch(&hdr[0], 1);
+    atomicMax(&hdr[3], level);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -682,8 +827,8 @@ __global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k
   const char* ws = ws_all + (size_t)bi * stride;
   const int* hdr = reinterpret_cast<const int*>(ws);
   if (hdr[0] != 0) { if (j == 0) atomicExch(flag, 1); return; }
-  const KtNode* nodes = reinterpret_cast<const KtNode*>(ws + kt_align(16) + kt_align((size_t)n * 4));
-  const KtFrame* bst = reinterpret_cast<const KtFrame*>(ws + kt_align(16) + kt_align((size_t)n * 4) + kt_align((size_t)2 * n * sizeof(KtNode)));
+  const KtNode* nodes = reinterpret_cast<const KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
+  const KtFrame* bst = reinterpret_cast<const KtFrame*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4) + kt_align((size_t)KT_NNODES(n) * sizeof(KtNode)));
   const float4* recs = reinterpret_cast<const float4*>(ws + recs_off);
   const float* rootbox = bst[1].bbox;
   const bool live = j < m;
@@ -859,6 +1004,24 @@ __global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k
 
 using namespace pasnl;
 
+// LDS of a subtree's workgroup: records + scratch positions (18 bytes per point) for a subtree of up to min(n, KTB_LDS_NMAX)
+// points (the first phase keeps larger ones to itself), or those of KTD_LDSQ_MAX points plus their two level queues --
+// whichever is larger
+static int knn_tree_deep_launch(int b, int n, char* clouds, size_t stride, size_t recs_off, hipStream_t st) {
+  using namespace pasnl;
+  const size_t cmax = (size_t)(n < KTB_LDS_NMAX ? n : KTB_LDS_NMAX);
+  const size_t c = cmax < (size_t)KTD_LDSQ_MAX ? cmax : (size_t)KTD_LDSQ_MAX;
+  const size_t with_q = ((c * 18 + 15) & ~(size_t)15) + 16 + 2 * (c / (KT_LEAF + 1) + 2) * sizeof(KtWork);
+  const size_t without = ((cmax * 18 + 15) & ~(size_t)15) + 16;
+  const size_t lds2 = with_q > without ? with_q : without;
+  if (lds2 > 160 * 1024) return PASNL_EUNSUPPORTED;
+  if (lds2 > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_tree_build_deep_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+    return PASNL_ELAUNCH;
+  hipLaunchKernelGGL(knn_tree_build_deep_kernel, dim3(KTD_MAXWORK, b), dim3(KTB_WAVES * 64), lds2, st, n, clouds, stride, recs_off);
+  return PASNL_OK;
+}
+
 extern "C" size_t pasnl_knn_tree_workspace_bytes(int b, int n, int m, int k) {
   if (b <= 0 || n <= 0 || m <= 0 || k <= 0) return 0;
   return 256 + (size_t)b * kt_cloud_bytes(n);  // (the search keeps its result sets in LDS)
@@ -888,13 +1051,25 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_tree_build_lds_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return PASNL_ELAUNCH;
-    hipLaunchKernelGGL(knn_tree_build_lds_kernel, dim3(b), dim3(KTB_WAVES * 64), lds, st, n, support, clouds, stride, recs_off);
+    const int two_phase = tune_env("PASNL_KNN_TREE_ONE_PHASE") == nullptr;  // (tuning build: A/B)
+    hipLaunchKernelGGL(knn_tree_build_lds_kernel, dim3(b), dim3(KTB_WAVES * 64), lds, st, n, support, clouds, stride, recs_off,
+                       two_phase ? KTD_TOP : 0);
+    if (two_phase) {
+      const int rc = knn_tree_deep_launch(b, n, clouds, stride, recs_off, st);
+      if (rc != PASNL_OK) return rc;
+    }
   } else {
     const size_t lds = (size_t)n * 8 + (size_t)((n + 1) & ~1) * 2 + (KTB_WAVES * 6 + 4) * 4;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_tree_build_par_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return PASNL_ELAUNCH;
-    hipLaunchKernelGGL(knn_tree_build_par_kernel, dim3(b), dim3(KTB_WAVES * 64), lds, st, n, support, clouds, stride, recs_off);
+    const int two_phase = tune_env("PASNL_KNN_TREE_ONE_PHASE") == nullptr;  // (tuning build: A/B)
+    hipLaunchKernelGGL(knn_tree_build_par_kernel, dim3(b), dim3(KTB_WAVES * 64), lds, st, n, support, clouds, stride, recs_off,
+                       two_phase ? KTD_TOP : 0);
+    if (two_phase) {
+      const int rc = knn_tree_deep_launch(b, n, clouds, stride, recs_off, st);
+      if (rc != PASNL_OK) return rc;
+    }
   }
   dim3 grid((m + 63) / 64, b);
   const size_t lds = (size_t)KT_LDS_DEPTH * 3 * 64 * 4 + (size_t)((k + 7) & ~7) * 64 * 8;
