@@ -2744,7 +2744,7 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   PASNL_REQUIRE((long)b * n * c < (1L << 32), PASNL_EUNSUPPORTED);  // feature rows are addressed by 32-bit element offsets
   PASNL_REQUIRE(xyz && feature && idx && w0 && b0 && ww && bw && out && skip_max, PASNL_ENULL);
   // w1 == NULL: the layer has ONE convolution (mlp = [c, c]: the *_2 layers of pointasnl_sem_seg_res.py) -- the wide kernel only
-  PASNL_REQUIRE((w1 && b1) || c1 >= 256, PASNL_ENULL);
+  PASNL_REQUIRE((w1 && b1) || c1 >= 128, PASNL_ENULL);
   // new_xyz == NULL: the centre of a group is its neighbour 0.  The kernel's centre prefetch stays unconditional and is
   // pointed at xyz, whose b*n*3 floats cover the b*m*3 it touches when m <= n
   PASNL_REQUIRE(new_xyz || m <= n, PASNL_EUNSUPPORTED);
@@ -2757,6 +2757,12 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   // the row's last chunk: live MFMA steps (0 = the width is a multiple of 32); see TAIL8
   const int wi = 8 + c, rem = wi & 31;
   const bool tail8 = rem != 0 && (vec ? rem : (rem + 1) >> 1) <= 8;
+  if (c1 == 128 && c2 == 128 && !w1) {
+    // a 128-channel layer with ONE convolution (mlp = [128, 128]: pointasnl_sem_seg_res.py layer2_2) on the wide kernel's
+    // single-convolution form -- the persistent kernel below would need an identity conv1 (43 % of its matrix work)
+    PASNL_REQUIRE(k == 32 && c % 16 == 0 && new_xyz && reinterpret_cast<uintptr_t>(feature) % 16 == 0, PASNL_EUNSUPPORTED);
+    return sa_cell_wide_launch<128, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
+  }
   if ((c1 == 256 && c2 == 256) || (c1 == 512 && c2 == 512)) {  // the wide layers: one workgroup per group, weights from L2
     PASNL_REQUIRE(k == 32 && c % 16 == 0 && new_xyz && reinterpret_cast<uintptr_t>(feature) % 16 == 0, PASNL_EUNSUPPORTED);
     if (c1 == 256)

@@ -86,6 +86,7 @@ def sa_group(xyz, feature, idx, new_xyz):
 SA_TAIL_MIN_ROWS = 2048
 SA_TAIL_FUSED = True     # skip conv + back-projection + adds + aggregation in one kernel (pasnl_sa_tail); False = op by op
 SA_CELL_GATHER = True    # grouping fused into the local cell (pasnl_sa_cell); False = pasnl_sa_group + pasnl_sa_local_cell
+SA_CELL_SINGLE128 = True  # mlp = [128, 128] (one convolution) on the wide kernel's single-convolution form instead of an identity conv1
 SA_CELL_WIDE = True      # the 256- / 512-channel layers on pasnl_sa_cell too (False: pasnl_sa_group + the vendor chain, A/B)
 LOCAL_CELL_FUSED = True  # False = the reference's op-by-op chain on the vendor BLAS (kept for A/B and as fallback)
 
@@ -142,8 +143,8 @@ def _sa_cell_weights(w_in, mlp, bn, weight_decay, native16=False):
         if len(mlp) == 3:
             with tf_util.variable_scope('conv1'):
                 w1, b1 = st.layer(c1, mlp[1], bn, weight_decay)
-        elif c1 >= 256:
-            w1, b1 = None, None  # the wide kernel takes "no conv1" as such (no 256 x 256 identity product)
+        elif c1 >= 256 or (c1 == 128 and SA_CELL_WIDE and SA_CELL_SINGLE128):
+            w1, b1 = None, None  # the wide kernel takes "no conv1" as such (no c x c identity product)
         else:
             w1, b1 = torch.eye(c1, dtype=torch.float32, device=w0.device), torch.zeros(c1, dtype=torch.float32, device=w0.device)
         with tf_util.variable_scope('weight_net'), tf_util.variable_scope('wconv0'):

@@ -268,7 +268,8 @@ def test_sa_cell_16_channels_native_kernel(b, n, m, monkeypatch):
 
 
 @pytest.mark.parametrize("b,n,c,m,c1,conv1", [(2, 300, 256, 40, 256, True), (1, 128, 256, 33, 256, False), (2, 96, 512, 20, 512, False),
-                                               (1, 64, 128, 7, 256, True), (1, 80, 512, 3, 512, True)])
+                                               (1, 64, 128, 7, 256, True), (1, 80, 512, 3, 512, True),
+                                               (2, 320, 128, 320, 128, False), (1, 77, 64, 9, 128, False)])
 def test_sa_cell_wide_layers(b, n, c, m, c1, conv1):
     """The 256- / 512-channel layers (pointasnl_sem_seg.py:34, pointasnl_sem_seg_res.py:46-51) on pasnl_sa_cell: one workgroup per
     group, weights from L2; with conv1 (mlp [c, c, out]) and without (mlp [c, c]: the *_2 layers).  fp64 restatement to 1e-5,
