@@ -1014,7 +1014,9 @@ __device__ __forceinline__ float vmaxf(float a, float b) {
 
 constexpr int SA_SKIP_REP = 4;
 
-template <int C1, int C2, int NW, bool VEC, bool TAIL8, bool XYZ3 = false>  // XYZ3: the feature rows are 3 wide (xyz-only first layers)
+// SINGLE: the layer has ONE convolution (mlp = [c, c]): conv0 is formed with its operands swapped -- H1 = X . W0 with rows =
+// neighbours, the layout the matmul takes as conv1's output -- and there is no conv1 (w1 / b1 are not read)
+template <int C1, int C2, int NW, bool VEC, bool TAIL8, bool XYZ3 = false, bool SINGLE = false>  // XYZ3: the feature rows are 3 wide (xyz-only first layers)
 __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, int w, SaGatherSrc src,
                                                          const float* __restrict__ w0, const float* __restrict__ b0,
                                                          const float* __restrict__ w1, const float* __restrict__ b1,
@@ -1058,7 +1060,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
         if (base + u * T < n0) reinterpret_cast<float4*>(W0s)[base + u * T] = v[u];
     }
     constexpr int N1 = C1 * C2 / 4;
-    for (int base = tid; base < N1; base += SB * T) {
+    for (int base = tid; base < (SINGLE ? 0 : N1); base += SB * T) {
       float4 v[SB];
 #pragma unroll
       for (int u = 0; u < SB; ++u) v[u] = reinterpret_cast<const float4*>(w1)[min(base + u * T, N1 - 1)];
@@ -1075,7 +1077,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       else if (r >= 8 && r < wi) v = w0[(size_t)(r - 2) * C1 + c1];
       W0s[i] = v;
     }
-    for (int i = tid; i < C1 * C2; i += T) W1s[i] = w1[i];
+    for (int i = tid; i < (SINGLE ? 0 : C1 * C2); i += T) W1s[i] = w1[i];
   }
   for (int i = tid; i < 6 * 32; i += NW * 64) {
     const int t = i / 64, hh = (i >> 5) & 1, j = i & 31;
@@ -1090,7 +1092,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 
   float b1r[C2 / 32];
 #pragma unroll
-  for (int cb = 0; cb < C2 / 32; ++cb) b1r[cb] = b1[cb * 32 + ql];
+  for (int cb = 0; cb < C2 / 32; ++cb) b1r[cb] = SINGLE ? 0.f : b1[cb * 32 + ql];
   const float bwr = bw[ql];
   const int nchunk = wp / 32;
   const int cf4 = cf >> 2;
@@ -1338,7 +1340,8 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
           for (int u = 0; u < BT; ++u)
 #pragma unroll
             for (int ob = 0; ob < C1 / 32; ++ob)
-              H1T[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j & 1][u][ob], xr[j * BT + u], H1T[ob], 0, 0, 0);
+              H1T[ob] = SINGLE ? __builtin_amdgcn_mfma_f32_32x32x2f32(xr[j * BT + u], wa[j & 1][u][ob], H1T[ob], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j & 1][u][ob], xr[j * BT + u], H1T[ob], 0, 0, 0);
           if constexpr (STREAM) {
             constexpr int GR = VEC ? 4 : 1;  // operands per load
             // the load groups whose last step the PREVIOUS batch finished: [floor((j-1)*BT / GR), floor(j*BT / GR)) * GR.
@@ -1391,10 +1394,27 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
 #pragma unroll
       for (int ob = 0; ob < C1 / 32; ++ob)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) H1T[ob][r] = vmaxf(H1T[ob][r], 0.f);
+        for (int r = 0; r < 16; ++r) {
+          // SINGLE: the ReLU as a signed-integer maximum of the bits (negative floats are negative integers) -- a plain
+          // instruction.  vmaxf() is inline assembly, which the compiler's hazard recogniser cannot see into: in this form it
+          // sank each v_max_f32 right behind the product that reads the SAME register as an operand (matmul step t: A = v0;
+          // then v0 = relu of step t + 1) with no wait state in between, and the results were off by a few per cent
+          if constexpr (SINGLE) H1T[ob][r] = __int_as_float(max(__float_as_int(H1T[ob][r]), 0));
+          else H1T[ob][r] = vmaxf(H1T[ob][r], 0.f);
+        }
 #pragma unroll
       for (int r = 0; r < 16; ++r) G[r] = fmaxf(G[r] + bwr, 0.f);
 
+      if constexpr (SINGLE) {
+        // mlp = [c, c]: ONE convolution (the *_2 layers of pointasnl_sem_seg_res.py); its ReLU-ed output -- rows = neighbours,
+        // thanks to the swapped conv0 -- IS the matmul's operand.  (As an identity conv1 -- relu(h * 1 + 0) = h bit for bit --
+        // the same result cost 43-47 % more matrix work.)
+        static_assert(C1 == C2, "the single-convolution form keeps the block structure");
+#pragma unroll
+        for (int cb = 0; cb < C2 / 32; ++cb)
+#pragma unroll
+          for (int t = 0; t < 16; ++t) M[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(H1T[cb][t], G[t], M[cb], 0, 0, 0);
+      } else
 #pragma unroll
       for (int cb = 0; cb < C2 / 32; ++cb) {
         f32x16 H2;
@@ -2385,13 +2405,13 @@ static int local_cell_dispatch(long groups, int k, int w, int c1, int c2, const 
   return PASNL_EUNSUPPORTED;
 }
 
-template <int C1, int C2, int NW, bool VEC, bool TAIL8, bool XYZ3 = false>
+template <int C1, int C2, int NW, bool VEC, bool TAIL8, bool XYZ3 = false, bool SINGLE = false>
 static int sa_cell_launch(long groups, int k, int w, SaGatherSrc src, const float* w0, const float* b0, const float* w1,
                           const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
   const int wp = (8 + (w - 6) + 31) & ~31;  // internal width: [xyz-c | xyz | 1 | 0 | feature], padded to 32-chunks
   size_t lds = ((size_t)wp * C1 + (size_t)C1 * C2 + 6 * 32 + (size_t)NW * SA_SKIP_REP * (wp + 4)) * sizeof(float);
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
-  auto kern = sa_cell_kernel<C1, C2, NW, VEC, TAIL8, XYZ3>;
+  auto kern = sa_cell_kernel<C1, C2, NW, VEC, TAIL8, XYZ3, SINGLE>;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
@@ -2712,6 +2732,10 @@ static int sa_cell_cfg(bool vec, bool tail8, long groups, int k, int w, SaGather
   // NG: the 64-channel forms no model uses (no 8-step tail, or scalar loads of a row that is not xyz-only) need more than the
   // 256 registers two waves per SIMD leave each -- they ran with 150-300 bytes of spills; one wave per SIMD instead
   constexpr int NG = C1 >= 64 ? 4 : 8;
+  if (!w1) {  // one convolution: the form every model's *_2 layers have (16-byte feature rows, an 8-step last chunk)
+    if (vec && tail8) return sa_cell_launch<C1, C2, NW, true, true, false, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
+    return PASNL_EUNSUPPORTED;
+  }
   if (vec) return tail8 ? sa_cell_launch<C1, C2, NW, true, true>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st)
                         : sa_cell_launch<C1, C2, NG, true, false>(groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   if constexpr (C1 <= 64) {
@@ -2744,7 +2768,7 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   PASNL_REQUIRE((long)b * n * c < (1L << 32), PASNL_EUNSUPPORTED);  // feature rows are addressed by 32-bit element offsets
   PASNL_REQUIRE(xyz && feature && idx && w0 && b0 && ww && bw && out && skip_max, PASNL_ENULL);
   // w1 == NULL: the layer has ONE convolution (mlp = [c, c]: the *_2 layers of pointasnl_sem_seg_res.py) -- the wide kernel only
-  PASNL_REQUIRE((w1 && b1) || c1 >= 128, PASNL_ENULL);
+  PASNL_REQUIRE((w1 && b1) || c1 >= 32, PASNL_ENULL);  // (the 16-channel kernel has both convolutions)
   // new_xyz == NULL: the centre of a group is its neighbour 0.  The kernel's centre prefetch stays unconditional and is
   // pointed at xyz, whose b*n*3 floats cover the b*m*3 it touches when m <= n
   PASNL_REQUIRE(new_xyz || m <= n, PASNL_EUNSUPPORTED);
@@ -2757,10 +2781,10 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   // the row's last chunk: live MFMA steps (0 = the width is a multiple of 32); see TAIL8
   const int wi = 8 + c, rem = wi & 31;
   const bool tail8 = rem != 0 && (vec ? rem : (rem + 1) >> 1) <= 8;
-  if (c1 == 128 && c2 == 128 && !w1) {
+  if (c1 == 128 && c2 == 128 && !w1 && k == 32 && c % 16 == 0 && new_xyz && reinterpret_cast<uintptr_t>(feature) % 16 == 0) {
     // a 128-channel layer with ONE convolution (mlp = [128, 128]: pointasnl_sem_seg_res.py layer2_2) on the wide kernel's
-    // single-convolution form -- the persistent kernel below would need an identity conv1 (43 % of its matrix work)
-    PASNL_REQUIRE(k == 32 && c % 16 == 0 && new_xyz && reinterpret_cast<uintptr_t>(feature) % 16 == 0, PASNL_EUNSUPPORTED);
+    // single-convolution form: 60 us at 2560 groups (86 with an identity conv1 on the persistent kernel below, which takes
+    // the layer -- without the identity -- where the wide kernel's conditions do not hold)
     return sa_cell_wide_launch<128, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
   }
   if ((c1 == 256 && c2 == 256) || (c1 == 512 && c2 == 512)) {  // the wide layers: one workgroup per group, weights from L2

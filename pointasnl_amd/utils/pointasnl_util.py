@@ -86,7 +86,7 @@ def sa_group(xyz, feature, idx, new_xyz):
 SA_TAIL_MIN_ROWS = 2048
 SA_TAIL_FUSED = True     # skip conv + back-projection + adds + aggregation in one kernel (pasnl_sa_tail); False = op by op
 SA_CELL_GATHER = True    # grouping fused into the local cell (pasnl_sa_cell); False = pasnl_sa_group + pasnl_sa_local_cell
-SA_CELL_SINGLE128 = True  # mlp = [128, 128] (one convolution) on the wide kernel's single-convolution form instead of an identity conv1
+SA_CELL_SINGLE = True     # mlp = [c, c] (one convolution, c = 32 / 64 / 128): no conv1 at all instead of an identity conv1 (False: A/B)
 SA_CELL_WIDE = True      # the 256- / 512-channel layers on pasnl_sa_cell too (False: pasnl_sa_group + the vendor chain, A/B)
 LOCAL_CELL_FUSED = True  # False = the reference's op-by-op chain on the vendor BLAS (kept for A/B and as fallback)
 
@@ -125,17 +125,18 @@ def sa_local_cell(new_point, mlp, is_training, bn_decay, weight_decay, bn):
 SA_CELL16 = True  # the 16-channel first layer on its own 16x16x4 kernel (False: zero-padded on the 32-channel kernel, A/B)
 
 
-def _sa_cell_weights(w_in, mlp, bn, weight_decay, native16=False):
+def _sa_cell_weights(w_in, mlp, bn, weight_decay, native16=False, single=False):
     """(w0, b0, w1, b1, ww, bw, c_kernel) for pasnl_sa_cell, whose two convolutions are c x c with c in {32, 64, 128}:
       * mlp = [c, c, out]: the layer's own conv0 / conv1;
       * mlp = [16, 16, out] (pointasnl_sem_seg_res.py layer0): as they are where the 16-channel kernel applies (xyz-only rows,
         32 neighbours, centres from a table: native16); otherwise zero-padded to 32 channels -- the padded channels are
         relu(0 + 0) = 0 and feed zero rows, so channels 0..15 are bit-identical to the unpadded arithmetic;
-      * mlp = [c, out] (the *_2 residual layers: ONE convolution, pointasnl_util.py:264-269 with len(mlp) == 2): conv1 = the
-        identity with zero bias -- relu(h * 1 + 0) = h exactly for h = relu(.) >= 0.
+      * mlp = [c, out] (the *_2 residual layers: ONE convolution, pointasnl_util.py:264-269 with len(mlp) == 2): w1 = None, the
+        kernels skip conv1 (SA_CELL_SINGLE = False: conv1 = the identity with zero bias -- relu(h * 1 + 0) = h exactly for
+        h = relu(.) >= 0 -- the same bits for 43-47 % more matrix work).
     The folded / padded tensors are cached in the store like every other folded weight."""
     st = tf_util.store()
-    key = st.path("sa_cell_weights16" if native16 else "sa_cell_weights")
+    key = st.path("sa_cell_weights16" if native16 else ("sa_cell_weights1" if single else "sa_cell_weights"))
     if key not in st._folded:
         c1 = mlp[0]
         with tf_util.variable_scope('conv0'):
@@ -143,8 +144,8 @@ def _sa_cell_weights(w_in, mlp, bn, weight_decay, native16=False):
         if len(mlp) == 3:
             with tf_util.variable_scope('conv1'):
                 w1, b1 = st.layer(c1, mlp[1], bn, weight_decay)
-        elif c1 >= 256 or (c1 == 128 and SA_CELL_WIDE and SA_CELL_SINGLE128):
-            w1, b1 = None, None  # the wide kernel takes "no conv1" as such (no c x c identity product)
+        elif c1 >= 256 or single:
+            w1, b1 = None, None  # the kernels take "no conv1" as such (no c x c identity product)
         else:
             w1, b1 = torch.eye(c1, dtype=torch.float32, device=w0.device), torch.zeros(c1, dtype=torch.float32, device=w0.device)
         with tf_util.variable_scope('weight_net'), tf_util.variable_scope('wconv0'):
@@ -169,7 +170,9 @@ def sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay
     b, n, c = feature.shape
     _, p, k = idx.shape
     native16 = SA_CELL16 and len(mlp) == 3 and mlp[0] == 16 and c == 3 and k == 32 and new_xyz is not None
-    w0, b0, w1, b1, ww, bw, ck = _sa_cell_weights(6 + c, mlp, bn, weight_decay, native16)
+    # one convolution without an identity conv1: where the kernels have that form (16-byte rows that end with an 8-step chunk)
+    single = SA_CELL_SINGLE and len(mlp) == 2 and mlp[0] in (32, 64, 128) and c % 32 == 0 and k == 32
+    w0, b0, w1, b1, ww, bw, ck = _sa_cell_weights(6 + c, mlp, bn, weight_decay, native16, single)
     xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
     out = torch.empty((b, p, ck, 32), dtype=torch.float32, device=xyz.device)
     skip = torch.empty((b, p, 6 + c), dtype=torch.float32, device=xyz.device)

@@ -300,6 +300,30 @@ def test_sa_cell_wide_layers(b, n, c, m, c1, conv1):
     assert np.abs(got.cpu().numpy() - want).max() / np.abs(want).max() < 1e-5
 
 
+@pytest.mark.parametrize("b,n,c,m,c1,centre0", [(2, 400, 32, 100, 64, True), (2, 400, 32, 100, 64, False), (1, 300, 64, 40, 128, True),
+                                                (2, 256, 16, 256, 32, False)])
+def test_sa_cell_single_convolution_equals_identity_conv1(b, n, c, m, c1, centre0, monkeypatch):
+    """mlp = [c, c] (one convolution): the kernels skip conv1; with SA_CELL_SINGLE off the same layer runs an identity conv1 --
+    relu(h * 1 + 0) = h -- and the outputs have to be the same BITS (persistent kernel, with a centre table and with the
+    groups' neighbour 0 as centres)."""
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    rng = np.random.default_rng(c1 + m)
+    xyz = clouds(27, b, n)
+    feat = rng.standard_normal((b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, 32)).astype(np.int32)
+    new_xyz = None if centre0 else dev(clouds(28, b, m))
+    outs = []
+    for single in (True, False):
+        monkeypatch.setattr(U, "SA_CELL_SINGLE", single)
+        st = _store(77)
+        with st.scope("L"):
+            r = U.sa_cell(dev(xyz), dev(feat), dev(idx), new_xyz, [c1, c1], False, None, None, True)
+        outs.append([t.cpu().numpy() for t in r[:2]])
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 def test_sa_cell_unaligned_weights_take_the_scalar_staging_path():
     """The C-ABI takes any float pointers: weights that are not 16-byte aligned are staged with dword copies and give
     bit-identical results."""

@@ -6,4 +6,4 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'prefetch ms', d['ms_per_step'], 'serial', d['config'].get('serial_ms_per_step'), 'agree', d['config'].get('outputs_agree'))
 for k in d['kernels']:
     if 'sa_cell' in k['kernel']: print('   ', k['kernel'], k['dims'], k.get('avg_us'), 'us', k.get('TFLOP/s'), 'TF')"; }
-run ""; run "--set pointasnl_util.SA_CELL_SINGLE128=0"; run ""; run "--set pointasnl_util.SA_CELL_SINGLE128=0"
+run ""; run "--set pointasnl_util.SA_CELL_SINGLE=0"; run ""; run "--set pointasnl_util.SA_CELL_SINGLE=0"
