@@ -993,6 +993,11 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
 //   * skip connection: every lane folds its operands into one of 4 replica rows of the wave with ds_max_f32 (no return
 //     value: nothing waits for it); the rows are combined and written out once per group.
 // =============================================================================================
+// max(x, 0) as a signed-integer maximum of the bits (negative floats are negative integers; -0 -> +0): ONE plain instruction.
+// Use this, not vmaxf(), wherever the value comes out of or goes into a matrix instruction close by: the compiler's hazard
+// recogniser does not look into inline assembly (EXPERIMENTS.md, round 4: a v_max_f32 sunk behind the v_mfma that read its
+// target register).
+__device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
 __device__ __forceinline__ float vmaxf(float a, float b) {
   // plain v_max_f32: fmaxf() would canonicalise both operands first (IEEE mode), 3 instructions instead of 1
   float r;
@@ -1399,7 +1404,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
           // instruction.  vmaxf() is inline assembly, which the compiler's hazard recogniser cannot see into: in this form it
           // sank each v_max_f32 right behind the product that reads the SAME register as an operand (matmul step t: A = v0;
           // then v0 = relu of step t + 1) with no wait state in between, and the results were off by a few per cent
-          if constexpr (SINGLE) H1T[ob][r] = __int_as_float(max(__float_as_int(H1T[ob][r]), 0));
+          if constexpr (SINGLE) H1T[ob][r] = relu_bits(H1T[ob][r]);
           else H1T[ob][r] = vmaxf(H1T[ob][r], 0.f);
         }
 #pragma unroll
@@ -2504,10 +2509,10 @@ __global__ __launch_bounds__(NW * 64) void sa_cell16_kernel(long groups, SaGathe
         G[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
         G[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gx, wn[jt], G[jt], 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) G[jt][r] = vmaxf(G[jt][r], 0.f);
+        for (int r = 0; r < 4; ++r) G[jt][r] = relu_bits(G[jt][r]);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) H1[r] = vmaxf(H1[r], 0.f);  // (the conv0 bias came with the MFMA)
+      for (int r = 0; r < 4; ++r) H1[r] = relu_bits(H1[r]);  // (the conv0 bias came with the MFMA)
       f32x4 H2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 4; ++s) H2 = __builtin_amdgcn_mfma_f32_16x16x4f32(H1[s], w1r[s], H2, 0, 0, 0);
