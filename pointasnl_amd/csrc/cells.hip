@@ -993,17 +993,14 @@ __global__ __launch_bounds__(256) void sa_local_cell_kernel(long groups, int k, 
 //   * skip connection: every lane folds its operands into one of 4 replica rows of the wave with ds_max_f32 (no return
 //     value: nothing waits for it); the rows are combined and written out once per group.
 // =============================================================================================
-// max(x, 0) as a signed-integer maximum of the bits (negative floats are negative integers; -0 -> +0): ONE plain instruction.
-// Use this, not vmaxf(), wherever the value comes out of or goes into a matrix instruction close by: the compiler's hazard
-// recogniser does not look into inline assembly (EXPERIMENTS.md, round 4: a v_max_f32 sunk behind the v_mfma that read its
-// target register).
+// max(x, 0) as a signed-integer maximum of the bits (negative floats are negative integers; -0 -> +0): ONE plain instruction
+// the compiler can see.  There is NO inline-assembly arithmetic in this file: the compiler's hazard recogniser does not look
+// into inline assembly (EXPERIMENTS.md, round 4: an asm v_max_f32 sunk behind the v_mfma that read its target register gave
+// results a few per cent off); tools/asm_scan.py fails on any inline-asm vector instruction in a kernel that issues v_mfma.
 __device__ __forceinline__ float relu_bits(float x) { return __int_as_float(max(__float_as_int(x), 0)); }
-__device__ __forceinline__ float vmaxf(float a, float b) {
-  // plain v_max_f32: fmaxf() would canonicalise both operands first (IEEE mode), 3 instructions instead of 1
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
+// the larger of two floats as a compare + select (fmaxf() would canonicalise both operands first in IEEE mode); a NaN in `b`
+// keeps `a`
+__device__ __forceinline__ float max_sel(float a, float b) { return b > a ? b : a; }
 // Internal column order of the cell input X (a permutation of the reference's [xyz-centre | xyz | feature], chosen
 // so that a lane's 16 operands of a chunk are 64 contiguous, 16-byte aligned bytes of a feature row):
 //     0..2 xyz - centre    3..5 xyz    6 the constant 1 (row 6 of W0 = b0: the conv0 bias rides on the MFMA)
@@ -1400,12 +1397,10 @@ __global__ __launch_bounds__(NW * 64) void sa_cell_kernel(long groups, int k, in
       for (int ob = 0; ob < C1 / 32; ++ob)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          // SINGLE: the ReLU as a signed-integer maximum of the bits (negative floats are negative integers) -- a plain
-          // instruction.  vmaxf() is inline assembly, which the compiler's hazard recogniser cannot see into: in this form it
-          // sank each v_max_f32 right behind the product that reads the SAME register as an operand (matmul step t: A = v0;
-          // then v0 = relu of step t + 1) with no wait state in between, and the results were off by a few per cent
-          if constexpr (SINGLE) H1T[ob][r] = relu_bits(H1T[ob][r]);
-          else H1T[ob][r] = vmaxf(H1T[ob][r], 0.f);
+          // the ReLU as a signed-integer maximum of the bits: a plain instruction between two matrix products that the
+          // hazard recogniser sees (an inline-assembly v_max_f32 here was sunk right behind the product that reads the SAME
+          // register as an operand, with no wait state in between: results off by a few per cent, round 4)
+          H1T[ob][r] = relu_bits(H1T[ob][r]);
         }
 #pragma unroll
       for (int r = 0; r < 16; ++r) G[r] = fmaxf(G[r] + bwr, 0.f);
@@ -2496,7 +2491,7 @@ __global__ __launch_bounds__(NW * 64) void sa_cell16_kernel(long groups, SaGathe
       const float dx = px - cx, dy = py - cy, dz = pz - cz;
       // this lane's operand of the three conv0 steps = columns q, 4 + q, 8 + q of its row
       const float x0 = pick(dx, dy, dz, px), x1 = pick(py, pz, fx, fy), x2 = pick(fz, 1.f, 0.f, 0.f);
-      sk[0] = vmaxf(sk[0], x0); sk[1] = vmaxf(sk[1], x1); sk[2] = vmaxf(sk[2], x2);
+      sk[0] = max_sel(sk[0], x0); sk[1] = max_sel(sk[1], x1); sk[2] = max_sel(sk[2], x2);
       f32x4 H1 = {0.f, 0.f, 0.f, 0.f};
       H1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[0], x0, H1, 0, 0, 0);
       H1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[1], x1, H1, 0, 0, 0);

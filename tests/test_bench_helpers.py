@@ -83,3 +83,50 @@ def test_stale_traffic_is_not_reported(tmp_path, monkeypatch):
     json.dump({key: 123, "_source": {"commit": "abc", "csrc_sha256": stale}}, open(prof / "traffic.json", "w"))
     val, why = bench.measured_traffic("pasnl_query_ball_point", [64, 1024, 512, 32])
     assert val is None and "stale" in why and "grouping.hip" in why
+
+
+def test_asm_scan_flags_inline_assembly_next_to_matrix_instructions():
+    """tools/asm_scan.py: a vector instruction inside ;;#ASMSTART .. ;;#ASMEND that shares a register with a
+    v_mfma close by is reported (the hazard recogniser cannot see it); the same instruction far enough away, or outside inline
+    assembly, is not."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("asm_scan", os.path.join(ROOT, "tools", "asm_scan.py"))
+    asm_scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(asm_scan)
+    bad = """_Zk:
+	v_mfma_f32_32x32x2_f32 a[0:15], v0, v1, a[0:15]
+	;;#ASMSTART
+	v_max_f32 v0, v0, v2
+	;;#ASMEND
+	s_nop 7
+	s_nop 7
+	s_nop 7
+	;;#ASMSTART
+	v_max_f32 v5, v6, v7
+	;;#ASMEND
+	v_mfma_f32_32x32x2_f32 a[0:15], v5, v1, a[0:15]
+	v_mfma_f32_16x16x4_f32 v[8:11], v5, v1, v[8:11]
+	v_add_f32 v3, v3, v3
+	;;#ASMSTART
+	s_nop 1
+	v_max_f32_dpp v9, v9, v9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf
+	;;#ASMEND
+""".split("\n")
+    found = asm_scan.asm_mfma_hazards(bad, 0, len(bad))
+    assert len(found) == 3 and "v0" in found[0] and "v5" in found[1] and "v9" in found[2]
+    good = """_Zk:
+	v_mfma_f32_32x32x2_f32 a[0:15], v0, v1, a[0:15]
+	v_max_f32 v0, v0, v2
+	;;#ASMSTART
+	v_max_f32 v20, v21, v22
+	;;#ASMEND
+	s_nop 7
+	s_nop 7
+	s_nop 7
+	;;#ASMSTART
+	v_max_f32 v1, v1, v1
+	;;#ASMEND
+""".split("\n")
+    assert asm_scan.asm_mfma_hazards(good, 0, len(good)) == []
+    assert asm_scan.regs_of("v[4:7]") == {"v4", "v5", "v6", "v7"} and asm_scan.regs_of("a3") == {"a3"} and asm_scan.regs_of("s[0:1]") == set()

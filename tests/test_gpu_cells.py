@@ -301,18 +301,22 @@ def test_sa_cell_wide_layers(b, n, c, m, c1, conv1):
 
 
 @pytest.mark.parametrize("b,n,c,m,c1,centre0", [(2, 400, 32, 100, 64, True), (2, 400, 32, 100, 64, False), (1, 300, 64, 40, 128, True),
-                                                (2, 256, 16, 256, 32, False)])
+                                                (2, 256, 16, 256, 32, False), (1, 200, 32, 50, 32, True), (3, 128, 64, 128, 64, False),
+                                                (1, 90, 128, 17, 128, False)])
 def test_sa_cell_single_convolution_equals_identity_conv1(b, n, c, m, c1, centre0, monkeypatch):
-    """mlp = [c, c] (one convolution): the kernels skip conv1; with SA_CELL_SINGLE off the same layer runs an identity conv1 --
-    relu(h * 1 + 0) = h -- and the outputs have to be the same BITS (persistent kernel, with a centre table and with the
-    groups' neighbour 0 as centres)."""
+    """mlp = [c, c] (one convolution, the *_2 layers of pointasnl_sem_seg_res.py:36,41): the kernels skip conv1.  (1) Against the
+    ORACLE: the fp64 restatement of pointasnl_util.py:63-74,248-249,264-274 with one convolution, 1e-5 of the output scale and
+    elementwise rtol 1e-4 / atol 1e-5 of the scale, skip maxima bit-equal to the gathered maximum -- for the persistent kernel's
+    SINGLE form at 32 / 64 / 128 channels, with a centre table and with the groups' neighbour 0 as centres.  (2) With
+    SA_CELL_SINGLE off the same layer runs an identity conv1 -- relu(h * 1 + 0) = h -- and the outputs have to be the same BITS."""
     from pointasnl_amd.utils import pointasnl_util as U
 
     rng = np.random.default_rng(c1 + m)
     xyz = clouds(27, b, n)
     feat = rng.standard_normal((b, n, c)).astype(np.float32)
     idx = rng.integers(0, n, (b, m, 32)).astype(np.int32)
-    new_xyz = None if centre0 else dev(clouds(28, b, m))
+    centres = clouds(28, b, m)
+    new_xyz = None if centre0 else dev(centres)
     outs = []
     for single in (True, False):
         monkeypatch.setattr(U, "SA_CELL_SINGLE", single)
@@ -320,6 +324,21 @@ def test_sa_cell_single_convolution_equals_identity_conv1(b, n, c, m, c1, centre
         with st.scope("L"):
             r = U.sa_cell(dev(xyz), dev(feat), dev(idx), new_xyz, [c1, c1], False, None, None, True)
         outs.append([t.cpu().numpy() for t in r[:2]])
+        if single:
+            p = st.export_numpy()
+    bi = np.arange(b)[:, None, None]
+    gx = xyz[bi, idx]
+    cen = gx[:, :, 0, :] if centre0 else centres
+    x = np.concatenate([gx - cen[:, :, None, :], gx, feat[bi, idx]], axis=-1)  # float32, exact
+    np.testing.assert_array_equal(outs[0][1], x.max(axis=2))
+    x64 = x.astype(np.float64)
+    h = cells._layer(x64, p["L/conv0"], "relu")
+    wn = cells._layer(x64[..., :3], p["L/weight_net/wconv0"], "relu")
+    want = np.swapaxes(h, 2, 3) @ wn
+    scale = np.abs(want).max()
+    assert outs[0][0].shape == want.shape
+    assert np.abs(outs[0][0] - want).max() / scale < 1e-5
+    np.testing.assert_allclose(outs[0][0], want, rtol=1e-4, atol=1e-5 * scale)
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 

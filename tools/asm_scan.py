@@ -8,7 +8,17 @@ a select"):
                           `ok ? p[i] : 0.f` in the source); such a load cannot be counted, its use waits for vmcnt(0);
   * drained loop heads -- a loop header whose first wait is `s_waitcnt vmcnt(0)` before the body has issued any load: the
                           loads in flight across the back edge (a prefetch) are all awaited there.
-Neither is wrong by itself (rare paths, epilogues, third-party rocPRIM code); the list is where to look first."""
+Neither is wrong by itself (rare paths, epilogues, third-party rocPRIM code); the list is where to look first.
+
+And one pattern that IS wrong: `asm_mfma` -- a vector instruction inside an inline-assembly block
+(`;;#ASMSTART` .. `;;#ASMEND`) close to a matrix instruction it shares a register with.  The compiler's hazard recogniser
+inserts the wait states gfx950 needs between `v_mfma` and vector instructions only for instructions it can see; inline
+assembly is opaque to it.  Flagged, conservatively (straight-line distance, every instruction = one wait state, `s_nop n`
+= n + 1):
+  * a `v_mfma` at most MFMA_BEFORE wait states BEFORE the asm instruction that writes a register the asm instruction reads
+    or writes, or reads (A, B or C operand) a register the asm instruction writes;
+  * a `v_mfma` at most MFMA_AFTER wait states AFTER it that reads a register the asm instruction writes.
+The script exits non-zero when one is found."""
 import argparse
 import glob
 import os
@@ -28,6 +38,80 @@ def demangle(name):
         return name
 
 
+MFMA_BEFORE, MFMA_AFTER = 20, 6  # wait states: a 16-pass product's result -> vector read needs 19; vector write -> product read 2..4
+
+
+def regs_of(operand):
+    """{'v12', 'a3', ...} named by one assembly operand (v12, v[4:7], a[0:15]; anything else: empty)."""
+    m = re.fullmatch(r"([va])(\d+)", operand)
+    if m:
+        return {f"{m.group(1)}{int(m.group(2))}"}
+    m = re.fullmatch(r"([va])\[(\d+):(\d+)\]", operand)
+    if m:
+        return {f"{m.group(1)}{i}" for i in range(int(m.group(2)), int(m.group(3)) + 1)}
+    return set()
+
+
+def split_instr(t):
+    """mnemonic, [operands] of one line of assembly (comments and modifiers such as `row_shr:1` dropped)."""
+    t = t.split(";")[0].split("//")[0].strip()
+    if not t or t.endswith(":") or t.startswith("."):
+        return None, []
+    parts = t.split(None, 1)
+    ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
+    return parts[0], [o.split()[0] if o.split() else o for o in ops]
+
+
+def asm_mfma_hazards(lines, start, end):
+    """Inline-assembly vector instructions of lines[start:end] that share a register with a nearby v_mfma (see the header)."""
+    instrs, in_asm = [], False  # (line number, mnemonic, writes, reads, inside inline asm, wait states it stands for)
+    for k in range(start, end):
+        t = lines[k].strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        mn, ops = split_instr(t)
+        if mn is None:
+            continue
+        wait = 1
+        if mn == "s_nop" and ops and ops[0].isdigit():
+            wait = int(ops[0]) + 1
+        regs = [regs_of(o) for o in ops]
+        writes = regs[0] if regs and mn.startswith("v_") and not mn.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) else set()
+        reads = set().union(*regs[1:]) if len(regs) > 1 else set()
+        if mn.startswith(("v_readlane", "v_readfirstlane", "v_cmp")):
+            reads = set().union(*regs) if regs else set()
+        if mn.startswith(("ds_", "global_", "buffer_", "flat_", "scratch_")):  # memory instructions: every register is read or a loaded destination
+            writes, reads = set(), set().union(*regs) if regs else set()
+        instrs.append((k + 1, mn, writes, reads, in_asm, wait))
+    found = []
+    for i, (ln, mn, wr, rd, ia, _) in enumerate(instrs):
+        if not ia or not mn.startswith("v_"):
+            continue
+        dist = 0
+        for j in range(i - 1, -1, -1):
+            l2, m2, w2, r2, _, wt = instrs[j]
+            dist += wt
+            if dist > MFMA_BEFORE:
+                break
+            if m2.startswith(("v_mfma", "v_smfmac")) and ((w2 & (rd | wr)) or (r2 & wr)):
+                found.append(f"line {ln}: inline-asm `{mn}` {dist} wait state(s) behind `{m2}` (line {l2}) sharing {sorted((w2 & (rd | wr)) | (r2 & wr))[:4]}")
+                break
+        dist = 0
+        for j in range(i + 1, len(instrs)):
+            l2, m2, w2, r2, _, wt = instrs[j]
+            if m2.startswith(("v_mfma", "v_smfmac")) and (r2 & wr) and dist < MFMA_AFTER:
+                found.append(f"line {ln}: inline-asm `{mn}` writes {sorted(r2 & wr)[:4]} {dist} wait state(s) ahead of `{m2}` (line {l2})")
+                break
+            dist += wt
+            if dist >= MFMA_AFTER:
+                break
+    return found
+
+
 def scan(asm):
     lines = asm.split("\n")
     kern, out = None, {}
@@ -35,7 +119,7 @@ def scan(asm):
         m = re.match(r"^(_Z\S+):", l)
         if m:
             kern = m.group(1)
-            out.setdefault(kern, {"pred": 0, "drain": []})
+            out.setdefault(kern, {"pred": 0, "drain": [], "start": k})
         if kern is None:
             continue
         t = l.strip()
@@ -57,6 +141,14 @@ def scan(asm):
                 if u.startswith("s_waitcnt") and "vmcnt(0)" in u:
                     out[kern]["drain"].append(l.split(":")[0])
                     break
+    starts = sorted((v["start"], kern) for kern, v in out.items())
+    for i, (st, kern) in enumerate(starts):
+        en = starts[i + 1][0] if i + 1 < len(starts) else len(lines)
+        for k in range(st, en):
+            if lines[k].strip().startswith(".Lfunc_end"):
+                en = k
+                break
+        out[kern]["asm_mfma"] = asm_mfma_hazards(lines, st, en)
     meta = {}
     for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_count:\s+(\d+)",
                          asm, re.S):
@@ -84,17 +176,24 @@ def main():
                 if kern not in meta:
                     continue  # a device function, not a kernel
                 vg, ag, sc = meta[kern]
-                rows.append((os.path.basename(f), demangle(kern), vg, ag, sc, v["pred"], len(v["drain"])))
+                rows.append((os.path.basename(f), demangle(kern), vg, ag, sc, v["pred"], len(v["drain"]), v["asm_mfma"]))
     rows.sort(key=lambda r: (-(r[5] + 4 * r[6]), r[0], r[1]))
-    text = ["file            vgpr(total) agpr scratch predicated_loads drained_loop_heads  kernel"]
-    for f, k, vg, ag, sc, pr, dr in rows:
+    hazards = [(f, k, h) for f, k, _, _, _, _, _, hz in rows for h in hz]
+    text = [f"inline-assembly vector instructions sharing a register with a matrix instruction within {MFMA_BEFORE} wait states before / "
+            f"{MFMA_AFTER} after: {len(hazards)}" + (" (clean)" if not hazards else "")]
+    for f, k, h in hazards:
+        text.append(f"  HAZARD {f}  {k[:120]}\n         {h}")
+    text.append("")
+    text.append("file            vgpr(total) agpr scratch predicated_loads drained_loop_heads asm_mfma  kernel")
+    for f, k, vg, ag, sc, pr, dr, hz in rows:
         if "rocprim" in k:
             k = "rocprim::" + k.split("rocprim::")[-1][:60] + " (third party)"
-        text.append(f"{f:<16}{vg:>10} {ag:>5} {sc:>7} {pr:>16} {dr:>18}  {k[:150]}")
+        text.append(f"{f:<16}{vg:>10} {ag:>5} {sc:>7} {pr:>16} {dr:>18} {len(hz):>8}  {k[:150]}")
     text = "\n".join(text)
     print(text)
     if a.out:
         open(a.out, "w").write(text + "\n")
+    sys.exit(1 if hazards else 0)
 
 
 if __name__ == "__main__":
