@@ -2781,14 +2781,15 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   // the row's last chunk: live MFMA steps (0 = the width is a multiple of 32); see TAIL8
   const int wi = 8 + c, rem = wi & 31;
   const bool tail8 = rem != 0 && (vec ? rem : (rem + 1) >> 1) <= 8;
-  if (c1 == 128 && c2 == 128 && !w1 && k == 32 && c % 16 == 0 && new_xyz && reinterpret_cast<uintptr_t>(feature) % 16 == 0) {
+  if (c1 == 128 && c2 == 128 && !w1 && k == 32 && c % 16 == 0 && c >= 32 && new_xyz && reinterpret_cast<uintptr_t>(feature) % 16 == 0) {
     // a 128-channel layer with ONE convolution (mlp = [128, 128]: pointasnl_sem_seg_res.py layer2_2) on the wide kernel's
     // single-convolution form: 60 us at 2560 groups (86 with an identity conv1 on the persistent kernel below, which takes
     // the layer -- without the identity -- where the wide kernel's conditions do not hold)
     return sa_cell_wide_launch<128, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
   }
   if ((c1 == 256 && c2 == 256) || (c1 == 512 && c2 == 512)) {  // the wide layers: one workgroup per group, weights from L2
-    PASNL_REQUIRE(k == 32 && c % 16 == 0 && new_xyz && reinterpret_cast<uintptr_t>(feature) % 16 == 0, PASNL_EUNSUPPORTED);
+    // c >= 32: the wide kernel preloads TWO batches of conv0's weight rows and of the LDS row unconditionally (nsteps = c / 2 >= 2 BT)
+    PASNL_REQUIRE(k == 32 && c % 16 == 0 && c >= 32 && new_xyz && reinterpret_cast<uintptr_t>(feature) % 16 == 0, PASNL_EUNSUPPORTED);
     if (c1 == 256)
       return w1 ? sa_cell_wide_launch<256, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st)
                 : sa_cell_wide_launch<256, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);

@@ -19,22 +19,43 @@ from pointasnl_amd import _hip
 GRID = True  # False: brute-force kernels for every size (A/B, and the reference point of the grid kernel's parity test)
 
 
+# Tree-depth flags of tie_order="nanoflann" searches that were CAPTURED into a HIP graph: the flag (first word of the search's
+# workspace) cannot be read while capturing, so it stays on the device -- the workspace is kept alive here -- and
+# check_deferred_flags() reads them after a replay (one synchronisation per step instead of one per search).
+_DEFERRED_FLAGS = []
+_DEPTH_MSG = "knn_batch(tie_order='nanoflann'): a KD-tree deeper than 96 levels (pathologically clustered cloud)"
+
+
+def check_deferred_flags(clear=False):
+    """Raise PasnlUnsupported if any captured tie_order="nanoflann" search met a tree deeper than its stack (its rows are then
+    undefined).  Call it after replaying the graph; synchronises with the device.  clear=True forgets the captured searches
+    (their graph is gone)."""
+    bad = any(int(f.item()) != 0 for f in _DEFERRED_FLAGS)
+    if clear:
+        _DEFERRED_FLAGS.clear()
+    if bad:
+        raise _hip.PasnlUnsupported(_DEPTH_MSG)
+
+
 def _knn_tree_dev(pts, queries, K, i64):
-    """The reference's own order among equal distances (csrc/knn_tree.hip): nanoflann's tree and search rebuilt on the GPU."""
+    """The reference's own order among equal distances (csrc/knn_tree.hip): nanoflann's tree and search rebuilt on the GPU.
+    Limits of the kernels (16-bit arrival / index packing, result sets in LDS): K <= 64, N <= 65535 -- beyond them the launcher
+    answers PASNL_EUNSUPPORTED and this raises PasnlUnsupported (use the canonical order there: it differs only inside runs of
+    exactly equal distances)."""
     b, n, _ = pts.shape
     m = queries.shape[1]
     if K > n:
         raise ValueError("knn_batch(tie_order='nanoflann') needs K <= number of points")
-    if torch.cuda.is_current_stream_capturing():  # the overflow flag below is read back on the host: eager-only
-        raise _hip.PasnlUnsupported("knn_batch(tie_order='nanoflann') synchronises with the host (tree-depth flag) and cannot be "
-                                    "captured into a HIP graph: run it eagerly (pointasnl_util.KNN_TIE_ORDER='nanoflann' is eager-only)")
     out = torch.empty((b, m, int(K)), dtype=torch.int64 if i64 else torch.int32, device=pts.device)
     nbytes = int(_hip.lib().pasnl_knn_tree_workspace_bytes(b, n, m, int(K)))
     ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=pts.device)
     _hip.launch("pasnl_knn_batch_tree", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
                 _hip.ptr(ws), ctypes.c_size_t(nbytes))
-    if int(ws[:4].view(torch.int32).item()) != 0:  # (a synchronisation: this mode is about exactness, not speed)
-        raise _hip.PasnlUnsupported("knn_batch(tie_order='nanoflann'): a KD-tree deeper than 96 levels (pathologically clustered cloud)")
+    flag = ws[:4].view(torch.int32)
+    if torch.cuda.is_current_stream_capturing():
+        _DEFERRED_FLAGS.append(flag)  # stays on the device: check_deferred_flags() after the replay
+    elif int(flag.item()) != 0:  # eager: checked at once (a synchronisation: this mode is about exactness, not speed)
+        raise _hip.PasnlUnsupported(_DEPTH_MSG)
     return out
 
 
@@ -68,7 +89,9 @@ def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="index"):
     the cast the models do at pointasnl_util.py:30).  ``omp`` is accepted and ignored.
     tie_order: "index" (default) = ascending (distance, index), the canonical order and what the models use; "nanoflann" =
     the reference's own order among EXACTLY equal distances (its KD-tree's visit order), bit-identical to cpp_knn_batch on
-    lattices and duplicated points too -- slower (the tree is rebuilt per call), for exact reproduction only."""
+    lattices and duplicated points too -- slower (the tree is rebuilt per call), for exact reproduction only; K <= 64 and
+    N <= 65535 (PasnlUnsupported beyond).  Captured into a HIP graph its tree-depth flag stays on the device:
+    check_deferred_flags() after the replay."""
     host = not isinstance(pts, torch.Tensor)
     p = _hip.as_dev(pts, torch.float32)
     q = _hip.as_dev(queries, torch.float32)

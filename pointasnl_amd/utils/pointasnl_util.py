@@ -171,9 +171,11 @@ def sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay
     _, p, k = idx.shape
     native16 = SA_CELL16 and len(mlp) == 3 and mlp[0] == 16 and c == 3 and k == 32 and new_xyz is not None
     # one convolution without an identity conv1: where the kernels have that form (16-byte rows that end with an 8-step chunk)
-    single = SA_CELL_SINGLE and len(mlp) == 2 and mlp[0] in (32, 64, 128) and c % 32 == 0 and k == 32
-    w0, b0, w1, b1, ww, bw, ck = _sa_cell_weights(6 + c, mlp, bn, weight_decay, native16, single)
     xyz, feature, idx = xyz.contiguous(), feature.contiguous(), idx.contiguous()
+    # (an unaligned feature view keeps the fused kernel: the identity-conv1 form takes rows that are not 16-byte aligned)
+    single = (SA_CELL_SINGLE and len(mlp) == 2 and mlp[0] in (32, 64, 128) and c % 32 == 0 and k == 32
+              and feature.data_ptr() % 16 == 0)
+    w0, b0, w1, b1, ww, bw, ck = _sa_cell_weights(6 + c, mlp, bn, weight_decay, native16, single)
     out = torch.empty((b, p, ck, 32), dtype=torch.float32, device=xyz.device)
     skip = torch.empty((b, p, 6 + c), dtype=torch.float32, device=xyz.device)
     c_out = mlp[0] if len(mlp) == 2 else mlp[1]
@@ -481,14 +483,21 @@ class Forked:
 
 
 class Deferred:
-    """.get() like Forked: a value put together from forked pieces on the CONSUMER's stream, once (later consumers reuse it)."""
+    """.get() like Forked: a value put together from forked pieces on the FIRST consumer's stream, once; an event recorded
+    behind the joining work makes any later consumer on ANOTHER stream wait for it (like Forked.get() does for every consumer)."""
 
     def __init__(self, fn):
-        self._fn, self._have, self.value = fn, False, None
+        self._fn, self._have, self.value, self._stream, self._event = fn, False, None, None, None
 
     def get(self):
         if not self._have:
             self.value, self._have, self._fn = self._fn(), True, None
+            if torch.cuda.is_available():
+                self._stream = torch.cuda.current_stream()
+                self._event = torch.cuda.Event()
+                self._event.record(self._stream)
+        elif self._event is not None and torch.cuda.current_stream() != self._stream:
+            torch.cuda.current_stream().wait_event(self._event)
         return self.value
 
 
