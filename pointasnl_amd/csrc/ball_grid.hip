@@ -90,6 +90,36 @@ __device__ __forceinline__ int bg_cvt_i32(float x) {
 __device__ __forceinline__ float bg_uni(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 __device__ __forceinline__ int bg_uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// Order-preserving integer key of a float (signed-integer order = float order; -0 < +0; NaNs beyond the infinities) and back
+// (the map is its own inverse): the bounding box is reduced on keys with ONE v_min_i32_dpp per step -- fminf() on floats
+// compiles to four instructions per step (identity move, dpp move, canonicalisation, minimum): 144 for six values
+__device__ __forceinline__ int bg_key(float f) { const int x = __float_as_int(f); return x ^ ((x >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float bg_unkey(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+// minimum over the wave, valid in lane 63 (rows of 16: shr 1, 2, 4, 8, then the two row broadcasts).  (Inline assembly is fine
+// in THIS file: no matrix instructions here; the s_nop keep the dpp read two wait states behind the write.)
+__device__ __forceinline__ int bg_wave_min_to_lane63(int x) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+      : "+v"(x));
+  return x;
+}
+// minimum over every group of eight lanes, valid in the group's last lane
+__device__ __forceinline__ int bg_min8_to_last(int x) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+      "v_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+      : "+v"(x));
+  return x;
+}
+
 // c + (the lane's bit of `mask`, a scalar-ALU result): one v_addc with the mask as carry-in
 __device__ __forceinline__ int bg_add_bit(int c, unsigned long long mask) {
   asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(c) : "s"(mask) : "vcc");
@@ -106,14 +136,12 @@ struct BgPair {
 
 template <int NW32>  // bit-row words per lane in tier 2: n <= 32*NW32
 __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kernel(
-    int n, int m, float rpad, float thr2, float r3, int nsample, uint32_t ns_magic, int qchunk, int aligned,
+    int n, int m, float rpad, float thr2, float r3, int nsample, uint32_t ns_magic, int qchunk,
     const float* __restrict__ xyz1, const float* __restrict__ xyz2, int* __restrict__ idx, int* __restrict__ pts_cnt) {
   constexpr int PPT = NW32 * 32 / BG_THREADS > 0 ? NW32 * 32 / BG_THREADS : 1;  // points per thread
-  constexpr int V4PT = (NW32 * 32 * 3 / 4 + BG_THREADS - 1) / BG_THREADS;        // 16-byte pieces of the cloud per thread
   constexpr int LP = 1024 / NW32 > 64 ? 64 : 1024 / NW32;                        // tier 2: lanes whose bit rows fit 4 KiB
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* spt = reinterpret_cast<float4*>(smem);                                  // [n] cell-sorted {x,y,z,index bits}
-  float* raw = reinterpret_cast<float*>(smem);                                    // build: the (n,3) array as it is in memory
   char* regions = reinterpret_cast<char*>(spt + n);                               // [BG_WAVES][BG_REGION bytes]
   unsigned short* cstart = reinterpret_cast<unsigned short*>(regions + BG_WAVES * BG_REGION);  // [BG_NC + 3]
   int* ccount = reinterpret_cast<int*>(regions);  // cell counters during the build (the regions are not live yet)
@@ -144,77 +172,48 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
     const float* qp = xyz2 + ((size_t)bi * m + (live ? j : qbase)) * 3;
     qx = qp[0]; qy = qp[1]; qz = qp[2];
   }
-  // ---- A. the cloud: flat 16-byte loads into LDS (768 requests for 1024 points where a load per coordinate is 3072),
-  // bounding box straight from the loaded registers: piece q holds elements 4q .. 4q+3 of the flat array, element e of it
-  // belongs to axis (q + e) mod 3
+  // ---- A. the cloud: ONE 12-byte load per point (a wave's 64 loads cover 768 contiguous bytes), every load of the thread
+  // unconditional with a clamped index and requested before the first one is used (a conditional load is waited for where it
+  // is issued: round 4's two 16-byte pieces per thread were two memory round trips in a row, then a pass through LDS and a
+  // rotation of the axes to undo the flat layout)
   float px[PPT], py[PPT], pz[PPT];
-  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-  if (aligned) {
-    const float4* c4 = reinterpret_cast<const float4*>(cloud);
-    const int n4 = (n * 3) >> 2;
-    // t[a] / T[a]: min / max over the thread's pieces of the axis (tid + a) mod 3
-    float t[3] = {INFINITY, INFINITY, INFINITY}, T[3] = {-INFINITY, -INFINITY, -INFINITY};
+  float lo[3], hi[3];
+  {
+    const int lastp = n - 1;  // n > 0 (the entry point requires it)
 #pragma unroll
-    for (int i = 0; i < V4PT; ++i) {
-      const int q = i * BG_THREADS + tid;
-      if (q < n4) {
-        const float4 v = c4[q];
-        reinterpret_cast<float4*>(raw)[q] = v;
-        // piece q starts at axis q mod 3 = (tid + 2 i) mod 3 (BG_THREADS = 512 = 2 mod 3): a compile-time rotation of t[]
-        constexpr int R[3] = {0, 2, 1};
-        const int r0 = R[i % 3];
-        t[r0] = fminf(t[r0], fminf(v.x, v.w)); T[r0] = fmaxf(T[r0], fmaxf(v.x, v.w));
-        t[(r0 + 1) % 3] = fminf(t[(r0 + 1) % 3], v.y); T[(r0 + 1) % 3] = fmaxf(T[(r0 + 1) % 3], v.y);
-        t[(r0 + 2) % 3] = fminf(t[(r0 + 2) % 3], v.z); T[(r0 + 2) % 3] = fmaxf(T[(r0 + 2) % 3], v.z);
-      }
+    for (int i = 0; i < PPT; ++i) {
+      const float* pp = cloud + (size_t)min(i * BG_THREADS + tid, lastp) * 3;
+      px[i] = pp[0]; py[i] = pp[1]; pz[i] = pp[2];
     }
-    // axis a = (tid + j) mod 3  ->  t[j] with j = (a - tid) mod 3
-    const int s = tid % 3;
+    // bounding box on integer keys: per thread the minimum of key(x) and of key(-x) over its points -- a clamped index loaded
+    // a point of the cloud again, which changes no minimum: no masks -- then six single-instruction dpp reductions.  (A NaN
+    // coordinate ends up in the box and the grid degenerates to one cell, like an infinite one: exact, slower.)
+    int kmin[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) kmin[a] = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      kmin[0] = min(kmin[0], bg_key(px[i])); kmin[3] = min(kmin[3], bg_key(-px[i]));
+      kmin[1] = min(kmin[1], bg_key(py[i])); kmin[4] = min(kmin[4], bg_key(-py[i]));
+      kmin[2] = min(kmin[2], bg_key(pz[i])); kmin[5] = min(kmin[5], bg_key(-pz[i]));
+    }
+    int* redk = reinterpret_cast<int*>(red);  // [6][BG_WAVES]: the minima of the keys of x, y, z, -x, -y, -z per wave
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      kmin[a] = bg_wave_min_to_lane63(kmin[a]);
+      if (lane == 63) redk[a * BG_WAVES + wave] = kmin[a];
+    }
+    for (int c = tid; c < BG_NC; c += BG_THREADS) ccount[c] = 0;
+    __syncthreads();
+    // the 48 partials in lanes 0..47 (axis-major, one wave's value per lane): three dpp steps reduce every group of eight lanes
+    // into its last lane, six readlanes put the box into SGPRs, and the keys become floats again on the scalar unit
+    static_assert(BG_WAVES == 8, "the groups of the reduction are eight lanes wide");
+    const int v = bg_min8_to_last(lane < 6 * BG_WAVES ? redk[lane] : 0x7fffffff);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      lo[a] = s == 0 ? t[a] : (s == 1 ? t[(a + 2) % 3] : t[(a + 1) % 3]);
-      hi[a] = s == 0 ? T[a] : (s == 1 ? T[(a + 2) % 3] : T[(a + 1) % 3]);
+      lo[a] = bg_unkey(__builtin_amdgcn_readlane(v, a * 8 + 7));
+      hi[a] = -bg_unkey(__builtin_amdgcn_readlane(v, (3 + a) * 8 + 7));
     }
-  } else {
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int k = i * BG_THREADS + tid;
-      px[i] = py[i] = pz[i] = 0.f;
-      if (k < n) {
-        px[i] = cloud[k * 3]; py[i] = cloud[k * 3 + 1]; pz[i] = cloud[k * 3 + 2];
-        lo[0] = fminf(lo[0], px[i]); hi[0] = fmaxf(hi[0], px[i]);
-        lo[1] = fminf(lo[1], py[i]); hi[1] = fmaxf(hi[1], py[i]);
-        lo[2] = fminf(lo[2], pz[i]); hi[2] = fmaxf(hi[2], pz[i]);
-      }
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) { lo[a] = wave_min_f32(lo[a]); hi[a] = wave_max_f32(hi[a]); }
-  if (lane == 0) {  // [6][BG_WAVES]: the minima, and the maxima NEGATED (one kind of reduction below; negation is exact)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { red[a * BG_WAVES + wave] = lo[a]; red[(3 + a) * BG_WAVES + wave] = -hi[a]; }
-  }
-  for (int c = tid; c < BG_NC; c += BG_THREADS) ccount[c] = 0;
-  __syncthreads();
-  if (aligned) {
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int k = i * BG_THREADS + tid;
-      px[i] = py[i] = pz[i] = 0.f;
-      if (k < n) { px[i] = raw[k * 3]; py[i] = raw[k * 3 + 1]; pz[i] = raw[k * 3 + 2]; }  // stride 3 dwords: conflict-free
-    }
-  }
-  {
-    // the 48 partials in lanes 0..47 (axis-major, one wave's value per lane): three DPP steps reduce every group of eight lanes
-    // into its last lane, six readlanes put the box into SGPRs (48 LDS reads and 42 min / max per thread before)
-    static_assert(BG_WAVES == 8, "the groups of the reduction are eight lanes wide");
-    float v = lane < 6 * BG_WAVES ? red[lane] : INFINITY;
-    const float inf = INFINITY;
-#define PASNL_BG_MIN8(CTRL) v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(inf), __float_as_int(v), CTRL, 0xf, 0xf, false)));
-    PASNL_BG_MIN8(DPP_ROW_SHR1) PASNL_BG_MIN8(DPP_ROW_SHR2) PASNL_BG_MIN8(DPP_ROW_SHR4)
-#undef PASNL_BG_MIN8
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { lo[a] = readlane_f(v, a * 8 + 7); hi[a] = -readlane_f(v, (3 + a) * 8 + 7); }
   }
   // ---- B. grid geometry (identical in every thread)
   const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
@@ -222,9 +221,12 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   float inv_h = 0.f, inv_hx = 0.f, hcell = INFINITY;
   int gx = 1, gy = 1, gz = 1;
   if (maxext < INFINITY && rpad < INFINITY) {  // false for NaN / inf extents and for empty clouds (-inf)
-    const float h = fmaxf(rpad, maxext / (float)BG_G);
+    // (a product and a reciprocal of ~1 ulp instead of two IEEE divisions -- 20 instructions in every thread: any h and any
+    // inv_h do as long as points and queries go through the SAME monotone map; a cell count that comes out one too large is
+    // clamped below, and the margins of a thousandth of a cell dwarf an ulp)
+    const float h = fmaxf(rpad, maxext * (1.0f / (float)BG_G));
     if (h > 0.f && h < INFINITY) {
-      inv_h = 1.0f / h;
+      inv_h = __builtin_amdgcn_rcpf(h);
       inv_hx = inv_h * (float)BG_XS;
       if (inv_hx < INFINITY) {
         hcell = h;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
     }
     if (tid == 0) { cstart[ncell] = (unsigned short)n; cstart[ncell + 1] = (unsigned short)n; cstart[ncell + 2] = (unsigned short)n; }
   }
-  __syncthreads();  // every thread has read its points from `raw` long ago: the records may overwrite it
+  __syncthreads();  // the cell starts are complete
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int k = i * BG_THREADS + tid;
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   BG_MARK(0);
 
 
-  // The nine runs of x-adjacent cells around a query, packed start | end << 16, zero when empty or outside the grid.
+  // The nine runs of x-adjacent cells around a query.
   // Per row of cells the x window is as wide as the ball is THERE: a point of row (dy, dz) is at least day / daz cell edges
   // away from the query in y / z (its distance to the row's slab), so it can only be a hit within
   // sqrt(rho^2 - day^2 - daz^2) edges in x (rho = 1.001 radius / h <= 1); rows beyond rho are dropped.  Margins of a
@@ -301,20 +303,26 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   const float gxf1 = bg_uni((float)(gx + 1)), gyf = bg_uni((float)gy), gzf = bg_uni((float)gz);
   const int cbase2 = (int)((reinterpret_cast<char*>(cstart) - smem) >> 1);  // cstart's offset in 16-bit units
   const int rowz = gy * gx;
-  auto runs_of = [&](float qx, float qy, float qz, bool live, uint32_t (&rpk)[9]) {
+  // -> rs[r] = first record of run r, rl[r] = its length (0: empty, outside the grid, or beyond the ball; rs is then arbitrary
+  //    but < n: a table entry made of it is a run of zero records)
+  auto runs_of = [&](float qx, float qy, float qz, bool live, uint32_t (&rs)[9], uint32_t (&rl)[9]) {
     const float ux = (qx - lo[0]) * inv_hx, uy = (qy - lo[1]) * inv_h, uz = (qz - lo[2]) * inv_h;
     const float uxc = fminf(fmaxf(ux, -2.f), gxf1);  // a query outside the grid looks from its border: a superset
     const int cx = (int)floorf(uxc);
     const int cy = (int)floorf(fminf(fmaxf(uy, -1.f), gyf));
     const int cz = (int)floorf(fminf(fmaxf(uz, -1.f), gzf));
     // squared distance (cell edges) from the query to the slabs of rows cy-1, cy, cy+1 (clamped cell coordinates keep this
-    // right for queries outside the grid: the rows that exist are then all on one side)
-    float ay2[3], az2[3];
+    // right for queries outside the grid: the rows that exist are then all on one side); what is left of rho^2 per row,
+    // on pairs (one packed instruction per two rows)
+    float rem[3][3];  // [dz + 1][dy + 1]
     {
-      const float a0 = fmaxf(uy - (float)cy - 1e-3f, 0.f), a2 = fmaxf((float)(cy + 1) - uy - 1e-3f, 0.f);
-      const float b0 = fmaxf(uz - (float)cz - 1e-3f, 0.f), b2 = fmaxf((float)(cz + 1) - uz - 1e-3f, 0.f);
-      ay2[0] = a0 * a0; ay2[1] = 0.f; ay2[2] = a2 * a2;
-      az2[0] = b0 * b0; az2[1] = 0.f; az2[2] = b2 * b2;
+      const pasnl_f32x2 a{fmaxf(uy - (float)cy - 1e-3f, 0.f), fmaxf((float)(cy + 1) - uy - 1e-3f, 0.f)};
+      const pasnl_f32x2 b{fmaxf(uz - (float)cz - 1e-3f, 0.f), fmaxf((float)(cz + 1) - uz - 1e-3f, 0.f)};
+      const pasnl_f32x2 a2 = a * a, b2 = b * b, r2{rho2, rho2};
+      const pasnl_f32x2 ry = r2 - a2, rz = r2 - b2;                                                      // dz = 0 / dy = 0
+      const pasnl_f32x2 c0 = r2 - (a2 + pasnl_f32x2{b2[0], b2[0]}), c2 = r2 - (a2 + pasnl_f32x2{b2[1], b2[1]});  // dz = -1 / +1
+      rem[1][1] = rho2; rem[1][0] = ry[0]; rem[1][2] = ry[1]; rem[0][1] = rz[0]; rem[2][1] = rz[1];
+      rem[0][0] = c0[0]; rem[0][2] = c0[1]; rem[2][0] = c2[0]; rem[2][2] = c2[1];
     }
     const int xl = max(cx - BG_XS, 0), xh = min(cx + BG_XS, gx - 1);  // the proven outer bounds (header); xl <= xh
     // rows that exist: y = cy + dy in [0, gy), z = cz + dz in [0, gz)   (cy in [-1, gy], cz in [-1, gz])
@@ -326,17 +334,19 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy) {
         const int r = (dz + 1) * 3 + dy + 1;
-        const float rem = rho2 - (ay2[dy + 1] + az2[dz + 1]);
-        const float wc = __builtin_amdgcn_sqrtf(fmaxf(rem, 0.f)) * (float)BG_XS + 2e-3f * (float)BG_XS;
+        const float rm = rem[dz + 1][dy + 1];
+        const float wc = __builtin_fmaf(__builtin_amdgcn_sqrtf(fmaxf(rm, 0.f)), (float)BG_XS, 2e-3f * (float)BG_XS);
         // truncation instead of floor: the lower bound is clamped at xl >= 0 anyway, the upper bound only gets wider
         const int x0 = max(bg_cvt_i32(uxc - wc), xl), x1 = min(bg_cvt_i32(uxc + wc), xh);
-        const bool ok = yok[dy + 1] && zok[dz + 1] && rem > 0.f;
+        const bool ok = yok[dy + 1] && zok[dz + 1] && rm > 0.f;
         const int cb = ok ? cbc + dy * gx + dz * rowz : cbase2;
         // x0 in [0, gx + 1], x1 + 1 in [-2 + 1, gx]: an inverted window reads e <= s (the cell starts are monotone, three
         // entries of padding follow the last cell) and is dropped below
-        const uint32_t s = reinterpret_cast<const unsigned short*>(smem)[cb + x0];
-        const uint32_t e = reinterpret_cast<const unsigned short*>(smem)[cb + max(x1 + 1, 0)];
-        rpk[r] = (ok && e > s) ? (s | (e << 16)) : 0u;
+        const int sv = reinterpret_cast<const unsigned short*>(smem)[cb + x0];
+        const int ev = reinterpret_cast<const unsigned short*>(smem)[cb + max(x1 + 1, 0)];
+        const int len = ev - sv;
+        rs[r] = (uint32_t)sv;
+        rl[r] = (ok && len > 0) ? (uint32_t)len : 0u;
       }
   };
 
@@ -344,8 +354,12 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
 
   // ---- D. queries: one per lane and round; a wave works in its own region only (no workgroup barrier from here on)
   char* wr = regions + wave * BG_REGION;                                           // this wave's region
-  unsigned short* hl = reinterpret_cast<unsigned short*>(wr);                      // tier 1: hit lists
-  unsigned short* tab = reinterpret_cast<unsigned short*>(wr + BG_TAB_OFF);        // tier 1: run tables
+  // tier 1: hit lists and run tables, slots of 128 bytes (one 16-bit entry per lane).  Lane l's entry sits at byte
+  // 4 (l mod 32) + 2 (l / 32): the 32 lanes the LDS serves per cycle then fall on 32 DIFFERENT banks whatever slots they
+  // address (lane-minor order put lanes 2 b and 2 b + 1 on bank b: a 2-way conflict whenever their counts differed)
+  const int lofs = ((lane & 31) << 1) | (lane >> 5);                               // in 16-bit units
+  unsigned short* hl = reinterpret_cast<unsigned short*>(wr) + lofs;               // hit lists: hl[slot * 64]
+  unsigned short* tab = reinterpret_cast<unsigned short*>(wr + BG_TAB_OFF) + lofs; // run tables: tab[slot * 64]
   uint32_t* brow = reinterpret_cast<uint32_t*>(wr);                                // tier 2: bit rows [word][lane % LP]
   uint32_t* stage = reinterpret_cast<uint32_t*>(wr);                               // tier 1: 32 padded rows of 32 entries
   const int last = n > 0 ? n - 1 : 0;
@@ -370,71 +384,77 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
       // (2) the lane's non-empty runs, compacted: 16-bit entries start | length << 11
       uint32_t seen = 0u;
       {
-        uint32_t rpk[9];
-        runs_of(qx, qy, qz, live, rpk);
+        uint32_t rs[9], rl[9];
+        runs_of(qx, qy, qz, live, rs, rl);
         int cntr = 0;
 #pragma unroll
         for (int r = 0; r < 9; ++r) {
-          const uint32_t st = rpk[r] & 0xFFFFu, len = (rpk[r] >> 16) - st;  // an empty run: 0, 0
-          const uint32_t ent = st | (len << 11);
+          const uint32_t ent = rs[r] | (rl[r] << 11);
           seen |= ent;
-          tab[cntr * 64 + lane] = (unsigned short)ent;  // an empty run writes the zero that closes the table (or is overwritten)
-          cntr += rpk[r] != 0u;
+          // an empty run writes an entry of ZERO records where the next run goes: overwritten, or -- behind the lane's last
+          // run -- crossed in the walk in one step whose pair is masked (the slots behind it are the fill's zeros)
+          tab[cntr * 64] = (unsigned short)ent;
+          cntr += rl[r] != 0u;
         }
       }
       const bool longrun = (seen >> 16) != 0u;  // a run of more than 31 records does not fit its entry: this lane -> tier 2
       if (longrun) {                            // ... and walks nothing here (rare: the block is skipped when no lane is)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) tab[t * 64 + lane] = 0;
+        for (int t = 0; t < 9; ++t) tab[t * 64] = 0;
       }
       BG_MARK(2);
       // (3) the flat walk: two candidates per step, software-pipelined: the records of the NEXT pair are requested before the
       // current pair is evaluated (a wave alone on its SIMD otherwise waits out one LDS round trip per step), and the
-      // table entry one step earlier still.  (p, left): the record position and how many records of the current run remain.
-      uint32_t p = 0, ti = 0, nx = tab[lane];
-      int left = 0, c = 0;
+      // table entry one step earlier still.  The walk's state is ONE register in the table's own format,
+      // cur = position | records left << 11: a step is one add, one compare and one select (round 4: position and count apart,
+      // unpacked from the entry at every step: 5 instructions more per step).
+      uint32_t cur = 0, ti = 0, nx = tab[0];
+      int c = 0;
       const pasnl_f32x2 qxy{qx, qy}, qzz{qz, qz};
-      auto advance = [&]() {  // (p, left) <- the pair to examine next; a lane that reached its zeros never leaves them
-        const bool adv = left <= 0;
-        p = adv ? (nx & 0x7FFu) : p;
-        left = adv ? (int)(nx >> 11) : left;
-        ti += adv ? 1u : 0u;
-        nx = tab[min(ti, (uint32_t)(BG_TAB_SLOTS - 1)) * 64 + lane];  // slot 9 is always zero
+      constexpr uint32_t ONE = 1u << 11;  // one record left
+      auto advance = [&](bool adv, uint32_t stepped) {  // cur <- the pair to examine next; a lane that reached its zeros stays there
+        cur = adv ? nx : stepped;
+        ti = (uint32_t)bg_add_bit((int)ti, __builtin_amdgcn_ballot_w64(adv));
+        nx = tab[min(ti, (uint32_t)(BG_TAB_SLOTS - 1)) * 64];  // slot 9 is always zero
       };
-      auto fetch = [&](BgPair& r) {  // p + 1 <= n: at worst the 16 bytes behind the records, read and not used
-        const char* a = reinterpret_cast<const char*>(spt) + (p << 4);
+      auto fetch = [&](BgPair& r) {  // position + 1 <= n: at worst the 16 bytes behind the records, read and not used
+        uint32_t pos = cur & (ONE - 1u);
+        asm("" : "+v"(pos));  // (keeps the mask in front of the shift-and-add that forms the address: one instruction less)
+        const char* a = reinterpret_cast<const char*>(spt + pos);
         r.xy0 = *reinterpret_cast<const pasnl_f32x2*>(a);
         r.xy1 = *reinterpret_cast<const pasnl_f32x2*>(a + 16);
         r.zz = pasnl_f32x2{*reinterpret_cast<const float*>(a + 8), *reinterpret_cast<const float*>(a + 24)};
         r.k0 = *reinterpret_cast<const uint32_t*>(a + 12);
         r.k1 = *reinterpret_cast<const uint32_t*>(a + 28);
       };
-      // one step: evaluate the pair `cur`; request the next pair's records into `nxt`
-#define PASNL_BG_STEP(cur, nxt)                                                                                         \
+      // one step: evaluate the pair `cur`; request the next pair's records into `nxt`.  A run ends when at most two of its
+      // records were left BEFORE the step (tested on the old state: the position never carries into the count)
+#define PASNL_BG_STEP(cur_, nxt_)                                                                                       \
       {                                                                                                                 \
-        const unsigned long long m0 = __builtin_amdgcn_ballot_w64(left > 0), m1 = __builtin_amdgcn_ballot_w64(left > 1); \
-        if (m0 == 0ull) break;                                                                                          \
-        p += 2u;                                                                                                        \
-        left -= 2;                                                                                                      \
-        advance();                                                                                                      \
-        fetch(nxt);                                                                                                     \
+        const unsigned long long m1 = __builtin_amdgcn_ballot_w64(cur >= 2u * ONE);                                     \
+        advance(cur < 3u * ONE, cur + 2u - 2u * ONE);                                                                   \
+        fetch(nxt_);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0); /* the requests go out before the current pair's arithmetic */               \
-        const pasnl_f32x2 e0 = cur.xy0 - qxy, e1 = cur.xy1 - qxy, ez2 = cur.zz - qzz;                                   \
+        const pasnl_f32x2 e0 = cur_.xy0 - qxy, e1 = cur_.xy1 - qxy, ez2 = cur_.zz - qzz;                                \
         const pasnl_f32x2 s0 = e0 * e0, s1 = e1 * e1, sz = ez2 * ez2;                                                   \
         float t0 = s0[0] + s0[1], t1 = s1[0] + s1[1];                                                                   \
         asm("" : "+v"(t0), "+v"(t1)); /* two plain adds into a register pair, not a packed add behind three moves */    \
         const pasnl_f32x2 dd = pasnl_f32x2{t0, t1} + sz; /* ((dx*dx)+(dy*dy))+(dz*dz), twice */                         \
-        hl[c * 64 + lane] = (unsigned short)cur.k0; /* unconditional: a miss is overwritten */                          \
+        hl[c * 64] = (unsigned short)cur_.k0; /* unconditional: a miss is overwritten */                                \
         c = bg_add_bit(c, m0 & __builtin_amdgcn_ballot_w64(dd[0] < thr2));                                              \
-        hl[c * 64 + lane] = (unsigned short)cur.k1;                                                                     \
+        hl[c * 64] = (unsigned short)cur_.k1;                                                                           \
         c = bg_add_bit(c, m1 & __builtin_amdgcn_ballot_w64(dd[1] < thr2));                                              \
         c = min(c, BG_CAP); /* a count that reaches BG_CAP stays there: the lane's row then comes from tier 2 */        \
+        m0 = __builtin_amdgcn_ballot_w64(cur >= ONE); /* lanes with a pair to examine in the NEXT step */               \
         BG_COUNT(7, 1);                                                                                                 \
       }
-      advance();
+      advance(true, 0u);
       BgPair ra, rb;
       fetch(ra);
-      for (;;) {
+      // two steps per trip and ONE exit test (on the mask the next step needs anyway, a scalar carried around the loop): a
+      // wave's last trip may run one idle step, cheaper than a second test per trip and the copies that merge two exits
+      unsigned long long m0 = __builtin_amdgcn_ballot_w64(cur >= ONE);
+      while (m0 != 0ull) {
         PASNL_BG_STEP(ra, rb)
         PASNL_BG_STEP(rb, ra)
       }
@@ -444,7 +464,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
       need2 = live && !done;
       const unsigned long long donemask = __builtin_amdgcn_ballot_w64(done);
       if (donemask != 0ull) {
-        hl[c * 64 + lane] = 0xFFFFu;  // whatever a miss left behind the last hit
+        hl[c * 64] = 0xFFFFu;  // whatever a miss left behind the last hit
         // (4) lists -> registers -> sorting network.  The network size follows the wave's largest count.
         uint32_t v[20];
         const int cs = done ? c : 0;
@@ -452,20 +472,20 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
 #define PASNL_CE(a, b) { const uint32_t lo_ = min(v[a], v[b]), hi_ = max(v[a], v[b]); v[a] = lo_; v[b] = hi_; }
         // entries are read sign-extended: the closing 0xFFFF becomes 0xFFFFFFFF, last for the unsigned network and -1 for
         // the signed maximum that turns it into the row's padding below
-        const short* hs = reinterpret_cast<const short*>(hl);
+        const short* hs = reinterpret_cast<const short*>(hl);  // (the lane's offset inside a slot is part of the pointer)
         if (big) {
 #pragma unroll
-          for (int s = 0; s < 20; ++s) v[s] = (uint32_t)(int)hs[s * 64 + lane];
+          for (int s = 0; s < 20; ++s) v[s] = (uint32_t)(int)hs[s * 64];
           PASNL_SORTNET_20
         } else if (mid) {
 #pragma unroll
-          for (int s = 0; s < 16; ++s) v[s] = (uint32_t)(int)hs[s * 64 + lane];
+          for (int s = 0; s < 16; ++s) v[s] = (uint32_t)(int)hs[s * 64];
 #pragma unroll
           for (int s = 16; s < 20; ++s) v[s] = 0xFFFFFFFFu;
           PASNL_SORTNET_16
         } else {
 #pragma unroll
-          for (int s = 0; s < 8; ++s) v[s] = (uint32_t)(int)hs[s * 64 + lane];
+          for (int s = 0; s < 8; ++s) v[s] = (uint32_t)(int)hs[s * 64];
 #pragma unroll
           for (int s = 8; s < 20; ++s) v[s] = 0xFFFFFFFFu;
           PASNL_SORTNET_8
@@ -545,8 +565,13 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
       // ---- tier 2: bit rows, LP lanes at a time, for the lanes that need it.  Word w of an active lane's row is
       // brow[w*LP + lane % LP]; the rows go straight to global memory (the rare path: no staging)
       int* orow = idx + ((size_t)bi * m + (live ? j : qbase)) * nsample;
-      uint32_t rpk[9];
-      runs_of(qx, qy, qz, need2, rpk);
+      uint32_t rpk[9];  // start | end << 16, zero when empty
+      {
+        uint32_t rs[9], rl[9];
+        runs_of(qx, qy, qz, need2, rs, rl);
+#pragma unroll
+        for (int r = 0; r < 9; ++r) rpk[r] = rl[r] != 0u ? (rs[r] | ((rs[r] + rl[r]) << 16)) : 0u;
+      }
       // ---- tier 1.5: a lane whose list overflowed but whose runs hold at most 128 candidates is served by the WHOLE wave:
       // lane l takes candidates l and l + 64 of the query's runs, the hits' indices are sorted across the wave (bitonic,
       // DPP) and lane s stores entry s of the row -- ~200 instructions per such query where a bit-row pass costs thousands
@@ -674,8 +699,6 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
   dim3 grid((m + qchunk - 1) / qchunk, b);
   const float rpad = radius * 1.001f;
   const float r3 = radius * radius * radius;
-  // the cloud is fetched in 16-byte pieces when every cloud of the batch starts on a 16-byte boundary
-  const int aligned = (n % 4 == 0) && (reinterpret_cast<uintptr_t>(xyz1) % 16 == 0);
   // e / d for e < 2^16 as umulhi(e, magic); d = 16-byte chunks (or entries) per row
   const unsigned div = (nsample & 3) == 0 ? (unsigned)nsample / 4 : (unsigned)nsample;
   const uint32_t ns_magic = div == 1 ? 0u : (uint32_t)((0x100000000ull / div) + 1ull);  // 0: divisor 1
@@ -685,7 +708,7 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(gk),                                        \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)      \
       return PASNL_ELAUNCH;                                                                                              \
-    hipLaunchKernelGGL(gk, grid, dim3(BG_THREADS), lds, stream, n, m, rpad, thr2, r3, nsample, ns_magic, qchunk, aligned, \
+    hipLaunchKernelGGL(gk, grid, dim3(BG_THREADS), lds, stream, n, m, rpad, thr2, r3, nsample, ns_magic, qchunk,          \
                        xyz1, xyz2, idx, pts_cnt);                                                                        \
   }
   if (nw32 == 8) PASNL_BG(8)

@@ -1022,6 +1022,11 @@ static int knn_tree_deep_launch(int b, int n, char* clouds, size_t stride, size_
   return PASNL_OK;
 }
 
+// The workspace's first 256 bytes (the flag word and its padding) zeroed by a KERNEL: a hipMemsetAsync of them captured into a
+// HIP graph wrote pointer-like garbage there from the second replay on (ROCm 7.2, measured: tools/dbg/tie_capture.py), and
+// the reference tie order has to work inside a captured forward
+__global__ void knn_tree_clear_kernel(int* __restrict__ flag) { flag[threadIdx.x] = 0; }
+
 extern "C" size_t pasnl_knn_tree_workspace_bytes(int b, int n, int m, int k) {
   if (b <= 0 || n <= 0 || m <= 0 || k <= 0) return 0;
   return 256 + (size_t)b * kt_cloud_bytes(n);  // (the search keeps its result sets in LDS)
@@ -1039,7 +1044,7 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
   hipStream_t st = pasnl_hip_stream(stream);
   char* base = static_cast<char*>(workspace);
   int* flag = reinterpret_cast<int*>(base);  // first word: set when a tree or a search was deeper than KT_DEPTH
-  if (hipMemsetAsync(flag, 0, 256, st) != hipSuccess) return PASNL_ELAUNCH;
+  hipLaunchKernelGGL(knn_tree_clear_kernel, dim3(1), dim3(64), 0, st, flag);
   char* clouds = base + 256;
   const size_t stride = kt_cloud_bytes(n);
   const bool serial = n > KTB_NMAX || tune_env("PASNL_KNN_TREE_SERIAL") != nullptr;  // (tuning build: the checker of the parallel build)

@@ -339,7 +339,12 @@ def test_sa_cell_single_convolution_equals_identity_conv1(b, n, c, m, c1, centre
     assert outs[0][0].shape == want.shape
     assert np.abs(outs[0][0] - want).max() / scale < 1e-5
     np.testing.assert_allclose(outs[0][0], want, rtol=1e-4, atol=1e-5 * scale)
-    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    if c1 == 128 and c >= 32 and not centre0:
+        # this layer takes the WIDE kernel's single-convolution form (another summation order than the persistent kernel's
+        # identity form): the same function, not the same bits
+        np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-6 * scale)
+    else:
+        np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
