@@ -177,6 +177,9 @@ def algorithmic(symbol, ints):
     if symbol in ("pasnl_decode_cell", "pasnl_decode_cell_tiled"):
         b, n, c, k = ints
         return 4 * b * n * (3 + c + k + (3 + c) * 32), 2 * b * n * k * ((3 + c) * 32 + 3 * 32), "hbm"
+    if symbol == "pasnl_mlp3_max_pool":
+        b, n, k0, c1, c2, c3 = ints[:6]
+        return 4 * (b * n * k0 + k0 * c1 + c1 * c2 + c2 * c3 + c1 + c2 + c3 + b * c3), 2 * b * n * (k0 * c1 + c1 * c2 + c2 * c3), "mfma"
     if symbol in ("pasnl_max_pool_rows", "pasnl_max_pool_rows_strided"):
         b, n, c = ints[:3]
         return 4 * b * c * (n + 1), 0, "hbm"
@@ -554,6 +557,9 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
     from pointasnl_amd.utils import pointasnl_util, tf_util
 
     model = importlib.import_module(f"pointasnl_amd.models.pointasnl_{spec['model']}")
+    if os.environ.get("PASNL_BENCH_GROUP_ALL") is not None:  # (tuning switch: which group_all modules take the fused kernel)
+        from pointasnl_amd.utils import pointnet_util
+        pointnet_util.GROUP_ALL_FUSED = tuple(int(v) for v in os.environ["PASNL_BENCH_GROUP_ALL"].split(",") if v)
     B, N = spec["batch"], spec["points"]
     pc = make_input(cfg_index, spec, rank)
     x = torch.from_numpy(pc).cuda()

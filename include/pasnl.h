@@ -248,6 +248,19 @@ int pasnl_max_pool_rows(int b, int n, int c, const float* x, float* out, pasnl_s
  * pointasnl_cls land side by side in the (B, 1536) input of fc1 (models/pointasnl_cls.py:43-45: the tf.concat is free). */
 int pasnl_max_pool_rows_strided(int b, int n, int c, const float* x, float* out, long out_stride, pasnl_stream_t stream);
 
+/* The "group all" set-abstraction module in one kernel (csrc/mlp_pool.hip): pointnet_sa_module(..., group_all=True) of
+ * utils/pointnet_util.py:87-137 as called at models/pointasnl_cls.py:39-40 -- the three 1x1 convolutions of `mlp` (BN folded
+ * into w / bias by the caller, ReLU) over every point of a cloud and tf.reduce_max over the points:
+ *   out[cloud * out_stride + ch] = max_i relu(relu(relu(x[cloud,i,:] w0 + b0) w1 + b1) w2 + b2)[ch]
+ * x (b,n,k0) rows [xyz | points] (sample_and_group_all's concat, pointnet_util.py:79; any leading alignment columns the
+ * caller added have zero rows in w0), w0 (k0,c1), w1 (c1,c2), w2 (c2,c3).  Covered: (c1,c2,c3) = (128,256,512) and
+ * (256,512,1024), k0 % 4 == 0, x 16-byte aligned; otherwise PASNL_EUNSUPPORTED (the caller runs the layers one by one).
+ * workspace: pasnl_mlp3_max_pool_workspace_bytes(b, n, c3) bytes (maxima per tile of 32 points; no need to clear it). */
+size_t pasnl_mlp3_max_pool_workspace_bytes(int b, int n, int c3);
+int pasnl_mlp3_max_pool(int b, int n, int k0, int c1, int c2, int c3, const float* x, const float* w0, const float* b0,
+                        const float* w1, const float* b1, const float* w2, const float* b2, float* out, long out_stride,
+                        void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
+
 /* ------------------------------------------------------------------ dense layers with few rows (csrc/dense.hip) */
 
 /* out (rows,n) = act(x (rows,kdim) . w (kdim,n) + bias), rows <= 128, relu != 0 -> ReLU: the classifier head

@@ -53,6 +53,55 @@ def max_pool_points(new_points, out=None):
     return out.unflatten(0, (b, p)).unsqueeze(2)
 
 
+# first-layer widths for which a group_all module runs on the fused kernel (csrc/mlp_pool.hip); the others run their three
+# convolutions on the vendor GEMM + a pooling kernel.  Measured (EXPERIMENTS.md, round 5): the fused kernel streams every
+# weight from L2 once per 32 / 64 rows and ties with the vendor chain at best -- see there for what is enabled and why.
+GROUP_ALL_FUSED = (128,)
+_GROUP_ALL_WS = {}
+
+
+def group_all_mlp_max(new_points, mlp, bn, pooled_out=None):
+    """The body of a group_all module (pointnet_util.py:123-137) in one launch (csrc/mlp_pool.hip): the three [1,1] convolutions
+    of `mlp` (BN folded, ReLU) over all n points of every cloud and the maximum over the points.
+    new_points (B,1,n,kp) [with `.input_pad` leading alignment columns the reference's tensor does not have] -> (B,1,1,mlp[-1]);
+    the variables are the ones conv2d would create (scopes conv0..2).  Raises PasnlUnsupported outside the kernel's shapes."""
+    b, one, n, kp = new_points.shape
+    if one != 1 or len(mlp) != 3:
+        raise _hip.PasnlUnsupported("group_all_mlp_max: one group per cloud, three convolutions")
+    pad = getattr(new_points, "input_pad", 0)
+    st = tf_util.store()
+    cin, ws = kp - pad, []
+    for i, c in enumerate(mlp):
+        with tf_util.variable_scope('conv%d' % i):
+            w, bb = st.layer(cin, c, bn)
+            if i == 0 and pad:  # zero rows for the alignment columns (the same cached tensor tf_util._dense would build)
+                key = st.path("") + "@pad%d" % pad
+                if key not in st._folded:
+                    st._folded[key] = (torch.cat([w.new_zeros((pad, w.shape[1])), w], dim=0).contiguous(), bb)
+                w, bb = st._folded[key]
+        ws += [w, bb]
+        cin = c
+    x = new_points.reshape(b, n, kp)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    c3 = mlp[-1]
+    if pooled_out is None:
+        out2d = torch.empty((b, c3), dtype=torch.float32, device=x.device)
+    else:
+        if tuple(pooled_out.shape) != (b, c3) or pooled_out.stride(1) != 1 or pooled_out.dtype != torch.float32:
+            raise ValueError("group_all_mlp_max: pooled_out must be a (B, C) float32 view with unit column stride")
+        out2d = pooled_out
+    nbytes = int(_hip.lib().pasnl_mlp3_max_pool_workspace_bytes(b, n, c3))
+    key = (x.device.index, torch.cuda.current_stream().cuda_stream, c3)
+    bufs = _GROUP_ALL_WS.setdefault(key, [])  # grow-only, per stream: a captured graph keeps the buffer it was captured with
+    if not bufs or bufs[-1].numel() < nbytes:
+        bufs.append(torch.empty(max(nbytes, 256), dtype=torch.uint8, device=x.device))
+    wsb = bufs[-1]
+    _hip.launch("pasnl_mlp3_max_pool", "mlp3_max_pool", b, n, kp, mlp[0], mlp[1], mlp[2], _hip.ptr(x), *[_hip.ptr(t) for t in ws],
+                _hip.ptr(out2d), ctypes.c_long(out2d.stride(0) if b > 1 else c3), _hip.ptr(wsb), ctypes.c_size_t(wsb.numel()))
+    return out2d.unflatten(0, (b, 1)).unsqueeze(2)
+
+
 def sample_and_group_all(xyz, points, use_xyz=True):
     '''
     Equivalent to sample_and_group with npoint=1, radius=inf, (0,0,0) as the centroid (pointnet_util.py:59-84).
@@ -95,11 +144,20 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
         else:
             new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, knn, use_xyz)
-        for i, num_out_channel in enumerate(mlp):
-            new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
-                                        is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay,
-                                        input_pad=getattr(new_points, "input_pad", 0) if i == 0 else 0)
-        new_points = max_pool_points(new_points, out=pooled_out)
+        fused = None
+        if group_all and len(mlp) == 3 and mlp[0] in GROUP_ALL_FUSED and new_points.is_cuda and not is_training:
+            try:
+                fused = group_all_mlp_max(new_points, mlp, bn, pooled_out.reshape(-1, mlp[-1]) if pooled_out is not None else None)
+            except _hip.PasnlUnsupported:
+                fused = None  # other widths: layer by layer below
+        if fused is not None:
+            new_points = fused
+        else:
+            for i, num_out_channel in enumerate(mlp):
+                new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,
+                                            is_training=is_training, scope='conv%d' % (i), bn_decay=bn_decay,
+                                            input_pad=getattr(new_points, "input_pad", 0) if i == 0 else 0)
+            new_points = max_pool_points(new_points, out=pooled_out)
         if mlp2 is not None:
             for i, num_out_channel in enumerate(mlp2):
                 new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,

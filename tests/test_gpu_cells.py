@@ -348,6 +348,57 @@ def test_sa_cell_single_convolution_equals_identity_conv1(b, n, c, m, c1, centre
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("b,n,c,mlp", [(3, 512, 128, [128, 256, 512]), (2, 128, 256, [256, 512, 1024]), (2, 77, 128, [128, 256, 512]),
+                                        (1, 32, 256, [256, 512, 1024]), (5, 200, 60, [256, 512, 1024])])
+def test_group_all_module_in_one_kernel(b, n, c, mlp, monkeypatch):
+    """pointnet_sa_module(group_all=True) (pointnet_util.py:87-137; models/pointasnl_cls.py:39-40) on csrc/mlp_pool.hip: three
+    convolutions + the maximum over the cloud's points in one kernel -- against the fp64 restatement of the module (elementwise
+    rtol 1e-4 / atol 1e-5 of the output scale), with and without the producer's [0 | xyz | points] rows and the pooled_out view,
+    ragged last tiles, and the same function as the layer-by-layer path on the vendor GEMM."""
+    from pointasnl_amd import _hip
+    from pointasnl_amd.utils import pointnet_util as PU
+
+    rng = np.random.default_rng(b * 100 + n)
+    xyz = clouds(31, b, n)
+    pts = rng.standard_normal((b, n, c)).astype(np.float32)
+    x64 = np.concatenate([xyz, pts], axis=-1).astype(np.float64)
+    outs = {}
+    for mode in ("fused", "fused_cat", "layers"):
+        monkeypatch.setattr(PU, "GROUP_ALL_FUSED", (128, 256) if mode != "layers" else ())
+        st = _store(5)
+        p_t = dev(pts)
+        x_t = dev(xyz)
+        if mode == "fused_cat":  # rows as PointASNLSetAbstraction(xyz_concat=True) leaves them: one zero column in front
+            p_t.xyz_concat = (x_t, torch.cat([torch.zeros((b, n, 1), device="cuda"), x_t, p_t], dim=2).contiguous())
+        wide = torch.zeros((b, mlp[-1] + 8), device="cuda")
+        _hip.PROFILE = []
+        try:
+            with torch.no_grad():
+                _, got, _ = PU.pointnet_sa_module(x_t, p_t, npoint=None, radius=None, nsample=None, mlp=mlp, mlp2=None,
+                                                  group_all=True, is_training=False, bn_decay=None, scope="L",
+                                                  pooled_out=wide[:, 8:] if mode != "layers" else None)
+            launched = [sym for sym, _, _, _ in _hip.PROFILE]
+        finally:
+            _hip.PROFILE = None
+        # the producer's 16-byte rows take the fused kernel; the reference's own 3 + c wide rows (not a multiple of 4 floats)
+        # and the switch take the layers one by one
+        assert ("pasnl_mlp3_max_pool" in launched) == (mode == "fused_cat"), (mode, launched)
+        outs[mode] = got.cpu().numpy()
+        assert got.shape == (b, 1, mlp[-1])
+        if mode != "layers":
+            np.testing.assert_array_equal(wide[:, 8:].cpu().numpy(), outs[mode][:, 0])  # written in place, nothing beside it
+            assert float(wide[:, :8].abs().max()) == 0.0
+        params = st.export_numpy()
+    hcell = x64[:, None]
+    for i in range(3):
+        hcell = cells._layer(hcell, params[f"L/conv{i}"], "relu")
+    want = hcell.max(axis=2)  # (b, 1, c3)
+    scale = np.abs(want).max()
+    for mode in ("fused", "fused_cat", "layers"):
+        assert np.abs(outs[mode] - want).max() / scale < 1e-5, mode
+        np.testing.assert_allclose(outs[mode], want, rtol=1e-4, atol=1e-5 * scale)
+
+
 def test_sa_cell_unaligned_weights_take_the_scalar_staging_path():
     """The C-ABI takes any float pointers: weights that are not 16-byte aligned are staged with dword copies and give
     bit-identical results."""
