@@ -605,18 +605,26 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
             nsamp, npnt = first["nsample"], first["npoint"]
             res = spec["model"] == "sem_seg_res"
 
-            def prefix(t, kf=None):
+            def prefix(t, kf=None, into=None):
                 """The coordinate-only searches at the head of a forward, as the model itself computes them (bit-identical
                 results: exact kNN, the same sampler): cls / sem_seg -- layer1's sa_search = FPS + gather + kNN of the sampled
                 points -> [new_xyz, idx]; sem_seg_res -- layer0's self-kNN (kf: already running on another side stream, or
-                computed here) and layer1's FPS, whose neighbour lists are rows of that kNN -> [k_all, new_xyz, idx]."""
+                computed here) and layer1's FPS, whose neighbour lists are rows of that kNN -> [k_all, new_xyz, idx].
+                into: the hand-over buffers of the step -- the kernels write them directly (no copy behind them)."""
                 xyz = xyz_of(t)
+                o = into if into is not None else [None, None, None]
                 if not res:
-                    _, new_xyz = tf_sampling.farthest_point_sample_gather(npnt, xyz)
-                    return [new_xyz, pointasnl_util.knn_query(nsamp, xyz, new_xyz)]
-                fps_idx, new_xyz = tf_sampling.farthest_point_sample_gather(N // 8, xyz)
-                k_all = kf.get() if kf is not None else pointasnl_util.knn_query(32, xyz, xyz)
-                return [k_all, new_xyz, pointasnl_util._gather_index_rows(k_all, fps_idx)]
+                    _, new_xyz = tf_sampling.farthest_point_sample_gather(npnt, xyz, out=(None, o[0]))
+                    return [new_xyz, pointasnl_util.knn_query(nsamp, xyz, new_xyz, out=o[1])]
+                fps_idx, new_xyz = tf_sampling.farthest_point_sample_gather(N // 8, xyz, out=(None, o[1]))
+                if kf is not None:
+                    k_all = kf.get()
+                    if o[0] is not None:
+                        o[0].copy_(k_all)  # (the self-kNN ran on another branch into a buffer of its own)
+                        k_all = o[0]
+                else:
+                    k_all = pointasnl_util.knn_query(32, xyz, xyz, out=o[0])
+                return [k_all, new_xyz, pointasnl_util._gather_index_rows(k_all, fps_idx, out=o[2])]
 
             def as_search(t, bufs):
                 if not res:
@@ -636,8 +644,9 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
                         # sem_seg_res: the sampler and the self-kNN each ALONE on a side branch, their join (the rows of the
                         # sampled points + the hand-over copies) on the forward's stream once both are back -- a branch that
                         # waits for another branch inside misleads the graph executor's placement (EXPERIMENTS.md, round 4)
-                        ff = pointasnl_util.Forked(lambda: tf_sampling.farthest_point_sample_gather(N // 8, xyz_of(xs[nxt])), slot=PREFETCH_SLOTS[0])
-                        kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt])), slot=PREFETCH_SLOTS[1])
+                        # (both branches write the hand-over buffers of the next step themselves)
+                        ff = pointasnl_util.Forked(lambda: tf_sampling.farthest_point_sample_gather(N // 8, xyz_of(xs[nxt]), out=(None, S[nxt][1])), slot=PREFETCH_SLOTS[0])
+                        kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt]), out=S[nxt][0]), slot=PREFETCH_SLOTS[1])
                         fk.extend([ff, kf])
                         late.append((ff, kf))
                         return
@@ -645,8 +654,7 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
                         if res else None
 
                     def run_prefix():
-                        for dst, src in zip(S[nxt], prefix(xs[nxt], kf)):
-                            dst.copy_(src)
+                        prefix(xs[nxt], kf, into=S[nxt])
                         return True
                     fk.append(pointasnl_util.Forked(run_prefix, slot=PREFETCH_SLOTS[0]))
                     if kf is not None:
@@ -657,9 +665,8 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
                 for f in fk:
                     f.get()  # join: the graph ends when everything has finished
                 for ff, kf in late:
-                    (fps_idx, new_xyz), k_all = ff.get(), kf.get()
-                    for dst, src in zip(S[nxt], [k_all, new_xyz, pointasnl_util._gather_index_rows(k_all, fps_idx)]):
-                        dst.copy_(src)
+                    (fps_idx, _), k_all = ff.get(), kf.get()
+                    pointasnl_util._gather_index_rows(k_all, fps_idx, out=S[nxt][2])
                 return o
 
             for cur in (0, 1):

@@ -76,18 +76,30 @@ def farthest_point_sample(npoint, inp):
     return out
 
 
-def farthest_point_sample_gather(npoint, inp):
+def _out_buffer(t, shape, dtype, device, what):
+    """a caller's output buffer: contiguous, of the result's shape / dtype / device (a serving loop hands its own buffers over
+    so that nothing is copied behind the kernel)"""
+    if t is None:
+        return torch.empty(shape, dtype=dtype, device=device)
+    if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device or not t.is_contiguous():
+        raise ValueError(f"{what}: out must be a contiguous {dtype} tensor of shape {tuple(shape)} on {device}")
+    return t
+
+
+def farthest_point_sample_gather(npoint, inp, out=None):
     '''farthest_point_sample + gather_point of its picks in ONE launch (not a symbol of the reference module: its callers run
     the two back to back, pointasnl_util.py:33-49, pointnet_util.py:44).  inp (B,ndataset,3) f32
-    -> idx (B,npoint) int32, new_xyz (B,npoint,3) f32 == gather_point(inp, idx) bit for bit.  No gradient path.'''
+    -> idx (B,npoint) int32, new_xyz (B,npoint,3) f32 == gather_point(inp, idx) bit for bit.  No gradient path.
+    out: optional (idx, new_xyz) buffers to write into (either may be None).'''
     if int(npoint) <= 0:
         raise ValueError("FarthestPointSample expects positive npoint")
     inp = _hip.as_dev(inp, torch.float32)
     if inp.dim() != 3 or inp.shape[2] != 3:
         raise ValueError("FarthestPointSample expects (batch_size,num_points,3) inp shape")
     b, n, _ = inp.shape
-    out = torch.empty((b, int(npoint)), dtype=torch.int32, device=inp.device)
-    new_xyz = torch.empty((b, int(npoint), 3), dtype=torch.float32, device=inp.device)
-    _hip.launch("pasnl_farthest_point_sample_gather", "FarthestPointSample", b, n, int(npoint), _hip.ptr(inp), _hip.ptr(out),
+    o_idx, o_xyz = out if out is not None else (None, None)
+    idx = _out_buffer(o_idx, (b, int(npoint)), torch.int32, inp.device, "farthest_point_sample_gather")
+    new_xyz = _out_buffer(o_xyz, (b, int(npoint), 3), torch.float32, inp.device, "farthest_point_sample_gather")
+    _hip.launch("pasnl_farthest_point_sample_gather", "FarthestPointSample", b, n, int(npoint), _hip.ptr(inp), _hip.ptr(idx),
                 _hip.ptr(new_xyz))
-    return out, new_xyz
+    return idx, new_xyz

@@ -37,7 +37,7 @@ def check_deferred_flags(clear=False):
         raise _hip.PasnlUnsupported(_DEPTH_MSG)
 
 
-def _knn_tree_dev(pts, queries, K, i64):
+def _knn_tree_dev(pts, queries, K, i64, out=None):
     """The reference's own order among equal distances (csrc/knn_tree.hip): nanoflann's tree and search rebuilt on the GPU.
     Limits of the kernels (16-bit arrival / index packing, result sets in LDS): K <= 64, N <= 65535 -- beyond them the launcher
     answers PASNL_EUNSUPPORTED and this raises PasnlUnsupported (use the canonical order there: it differs only inside runs of
@@ -46,7 +46,7 @@ def _knn_tree_dev(pts, queries, K, i64):
     m = queries.shape[1]
     if K > n:
         raise ValueError("knn_batch(tie_order='nanoflann') needs K <= number of points")
-    out = torch.empty((b, m, int(K)), dtype=torch.int64 if i64 else torch.int32, device=pts.device)
+    out = _out_buffer(out, (b, m, int(K)), torch.int64 if i64 else torch.int32, pts.device)
     nbytes = int(_hip.lib().pasnl_knn_tree_workspace_bytes(b, n, m, int(K)))
     ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=pts.device)
     _hip.launch("pasnl_knn_batch_tree", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
@@ -59,11 +59,19 @@ def _knn_tree_dev(pts, queries, K, i64):
     return out
 
 
-def _knn_dev(pts, queries, K, i64, tie_order="index"):
+def _out_buffer(t, shape, dtype, device):
+    if t is None:
+        return torch.empty(shape, dtype=dtype, device=device)
+    if tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != device or not t.is_contiguous():
+        raise ValueError(f"knn_batch: out must be a contiguous {dtype} tensor of shape {tuple(shape)} on {device}")
+    return t
+
+
+def _knn_dev(pts, queries, K, i64, tie_order="index", out=None):
     if tie_order == "nanoflann":
         if pts.dim() != 3 or pts.shape[2] != 3 or queries.dim() != 3 or queries.shape[2] != 3 or queries.shape[0] != pts.shape[0]:
             raise ValueError("knn_batch expects (B,N,3) pts and (B,M,3) queries")
-        return _knn_tree_dev(pts, queries, K, i64)
+        return _knn_tree_dev(pts, queries, K, i64, out)
     if tie_order != "index":
         raise ValueError("tie_order is 'index' (canonical (distance, index) order) or 'nanoflann' (the reference's visit order)")
     if pts.dim() != 3 or pts.shape[2] != 3 or queries.dim() != 3 or queries.shape[2] != 3:
@@ -72,7 +80,7 @@ def _knn_dev(pts, queries, K, i64, tie_order="index"):
         raise ValueError("knn_batch expects the same batch size for pts and queries")
     b, n, _ = pts.shape
     m = queries.shape[1]
-    out = torch.empty((b, m, int(K)), dtype=torch.int64 if i64 else torch.int32, device=pts.device)
+    out = _out_buffer(out, (b, m, int(K)), torch.int64 if i64 else torch.int32, pts.device)
     nbytes = int(_hip.lib().pasnl_knn_workspace_bytes(b, n)) if GRID and K <= 64 else 0
     if nbytes:  # large clouds: grid-pruned search in a scratch workspace (bit-identical results, csrc/knn_grid.hip)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=pts.device)
@@ -84,19 +92,21 @@ def _knn_dev(pts, queries, K, i64, tie_order="index"):
     return out
 
 
-def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="index"):
+def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="index", out=None):
     """(B,N,3), (B,M,3) -> (B,M,K) neighbour indices (int64 like the reference; ``dtype=torch.int32`` skips
     the cast the models do at pointasnl_util.py:30).  ``omp`` is accepted and ignored.
     tie_order: "index" (default) = ascending (distance, index), the canonical order and what the models use; "nanoflann" =
     the reference's own order among EXACTLY equal distances (its KD-tree's visit order), bit-identical to cpp_knn_batch on
     lattices and duplicated points too -- slower (the tree is rebuilt per call), for exact reproduction only; K <= 64 and
     N <= 65535 (PasnlUnsupported beyond).  Captured into a HIP graph its tree-depth flag stays on the device:
-    check_deferred_flags() after the replay."""
+    check_deferred_flags() after the replay.  out: optional device buffer (B,M,K) of the result's dtype to write into."""
     host = not isinstance(pts, torch.Tensor)
     p = _hip.as_dev(pts, torch.float32)
     q = _hip.as_dev(queries, torch.float32)
     i64 = dtype in (None, torch.int64, np.int64)
-    out = _knn_dev(p, q, K, i64, tie_order)
+    if out is not None and host:
+        raise ValueError("knn_batch: out= takes a device tensor (device inputs only)")
+    out = _knn_dev(p, q, K, i64, tie_order, out)
     return out.cpu().numpy() if host else out
 
 

@@ -27,10 +27,11 @@ KNN_TIE_ORDER = "index"  # "nanoflann": neighbour lists in the reference's own o
 #                          coordinates; slower (a tree per call).  Distinct distances: both orders are the same list.
 
 
-def knn_query(k, support_pts, query_pts):
+def knn_query(k, support_pts, query_pts, out=None):
     """Mirror of pointasnl_util.py:22-30.  support_pts (B,N1,3), query_pts (B,N2,3) -> (B,N2,k) int32: for every query the
-    indices of its k nearest support points, nearest first.  No host round trip here: the search is a gfx950 kernel."""
-    return nearest_neighbors.knn_batch(support_pts, query_pts, k, omp=True, dtype=torch.int32, tie_order=KNN_TIE_ORDER)
+    indices of its k nearest support points, nearest first.  No host round trip here: the search is a gfx950 kernel.
+    out: optional (B,N2,k) int32 buffer to write into."""
+    return nearest_neighbors.knn_batch(support_pts, query_pts, k, omp=True, dtype=torch.int32, tie_order=KNN_TIE_ORDER, out=out)
 
 
 def _gather_rows(points, idx):
@@ -513,9 +514,18 @@ def neighbor0_xyz(xyz, idx):
     return _gather_rows(xyz, idx[:, :, 0].contiguous())
 
 
-def _gather_index_rows(table, idx):
-    """rows of an int32 table (B,N,K) at idx (B,M) -> (B,M,K): the row gather on the bit pattern"""
-    return _gather_rows(table.view(torch.float32), idx).view(torch.int32)
+def _gather_index_rows(table, idx, out=None):
+    """rows of an int32 table (B,N,K) at idx (B,M) -> (B,M,K): the row gather on the bit pattern.
+    out: optional contiguous (B,M,K) int32 buffer to write into (inference plumbing: no gradient path)."""
+    if out is None:
+        return _gather_rows(table.view(torch.float32), idx).view(torch.int32)
+    b, n, k = table.shape
+    m = idx.shape[1]
+    if tuple(out.shape) != (b, m, k) or out.dtype != torch.int32 or not out.is_contiguous() or out.device != table.device:
+        raise ValueError("_gather_index_rows: out must be a contiguous (B,M,K) int32 tensor on the table's device")
+    table, idx = table.contiguous(), idx.contiguous()
+    _hip.launch("pasnl_group_point", "GroupPoint", b, n, k, m, 1, _hip.ptr(table), _hip.ptr(idx), _hip.ptr(out))
+    return out
 
 
 def sa_search(xyz, feature, npoint, nsample, use_knn=True, radius=None, knn_all=None):
