@@ -2588,7 +2588,8 @@ __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGath
     }
     if (tid < 32) {
       const float* pp = src.xyz + ((size_t)bi * src.n + rows[tid]) * 3;
-      const float* cc = src.new_xyz + (size_t)g * 3;
+      // centre0: the centre of the group is its neighbour 0 (pointasnl_util.py:161-163)
+      const float* cc = src.centre0 ? src.xyz + ((size_t)bi * src.n + rows[0]) * 3 : src.new_xyz + (size_t)g * 3;
       const float px = pp[0], py = pp[1], pz = pp[2];
       float* d = Xs + tid * xp;
       d[0] = px - cc[0]; d[1] = py - cc[1]; d[2] = pz - cc[2];
@@ -2596,6 +2597,15 @@ __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGath
     }
   }
   __syncthreads();
+  if (src.centre0 && src.new_feature_out) {
+    // what pasnl_take_neighbor0 would have written: new_xyz = the centre, new_feature = [centre | feature row of neighbour 0]
+    float* nfo = src.new_feature_out + (size_t)g * (3 + cf);
+    for (int c = tid; c < 3 + cf; c += T) {
+      const float v = Xs[c < 3 ? 3 + c : 8 + (c - 3)];  // row 0 of the tile: columns 3..5 = xyz, 8.. = the feature row
+      nfo[c] = v;
+      if (c < 3) src.new_xyz_out[(size_t)g * 3 + c] = v;
+    }
+  }
   // skip maxima (pointasnl_util.py:258): reference column c = internal column c (c < 6) or c + 2
   for (int c = tid; c < w; c += T) {
     const float* col = Xs + (c < 6 ? c : c + 2);
@@ -2772,7 +2782,6 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   // new_xyz == NULL: the centre of a group is its neighbour 0.  The kernel's centre prefetch stays unconditional and is
   // pointed at xyz, whose b*n*3 floats cover the b*m*3 it touches when m <= n
   PASNL_REQUIRE(new_xyz || m <= n, PASNL_EUNSUPPORTED);
-  PASNL_REQUIRE(!new_feature_out || c <= 128, PASNL_EUNSUPPORTED);  // two words per lane carry neighbour 0's row
   SaGatherSrc src{xyz, feature, idx, new_xyz ? new_xyz : xyz, skip_max, n, m, new_xyz ? 0 : 1, new_xyz_out, new_feature_out};
   hipStream_t st = pasnl_hip_stream(stream);
   const int w = 6 + c;
@@ -2787,9 +2796,16 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
     // the layer -- without the identity -- where the wide kernel's conditions do not hold)
     return sa_cell_wide_launch<128, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
   }
+  // A 128-channel layer with FEW groups (pointasnl_sem_seg_res.py layer3_1: 640 groups, pointasnl_sem_seg.py layer3: 1024) on
+  // the wide kernel as well: the persistent kernel stages 144 KB of weights into the LDS of each of 256 workgroups before a
+  // wave sees its first -- and here only -- group (267 us for 640 groups, 121 us for 1 024; 354 us for the classifier's 8 192)
+  constexpr long SA_WIDE128_MAX_GROUPS = 2048;
+  if (c1 == 128 && c2 == 128 && w1 && groups <= SA_WIDE128_MAX_GROUPS && k == 32 && c % 16 == 0 && c >= 32 &&
+      reinterpret_cast<uintptr_t>(feature) % 16 == 0)
+    return sa_cell_wide_launch<128, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
   if ((c1 == 256 && c2 == 256) || (c1 == 512 && c2 == 512)) {  // the wide layers: one workgroup per group, weights from L2
     // c >= 32: the wide kernel preloads TWO batches of conv0's weight rows and of the LDS row unconditionally (nsteps = c / 2 >= 2 BT)
-    PASNL_REQUIRE(k == 32 && c % 16 == 0 && c >= 32 && new_xyz && reinterpret_cast<uintptr_t>(feature) % 16 == 0, PASNL_EUNSUPPORTED);
+    PASNL_REQUIRE(k == 32 && c % 16 == 0 && c >= 32 && reinterpret_cast<uintptr_t>(feature) % 16 == 0, PASNL_EUNSUPPORTED);
     if (c1 == 256)
       return w1 ? sa_cell_wide_launch<256, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st)
                 : sa_cell_wide_launch<256, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
@@ -2800,6 +2816,7 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
     PASNL_REQUIRE(c == 3 && k == 32 && new_xyz, PASNL_EUNSUPPORTED);
     return sa_cell16_launch(groups, src, w0, b0, w1, b1, ww, bw, out, st);
   }
+  PASNL_REQUIRE(!new_feature_out || c <= 128, PASNL_EUNSUPPORTED);  // persistent kernel: two words per lane carry neighbour 0's row
   if (c1 == 32 && c2 == 32) return sa_cell_cfg<32, 32>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   if (c1 == 64 && c2 == 64) return sa_cell_cfg<64, 64>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);
   if (c1 == 128 && c2 == 128) return sa_cell_cfg<128, 128>(vec, tail8, groups, k, w, src, w0, b0, w1, b1, ww, bw, out, st);

@@ -619,7 +619,9 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                 return nx, nf
             # the fused cell finds its centres in its own tiles and writes new_xyz / new_feature itself: no gather launch
             # between the search and the cell (pasnl_sa_cell_centre0)
-            centre0 = CENTRE0 and fused and SA_CELL_GATHER and npoint <= num_points and num_channel <= 128
+            # (rows wider than 128 channels: only the wide kernels -- mlp[0] = 256 / 512 -- write the neighbour-0 row themselves)
+            centre0 = (CENTRE0 and fused and SA_CELL_GATHER and npoint <= num_points
+                       and (num_channel <= 128 or (SA_CELL_WIDE and mlp[0] in (256, 512) and nsample == 32)))
             if not centre0:
                 new_xyz, new_feature = take0()
         elif num_points != npoint and AS_FUSED and as_neighbor <= 16:

@@ -269,7 +269,8 @@ def test_sa_cell_16_channels_native_kernel(b, n, m, monkeypatch):
 
 @pytest.mark.parametrize("b,n,c,m,c1,conv1", [(2, 300, 256, 40, 256, True), (1, 128, 256, 33, 256, False), (2, 96, 512, 20, 512, False),
                                                (1, 64, 128, 7, 256, True), (1, 80, 512, 3, 512, True),
-                                               (2, 320, 128, 320, 128, False), (1, 77, 64, 9, 128, False)])
+                                               (2, 320, 128, 320, 128, False), (1, 77, 64, 9, 128, False),
+                                               (2, 300, 128, 77, 128, True), (1, 96, 64, 640, 128, True)])  # 128 channels, few groups
 def test_sa_cell_wide_layers(b, n, c, m, c1, conv1):
     """The 256- / 512-channel layers (pointasnl_sem_seg.py:34, pointasnl_sem_seg_res.py:46-51) on pasnl_sa_cell: one workgroup per
     group, weights from L2; with conv1 (mlp [c, c, out]) and without (mlp [c, c]: the *_2 layers).  fp64 restatement to 1e-5,
@@ -682,6 +683,7 @@ def test_launch_refuses_tensors_of_another_device():
 
 @pytest.mark.parametrize("b,n,c,m,k,c1", [
     (3, 300, 3, 70, 32, 64), (2, 256, 128, 40, 64, 128), (17, 128, 32, 50, 32, 32), (2, 200, 64, 200, 96, 64),
+    (2, 300, 128, 40, 32, 128), (1, 200, 256, 24, 32, 256), (2, 100, 256, 60, 32, 512),  # the wide kernels (one workgroup per group)
 ])
 def test_sa_cell_takes_its_centres_from_neighbour_0(b, n, c, m, k, c1):
     """pasnl_sa_cell with new_xyz = NULL (AdaptiveSampling with as_neighbor == 0, pointasnl_util.py:161-163): the centre of a
