@@ -817,11 +817,17 @@ extern "C" int pasnl_knn_batch(int b, int n, int m, int k, const float* support,
   // small K over large clouds both kernels are bound by the distance loop and the single pass is ahead
   // (N=8192,K=16: 795 vs 982 us).  PASNL_KNN_INSERTION=1 forces the insertion kernel (A/B measurements).
   if (k <= 64 && (!(k <= 16 && n > 2048) || tune_env("PASNL_KNN_TWO_PASS")) && !tune_env("PASNL_KNN_INSERTION")) {
-    constexpr int QW = 4;
-    dim3 grid((m + SEARCH_WAVES * QW - 1) / (SEARCH_WAVES * QW), b), block(SEARCH_WAVES * 64);
-#define PASNL_KNN2(RR, T) hipLaunchKernelGGL((knn2_kernel<RR, QW, T>), grid, block, 0, st, n, m, k, support, queries, static_cast<T*>(idx), dist2)
-    if (k <= 32) { if (idx_is_i64) PASNL_KNN2(1, long long); else PASNL_KNN2(1, int); }
-    else { if (idx_is_i64) PASNL_KNN2(2, long long); else PASNL_KNN2(2, int); }
+    // queries per wave: a wave works through its queries one after the other (two in-wave sorts each), so a launch with few
+    // queries is ONE round of long chains (cls layer 2, 8 192 queries at four per wave: 2 048 waves on 1 024 SIMDs, 136 us of
+    // which 2/3 are the sorts); fewer queries per wave until the chip holds ~8 waves per SIMD
+    const long nq = (long)b * m;
+    const int qw = nq >= 4L * 8192 ? 4 : (nq >= 2L * 8192 ? 2 : 1);
+    dim3 grid((m + SEARCH_WAVES * qw - 1) / (SEARCH_WAVES * qw), b), block(SEARCH_WAVES * 64);
+#define PASNL_KNN2Q(RR, Q, T) hipLaunchKernelGGL((knn2_kernel<RR, Q, T>), grid, block, 0, st, n, m, k, support, queries, static_cast<T*>(idx), dist2)
+#define PASNL_KNN2(RR, T) { if (qw == 4) PASNL_KNN2Q(RR, 4, T); else if (qw == 2) PASNL_KNN2Q(RR, 2, T); else PASNL_KNN2Q(RR, 1, T); }
+    if (k <= 32) { if (idx_is_i64) PASNL_KNN2(1, long long) else PASNL_KNN2(1, int) }
+    else { if (idx_is_i64) PASNL_KNN2(2, long long) else PASNL_KNN2(2, int) }
+#undef PASNL_KNN2Q
 #undef PASNL_KNN2
     return pasnl_launch_status();
   }
