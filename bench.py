@@ -491,6 +491,7 @@ def protocol_only(args, rank, world):
 # ---------------------------------------------------------------------------------------------------------------
 _FORWARD_STREAM = None
 SPLIT_PREFIX = os.environ.get('PASNL_BENCH_SPLIT_PREFIX', '1') != '0'  # tuning switch: sem_seg_res prefix as two plain branches
+SELF_KNN_PREFIX = os.environ.get('PASNL_BENCH_SELF_KNN', '0') != '0'    # tuning switch: cls / sem_seg prefix = sampler || self-kNN, then a row gather (measured: 1.335-1.349 vs 1.315 ms)
 PREFETCH_SLOTS = tuple(int(v) for v in os.environ.get('PASNL_BENCH_PREFETCH_SLOTS', '3,4').split(','))  # side streams of the prefetch
 WORKLOADS = {
     1: dict(model="cls", AS=False, noise=0, batch=64, points=1024, name="configs[1]: ModelNet40 pointasnl_cls, 1024 pts"),
@@ -566,10 +567,13 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
     store = tf_util.set_store(tf_util.VariableStore(seed=1234))  # identical weights on every rank
     fch = spec.get("feature_channel", 0)
 
+    fork_at = os.environ.get("PASNL_BENCH_FORK_AT", spec.get("fork_at", "cell2"))  # (tuning switch; cls only)
+
     def forward(xin=None, search=None, before_head=None):
         xin = x if xin is None else xin
         if spec["model"] == "cls":
-            logits, _ = model.get_model(xin, is_training=False, adaptive_sample=spec["AS"], search=search, before_head=before_head)
+            logits, _ = model.get_model(xin, is_training=False, adaptive_sample=spec["AS"], search=search, before_head=before_head,
+                                        fork_at=fork_at)
             return logits
         logits, _ = model.get_model(xin, False, 20, feature_channel=fch, search=search, before_head=before_head)
         return logits.reshape(B, -1)
@@ -648,7 +652,17 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
                         ff = pointasnl_util.Forked(lambda: tf_sampling.farthest_point_sample_gather(N // 8, xyz_of(xs[nxt]), out=(None, S[nxt][1])), slot=PREFETCH_SLOTS[0])
                         kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt]), out=S[nxt][0]), slot=PREFETCH_SLOTS[1])
                         fk.extend([ff, kf])
-                        late.append((ff, kf))
+                        late.append((ff, kf, S[nxt][2]))
+                        return
+                    if not res and SELF_KNN_PREFIX:
+                        # cls / sem_seg: the neighbour lists of the sampled points as ROWS of the cloud's self-kNN (the queries are
+                        # support points: the same distances, the same (distance, index) order, bit for bit -- what sem_seg_res
+                        # does by construction).  Twice the search, but beside the sampler instead of BEHIND it: the step
+                        # ends with the sampler (+ a row gather), not with sampler + kNN
+                        ff = pointasnl_util.Forked(lambda: tf_sampling.farthest_point_sample_gather(npnt, xyz_of(xs[nxt]), out=(None, S[nxt][0])), slot=PREFETCH_SLOTS[0])
+                        kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(nsamp, xyz_of(xs[nxt]), xyz_of(xs[nxt])), slot=PREFETCH_SLOTS[1])
+                        fk.extend([ff, kf])
+                        late.append((ff, kf, S[nxt][1]))
                         return
                     kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt])), slot=PREFETCH_SLOTS[1]) \
                         if res else None
@@ -664,9 +678,9 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
                 o = forward(xs[cur], search=as_search(xs[cur], S[cur]), before_head=None if fk else fork)
                 for f in fk:
                     f.get()  # join: the graph ends when everything has finished
-                for ff, kf in late:
+                for ff, kf, dst in late:
                     (fps_idx, _), k_all = ff.get(), kf.get()
-                    pointasnl_util._gather_index_rows(k_all, fps_idx, out=S[nxt][2])
+                    pointasnl_util._gather_index_rows(k_all, fps_idx, out=dst)
                 return o
 
             for cur in (0, 1):

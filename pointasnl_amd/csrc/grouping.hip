@@ -821,7 +821,10 @@ extern "C" int pasnl_knn_batch(int b, int n, int m, int k, const float* support,
     // queries is ONE round of long chains (cls layer 2, 8 192 queries at four per wave: 2 048 waves on 1 024 SIMDs, 136 us of
     // which 2/3 are the sorts); fewer queries per wave until the chip holds ~8 waves per SIMD
     const long nq = (long)b * m;
-    const int qw = nq >= 4L * 8192 ? 4 : (nq >= 2L * 8192 ? 2 : 1);
+#ifndef PASNL_KNN2_MIN_WAVES
+#define PASNL_KNN2_MIN_WAVES 8192L
+#endif
+    const int qw = nq >= 4L * PASNL_KNN2_MIN_WAVES ? 4 : (nq >= 2L * PASNL_KNN2_MIN_WAVES ? 2 : 1);
     dim3 grid((m + SEARCH_WAVES * qw - 1) / (SEARCH_WAVES * qw), b), block(SEARCH_WAVES * 64);
 #define PASNL_KNN2Q(RR, Q, T) hipLaunchKernelGGL((knn2_kernel<RR, Q, T>), grid, block, 0, st, n, m, k, support, queries, static_cast<T*>(idx), dist2)
 #define PASNL_KNN2(RR, T) { if (qw == 4) PASNL_KNN2Q(RR, 4, T); else if (qw == 2) PASNL_KNN2Q(RR, 2, T); else PASNL_KNN2Q(RR, 1, T); }

@@ -128,6 +128,11 @@ __global__ __launch_bounds__(WAVES * 64) void fps_kernel(int n, int m, const flo
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* cloud = xyz + (size_t)blockIdx.x * n * 3;
+  // A sampler is m dependent rounds of a few hundred instructions on ONE wave per SIMD: beside a matrix kernel (a serving loop
+  // runs the next batch's sampler beside the current batch's dense layers) every instruction it loses in the issue
+  // arbitration lengthens the chain (212 -> 535 us measured), while what it takes from the other kernel is a few per cent of
+  // a SIMD's issue slots.  Highest wave priority.
+  __builtin_amdgcn_s_setprio(3);
 
   for (int f = tid; f < n * 3; f += T) {  // coalesced flat copy of the (n,3) array into 16-byte LDS records
     float v = cloud[f];

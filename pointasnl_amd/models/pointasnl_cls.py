@@ -15,11 +15,13 @@ def first_layer(num_point=None):
 
 
 def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, weight_decay=None, num_class=40,
-              adaptive_sample=False, search=None, before_head=None):
+              adaptive_sample=False, search=None, before_head=None, fork_at="head"):
     """ Classification PointNet, input is BxNx3 (BxNx6 with normals), output Bx40
     search / before_head (not in the reference signature; both optional): the search prefix of layer1 computed ahead by the
     caller, and a callback invoked once the set-abstraction layers are enqueued -- a serving loop forks the NEXT batch's
-    search prefix there, beside the classifier head, which leaves most of the GPU idle (bench.py --pipeline prefetch). """
+    search prefix there, beside the classifier head, which leaves most of the GPU idle (bench.py --pipeline prefetch).
+    fork_at: where that callback is invoked -- "head" (behind layer 2), "conv2" (before layer 2's after_conv GEMM) or "cell2"
+    (behind layer 2's cell): the prefix is ~0.3 ms of dependent rounds and has to END with the head. """
     batch_size = point_cloud.shape[0]
     end_points = {}
     if use_normal:
@@ -42,9 +44,11 @@ def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, w
     end_points['l1_xyz'] = l1_xyz
     l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=128, nsample=64, mlp=[128, 128, 256],
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
-                                                scope='layer2', as_neighbor=as_neighbor[1], search=search2[0], xyz_concat=True)
+                                                scope='layer2', as_neighbor=as_neighbor[1], search=search2[0], xyz_concat=True,
+                                                after_cell=before_head if fork_at == "cell2" else None,
+                                                before_after_conv=before_head if fork_at == "conv2" else None)
     end_points['l2_xyz'] = l1_xyz  # sic: the reference stores l1_xyz here (pointasnl_cls.py:38)
-    if before_head is not None:
+    if before_head is not None and fork_at == "head":
         before_head()
     # the two pooled vectors are written side by side into fc1's input: tf.concat([l3_points, l3_points_res]) for free
     net = torch.empty((batch_size, 1024 + 512), dtype=torch.float32, device=point_cloud.device)

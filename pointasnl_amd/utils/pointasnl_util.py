@@ -585,7 +585,7 @@ def sa_search_split(xyz, npoint, nsample, knn_all, slot=0):
 
 def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_decay, weight_decay, scope, bn=True,
                             use_knn=True, radius=None, as_neighbor=8, NL=True, search=None, after_sampling=None,
-                            xyz_concat=False):
+                            xyz_concat=False, after_cell=None, before_after_conv=None):
     '''Mirror of pointasnl_util.py:221-292: one PointASNL set-abstraction layer.
         xyz (B,N,3), feature (B,N,C)  ->  new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1])
     npoint points are sampled (FPS) and moved by AdaptiveSampling over their first `as_neighbor` neighbours; each keeps
@@ -678,6 +678,8 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                 new_point = new_point.transpose(2, 3)
                 new_point = torch.matmul(new_point, weight)
 
+        if after_cell is not None:
+            after_cell()  # (hooks for a serving loop: where the next batch's search prefix is forked, bench.py --pipeline prefetch)
         c_out = mlp[-1]
         # (layers with few groups -- the deep, wide ones: 512 rows x 512 channels -- are 16 workgroups of dependent MFMA
         # chains fed from L2; there the three small vendor GEMMs are faster: measured 101 vs ~45 us)
@@ -690,6 +692,8 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
             if NL:
                 att = PointNonLocalCell(feature, new_feature.unsqueeze(1), [cb, nl_channel], is_training, bn_decay,
                                         weight_decay, scope, bn, project=False)  # (B, P, cb)
+            if before_after_conv is not None:
+                before_after_conv()
             after = tf_util.conv2d(new_point, c_out, [1, new_point.shape[2]], padding='VALID', stride=[1, 1], bn=bn,
                                    is_training=is_training, scope='after_conv', bn_decay=bn_decay, weight_decay=weight_decay)
             st = tf_util.store()
