@@ -269,11 +269,10 @@ def cpu_baseline(pc_all, params, adaptive, seconds_budget=20.0):
         nn = {"shape": [16, 1024, 256], "seconds": round(time.perf_counter() - t0, 4), "threads": 1, "kind": "reference"}
     return {"value": round(bsz / med, 2), "unit": "point-clouds/s", "cores": int(torch.get_num_threads()),
             "kind": "reference" if ref.available("libref_knn.so") else "port",
-            "sample": f"{reps} forwards of the same B={bsz}x{sample.shape[1]} batch the GPU runs, median {med * 1e3:.1f} ms/forward; "
-                      f"kNN = the reference's knn_.cxx + nanoflann with OpenMP over the batch"
-                      f"{'' if ref.available('libref_knn.so') else ' (C PORT: oracle/_ref absent)'}, FPS/gathers = C port (the "
-                      f"reference has no CPU kernel), dense + attention = torch CPU fp32 on {torch.get_num_threads()} threads "
-                      f"({cores} logical cores)",
+            "sample": f"{reps} forwards of the GPU's own B={bsz}x{sample.shape[1]} batch, median {med * 1e3:.0f} ms each",
+            "how": f"kNN = the reference's knn_.cxx + nanoflann, OpenMP over the batch"
+                   f"{'' if ref.available('libref_knn.so') else ' (C PORT: oracle/_ref absent)'}; FPS / gathers = C port (the reference "
+                   f"has no CPU kernel); dense + attention = torch CPU fp32, {torch.get_num_threads()} threads of {cores} logical cores",
             "pieces_ms": {k: round(float(np.median(v)) * 1e3, 3) for k, v in pieces.items()},
             "three_nn_reference_1thread": nn}
 
@@ -491,6 +490,7 @@ def protocol_only(args, rank, world):
 # ---------------------------------------------------------------------------------------------------------------
 _FORWARD_STREAM = None
 SPLIT_PREFIX = os.environ.get('PASNL_BENCH_SPLIT_PREFIX', '1') != '0'  # tuning switch: sem_seg_res prefix as two plain branches
+FORK_AT_DEFAULT = os.environ.get("PASNL_BENCH_FORK_AT", "cell2")  # cls: where the next batch's prefix is forked (head / conv2 / cell2)
 SELF_KNN_PREFIX = os.environ.get('PASNL_BENCH_SELF_KNN', '0') != '0'    # tuning switch: cls / sem_seg prefix = sampler || self-kNN, then a row gather (measured: 1.335-1.349 vs 1.315 ms)
 PREFETCH_SLOTS = tuple(int(v) for v in os.environ.get('PASNL_BENCH_PREFETCH_SLOTS', '3,4').split(','))  # side streams of the prefetch
 WORKLOADS = {
@@ -567,7 +567,7 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
     store = tf_util.set_store(tf_util.VariableStore(seed=1234))  # identical weights on every rank
     fch = spec.get("feature_channel", 0)
 
-    fork_at = os.environ.get("PASNL_BENCH_FORK_AT", spec.get("fork_at", "cell2"))  # (tuning switch; cls only)
+    fork_at = FORK_AT_DEFAULT  # (tuning switch PASNL_BENCH_FORK_AT; cls only)
 
     def forward(xin=None, search=None, before_head=None):
         xin = x if xin is None else xin
@@ -1016,32 +1016,38 @@ def main():
 
     # The driver's record keeps the SCALAR values of `config` and the last 2 KB of this line: every figure the line is about is
     # repeated as a scalar in `config`, the long arrays come first and the compact summaries last.
+    # The driver's record keeps the FIRST 24 keys of `config`: what the round is about comes first (the workload, the serial
+    # figure, the ball-query fractions, every configuration's prefetch / serial ms); constants and the multi-rank checks follow.
     config = {"workload": spec["name"] + f", batch={res['B']}/GPU, seeded random weights",
               "global_batch": world * res["B"], "parallelism": f"batch-shard x{world}, RCCL all-gather of logits",
-              "rccl_ranks": rccl_ranks, "allreduce_check": allreduce_check, "gathered_rows_match_local": res["gathered_ok"],
-              "shards_differ": res["shards_differ"], "numa_node": numa_node, "cpus_bound": cpus_bound,
-              "enqueue_ms_per_step": round(res["enqueue_ms_per_step"], 4),
-              "hip_graph": res["graph"], "pipeline": res["pipeline"],
-              "outputs_agree": res["outputs_agree"],
-              "serial_ms_per_step": serial["ms_per_step"] if serial else None,
-              "serial_clouds_per_s": serial["clouds_per_s"] if serial else None,
-              "serial_outputs_agree": serial["outputs_agree"] if serial else None,
-              "switches": ",".join(args.set) if args.set else ""}
+              "pipeline": res["pipeline"], "outputs_agree": res["outputs_agree"],
+              "serial_ms_per_step": serial["ms_per_step"] if serial else None}
+    if sweep is not None:
+        for e in sweep:
+            config[f"ball_hbm_frac_b{e['B']}"] = e["hbm_frac"]
+        for e in sweep:
+            config[f"ball_us_b{e['B']}"] = e["median_us"]
     summary = None
     if others is not None:
         summary = []
-        for tag, o in zip(("cfg2", "cfg3", "cfg4") if main_index == 1 else tuple(f"cfg{ci}" for ci in WORKLOADS if ci != main_index), others):
+        tags = ("cfg2", "cfg3", "cfg4") if main_index == 1 else tuple(f"cfg{ci}" for ci in WORKLOADS if ci != main_index)
+        for tag, o in zip(tags, others):
             config[f"{tag}_ms"] = o["ms_per_step"]
             config[f"{tag}_serial_ms"] = o["serial_ms_per_step"]
-            config[f"{tag}_outputs_agree"] = o["outputs_agree"]
             r = o["roofline"] or {}
             summary.append({"cfg": tag, "ms": o["ms_per_step"], "serial_ms": o["serial_ms_per_step"], "clouds_per_s": o["clouds_per_s"],
                             "agree": o["outputs_agree"], "dominant": r.get("kernel"), "dims": r.get("dims"), "bound": r.get("bound"),
                             "frac": r.get("frac"), "avg_us": r.get("avg_us"), "traffic": r.get("traffic"), "alg_bytes": r.get("alg_bytes")})
-    if sweep is not None:
-        for e in sweep:
-            config[f"ball_hbm_frac_b{e['B']}"] = e["hbm_frac"]
-            config[f"ball_us_b{e['B']}"] = e["median_us"]
+        config["cfg_outputs_agree"] = all(bool(o["outputs_agree"]) for o in others)
+    config.update({"serial_outputs_agree": serial["outputs_agree"] if serial else None,
+                   "serial_clouds_per_s": serial["clouds_per_s"] if serial else None,
+                   "enqueue_ms_per_step": round(res["enqueue_ms_per_step"], 4), "hip_graph": res["graph"],
+                   "prefix_forked_at": FORK_AT_DEFAULT if args.model == "cls" else "head"})
+    if world > 1:  # multi-rank checks (constants / nulls at N = 1)
+        config.update({"rccl_ranks": rccl_ranks, "allreduce_check": allreduce_check, "gathered_rows_match_local": res["gathered_ok"],
+                       "shards_differ": res["shards_differ"], "numa_node": numa_node, "cpus_bound": cpus_bound})
+    if args.set:
+        config["switches"] = ",".join(args.set)
     out = {
         "metric": "point-clouds/sec fwd (Bx1024 pts, ModelNet40 cls)" if args.model == "cls" else
                   f"point-clouds/sec fwd (Bx{res['N']} pts, pointasnl_{args.model})",
