@@ -558,6 +558,11 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
     from pointasnl_amd.utils import pointasnl_util, tf_util
 
     model = importlib.import_module(f"pointasnl_amd.models.pointasnl_{spec['model']}")
+    # (tuning switch "model,prefix": are layer 2's search / the next batch's prefix enqueued behind the forward's next kernel;
+    # cls only.  Measured: 1.315 -> 1.288 ms without adaptive sampling; the segmentation models lose (their samplers are ~1 ms
+    # chains that have to start at once): 4.12 -> 5.0 and 2.27 -> 3.16 ms)
+    lz = os.environ.get("PASNL_BENCH_LAZY_FORK")
+    lazy_model, lazy_prefix = (tuple(v == "1" for v in lz.split(",")) if lz else (None, spec["model"] == "cls" and not spec.get("AS")))
     if os.environ.get("PASNL_BENCH_GROUP_ALL") is not None:  # (tuning switch: which group_all modules take the fused kernel)
         from pointasnl_amd.utils import pointnet_util
         pointnet_util.GROUP_ALL_FUSED = tuple(int(v) for v in os.environ["PASNL_BENCH_GROUP_ALL"].split(",") if v)
@@ -573,7 +578,7 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
         xin = x if xin is None else xin
         if spec["model"] == "cls":
             logits, _ = model.get_model(xin, is_training=False, adaptive_sample=spec["AS"], search=search, before_head=before_head,
-                                        fork_at=fork_at)
+                                        fork_at=fork_at, lazy_fork=lazy_model)
             return logits
         logits, _ = model.get_model(xin, False, 20, feature_channel=fch, search=search, before_head=before_head)
         return logits.reshape(B, -1)
@@ -670,7 +675,7 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
                     def run_prefix():
                         prefix(xs[nxt], kf, into=S[nxt])
                         return True
-                    fk.append(pointasnl_util.Forked(run_prefix, slot=PREFETCH_SLOTS[0]))
+                    fk.append(pointasnl_util.Forked(run_prefix, slot=PREFETCH_SLOTS[0], lazy=lazy_prefix))
                     if kf is not None:
                         fk.append(kf)
                 if os.environ.get("PASNL_BENCH_PREFETCH_AT", spec.get("prefetch_at", "head")) == "start":  # (tuning switch)
@@ -1043,7 +1048,7 @@ def main():
                    "serial_clouds_per_s": serial["clouds_per_s"] if serial else None,
                    "enqueue_ms_per_step": round(res["enqueue_ms_per_step"], 4), "hip_graph": res["graph"],
                    "prefix_forked_at": FORK_AT_DEFAULT if args.model == "cls" else "head"})
-    if world > 1:  # multi-rank checks (constants / nulls at N = 1)
+    if multi:  # multi-rank checks (constants / nulls in a plain N = 1 run; --force-dist rehearses them with one rank)
         config.update({"rccl_ranks": rccl_ranks, "allreduce_check": allreduce_check, "gathered_rows_match_local": res["gathered_ok"],
                        "shards_differ": res["shards_differ"], "numa_node": numa_node, "cpus_bound": cpus_bound})
     if args.set:

@@ -94,8 +94,21 @@ MARK_SKIP = False  # marked, but not to be counted (first launches that also cre
 TRACE = bool(os.environ.get("PASNL_TRACE"))  # debugging: print + synchronise around every launch
 
 
+AFTER_LAUNCH = []  # callables run behind the next C-ABI launch (pointasnl_util.Forked starts its lazy forks there)
+
+
 def launch(symbol, what, *args):
     """Call one pasnl_* entry point with the current stream appended; raise on a non-zero status."""
+    if AFTER_LAUNCH:
+        try:
+            return _launch(symbol, what, *args)
+        finally:
+            for cb in list(AFTER_LAUNCH):
+                cb()
+    return _launch(symbol, what, *args)
+
+
+def _launch(symbol, what, *args):
     fn = getattr(lib(), symbol)
     if TRACE:
         import sys

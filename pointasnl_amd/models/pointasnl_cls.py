@@ -15,13 +15,17 @@ def first_layer(num_point=None):
 
 
 def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, weight_decay=None, num_class=40,
-              adaptive_sample=False, search=None, before_head=None, fork_at="head"):
+              adaptive_sample=False, search=None, before_head=None, fork_at="head", lazy_fork=None):
     """ Classification PointNet, input is BxNx3 (BxNx6 with normals), output Bx40
     search / before_head (not in the reference signature; both optional): the search prefix of layer1 computed ahead by the
     caller, and a callback invoked once the set-abstraction layers are enqueued -- a serving loop forks the NEXT batch's
     search prefix there, beside the classifier head, which leaves most of the GPU idle (bench.py --pipeline prefetch).
     fork_at: where that callback is invoked -- "head" (behind layer 2), "conv2" (before layer 2's after_conv GEMM) or "cell2"
-    (behind layer 2's cell): the prefix is ~0.3 ms of dependent rounds and has to END with the head. """
+    (behind layer 2's cell): the prefix is ~0.3 ms of dependent rounds and has to END with the head.
+    lazy_fork: layer 2's search is enqueued behind the forward's next kernel instead of at the fork point (Forked(lazy=True):
+    the forward's chain keeps its hardware queue in a captured graph); default: without adaptive sampling. """
+    if lazy_fork is None:
+        lazy_fork = not adaptive_sample
     batch_size = point_cloud.shape[0]
     end_points = {}
     if use_normal:
@@ -40,7 +44,7 @@ def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, w
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
                                                 scope='layer1', as_neighbor=as_neighbor[0], search=search, xyz_concat=True,
                                                 after_sampling=lambda xyz1: search2.append(
-                                                    Forked(lambda: sa_search(xyz1, None, 128, 64))))
+                                                    Forked(lambda: sa_search(xyz1, None, 128, 64), lazy=lazy_fork)))
     end_points['l1_xyz'] = l1_xyz
     l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=128, nsample=64, mlp=[128, 128, 256],
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,

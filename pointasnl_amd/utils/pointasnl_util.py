@@ -450,6 +450,9 @@ def _side_stream(slot=0):
     return _SIDE_STREAMS[key]
 
 
+LAZY_FORK = False  # default of Forked(lazy=): True = a fork's side work is enqueued behind the caller's next kernel (see Forked.__init__)
+
+
 class Forked:
     """Work enqueued on a side stream of the SAME forward (fork), joined by .get().
 
@@ -460,14 +463,32 @@ class Forked:
     rejoins at .get()) and eagerly.  Allocator safety: every fork starts by waiting for the caller's stream, so a block a
     side-stream tensor gave back is never rewritten before its last consumer, which was enqueued earlier, has run."""
 
-    def __init__(self, fn, slot=0):
+    def __init__(self, fn, slot=0, lazy=None):
         self.stream = None
+        self._fn = None
         if not OVERLAP:
             self.value = fn()
             return
+        lazy = LAZY_FORK if lazy is None else lazy
         main = torch.cuda.current_stream()
-        side = _side_stream(slot)
-        side.wait_stream(main)
+        self._side = _side_stream(slot)
+        if lazy:
+            # The fork POINT is here (an event on the caller's stream), the side work is enqueued behind the caller's NEXT
+            # hand-written kernel (or at .get()).  In a captured graph the successor of a node that is captured first keeps
+            # that node's hardware queue and every other successor starts on another one, behind a cross-queue signal
+            # (~10 us measured between a cell's end and the next kernel of the forward's own chain when the fork was
+            # captured first): the forward's chain should be the one that stays.
+            self._fork_ev = torch.cuda.Event()
+            self._fork_ev.record(main)
+            self._main = main
+            self._fn = fn
+            _hip.AFTER_LAUNCH.append(self._start_if_main)
+            return
+        self._side.wait_stream(main)
+        self._run(fn)
+
+    def _run(self, fn):
+        side = self._side
         with torch.cuda.stream(side):
             self.value = fn()
             # the join point is THIS work's end, not whatever else is queued on the side stream by the time .get() runs
@@ -476,7 +497,22 @@ class Forked:
             self.done.record(side)
         self.stream = side
 
+    def _start_if_main(self):
+        if self._fn is not None and torch.cuda.current_stream() == self._main:
+            self._start()
+
+    def _start(self):
+        fn, self._fn = self._fn, None
+        if fn is None:
+            return
+        if self._start_if_main in _hip.AFTER_LAUNCH:
+            _hip.AFTER_LAUNCH.remove(self._start_if_main)
+        self._side.wait_event(self._fork_ev)
+        self._run(fn)
+
     def get(self):
+        if self._fn is not None:
+            self._start()
         # every consumer stream joins (a result may be consumed by the caller's stream AND by another fork)
         if self.stream is not None and torch.cuda.current_stream() != self.stream:
             torch.cuda.current_stream().wait_event(self.done)
