@@ -120,12 +120,11 @@ __device__ __forceinline__ int bg_min8_to_last(int x) {
   return x;
 }
 
-// c + (the lane's bit of `mask`, a scalar-ALU result): one v_addc with the mask as carry-in
-__device__ __forceinline__ int bg_add_bit(int c, unsigned long long mask) {
-  asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(c) : "s"(mask) : "vcc");
-  return c;
-}
-
+// (Round 5: there was an inline-assembly v_addc_co_u32 here that took a lane mask as carry-in.  The hazard recogniser does not
+// look into inline assembly: where the scheduler put it closer than the required wait states behind the vector compare that
+// had written the mask, the add read the OLD mask and a candidate outside its run was counted.  Correct by scheduling luck in
+// the shipped form; it surfaced as duplicated hits the moment the kernel body stood inside a loop (a persistent variant:
+// another schedule).  `c += cond ? 1 : 0` compiles to the same v_addc, visibly -- 30.5 instead of 28 instructions per step.)
 // two cell-adjacent records as the walk wants them: (x, y) of each as a pair, the two z as a pair, the two indices.  Two
 // ds_read_b128 (the compiler's choice; 4 LDS cycles each) and two moves for the z pair: three ds_read2 that deliver the pairs
 // directly cost 16 LDS cycles and were measured slower (155 -> 185 us at B = 4096: the LDS pipe is half busy as it is)
@@ -414,7 +413,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
       constexpr uint32_t ONE = 1u << 11;  // one record left
       auto advance = [&](bool adv, uint32_t stepped) {  // cur <- the pair to examine next; a lane that reached its zeros stays there
         cur = adv ? nx : stepped;
-        ti = (uint32_t)bg_add_bit((int)ti, __builtin_amdgcn_ballot_w64(adv));
+        ti += adv ? 1u : 0u;  // (v_addc with the compare's lane mask as carry-in, formed by the compiler)
         nx = tab[min(ti, (uint32_t)(BG_TAB_SLOTS - 1)) * 64];  // slot 9 is always zero
       };
       auto fetch = [&](BgPair& r) {  // position + 1 <= n: at worst the 16 bytes behind the records, read and not used
@@ -431,7 +430,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
       // records were left BEFORE the step (tested on the old state: the position never carries into the count)
 #define PASNL_BG_STEP(cur_, nxt_)                                                                                       \
       {                                                                                                                 \
-        const unsigned long long m1 = __builtin_amdgcn_ballot_w64(cur >= 2u * ONE);                                     \
+        const bool l0 = cur >= ONE, l1 = cur >= 2u * ONE; /* records of the pair that belong to the run */               \
         advance(cur < 3u * ONE, cur + 2u - 2u * ONE);                                                                   \
         fetch(nxt_);                                                                                                    \
         __builtin_amdgcn_sched_barrier(0); /* the requests go out before the current pair's arithmetic */               \
@@ -441,11 +440,11 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
         asm("" : "+v"(t0), "+v"(t1)); /* two plain adds into a register pair, not a packed add behind three moves */    \
         const pasnl_f32x2 dd = pasnl_f32x2{t0, t1} + sz; /* ((dx*dx)+(dy*dy))+(dz*dz), twice */                         \
         hl[c * 64] = (unsigned short)cur_.k0; /* unconditional: a miss is overwritten */                                \
-        c = bg_add_bit(c, m0 & __builtin_amdgcn_ballot_w64(dd[0] < thr2));                                              \
+        c += (l0 && dd[0] < thr2) ? 1 : 0;                                                                              \
         hl[c * 64] = (unsigned short)cur_.k1;                                                                           \
-        c = bg_add_bit(c, m1 & __builtin_amdgcn_ballot_w64(dd[1] < thr2));                                              \
+        c += (l1 && dd[1] < thr2) ? 1 : 0;                                                                              \
         c = min(c, BG_CAP); /* a count that reaches BG_CAP stays there: the lane's row then comes from tier 2 */        \
-        m0 = __builtin_amdgcn_ballot_w64(cur >= ONE); /* lanes with a pair to examine in the NEXT step */               \
+        m0 = __builtin_amdgcn_ballot_w64(cur >= ONE); /* lanes with a pair to examine in the NEXT step: the exit test */ \
         BG_COUNT(7, 1);                                                                                                 \
       }
       advance(true, 0u);

@@ -18,7 +18,10 @@ assembly is opaque to it.  Flagged, conservatively (straight-line distance, ever
   * a `v_mfma` at most MFMA_BEFORE wait states BEFORE the asm instruction that writes a register the asm instruction reads
     or writes, or reads (A, B or C operand) a register the asm instruction writes;
   * a `v_mfma` at most MFMA_AFTER wait states AFTER it that reads a register the asm instruction writes.
-The script exits non-zero when one is found."""
+And `asm_sgpr` (round 5: the ball query's inline-assembly v_addc read a lane mask that a vector compare had written too
+recently -- duplicated hits): an inline-assembly vector instruction that reads a scalar register (or vcc) which a vector
+instruction (v_cmp*, v_*_co_*, v_readlane, v_readfirstlane, v_div_scale*) wrote at most SGPR_BEFORE wait states earlier.
+The script exits non-zero when one of either kind is found."""
 import argparse
 import glob
 import os
@@ -39,6 +42,32 @@ def demangle(name):
 
 
 MFMA_BEFORE, MFMA_AFTER = 20, 6  # wait states: a 16-pass product's result -> vector read needs 19; vector write -> product read 2..4
+SGPR_BEFORE = 4                  # wait states between a vector instruction's scalar result and a vector instruction that reads it
+
+
+def sregs_of(operand):
+    """{'s4', 's5', 'vcc'} named by one assembly operand (s4, s[4:5], vcc, vcc_lo ...; anything else: empty)."""
+    if operand.startswith("vcc"):
+        return {"vcc"}
+    m = re.fullmatch(r"s(\d+)", operand)
+    if m:
+        return {f"s{int(m.group(1))}"}
+    m = re.fullmatch(r"s\[(\d+):(\d+)\]", operand)
+    if m:
+        return {f"s{i}" for i in range(int(m.group(1)), int(m.group(2)) + 1)}
+    return set()
+
+
+def valu_sgpr_writes(mn, ops):
+    """scalar registers a vector instruction writes: v_cmp* (dst = operand 0, or vcc in the e32 form), carry-outs of v_*_co_*
+    (operand 1), v_readlane / v_readfirstlane (operand 0), v_div_scale (operand 1)"""
+    if mn.startswith("v_cmp"):
+        return sregs_of(ops[0]) if ops and (ops[0].startswith("s") or ops[0].startswith("vcc")) else {"vcc"}
+    if mn.startswith(("v_readlane", "v_readfirstlane")):
+        return sregs_of(ops[0]) if ops else set()
+    if "_co_" in mn or mn.startswith("v_div_scale"):
+        return sregs_of(ops[1]) if len(ops) > 1 else set()
+    return set()
 
 
 def regs_of(operand):
@@ -86,14 +115,27 @@ def asm_mfma_hazards(lines, start, end):
             reads = set().union(*regs) if regs else set()
         if mn.startswith(("ds_", "global_", "buffer_", "flat_", "scratch_")):  # memory instructions: every register is read or a loaded destination
             writes, reads = set(), set().union(*regs) if regs else set()
-        instrs.append((k + 1, mn, writes, reads, in_asm, wait))
+        sread = set().union(*[sregs_of(o) for o in ops[1:]]) if len(ops) > 1 and mn.startswith("v_") else set()
+        swrite = valu_sgpr_writes(mn, ops) if mn.startswith("v_") else set()
+        if mn.startswith("v_") and "_co_" in mn and len(ops) > 1:
+            sread -= sregs_of(ops[1])  # (operand 1 of a carry instruction is its carry-OUT)
+        instrs.append((k + 1, mn, writes, reads, in_asm, wait, sread, swrite))
     found = []
-    for i, (ln, mn, wr, rd, ia, _) in enumerate(instrs):
+    for i, (ln, mn, wr, rd, ia, _, srd, _sw) in enumerate(instrs):
         if not ia or not mn.startswith("v_"):
             continue
         dist = 0
+        for j in range(i - 1, -1, -1):  # a scalar operand written by a vector instruction too recently
+            l2, m2, _, _, _, wt, _, sw2 = instrs[j]
+            dist += wt
+            if dist > SGPR_BEFORE:
+                break
+            if srd & sw2:
+                found.append(f"line {ln}: inline-asm `{mn}` reads {sorted(srd & sw2)[:3]} {dist} wait state(s) behind `{m2}` (line {l2})")
+                break
+        dist = 0
         for j in range(i - 1, -1, -1):
-            l2, m2, w2, r2, _, wt = instrs[j]
+            l2, m2, w2, r2, _, wt, _, _ = instrs[j]
             dist += wt
             if dist > MFMA_BEFORE:
                 break
@@ -102,7 +144,7 @@ def asm_mfma_hazards(lines, start, end):
                 break
         dist = 0
         for j in range(i + 1, len(instrs)):
-            l2, m2, w2, r2, _, wt = instrs[j]
+            l2, m2, w2, r2, _, wt, _, _ = instrs[j]
             if m2.startswith(("v_mfma", "v_smfmac")) and (r2 & wr) and dist < MFMA_AFTER:
                 found.append(f"line {ln}: inline-asm `{mn}` writes {sorted(r2 & wr)[:4]} {dist} wait state(s) ahead of `{m2}` (line {l2})")
                 break
@@ -180,7 +222,8 @@ def main():
     rows.sort(key=lambda r: (-(r[5] + 4 * r[6]), r[0], r[1]))
     hazards = [(f, k, h) for f, k, _, _, _, _, _, hz in rows for h in hz]
     text = [f"inline-assembly vector instructions sharing a register with a matrix instruction within {MFMA_BEFORE} wait states before / "
-            f"{MFMA_AFTER} after: {len(hazards)}" + (" (clean)" if not hazards else "")]
+            f"{MFMA_AFTER} after, or reading a scalar register a vector instruction wrote within {SGPR_BEFORE}: {len(hazards)}"
+            + (" (clean)" if not hazards else "")]
     for f, k, h in hazards:
         text.append(f"  HAZARD {f}  {k[:120]}\n         {h}")
     text.append("")
