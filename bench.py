@@ -505,6 +505,29 @@ WORKLOADS = {
 }
 
 
+def switch_target(target):
+    """"module.FLAG" (a module of pointasnl_amd.utils, or _hip) -> (module, flag)."""
+    import importlib
+    mod, flag = target.rsplit(".", 1)
+    m = importlib.import_module("pointasnl_amd." + mod if mod == "_hip" else "pointasnl_amd.utils." + mod)
+    if not hasattr(m, flag):
+        raise AttributeError(f"{m.__name__} has no {flag}")
+    return m, flag
+
+
+# Explicit MODES of the path, measured next to the default one (`modes` in the line; N = 1 only): the same workload with a
+# module-level switch of the host mirror set -- the arithmetic / the order they change is named in `what`, and the deviation
+# of the eager logits from the default mode's is measured, not assumed.
+MODES = [
+    dict(tag="bf16x3", cfg=3, switches={"tf_util.DENSE_BF16X3": True},
+         what="the long GEMMs (>= 256 output tiles, K >= 512) as six bf16 matrix products of three-term operand splits, fp32 "
+              "accumulation: fp32-grade (1e-5 of scale against fp64), not the fp32 chain's bits", dtype="f32 (bf16x3 products)"),
+    dict(tag="reference_tie_order", cfg=1, switches={"pointasnl_util.KNN_TIE_ORDER": "nanoflann"},
+         what="neighbour lists in the reference KD-tree's order among exactly equal distances (tree build + leaf-order search "
+              "captured in the graph, the depth flag read after the replays)", dtype="f32"),
+]
+
+
 def make_input(cfg_index, spec, rank):
     seed = 1234 + cfg_index + 100 * rank
     if spec.get("synth") == "scannet":
@@ -536,8 +559,18 @@ def roofline_of(rows):
             "alg_bytes": dom["alg_bytes"], "alg_flops": dom["alg_flops"]}
 
 
-def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, graph=True, kernel_pass=True, announce=True,
-               pipeline="serial"):
+def run_config(cfg_index, spec, *a, **kw):
+    """_run_config with the spec's mode switches (module flags of the host mirror) restored afterwards."""
+    switched = []
+    try:
+        return _run_config(cfg_index, spec, *a, _switched=switched, **kw)
+    finally:
+        for m, flag, old in reversed(switched):
+            setattr(m, flag, old)
+
+
+def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, graph=True, kernel_pass=True, announce=True,
+                pipeline="serial", _switched=None):
     """Measure one workload on the current device -> dict.  The timed region is `steps` forwards bracketed by
     (barrier +) torch.cuda.synchronize() on both sides, max over ranks.
 
@@ -587,6 +620,19 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
     gather = sharding.LogitsGather(world, B, width, x.device, force=multi) if multi else None
     if announce:
         beat("setup")
+    mode_dev = None
+    if spec.get("switches"):  # a MODE: the default mode's eager logits first, then the switches (restored on the way out)
+        with torch.no_grad():
+            ref_default = forward().clone()
+        for target, value in spec["switches"].items():
+            m, flag = switch_target(target)
+            _switched.append((m, flag, getattr(m, flag)))
+            setattr(m, flag, value)
+        with torch.no_grad():
+            got = forward()
+        mode_dev = {"max_abs_dev_of_logits": float((got - ref_default).abs().max()), "logits_scale": float(ref_default.abs().max()),
+                    "argmax_agree": float((got.reshape(-1, 20 if spec["model"] != "cls" else 40).argmax(1) ==
+                                           ref_default.reshape(-1, 20 if spec["model"] != "cls" else 40).argmax(1)).float().mean())}
     with torch.no_grad():
         # ---- warm-up (eager: creates weights, BLAS workspaces), then capture
         # ONE forward stream for every workload of the process (a new stream per workload lands on another hardware queue
@@ -782,9 +828,14 @@ def run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gra
             per_fwd = len(_hip.PROFILE) // max(1, reps)
             launch_order = [[sym, list(ints)] for sym, ints, _, _ in _hip.PROFILE[:per_fwd]]
             _hip.PROFILE = None
+    if spec.get("switches"):
+        from pointasnl_amd.utils.nearest_neighbors.lib.python import nearest_neighbors as NN
+        torch.cuda.synchronize()
+        NN.check_deferred_flags(clear=True)  # (reference tie order inside a graph: the tree-depth flags of the replays)
     return {"B": B, "N": N, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "enqueue_ms_per_step": enqueued / steps * 1e3, "clouds_per_s": world * B * steps / elapsed,
             "graph": bool(graphs), "pipeline": pipeline if graphs else "eager", "outputs_agree": agree, "gathered_ok": gathered_ok,
-            "shards_differ": shards_differ, "rows": rows, "launch_order": launch_order, "pc": pc, "store": store}
+            "shards_differ": shards_differ, "rows": rows, "launch_order": launch_order, "pc": pc, "store": store,
+            "mode_dev": mode_dev}
 
 
 def ball_query_sweep(batches=(64, 256, 1024, 4096), iters=20):
@@ -940,12 +991,11 @@ def main():
     from pointasnl_amd import _hip
     for item in args.set:  # A/B switches (module-level flags of the host mirror)
         import ast
-        import importlib
         target, value = item.split("=", 1)
-        mod, flag = target.rsplit(".", 1)
-        m = importlib.import_module("pointasnl_amd." + mod if mod == "_hip" else "pointasnl_amd.utils." + mod)
-        if not hasattr(m, flag):
-            raise SystemExit(f"--set {item}: {m.__name__} has no {flag}")
+        try:
+            m, flag = switch_target(target)
+        except AttributeError as e:
+            raise SystemExit(f"--set {item}: {e}")
         setattr(m, flag, ast.literal_eval(value))
 
     _hip.lib()
@@ -997,7 +1047,7 @@ def main():
         cpu = cpu_baseline(res["pc"], res["store"].export_numpy(), spec["AS"])
         beat("post")
 
-    others, sweep, sweep_traffic_source = None, None, None
+    others, sweep, sweep_traffic_source, modes = None, None, None, None
     if world == 1 and not args.no_others and not args.force_dist:
         others = []
         for ci, ospec in WORKLOADS.items():
@@ -1018,6 +1068,21 @@ def main():
                            "kernels": sorted(r["rows"], key=lambda k: -k["avg_us"])[:8]})
         sweep, sweep_traffic_source = ball_query_sweep()
         beat("post")
+        modes = []
+        for md in MODES:
+            if args.no_graph:
+                break
+            mspec = dict(WORKLOADS[md["cfg"]], switches=md["switches"])
+            r = run_config(md["cfg"], mspec, args.other_steps, 4, graph=True, kernel_pass=False, announce=False, pipeline=args.pipeline)
+            beat("post")
+            base = res if md["cfg"] == main_index else None
+            if base is None:
+                base_ms = next((o["ms_per_step"] for ci, o in zip([c for c in WORKLOADS if c != main_index], others) if ci == md["cfg"]), None)
+            else:
+                base_ms = round(base["ms_per_step"], 4)
+            modes.append({"mode": md["tag"], "workload": f"configs[{md['cfg']}]", "switches": {k: str(v) for k, v in md["switches"].items()},
+                          "what": md["what"], "dtype": md["dtype"], "pipeline": r["pipeline"], "ms_per_step": round(r["ms_per_step"], 4),
+                          "default_mode_ms_per_step": base_ms, "graph_equals_eager": r["outputs_agree"], **(r["mode_dev"] or {})})
 
     # The driver's record keeps the SCALAR values of `config` and the last 2 KB of this line: every figure the line is about is
     # repeated as a scalar in `config`, the long arrays come first and the compact summaries last.
@@ -1048,6 +1113,8 @@ def main():
                    "serial_clouds_per_s": serial["clouds_per_s"] if serial else None,
                    "enqueue_ms_per_step": round(res["enqueue_ms_per_step"], 4), "hip_graph": res["graph"],
                    "prefix_forked_at": FORK_AT_DEFAULT if args.model == "cls" else "head"})
+    for mo in modes or []:
+        config[f"mode_{mo['mode']}_ms"] = mo["ms_per_step"]
     if multi:  # multi-rank checks (constants / nulls in a plain N = 1 run; --force-dist rehearses them with one rank)
         config.update({"rccl_ranks": rccl_ranks, "allreduce_check": allreduce_check, "gathered_rows_match_local": res["gathered_ok"],
                        "shards_differ": res["shards_differ"], "numa_node": numa_node, "cpus_bound": cpus_bound})
@@ -1073,6 +1140,7 @@ def main():
         "handwritten_kernel_us_per_step": round(sum(r["avg_us"] * r["launches"] for r in rows) / max(1, min(args.steps, 20)), 1),
         "kernels": rows,
         "other_configs": others,
+        "modes": modes,
         "ball_traffic_source": sweep_traffic_source,
         "serial": serial,
         "other_configs_summary": summary,

@@ -261,6 +261,19 @@ int pasnl_mlp3_max_pool(int b, int n, int k0, int c1, int c2, int c3, const floa
                         const float* w1, const float* b1, const float* w2, const float* b2, float* out, long out_stride,
                         void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
 
+/* ------------------------------------------------------------------ fp32-grade products on the bf16 matrix pipe (csrc/dense_bf16x3.hip)
+ * An explicit MODE (the Python side's tf_util.DENSE_BF16X3; off by default, never used for the headline benchmark):
+ * out (rows,n) = act(x (rows,kdim; row stride lda) . w + bias) for the long GEMMs behind tf_util.conv2d over a flattened
+ * [nsample x channel] window (utils/pointasnl_util.py:275, 337; tf_util.py:120-185).  Every fp32 operand is split into three
+ * bf16 terms and the six products of weight >= 2^-16 are accumulated in fp32 on v_mfma_f32_32x32x16_bf16: about one more
+ * rounding per product than an fp32 fmaf chain (inside the 1e-5 contract, not the same bits).
+ *   pasnl_bf16x3_split_weights: w (kdim,n) fp32 -> wsplit (pasnl_bf16x3_weights_bytes(kdim, n) bytes, 16-byte aligned), once
+ *   per layer; pasnl_dense_bf16x3: kdim % 32 == 0, n % 128 == 0, lda % 4 == 0, x 16-byte aligned, else PASNL_EUNSUPPORTED. */
+size_t pasnl_bf16x3_weights_bytes(int kdim, int n);
+int pasnl_bf16x3_split_weights(int kdim, int n, const float* w, void* wsplit, pasnl_stream_t stream);
+int pasnl_dense_bf16x3(int rows, int kdim, int n, int lda, const float* x, const void* wsplit, const float* bias, int relu,
+                       float* out, pasnl_stream_t stream);
+
 /* ------------------------------------------------------------------ dense layers with few rows (csrc/dense.hip) */
 
 /* out (rows,n) = act(x (rows,kdim) . w (kdim,n) + bias), rows <= 128, relu != 0 -> ReLU: the classifier head

@@ -231,6 +231,33 @@ def _dense_splitk(x2d, w, b, relu):
     return out
 
 
+# fp32-grade products on the bf16 matrix pipe (csrc/dense_bf16x3.hip): an explicit MODE, off by default and off for the
+# headline benchmark -- every fp32 operand as three bf16 terms, six products, fp32 accumulation: ~2x the fp32 chain's rounding
+# error (inside the 1e-5 contract), not the same bits.  Taken by the long GEMMs only (after_conv / decode_after_conv windows).
+DENSE_BF16X3 = False
+BF16X3_MIN_TILES = 256  # 128 x 128 output tiles: one per CU at least (below that the vendor's split-K kernels win: x0.4 .. 0.9)
+BF16X3_MIN_K = 512
+
+
+def _dense_bf16x3(x2d, w, b, relu):
+    """act(x2d . w + b) on pasnl_dense_bf16x3; the split weights are cached in the store next to the folded ones."""
+    rows, cin = x2d.shape
+    cout = w.shape[1]
+    st = store()
+    key = "@bf16x3:%x" % w.data_ptr()
+    if key not in st._folded:
+        nbytes = int(_hip.lib().pasnl_bf16x3_weights_bytes(cin, cout))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=w.device)
+        wc = w.contiguous()
+        _hip.launch("pasnl_bf16x3_split_weights", "bf16x3_split", cin, cout, _hip.ptr(wc), _hip.ptr(ws))
+        st._folded[key] = (ws, w)  # (keeps `w` alive: the pointer in the key stays unique)
+    ws = st._folded[key][0]
+    out = torch.empty((rows, cout), dtype=torch.float32, device=x2d.device)
+    _hip.launch("pasnl_dense_bf16x3", "dense_bf16x3", rows, cin, cout, int(x2d.stride(0)), _hip.ptr(x2d), _hip.ptr(ws), _hip.ptr(b),
+                int(bool(relu)), _hip.ptr(out))
+    return out
+
+
 def _dense_rows(x2d, w, b, relu):
     """act(x2d . w + b) for a handful of rows: csrc/dense.hip (K slices over ~128 workgroups, fixed summation order)."""
     import ctypes
@@ -278,6 +305,15 @@ def _dense(inputs, num_output_channels, scope, bn, activation_fn, weight_decay=N
             return out.reshape(*inputs.shape[:-1], num_output_channels)
         except _hip.PasnlUnsupported:
             pass  # e.g. an unaligned view: the vendor GEMM below
+    if (DENSE_BF16X3 and x2d.is_cuda and x2d.dtype == torch.float32 and (is_relu or activation_fn is None)
+            and cin >= BF16X3_MIN_K and cin % 32 == 0 and num_output_channels % 128 == 0
+            and -(-x2d.shape[0] // 128) * (num_output_channels // 128) >= BF16X3_MIN_TILES
+            and x2d.stride(1) == 1 and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0):
+        try:
+            out = _dense_bf16x3(x2d, w, b, is_relu)
+            return out.reshape(*inputs.shape[:-1], num_output_channels)
+        except _hip.PasnlUnsupported:
+            pass
     if w.shape[0] >= WEIGHTS_TRANSPOSED_MIN_K and x2d.is_cuda:
         # long contractions (the [1,C] after_conv / decode_after_conv windows: K = 2048 ... 16480): the vendor library picks
         # a better kernel when the weights are stored (N,K) and handed over as a transposed view (tools/gemm_layout_probe.py:

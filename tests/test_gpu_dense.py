@@ -92,6 +92,65 @@ def test_dense_layer_takes_the_splitk_kernel_for_thin_long_products(P, monkeypat
         assert float((out.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("rows,k,n,relu,bias", [
+    (32768, 512, 128, True, True), (4096, 2048, 256, True, True), (130, 96, 128, False, True), (129, 32, 384, True, False),
+    (1000, 4192, 128, True, True), (257, 544, 256, False, False),
+])
+def test_dense_bf16x3_matches_fp64(P, rows, k, n, relu, bias):
+    """pasnl_dense_bf16x3 (every fp32 operand as three bf16 terms, six products on the bf16 matrix pipe, fp32 accumulation):
+    1e-5 of the output scale against the fp64 product -- the same contract as the fp32 chain, not the same bits --, ragged row
+    tiles, a row stride larger than K, with and without bias / activation; the same bits on every call."""
+    from pointasnl_amd.utils import tf_util
+    tf_util.set_store(tf_util.VariableStore(seed=5))
+    x, w, b = _dense_case(rows, k, n, 700 + rows + n)
+    want = x.astype(np.float64) @ w.astype(np.float64) + (b if bias else 0.0)
+    if relu:
+        want = np.maximum(want, 0)
+    xd = dev(np.concatenate([x, np.full((rows, 4), 7.0, np.float32)], axis=1))[:, :k]   # lda = k + 4
+    wd, bd = dev(w), (dev(b) if bias else None)
+    got = tf_util._dense_bf16x3(xd, wd, bd, relu)
+    assert torch.equal(got, tf_util._dense_bf16x3(xd, wd, bd, relu))
+    got = got.cpu().numpy()
+    assert got.shape == (rows, n) and got.dtype == np.float32
+    assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0)
+
+
+def test_dense_bf16x3_split_is_exact_to_24_bits(P):
+    """The three bf16 planes of the weights add up to the fp32 value within 2^-24 relative (hi + mid + lo carries 24 bits),
+    in the matrix-instruction operand order [plane][k / 8][n][k % 8]."""
+    from pointasnl_amd import _hip
+    k, n = 64, 128
+    w = torch.randn(k, n, device="cuda") * torch.logspace(-6, 6, n, device="cuda")
+    ws = torch.empty(int(_hip.lib().pasnl_bf16x3_weights_bytes(k, n)), dtype=torch.uint8, device="cuda")
+    _hip.launch("pasnl_bf16x3_split_weights", "bf16x3_split", k, n, _hip.ptr(w), _hip.ptr(ws))
+    planes = ws.view(torch.bfloat16).view(3, k // 8, n, 8).permute(0, 1, 3, 2).reshape(3, k, n).double()
+    back = planes[0] + planes[1] + planes[2]
+    assert float(((back - w.double()).abs() / w.double().abs().clamp_min(1e-30)).max()) <= 2.0 ** -23
+
+
+def test_dense_layer_takes_bf16x3_only_when_switched_on(P, monkeypatch):
+    """The product mode is opt-in (tf_util.DENSE_BF16X3) and only for products with a 128 x 128 tile per CU."""
+    from pointasnl_amd.utils import tf_util
+    from pointasnl_amd import _hip
+    launched = []
+    real = _hip.launch
+    monkeypatch.setattr(_hip, "launch", lambda sym, *a: (launched.append(sym), real(sym, *a))[1])
+    tf_util.set_store(tf_util.VariableStore(seed=4))
+    x = torch.randn(32768, 1024, device="cuda")
+    tf_util._dense(x, 128, "bx_off", False, "relu")
+    assert "pasnl_dense_bf16x3" not in launched
+    monkeypatch.setattr(tf_util, "DENSE_BF16X3", True)
+    out = tf_util._dense(x, 128, "bx_on", False, "relu")
+    assert "pasnl_dense_bf16x3" in launched
+    with tf_util.variable_scope("bx_on"):
+        w, b = tf_util.store().layer(1024, 128, False, None)
+    want = torch.relu(torch.addmm(b.double(), x.double(), w.double()))
+    assert float((out.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    del launched[:]
+    tf_util._dense(torch.randn(4096, 1024, device="cuda"), 128, "bx_small", False, "relu")
+    assert "pasnl_dense_bf16x3" not in launched, "32 tiles: the vendor library's product"
+
+
 def test_dense_rows_is_reproducible_and_leaves_its_counters_clean(P):
     # the K slices are summed in slice order by whichever workgroup arrives last: every run gives the same bits, and the
     # counters are back at zero for the next launch (50 back-to-back launches on one workspace)
