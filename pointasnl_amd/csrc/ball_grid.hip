@@ -49,6 +49,7 @@ constexpr int BG_TAB_OFF = BG_SLOTS * 128;     // u16 [10][lane]: the lane's non
 constexpr int BG_TAB_SLOTS = 10;
 constexpr int BG_REGION = BG_TAB_OFF + BG_TAB_SLOTS * 128;  // 4096 bytes per wave: lists | tables
 constexpr int BG_STAGE_ROWS = 32;              // rows of 32 entries a region stages at a time
+constexpr int BG_SPLIT_BELOW = 64;             // at most this many whole chunks of queries -> quarter chunks
 constexpr int BG_U = 4;                        // tier 2: candidates per lane and step
 constexpr float BG_DENSE_HITS = 12.f;          // expected hits per query above which a workgroup starts in tier 2
 static_assert(BG_REGION == 4096 && BG_REGION >= BG_STAGE_ROWS * 128, "a wave region stages 32 rows of 128 bytes and holds 4 KiB of bit rows");
@@ -146,6 +147,10 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   int* ccount = reinterpret_cast<int*>(regions);  // cell counters during the build (the regions are not live yet)
   float* red = reinterpret_cast<float*>(ccount + BG_NC);  // [BG_WAVES][6] bbox partials, [BG_WAVES] scan partials (build only)
 
+  // The build is a chain of five barriers and a memory round trip with ~270 instructions per wave in it, beside two other
+  // workgroups of the CU that are in their walks (~1 300 instructions per wave, no barrier): its waves go first at the issue
+  // ports, the walk takes what is left (a workgroup's slot is held for build + walk: -2 .. 3 % at b = 1024 .. 8192)
+  __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bi = blockIdx.y;
   const float* cloud = xyz1 + (size_t)bi * n * 3;
@@ -365,6 +370,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   const bool vec4 = (nsample & 3) == 0;
   const int nchunk = (nsample + 3) >> 2;
   {  // one round: a workgroup owns qchunk = BG_THREADS queries (no loop: nothing for the compiler to hoist into registers)
+    __builtin_amdgcn_s_setprio(0);
     if (!__any(live)) return;
     bool need2 = live;     // the lane's row still has to come from tier 2
 
@@ -693,8 +699,11 @@ int ball_grid_launch(int b, int n, int m, float radius, float thr2, int nsample,
   static_assert(BG_WAVES * BG_REGION >= BG_NC * 4 + (BG_WAVES * 7 + 8) * 4, "the cell counters and the build's partials alias the wave regions");
   static_assert(1024 * 16 + BG_WAVES * BG_REGION + ((BG_NC + 3 + 1) & ~1) * 2 <= 53760, "three workgroups per CU at n <= 1024");
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
-  // queries per workgroup: one round of 64 per wave
-  const int qchunk = BG_THREADS;
+  // queries per workgroup: one round of 64 per wave; FEW clouds: a cloud's queries over four workgroups (each builds the
+  // cloud's grid again, ~3 us of 8 waves, and only two of its waves walk), so that b = 64 reaches every CU: 16.9 -> 15.8 us;
+  // from b = 256 on (1024 quarter chunks) it loses: 20.2 -> 28.3 us
+  const long whole = (long)b * ((m + BG_THREADS - 1) / BG_THREADS);
+  const int qchunk = whole <= BG_SPLIT_BELOW ? BG_THREADS / 4 : BG_THREADS;
   dim3 grid((m + qchunk - 1) / qchunk, b);
   const float rpad = radius * 1.001f;
   const float r3 = radius * radius * radius;
