@@ -176,6 +176,15 @@ int pasnl_three_interpolate_grad(int b, int n, int c, int m, const float* grad_o
  * dist (rows,3) -> weight (rows,3) */
 int pasnl_three_weights(int rows, const float* dist, float* weight, pasnl_stream_t stream);
 
+/* The head of a feature-propagation module in one launch (utils/pointnet_util.py:212-219 pointnet_fp_module;
+ * utils/pointasnl_util.py:308-313 PointASNLDecodingLayer): the inverse-distance weights of pasnl_three_weights, the
+ * interpolation of pasnl_three_interpolate and tf.concat([interpolated, points1], axis=2), same arithmetic, same bits:
+ *   out (b,n,c2+c1) = [ sum_j w[b,i,j] points2[b, idx[b,i,j], :]  |  points1[b,i,:] ]
+ * dist, idx (b,n,3) = pasnl_three_nn's outputs; points2 (b,m,c2); points1 (b,n,c1) or NULL with c1 == 0 (no concat).
+ * Inference only (the differentiable path stays pasnl_three_interpolate + its gradient). */
+int pasnl_fp_interpolate_cat(int b, int m, int c2, int n, int c1, const float* points2, const int* idx, const float* dist,
+                             const float* points1, float* out, pasnl_stream_t stream);
+
 /* ------------------------------------------------- PointASNL cells (utils/pointasnl_util.py) */
 
 /* Fused Point-NonLocal attention core, mode 'dot' (pointasnl_util.py:197-212):
@@ -330,6 +339,12 @@ int pasnl_three_interpolate_grad_det(int b, int n, int c, int m, const float* gr
 int pasnl_sa_tail(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att, const float* ws,
                   const float* bs, const float* wb, const float* bb, const float* wagg, const float* bagg, float* out,
                   pasnl_stream_t stream);
+
+/* pasnl_sa_tail with the residual connection of the `_res` model in its epilogue (models/pointasnl_sem_seg_res.py:37,42,47,52:
+ * l1_2_points += l1_1_points ...):  out = pasnl_sa_tail(...) + residual, residual (rows,c). */
+int pasnl_sa_tail_res(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
+                      const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
+                      const float* bagg, const float* residual, float* out, pasnl_stream_t stream);
 
 /* pasnl_sa_tail that writes its rows a second time as out_cat (rows, c + 4) = [0 | new_xyz (rows,3) | out]: the
  * tf.concat([xyz, points]) the next group_all module starts with (pointnet_util.py:77-80, sample_and_group_all), one

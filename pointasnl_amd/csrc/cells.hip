@@ -2912,7 +2912,7 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
                                                          const float* __restrict__ Wb, const float* __restrict__ bb,
                                                          const float* __restrict__ Wagg, const float* __restrict__ bagg,
                                                          float* __restrict__ out, const float* __restrict__ xyz3,
-                                                         float* __restrict__ out_cat TAIL_ABL_PARAM) {
+                                                         float* __restrict__ out_cat, const float* __restrict__ res TAIL_ABL_PARAM) {
   constexpr int RPW = 32 / NW;  // tile rows a wave stages / writes back
   extern __shared__ float lds[];
   float* vt = lds;                         // [C][33]      V^T, then O^T
@@ -2934,6 +2934,18 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
       const long row = min(row0 + wave * RPW + i, rows - 1);
       cat_xyz[i] = xyz3[row * 3 + max(min(lane, 3) - 1, 0)];
     }
+  }
+  // the residual the caller adds to the layer's output (pointasnl_sem_seg_res.py:37,42,47,52), requested with the tiles:
+  // the rows this wave writes at the very end, 64 columns per segment (C <= 32 NW: at most NW / 2 segments)
+  float resv[NW / 2][RPW];
+  if (res) {
+#pragma unroll
+    for (int sgm = 0; sgm < NW / 2; ++sgm)
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const long row = min(row0 + wave * RPW + i, rows - 1);
+        resv[sgm][i] = res[row * C + min(sgm * 64 + lane, C - 1)];
+      }
   }
   if (!TAIL_ABL(0)) {
     constexpr int STAGE_DEPTH = 4;
@@ -3004,11 +3016,18 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
     for (int i = 0; i < 16; ++i) vt[(cbase + kappa(i, h)) * 33 + l32] = fmaxf(o[i], 0.f);
   }
   __syncthreads();
-  for (int c0 = 0; c0 < C; c0 += 64) {
+#pragma unroll
+  for (int sgm = 0; sgm < NW / 2; ++sgm) {
+    const int c0 = sgm * 64;
+    if (c0 >= C) break;
     const int c = c0 + lane;
     float v[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) v[i] = c < C ? vt[c * 33 + wave * RPW + i] : 0.f;
+    if (res) {
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) v[i] = v[i] + resv[sgm][i];
+    }
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
       const long row = row0 + wave * RPW + i;
@@ -3033,7 +3052,8 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
 #endif
 static int sa_tail_entry(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
                          const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
-                         const float* bagg, float* out, const float* xyz3, float* out_cat, pasnl_stream_t stream) {
+                         const float* bagg, float* out, const float* xyz3, float* out_cat, pasnl_stream_t stream,
+                         const float* residual = nullptr) {
   PASNL_REQUIRE(rows >= 0 && w > 0 && cb >= 0 && c > 0, PASNL_EINVAL);
   PASNL_REQUIRE(c % 32 == 0 && c <= 512, PASNL_EUNSUPPORTED);
   if (rows == 0) return PASNL_OK;
@@ -3047,7 +3067,7 @@ static int sa_tail_entry(int rows, int w, int cb, int c, const float* after, con
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)((rows + 31) / 32)), dim3(nw * 64), lds, pasnl_hip_stream(stream), (long)rows, w, cb, c,
-                     after, skip_max, cb ? att : nullptr, ws, bs, wb, bb, wagg, bagg, out, xyz3, out_cat TAIL_ABL_ARG);
+                     after, skip_max, cb ? att : nullptr, ws, bs, wb, bb, wagg, bagg, out, xyz3, out_cat, residual TAIL_ABL_ARG);
   return pasnl_launch_status();
 }
 
@@ -3055,6 +3075,13 @@ extern "C" int pasnl_sa_tail(int rows, int w, int cb, int c, const float* after,
                              const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
                              const float* bagg, float* out, pasnl_stream_t stream) {
   return sa_tail_entry(rows, w, cb, c, after, skip_max, att, ws, bs, wb, bb, wagg, bagg, out, nullptr, nullptr, stream);
+}
+
+extern "C" int pasnl_sa_tail_res(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
+                                 const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
+                                 const float* bagg, const float* residual, float* out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(rows == 0 || residual, PASNL_ENULL);
+  return sa_tail_entry(rows, w, cb, c, after, skip_max, att, ws, bs, wb, bb, wagg, bagg, out, nullptr, nullptr, stream, residual);
 }
 
 extern "C" int pasnl_sa_tail_cat(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,

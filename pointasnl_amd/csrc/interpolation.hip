@@ -149,6 +149,67 @@ __global__ __launch_bounds__(256) void three_weights_kernel(long rows, const flo
   }
 }
 
+// The head of a feature-propagation module in one pass (pointnet_util.py:212-219; pointasnl_util.py:308-313):
+//   w = three_weights(dist);  out[row] = [ three_interpolate(points2, idx, w)[row] | points1[row] ]
+// -- the weights (three_weights_kernel's arithmetic), the interpolation (three_interpolate_kernel's) and tf.concat's copy of
+// the dense level's own features, written once at their place in the wider row: three launches and two passes over the
+// interpolated features less.  A workgroup takes FP_ROWS rows: their weights and neighbours once into LDS, then one thread
+// per 16 bytes of output.
+constexpr int FP_ROWS = 16;
+template <int VEC>
+__global__ __launch_bounds__(256) void fp_interpolate_cat_kernel(int m, int c2, int n, int c1, long rows, uint32_t cpr_magic,
+                                                                 const float* __restrict__ points2, const int* __restrict__ idx,
+                                                                 const float* __restrict__ dist, const float* __restrict__ points1,
+                                                                 float* __restrict__ out) {
+  __shared__ float sw[FP_ROWS][3];
+  __shared__ int si[FP_ROWS][3];
+  const int ctot = c2 + c1, cpr = ctot / VEC, cpr2 = c2 / VEC;
+  const int tid = threadIdx.x;
+  for (long r0 = (long)blockIdx.x * FP_ROWS; r0 < rows; r0 += (long)gridDim.x * FP_ROWS) {
+    __syncthreads();  // the previous tile's weights have been read
+    if (tid < FP_ROWS && r0 + tid < rows) {
+      const long r = r0 + tid;
+      const float d0 = fmaxf(dist[r * 3], 1e-10f), d1 = fmaxf(dist[r * 3 + 1], 1e-10f), d2 = fmaxf(dist[r * 3 + 2], 1e-10f);
+      const float q0 = 1.0f / d0, q1 = 1.0f / d1, q2 = 1.0f / d2;
+      const float norm = (q0 + q1) + q2;
+      sw[tid][0] = q0 / norm; sw[tid][1] = q1 / norm; sw[tid][2] = q2 / norm;
+      si[tid][0] = idx[r * 3]; si[tid][1] = idx[r * 3 + 1]; si[tid][2] = idx[r * 3 + 2];
+    }
+    __syncthreads();
+    const int nrow = (int)min((long)FP_ROWS, rows - r0);
+    for (int e = tid; e < nrow * cpr; e += 256) {
+      const int rr = cpr_magic ? (int)__umulhi((uint32_t)e, cpr_magic) : e;  // e / cpr (e < 2^16)
+      const int ch = e - rr * cpr;
+      const long row = r0 + rr;
+      float* o = out + (size_t)row * ctot + (size_t)ch * VEC;
+      if (ch < cpr2) {
+        const long bi = row / n;
+        const float w1 = sw[rr][0], w2 = sw[rr][1], w3 = sw[rr][2];
+        const float* base = points2 + (size_t)bi * m * c2 + (size_t)ch * VEC;
+        const float* p1 = base + (size_t)si[rr][0] * c2;
+        const float* p2 = base + (size_t)si[rr][1] * c2;
+        const float* p3 = base + (size_t)si[rr][2] * c2;
+        if constexpr (VEC == 4) {
+          const float4 a = *reinterpret_cast<const float4*>(p1), bq = *reinterpret_cast<const float4*>(p2),
+                       cq = *reinterpret_cast<const float4*>(p3);
+          float4 r;
+          r.x = (a.x * w1 + bq.x * w2) + cq.x * w3;
+          r.y = (a.y * w1 + bq.y * w2) + cq.y * w3;
+          r.z = (a.z * w1 + bq.z * w2) + cq.z * w3;
+          r.w = (a.w * w1 + bq.w * w2) + cq.w * w3;
+          *reinterpret_cast<float4*>(o) = r;
+        } else {
+          *o = (*p1 * w1 + *p2 * w2) + *p3 * w3;
+        }
+      } else {
+        const float* q = points1 + (size_t)row * c1 + (size_t)(ch - cpr2) * VEC;
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(o) = *reinterpret_cast<const float4*>(q);
+        else *o = *q;
+      }
+    }
+  }
+}
+
 }  // namespace pasnl
 
 using namespace pasnl;
@@ -210,5 +271,28 @@ extern "C" int pasnl_three_weights(int rows, const float* dist, float* weight, p
   PASNL_REQUIRE(dist && weight, PASNL_ENULL);
   hipLaunchKernelGGL(three_weights_kernel, dim3(grid_for(rows)), dim3(256), 0, pasnl_hip_stream(stream), (long)rows, dist,
                      weight);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_fp_interpolate_cat(int b, int m, int c2, int n, int c1, const float* points2, const int* idx, const float* dist,
+                                        const float* points1, float* out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && m > 0 && c2 > 0 && n >= 0 && c1 >= 0, PASNL_EINVAL);
+  const long rows = (long)b * n;
+  if (rows == 0) return PASNL_OK;
+  PASNL_REQUIRE(points2 && idx && dist && out && (c1 == 0 || points1), PASNL_ENULL);
+  PASNL_REQUIRE(c2 + c1 <= 4096, PASNL_EUNSUPPORTED);  // (FP_ROWS rows of 16-byte pieces stay below 2^16)
+  hipStream_t st = pasnl_hip_stream(stream);
+  const bool vec4 = c2 % 4 == 0 && c1 % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(points2) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(points1)) % 16 == 0);
+  const unsigned cpr = (unsigned)(c2 + c1) / (vec4 ? 4u : 1u);
+  const uint32_t magic = cpr == 1 ? 0u : (uint32_t)((0x100000000ull / cpr) + 1ull);
+  const long tiles = (rows + FP_ROWS - 1) / FP_ROWS;
+  const unsigned grid = (unsigned)(tiles > 16384 ? 16384 : tiles);
+  if (vec4)
+    hipLaunchKernelGGL(fp_interpolate_cat_kernel<4>, dim3(grid), dim3(256), 0, st, m, c2, n, c1, rows, magic, points2, idx, dist,
+                       points1, out);
+  else
+    hipLaunchKernelGGL(fp_interpolate_cat_kernel<1>, dim3(grid), dim3(256), 0, st, m, c2, n, c1, rows, magic, points2, idx, dist,
+                       points1, out);
   return pasnl_launch_status();
 }

@@ -69,13 +69,13 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
     l1_xyz_box = []
     _, l0_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=num_point, nsample=32, mlp=[16, 16, 32],
                                            scope='layer0', as_neighbor=0, NL=False, search=srch[0], **kw)
-    # 1st Res Layer
+    # 1st Res Layer  (the residual sums "l1_2_points + l1_1_points" ... of pointasnl_sem_seg_res.py:37,42,47,52: `residual=`,
+    # added in the epilogue of the second layer's last kernel)
     l1_xyz, l1_1_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=num_points[0], nsample=32, mlp=[32, 32, 64],
                                                   scope='layer1_1', as_neighbor=8, search=srch[1],
                                                   after_sampling=lambda x: (l1_xyz_box.append(x), level1(x)), **kw)
     _, l1_2_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=num_points[0], nsample=32, mlp=[64, 64],
-                                             scope='layer1_2', as_neighbor=0, NL=False, search=srch[1], **kw)
-    l1_2_points = l1_2_points + l1_1_points
+                                             scope='layer1_2', as_neighbor=0, NL=False, search=srch[1], residual=l1_1_points, **kw)
     # 2nd Res Layer
     l2_xyz, l2_1_points = PointASNLSetAbstraction(l1_xyz, l1_2_points, npoint=num_points[1], nsample=32,
                                                   mlp=[64, 64, 128], scope='layer2_1', as_neighbor=4, search=srch[2],
@@ -84,20 +84,17 @@ def get_model(point_cloud, is_training, num_class, bn_decay=None, weight_decay=N
         before_head()            # decoder (long chains of small kernels that leave most of the GPU idle); bench.py --pipeline prefetch
     deep = srch["deep"].get()
     _, l2_2_points = PointASNLSetAbstraction(l2_xyz, l2_1_points, npoint=num_points[1], nsample=32, mlp=[128, 128],
-                                             scope='layer2_2', as_neighbor=0, NL=False, search=deep["s22"], **kw)
-    l2_2_points = l2_2_points + l2_1_points
+                                             scope='layer2_2', as_neighbor=0, NL=False, search=deep["s22"], residual=l2_1_points, **kw)
     # 3rd Res Layer
     l3_xyz, l3_1_points = PointASNLSetAbstraction(l2_xyz, l2_2_points, npoint=num_points[2], nsample=32,
                                                   mlp=[128, 128, 256], scope='layer3_1', as_neighbor=0, search=deep["s31"], **kw)
     _, l3_2_points = PointASNLSetAbstraction(l3_xyz, l3_1_points, npoint=num_points[2], nsample=32, mlp=[256, 256],
-                                             scope='layer3_2', as_neighbor=0, NL=False, search=deep["s32"], **kw)
-    l3_2_points = l3_2_points + l3_1_points
+                                             scope='layer3_2', as_neighbor=0, NL=False, search=deep["s32"], residual=l3_1_points, **kw)
     # 4th Res Layer  (sic: fed by l3_1_points, not l3_2_points -- pointasnl_sem_seg_res.py:50)
     l4_xyz, l4_1_points = PointASNLSetAbstraction(l3_xyz, l3_1_points, npoint=num_points[3], nsample=32,
                                                   mlp=[256, 256, 512], scope='layer4_1', as_neighbor=0, search=deep["s41"], **kw)
     _, l4_2_points = PointASNLSetAbstraction(l4_xyz, l4_1_points, npoint=num_points[3], nsample=32, mlp=[512, 512],
-                                             scope='layer4_2', as_neighbor=0, NL=False, search=deep["s42"], **kw)
-    l4_2_points = l4_2_points + l4_1_points
+                                             scope='layer4_2', as_neighbor=0, NL=False, search=deep["s42"], residual=l4_1_points, **kw)
     end_points['l1_xyz'] = l1_xyz
     # Feature decoding layers
     l3_points = pointnet_fp_module(l3_xyz, l4_xyz, l3_2_points, l4_2_points, [512, 512], is_training, bn_decay,

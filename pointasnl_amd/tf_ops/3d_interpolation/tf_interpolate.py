@@ -75,3 +75,25 @@ def three_weights(dist):
     w = torch.empty_like(dist)
     _hip.launch("pasnl_three_weights", "ThreeWeights", dist.numel() // 3, _hip.ptr(dist), _hip.ptr(w))
     return w
+
+
+def fp_interpolate_cat(points2, idx, dist, points1=None):
+    """three_weights + three_interpolate + tf.concat([interpolated, points1], axis=2) in one launch (pointnet_util.py:212-219,
+    pointasnl_util.py:308-313), bit-identical to the chain; inference only (no autograd node).
+    points2 (b,m,c2), idx / dist (b,n,3) from three_nn, points1 (b,n,c1) or None -> (b,n,c2+c1)."""
+    points2 = _hip.as_dev(points2, torch.float32)
+    idx, dist = _hip.as_dev(idx, torch.int32), _hip.as_dev(dist, torch.float32)
+    if points2.dim() != 3 or idx.dim() != 3 or idx.shape[2] != 3 or tuple(dist.shape) != tuple(idx.shape) or idx.shape[0] != points2.shape[0]:
+        raise ValueError("fp_interpolate_cat expects (b,m,c2) points2 and (b,n,3) idx / dist")
+    b, m, c2 = points2.shape
+    n = idx.shape[1]
+    c1 = 0
+    if points1 is not None:
+        points1 = _hip.as_dev(points1, torch.float32)
+        if points1.dim() != 3 or points1.shape[0] != b or points1.shape[1] != n:
+            raise ValueError("fp_interpolate_cat expects (b,n,c1) points1")
+        c1 = points1.shape[2]
+    out = torch.empty((b, n, c2 + c1), dtype=torch.float32, device=points2.device)
+    _hip.launch("pasnl_fp_interpolate_cat", "FpInterpolateCat", b, m, c2, n, c1, _hip.ptr(points2), _hip.ptr(idx), _hip.ptr(dist),
+                _hip.ptr(points1), _hip.ptr(out))
+    return out

@@ -16,7 +16,7 @@ import torch
 
 from pointasnl_amd import _hip
 from pointasnl_amd import tf_sampling, tf_grouping, nearest_neighbors
-from pointasnl_amd.tf_interpolate import three_nn, three_interpolate, three_weights
+from pointasnl_amd.tf_interpolate import three_nn, three_interpolate, three_weights, fp_interpolate_cat
 from pointasnl_amd.utils import tf_util
 
 NL_VARIANT = 0  # 0 auto / 1 vector-FMA / 2 MFMA  (pasnl_nl_attention); bench.py --ops sweeps it
@@ -85,6 +85,7 @@ def sa_group(xyz, feature, idx, new_xyz):
 
 
 SA_TAIL_MIN_ROWS = 2048
+FP_HEAD_FUSED = True     # PointASNLDecodingLayer (inference, no autograd): three_weights + three_interpolate as one kernel
 SA_TAIL_FUSED = True     # skip conv + back-projection + adds + aggregation in one kernel (pasnl_sa_tail); False = op by op
 SA_CELL_GATHER = True    # grouping fused into the local cell (pasnl_sa_cell); False = pasnl_sa_group + pasnl_sa_local_cell
 SA_CELL_SINGLE = True     # mlp = [c, c] (one convolution, c = 32 / 64 / 128): no conv1 at all instead of an identity conv1 (False: A/B)
@@ -621,7 +622,7 @@ def sa_search_split(xyz, npoint, nsample, knn_all, slot=0):
 
 def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_decay, weight_decay, scope, bn=True,
                             use_knn=True, radius=None, as_neighbor=8, NL=True, search=None, after_sampling=None,
-                            xyz_concat=False, after_cell=None, before_after_conv=None):
+                            xyz_concat=False, after_cell=None, before_after_conv=None, residual=None):
     '''Mirror of pointasnl_util.py:221-292: one PointASNL set-abstraction layer.
         xyz (B,N,3), feature (B,N,C)  ->  new_xyz (B,npoint,3), new_points (B,npoint,mlp[-1])
     npoint points are sampled (FPS) and moved by AdaptiveSampling over their first `as_neighbor` neighbours; each keeps
@@ -631,7 +632,9 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
     after_sampling: callback(new_xyz) the moment the level's coordinates are final (the caller forks the next searches).
     xyz_concat: the caller will feed tf.concat([new_xyz, new_points]) to a group_all module (pointasnl_cls layer3_x): the
     layer's last kernel then writes those rows as well, and the returned new_points carries them as `.xyz_concat`
-    = (new_xyz, (B,npoint,4+C) table [0 | xyz | points]) for pointnet_util.sample_and_group_all to pick up.'''
+    = (new_xyz, (B,npoint,4+C) table [0 | xyz | points]) for pointnet_util.sample_and_group_all to pick up.
+    residual: (B,npoint,mlp[-1]) added to the layer's output -- the `_res` model's "l1_2_points + l1_1_points"
+    (pointasnl_sem_seg_res.py:37,42,47,52) in the epilogue of the layer's last kernel instead of a pass of its own.'''
     with tf_util.variable_scope(scope):
         batch_size, num_points, num_channel = feature.shape
         # Farthest point sampling + neighbour search (the reference's sampling() / grouping(): pointasnl_util.py:236-242);
@@ -749,7 +752,11 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                     _hip.ptr(att), _hip.ptr(ws), _hip.ptr(bs), _hip.ptr(wb if NL else None),
                     _hip.ptr(bb if NL else None), _hip.ptr(wagg), _hip.ptr(bagg), _hip.ptr(out))
             try:
-                if xyz_concat and XYZ_CONCAT:
+                if residual is not None:
+                    residual = residual.contiguous()
+                    _hip.launch("pasnl_sa_tail_res", "sa_tail", *args[:-1], _hip.ptr(residual), args[-1])
+                    residual = None  # (added)
+                elif xyz_concat and XYZ_CONCAT:
                     new_xyz = new_xyz.contiguous()
                     cat = torch.empty((batch_size, npoint, 4 + c_out), dtype=torch.float32, device=xyz.device)
                     _hip.launch("pasnl_sa_tail_cat", "sa_tail", *args, _hip.ptr(new_xyz), _hip.ptr(cat))
@@ -763,7 +770,7 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                 if NL:
                     tail = tail + torch.relu_(torch.addmm(bb, att.reshape(rows, cb), wb))
                 out = torch.relu_(torch.addmm(bagg, tail, wagg)).reshape(batch_size, npoint, c_out)
-            return new_xyz, out
+            return new_xyz, (out if residual is None else out + residual)
 
         # ---- non-local cell (:251-255)
         if NL:
@@ -787,7 +794,7 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
         # ---- aggregation (:287-290)
         new_point = tf_util.conv1d(new_point, mlp[-1], 1, padding='VALID', stride=1, bn=bn, is_training=is_training,
                                    scope='aggregation', bn_decay=bn_decay, weight_decay=weight_decay)
-        return new_xyz, new_point
+        return new_xyz, (new_point if residual is None else new_point + residual)
 
 
 DECODE_CELL_FUSED = True  # False = the reference's op-by-op chain (gathers, concat, conv2d, transpose, batched matmul)
@@ -850,8 +857,11 @@ def PointASNLDecodingLayer(xyz1, xyz2, points1, points2, nsample, mlp, is_traini
         # nn = three_nn(xyz1, xyz2), knn_all = the self-kNN of xyz1 (B,N1,K>=nsample): both read coordinates only and may
         # have been computed ahead by the caller (tuple / tensor / Forked); the encoder layer of this level shares knn_all
         dist, idx = three_nn(xyz1, xyz2) if nn is None else _resolved(nn)
-        weight = three_weights(dist)  # pointasnl_util.py:308-311 as one kernel
-        interpolated_points = three_interpolate(points2, idx, weight)
+        if FP_HEAD_FUSED and not is_training and not torch.is_grad_enabled():
+            interpolated_points = fp_interpolate_cat(points2, idx, dist)  # weights + interpolation in one launch, the same bits
+        else:
+            weight = three_weights(dist)  # pointasnl_util.py:308-311 as one kernel
+            interpolated_points = three_interpolate(points2, idx, weight)
 
         # ---- local cell (:322-331)
         if DECODE_CELL_FUSED and use_xyz and use_knn and nsample in (16, 32):

@@ -9,7 +9,7 @@ import torch
 
 from pointasnl_amd.tf_sampling import farthest_point_sample, farthest_point_sample_gather, gather_point
 from pointasnl_amd.tf_grouping import query_ball_point, group_point, knn_point
-from pointasnl_amd.tf_interpolate import three_nn, three_interpolate, three_weights
+from pointasnl_amd.tf_interpolate import three_nn, three_interpolate, three_weights, fp_interpolate_cat
 from pointasnl_amd.utils import tf_util
 from pointasnl_amd import _hip
 
@@ -56,6 +56,7 @@ def max_pool_points(new_points, out=None):
 # first-layer widths for which a group_all module runs on the fused kernel (csrc/mlp_pool.hip); the others run their three
 # convolutions on the vendor GEMM + a pooling kernel.  Measured (EXPERIMENTS.md, round 5): the fused kernel streams every
 # weight from L2 once per 32 / 64 rows and ties with the vendor chain at best -- see there for what is enabled and why.
+FP_HEAD_FUSED = True  # pointnet_fp_module (inference, no autograd): three_weights + three_interpolate + concat as one kernel
 GROUP_ALL_FUSED = (128,)
 _GROUP_ALL_WS = {}
 
@@ -177,12 +178,16 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
     '''
     with tf_util.variable_scope(scope):
         dist, idx = three_nn(xyz1, xyz2) if nn is None else (nn.get() if hasattr(nn, "get") else nn)
-        weight = three_weights(dist)  # pointnet_util.py:212-215 as one kernel
-        interpolated_points = three_interpolate(points2, idx, weight)
-        if points1 is not None:
-            new_points1 = torch.cat([interpolated_points, points1], dim=2)
+        if FP_HEAD_FUSED and not is_training and not torch.is_grad_enabled():
+            # weights + interpolation + concat in one launch, the same bits (pasnl_fp_interpolate_cat)
+            new_points1 = fp_interpolate_cat(points2, idx, dist, points1)
         else:
-            new_points1 = interpolated_points
+            weight = three_weights(dist)  # pointnet_util.py:212-215 as one kernel
+            interpolated_points = three_interpolate(points2, idx, weight)
+            if points1 is not None:
+                new_points1 = torch.cat([interpolated_points, points1], dim=2)
+            else:
+                new_points1 = interpolated_points
         new_points1 = new_points1.unsqueeze(2)
         for i, num_out_channel in enumerate(mlp):
             new_points1 = tf_util.conv2d(new_points1, num_out_channel, [1, 1], padding='VALID', stride=[1, 1], bn=bn,

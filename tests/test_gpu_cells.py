@@ -815,6 +815,25 @@ def test_decoding_layer_tiled_matches_plain():
     assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("rows,w,cb,c", [(10240, 35, 0, 64), (2560, 67, 0, 128), (77, 134, 64, 256), (64, 16, 0, 512), (2049, 257, 33, 96)])
+def test_sa_tail_res_is_tail_plus_residual(rows, w, cb, c):
+    """pasnl_sa_tail_res (the `_res` model's residual sum, pointasnl_sem_seg_res.py:37,42,47,52, in the tail's epilogue):
+    pasnl_sa_tail's rows + the residual, bit for bit."""
+    from pointasnl_amd import _hip
+    rng = np.random.default_rng(rows + c)
+    f = lambda *sh: dev(rng.standard_normal(sh).astype(np.float32))
+    A, S, N, R = f(rows, c), f(rows, w), f(rows, max(cb, 1)), f(rows, c)
+    ws, bs, wb, bb, wagg, bagg = f(w, c) / np.sqrt(w), f(c), f(max(cb, 1), c), f(c), f(c, c) / np.sqrt(c), f(c)
+    null = _hip.ptr(None)
+    head = [rows, w, cb, c, _hip.ptr(A), _hip.ptr(S), _hip.ptr(N) if cb else null, _hip.ptr(ws), _hip.ptr(bs),
+            _hip.ptr(wb) if cb else null, _hip.ptr(bb) if cb else null, _hip.ptr(wagg), _hip.ptr(bagg)]
+    plain = torch.full((rows, c), float("nan"), device="cuda")
+    summed = torch.full((rows, c), float("nan"), device="cuda")
+    _hip.launch("pasnl_sa_tail", "sa_tail", *head, _hip.ptr(plain))
+    _hip.launch("pasnl_sa_tail_res", "sa_tail", *head, _hip.ptr(R), _hip.ptr(summed))
+    assert torch.equal(summed, plain + R)
+
+
 @pytest.mark.parametrize("rows,w,cb,c,cat", [
     (32768, 9, 32, 128, True),    # cls layer1 (narrow skip product: 9 columns), with the [0 | xyz | out] rows
     (8192, 134, 64, 256, False),  # cls layer2

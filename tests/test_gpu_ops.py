@@ -301,6 +301,26 @@ def test_three_interpolate_and_grad(P, b, m, c, n):
     np.testing.assert_array_equal(x.grad.cpu().numpy(), O.three_interpolate_grad(pts, i, w, g))
 
 
+@pytest.mark.parametrize("b,m,c2,n,c1", [(8, 1280, 128, 10240, 32), (2, 80, 512, 320, 256), (2, 50, 7, 33, 5), (3, 40, 64, 17, 0),
+                                          (1, 64, 12, 100, 6), (2, 128, 256, 512, 128)])
+def test_fp_interpolate_cat_is_weights_interpolate_concat(P, b, m, c2, n, c1):
+    """pasnl_fp_interpolate_cat = three_weights -> three_interpolate -> tf.concat (pointnet_util.py:212-219) in one launch:
+    the oracle's values bit for bit (same operations, same order), rows that do not fill a tile of 16, channel counts that
+    are not multiples of 4 (scalar path), no points1 (the decoding layer's use)."""
+    rng = np.random.default_rng(m + c1)
+    p2 = rng.standard_normal((b, m, c2)).astype(np.float32)
+    p1 = rng.standard_normal((b, n, c1)).astype(np.float32) if c1 else None
+    x1, x2 = clouds(73, b, n, "cube"), clouds(74, b, m, "cube")
+    x1[0, :3] = x2[0, :3]  # zero distances: the 1e-10 floor of the weights
+    d, i = O.three_nn(x1, x2)
+    want = O.three_interpolate(p2, i, O.three_weights(d))
+    if c1:
+        want = np.concatenate([want, p1], axis=2)
+    got = P.tf_interpolate.fp_interpolate_cat(dev(p2), dev(i), dev(d), dev(p1) if c1 else None).cpu().numpy()
+    assert got.shape == (b, n, c2 + c1)
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("b,n,m", [(2, 100, 10), (3, 8192 + 1000, 2048), (2, 5, 100), (1, 20000, 64)])
 def test_prob_sample(P, b, n, m):
     rng = np.random.default_rng(n)
