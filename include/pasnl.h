@@ -262,9 +262,13 @@ int pasnl_max_pool_rows_strided(int b, int n, int c, const float* x, float* out,
  * into w / bias by the caller, ReLU) over every point of a cloud and tf.reduce_max over the points:
  *   out[cloud * out_stride + ch] = max_i relu(relu(relu(x[cloud,i,:] w0 + b0) w1 + b1) w2 + b2)[ch]
  * x (b,n,k0) rows [xyz | points] (sample_and_group_all's concat, pointnet_util.py:79; any leading alignment columns the
- * caller added have zero rows in w0), w0 (k0,c1), w1 (c1,c2), w2 (c2,c3).  Covered: (c1,c2,c3) = (128,256,512) and
- * (256,512,1024), k0 % 4 == 0, x 16-byte aligned; otherwise PASNL_EUNSUPPORTED (the caller runs the layers one by one).
- * workspace: pasnl_mlp3_max_pool_workspace_bytes(b, n, c3) bytes (maxima per tile of 32 points; no need to clear it). */
+ * caller added have zero rows in w0).  w0 (k0,c1), w1 (c1,c2), w2 (c2,c3) are handed over PACKED in the matrix instruction's
+ * operand order -- pasnl_mlp3_pack_weights(k, n, w, packed) once per variable into pasnl_mlp3_packed_weights_bytes(k, n) bytes
+ * (16-byte aligned): packed[((bt * 2 + h) * n + col) * 8 + u] = w[16 bt + 2 u + h][col], zero beyond k.  Covered: (c1,c2,c3) =
+ * (128,256,512) and (256,512,1024), k0 % 4 == 0, x 16-byte aligned; otherwise PASNL_EUNSUPPORTED (the caller runs the layers
+ * one by one).  workspace: pasnl_mlp3_max_pool_workspace_bytes(b, n, c3) bytes (maxima per tile of 32 points; no need to clear it). */
+size_t pasnl_mlp3_packed_weights_bytes(int k, int n);
+int pasnl_mlp3_pack_weights(int k, int n, const float* w, float* packed, pasnl_stream_t stream);
 size_t pasnl_mlp3_max_pool_workspace_bytes(int b, int n, int c3);
 int pasnl_mlp3_max_pool(int b, int n, int k0, int c1, int c2, int c3, const float* x, const float* w0, const float* b0,
                         const float* w1, const float* b1, const float* w2, const float* b2, float* out, long out_stride,

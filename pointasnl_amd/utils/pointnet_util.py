@@ -80,6 +80,15 @@ def group_all_mlp_max(new_points, mlp, bn, pooled_out=None):
                 if key not in st._folded:
                     st._folded[key] = (torch.cat([w.new_zeros((pad, w.shape[1])), w], dim=0).contiguous(), bb)
                 w, bb = st._folded[key]
+            # the kernel takes its weights in the matrix instruction's operand order (pasnl_mlp3_pack_weights), packed once
+            key = st.path("") + "@mlp3:%x" % w.data_ptr()
+            if key not in st._folded:
+                wc = w.contiguous()
+                pk = torch.empty(int(_hip.lib().pasnl_mlp3_packed_weights_bytes(wc.shape[0], wc.shape[1])) // 4, dtype=torch.float32,
+                                 device=w.device)
+                _hip.launch("pasnl_mlp3_pack_weights", "mlp3_pack", int(wc.shape[0]), int(wc.shape[1]), _hip.ptr(wc), _hip.ptr(pk))
+                st._folded[key] = (pk, w)  # (keeps `w` alive: the pointer in the key stays unique)
+            w = st._folded[key][0]
         ws += [w, bb]
         cin = c
     x = new_points.reshape(b, n, kp)

@@ -11,10 +11,15 @@ for (b, n, k0, c) in ((64, 512, 132, (128, 256, 512)), (64, 128, 260, (256, 512,
     for co in c:
         ws += [torch.randn(cin, co, device="cuda", generator=g) * 0.05, torch.randn(co, device="cuda", generator=g) * 0.05]
         cin = co
+    def packed(w):
+        pk = torch.empty(int(_hip.lib().pasnl_mlp3_packed_weights_bytes(w.shape[0], w.shape[1])) // 4, device="cuda")
+        _hip.launch("pasnl_mlp3_pack_weights", "mlp3_pack", w.shape[0], w.shape[1], _hip.ptr(w), _hip.ptr(pk))
+        return pk
+    wp = [packed(t) if t.dim() == 2 else t for t in ws]
     out = torch.zeros(b, c[2], device="cuda")
     wsb = torch.empty(int(_hip.lib().pasnl_mlp3_max_pool_workspace_bytes(b, n, c[2])), dtype=torch.uint8, device="cuda")
     def run():
-        _hip.launch("pasnl_mlp3_max_pool", "mlp3", b, n, k0, c[0], c[1], c[2], _hip.ptr(x), *[_hip.ptr(t) for t in ws], _hip.ptr(out), ctypes.c_long(c[2]), _hip.ptr(wsb), ctypes.c_size_t(wsb.numel()))
+        _hip.launch("pasnl_mlp3_max_pool", "mlp3", b, n, k0, c[0], c[1], c[2], _hip.ptr(x), *[_hip.ptr(t) for t in wp], _hip.ptr(out), ctypes.c_long(c[2]), _hip.ptr(wsb), ctypes.c_size_t(wsb.numel()))
     def vendor():
         h = x.reshape(b * n, k0)
         for i in range(3):
