@@ -164,9 +164,10 @@ def algorithmic(symbol, ints):
         centres = 3 * g if symbol == "pasnl_sa_cell" else 3 * g + (3 + c) * g
         return (4 * (b * n * (3 + c) + g * k + centres + g * c2 * 32 + g * w + w * c1 + c1 * c2),
                 g * (2 * k * (w * c1 + c1 * c2 + 3 * 32) + 2 * c2 * k * 32), "mfma")
-    if symbol in ("pasnl_sa_tail", "pasnl_sa_tail_cat"):
-        rows, w, cb, c = ints
-        extra = rows * (c + 4 + 3) if symbol.endswith("_cat") else 0
+    if symbol in ("pasnl_sa_tail", "pasnl_sa_tail_cat", "pasnl_sa_tail_res", "pasnl_sa_tail_packed"):
+        rows, w, cb, c = ints[:4]
+        # (the packed form's optional concat rows / residual are pointer arguments: not counted -- a lower bound of its bytes)
+        extra = rows * (c + 4 + 3) if symbol.endswith("_cat") else (rows * c if symbol.endswith("_res") else 0)
         return 4 * (rows * (2 * c + w + cb) + c * (w + cb + c) + extra), 2 * rows * c * (w + cb + c), "mfma"
     if symbol == "pasnl_dense_rows":
         rows, k, n, _relu = ints

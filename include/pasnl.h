@@ -350,6 +350,17 @@ int pasnl_sa_tail_res(int rows, int w, int cb, int c, const float* after, const 
                       const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
                       const float* bagg, const float* residual, float* out, pasnl_stream_t stream);
 
+/* pasnl_sa_tail / _res / _cat with the three weight matrices PACKED in the matrix instruction's operand order (the kernel then
+ * reads them in 16-byte pieces: 3-5 us per launch): pasnl_sa_tail_pack_weights(k, c, w, packed) once per variable into
+ * pasnl_sa_tail_packed_weights_bytes(k, c) bytes (16-byte aligned): packed[((chunk * 2 + h) * c + col) * 16 + t] =
+ * w[32 chunk + 2 t + h][col], zero beyond k.  residual (rows,c) or NULL; out_cat + new_xyz or NULL (see pasnl_sa_tail_cat). */
+size_t pasnl_sa_tail_packed_weights_bytes(int k, int c);
+int pasnl_sa_tail_pack_weights(int k, int c, const float* w, float* packed, pasnl_stream_t stream);
+int pasnl_sa_tail_packed(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
+                         const float* ws_packed, const float* bs, const float* wb_packed, const float* bb, const float* wagg_packed,
+                         const float* bagg, const float* residual, const float* new_xyz, float* out_cat, float* out,
+                         pasnl_stream_t stream);
+
 /* pasnl_sa_tail that writes its rows a second time as out_cat (rows, c + 4) = [0 | new_xyz (rows,3) | out]: the
  * tf.concat([xyz, points]) the next group_all module starts with (pointnet_util.py:77-80, sample_and_group_all), one
  * zero column in front so that the rows stay 16-byte aligned (the consumer's weights get a zero row in front). */

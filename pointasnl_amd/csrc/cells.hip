@@ -2858,10 +2858,25 @@ namespace pasnl {
 // A-operand stream of one 32-channel output block: weight rows k (lanes 0-31) / k+1 (lanes 32-63), 16 k-steps per chunk,
 // the next chunk requested while the current one feeds the MFMAs.
 constexpr int TAIL_KS = 16;  // k-steps (pairs of input channels) per operand chunk
+// PACKED: the matrix in operand order (pasnl_sa_tail_pack_weights): P[chunk][h][column][t] = W[32 chunk + 2 t + h][column], zero
+// beyond kdim -- a lane's 16 words of a chunk are 64 contiguous bytes = four 16-byte loads instead of sixteen 4-byte ones (the
+// weight loads were 5 of a launch's 31 us: EXPERIMENTS "Round 5")
+template <bool PACKED>
 struct TailW {
-  const float* __restrict__ base;  // W + cbase + l32
+  const float* __restrict__ base;  // W + cbase + l32  (PACKED: the matrix itself)
   int C, kdim, h;
+  int col;                         // PACKED: cbase + l32
   __device__ __forceinline__ void load(int k0, float (&a)[TAIL_KS]) const {
+    if constexpr (PACKED) {
+      const int chunk = min(k0 >> 5, ((kdim + 31) >> 5) - 1);  // (the request behind the last chunk re-reads it)
+      const float4* p = reinterpret_cast<const float4*>(base + ((size_t)(chunk * 2 + h) * C + col) * TAIL_KS);
+#pragma unroll
+      for (int q = 0; q < TAIL_KS / 4; ++q) {
+        const float4 v = p[q];
+        a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < TAIL_KS; ++t) {
       // rows past kdim are CLAMPED, not skipped: the X tile is zero there, so any finite weight contributes nothing, and
@@ -2875,7 +2890,8 @@ struct TailW {
 
 // acc += W[:, block]^T . X^T for X rows held in LDS as xs[k * 33 + row] (k-major, zero-padded to a multiple of 2 TAIL_KS
 // channels).  Chunks of TAIL_KS unconditional MFMAs (zero X beyond kdim), the next chunk's weights in flight.
-__device__ __forceinline__ f32x16 tail_product(const TailW& W, const float* __restrict__ xs, int l32, f32x16 acc) {
+template <bool PACKED>
+__device__ __forceinline__ f32x16 tail_product(const TailW<PACKED>& W, const float* __restrict__ xs, int l32, f32x16 acc) {
   // `a` feeds the products while `b` (the next chunk) is in flight, covered by TAIL_KS products (~1000 cycles: an L2 round
   // trip).  One loop body without an early exit -- an exit between a load and its use lets the compiler sink the load behind
   // the exit, right in front of its use -- and the rotation as register copies after the products: by then `b` has arrived.
@@ -2905,7 +2921,7 @@ __device__ __forceinline__ f32x16 tail_product(const TailW& W, const float* __re
 #define TAIL_ABL_PARAM
 #define TAIL_ABL(bit) 0
 #endif
-template <int NW>  // waves per workgroup = 32-channel output blocks in flight (one per wave): C <= 32 NW
+template <int NW, bool PACKED>  // waves per workgroup = 32-channel output blocks in flight (one per wave): C <= 32 NW
 __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int cb, int C, const float* __restrict__ A,
                                                          const float* __restrict__ S, const float* __restrict__ N,
                                                          const float* __restrict__ Ws, const float* __restrict__ bs,
@@ -2985,14 +3001,14 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = bs[cbase + kappa(i, h)];
-    acc = tail_product(TailW{Ws + cbase + l32, C, w, h}, st, l32, acc);
+    acc = tail_product(PACKED ? TailW<PACKED>{Ws, C, w, h, cbase + l32} : TailW<PACKED>{Ws + cbase + l32, C, w, h, 0}, st, l32, acc);
     f32x16 v;
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
     if (N) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = bb[cbase + kappa(i, h)];
-      acc = tail_product(TailW{Wb + cbase + l32, C, cb, h}, nt_, l32, acc);
+      acc = tail_product(PACKED ? TailW<PACKED>{Wb, C, cb, h, cbase + l32} : TailW<PACKED>{Wb + cbase + l32, C, cb, h, 0}, nt_, l32, acc);
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] += fmaxf(acc[i], 0.f);
     }
@@ -3008,7 +3024,8 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
   if (mine) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[i] = bagg[cbase + kappa(i, h)];
-    if (!TAIL_ABL(2)) o = tail_product(TailW{Wagg + cbase + l32, C, C, h}, vt, l32, o);
+    if (!TAIL_ABL(2))
+      o = tail_product(PACKED ? TailW<PACKED>{Wagg, C, C, h, cbase + l32} : TailW<PACKED>{Wagg + cbase + l32, C, C, h, 0}, vt, l32, o);
   }
   __syncthreads();  // every wave has read V^T: the tile becomes O^T
   if (mine) {
@@ -3053,7 +3070,7 @@ __global__ __launch_bounds__(NW * 64) void sa_tail_kernel(long rows, int w, int 
 static int sa_tail_entry(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
                          const float* ws, const float* bs, const float* wb, const float* bb, const float* wagg,
                          const float* bagg, float* out, const float* xyz3, float* out_cat, pasnl_stream_t stream,
-                         const float* residual = nullptr) {
+                         const float* residual = nullptr, bool packed = false) {
   PASNL_REQUIRE(rows >= 0 && w > 0 && cb >= 0 && c > 0, PASNL_EINVAL);
   PASNL_REQUIRE(c % 32 == 0 && c <= 512, PASNL_EUNSUPPORTED);
   if (rows == 0) return PASNL_OK;
@@ -3062,7 +3079,11 @@ static int sa_tail_entry(int rows, int w, int cb, int c, const float* after, con
   const size_t lds = ((size_t)c + ((w + 31) & ~31) + ((cb + 31) & ~31)) * 33 * sizeof(float);  // tiles padded to 2 TAIL_KS rows
   PASNL_REQUIRE(lds <= 160 * 1024, PASNL_EUNSUPPORTED);
   const int nw = c <= 128 ? 4 : (c <= 256 ? 8 : 16);  // one wave per 32-channel block (>= 4 waves stage the tiles)
-  auto kern = nw == 4 ? pasnl::sa_tail_kernel<4> : (nw == 8 ? pasnl::sa_tail_kernel<8> : pasnl::sa_tail_kernel<16>);
+  if (packed)
+    PASNL_REQUIRE((reinterpret_cast<uintptr_t>(ws) | reinterpret_cast<uintptr_t>(wagg) | (cb ? reinterpret_cast<uintptr_t>(wb) : 0)) % 16 == 0,
+                  PASNL_EUNSUPPORTED);
+  auto kern = packed ? (nw == 4 ? pasnl::sa_tail_kernel<4, true> : (nw == 8 ? pasnl::sa_tail_kernel<8, true> : pasnl::sa_tail_kernel<16, true>))
+                     : (nw == 4 ? pasnl::sa_tail_kernel<4, false> : (nw == 8 ? pasnl::sa_tail_kernel<8, false> : pasnl::sa_tail_kernel<16, false>));
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
@@ -3082,6 +3103,51 @@ extern "C" int pasnl_sa_tail_res(int rows, int w, int cb, int c, const float* af
                                  const float* bagg, const float* residual, float* out, pasnl_stream_t stream) {
   PASNL_REQUIRE(rows == 0 || residual, PASNL_ENULL);
   return sa_tail_entry(rows, w, cb, c, after, skip_max, att, ws, bs, wb, bb, wagg, bagg, out, nullptr, nullptr, stream, residual);
+}
+
+namespace pasnl {
+// W (K, C) row-major -> P[chunk][h][column][t] = W[32 chunk + 2 t + h][column] (zero beyond K): one thread per 16-byte piece
+__global__ __launch_bounds__(256) void sa_tail_pack_kernel(int K, int C, const float* __restrict__ W, float* __restrict__ P) {
+  const long total = (long)((K + 31) >> 5) * 2 * C * (TAIL_KS / 4);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int q = (int)(e & (TAIL_KS / 4 - 1));
+    const long lane = e / (TAIL_KS / 4);  // (chunk * 2 + h) * C + column
+    const int col = (int)(lane % C);
+    const long ch = lane / C;
+    const int h = (int)(ch & 1), chunk = (int)(ch >> 1);
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 32 * chunk + 2 * (4 * q + j) + h;
+      v[j] = k < K ? W[(size_t)k * C + col] : 0.f;
+    }
+    reinterpret_cast<float4*>(P)[e] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+}  // namespace pasnl
+
+extern "C" size_t pasnl_sa_tail_packed_weights_bytes(int k, int c) {
+  if (k <= 0 || c <= 0) return 0;
+  return (size_t)((k + 31) & ~31) * c * sizeof(float);
+}
+
+extern "C" int pasnl_sa_tail_pack_weights(int k, int c, const float* w, float* packed, pasnl_stream_t stream) {
+  PASNL_REQUIRE(k > 0 && c > 0, PASNL_EINVAL);
+  PASNL_REQUIRE(w && packed, PASNL_ENULL);
+  PASNL_REQUIRE(reinterpret_cast<uintptr_t>(packed) % 16 == 0, PASNL_EUNSUPPORTED);
+  const long pieces = (long)((k + 31) >> 5) * 2 * c * 4;
+  const long g = (pieces + 255) / 256;
+  hipLaunchKernelGGL(pasnl::sa_tail_pack_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, pasnl_hip_stream(stream), k, c, w, packed);
+  return pasnl_launch_status();
+}
+
+extern "C" int pasnl_sa_tail_packed(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,
+                                    const float* ws_packed, const float* bs, const float* wb_packed, const float* bb,
+                                    const float* wagg_packed, const float* bagg, const float* residual, const float* new_xyz,
+                                    float* out_cat, float* out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(rows == 0 || !out_cat || new_xyz, PASNL_ENULL);
+  return sa_tail_entry(rows, w, cb, c, after, skip_max, att, ws_packed, bs, wb_packed, bb, wagg_packed, bagg, out, out_cat ? new_xyz : nullptr,
+                       out_cat, stream, residual, true);
 }
 
 extern "C" int pasnl_sa_tail_cat(int rows, int w, int cb, int c, const float* after, const float* skip_max, const float* att,

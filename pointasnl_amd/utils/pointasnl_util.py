@@ -86,6 +86,7 @@ def sa_group(xyz, feature, idx, new_xyz):
 
 SA_TAIL_MIN_ROWS = 2048
 FP_HEAD_FUSED = True     # PointASNLDecodingLayer (inference, no autograd): three_weights + three_interpolate as one kernel
+SA_TAIL_PACKED = True    # pasnl_sa_tail with its weights packed in operand order (16-byte weight loads)
 SA_TAIL_FUSED = True     # skip conv + back-projection + adds + aggregation in one kernel (pasnl_sa_tail); False = op by op
 SA_CELL_GATHER = True    # grouping fused into the local cell (pasnl_sa_cell); False = pasnl_sa_group + pasnl_sa_local_cell
 SA_CELL_SINGLE = True     # mlp = [c, c] (one convolution, c = 32 / 64 / 128): no conv1 at all instead of an identity conv1 (False: A/B)
@@ -620,6 +621,18 @@ def sa_search_split(xyz, npoint, nsample, knn_all, slot=0):
     return Deferred(join)
 
 
+def _tail_packed(st, w):
+    """`w` (k, c) in pasnl_sa_tail's operand order, packed once per variable (cached next to the folded weights)."""
+    key = "@tailpk:%x" % w.data_ptr()
+    if key not in st._folded:
+        wc = w.contiguous()
+        pk = torch.empty(int(_hip.lib().pasnl_sa_tail_packed_weights_bytes(wc.shape[0], wc.shape[1])) // 4, dtype=torch.float32,
+                         device=w.device)
+        _hip.launch("pasnl_sa_tail_pack_weights", "sa_tail_pack", int(wc.shape[0]), int(wc.shape[1]), _hip.ptr(wc), _hip.ptr(pk))
+        st._folded[key] = (pk, w)  # (keeps `w` alive: the pointer in the key stays unique)
+    return st._folded[key][0]
+
+
 def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_decay, weight_decay, scope, bn=True,
                             use_knn=True, radius=None, as_neighbor=8, NL=True, search=None, after_sampling=None,
                             xyz_concat=False, after_cell=None, before_after_conv=None, residual=None):
@@ -752,7 +765,21 @@ def PointASNLSetAbstraction(xyz, feature, npoint, nsample, mlp, is_training, bn_
                     _hip.ptr(att), _hip.ptr(ws), _hip.ptr(bs), _hip.ptr(wb if NL else None),
                     _hip.ptr(bb if NL else None), _hip.ptr(wagg), _hip.ptr(bagg), _hip.ptr(out))
             try:
-                if residual is not None:
+                if SA_TAIL_PACKED:
+                    # the three matrices in the matrix instruction's operand order, packed once per variable
+                    pk = [_tail_packed(st, m) if m is not None else None for m in (ws, wb if NL else None, wagg)]
+                    cat = None
+                    if xyz_concat and XYZ_CONCAT:
+                        new_xyz = new_xyz.contiguous()
+                        cat = torch.empty((batch_size, npoint, 4 + c_out), dtype=torch.float32, device=xyz.device)
+                    res_c = residual.contiguous() if residual is not None else None
+                    _hip.launch("pasnl_sa_tail_packed", "sa_tail", *args[:7], _hip.ptr(pk[0]), args[8], _hip.ptr(pk[1]), args[10],
+                                _hip.ptr(pk[2]), args[12], _hip.ptr(res_c), _hip.ptr(new_xyz if cat is not None else None),
+                                _hip.ptr(cat), args[13])
+                    residual = None  # (added)
+                    if cat is not None:
+                        out.xyz_concat = (new_xyz, cat)
+                elif residual is not None:
                     residual = residual.contiguous()
                     _hip.launch("pasnl_sa_tail_res", "sa_tail", *args[:-1], _hip.ptr(residual), args[-1])
                     residual = None  # (added)

@@ -815,6 +815,50 @@ def test_decoding_layer_tiled_matches_plain():
     assert torch.allclose(outs[0], outs[1], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("rows,w,cb,c,cat,res", [
+    (32768, 9, 32, 128, True, False), (8192, 134, 64, 256, False, False), (100, 9, 32, 128, False, True), (77, 134, 64, 256, True, True),
+    (33, 70, 0, 32, False, False), (64, 16, 16, 512, False, True), (1, 1, 1, 32, True, False), (2049, 257, 33, 96, False, False),
+])
+def test_sa_tail_packed_weights_give_the_same_bits(rows, w, cb, c, cat, res):
+    """pasnl_sa_tail_packed (weights in the matrix instruction's operand order, read in 16-byte pieces) == pasnl_sa_tail / _cat /
+    _res on the row-major matrices, bit for bit: contraction lengths that are no multiple of a 32-index chunk (zero padding
+    inside the packed matrices), with and without back-projection, concat rows and residual."""
+    from pointasnl_amd import _hip
+    rng = np.random.default_rng(7 * rows + c)
+    f = lambda *sh: dev(rng.standard_normal(sh).astype(np.float32))
+    A, S, N, R, xyz = f(rows, c), f(rows, w), f(rows, max(cb, 1)), f(rows, c), f(rows, 3)
+    ws, bs, wb, bb, wagg, bagg = f(w, c) / np.sqrt(w), f(c), f(max(cb, 1), c), f(c), f(c, c) / np.sqrt(c), f(c)
+    null = _hip.ptr(None)
+
+    def packed(m):
+        pk = torch.empty(int(_hip.lib().pasnl_sa_tail_packed_weights_bytes(m.shape[0], m.shape[1])) // 4, device="cuda")
+        _hip.launch("pasnl_sa_tail_pack_weights", "pack", m.shape[0], m.shape[1], _hip.ptr(m), _hip.ptr(pk))
+        return pk
+    head = [rows, w, cb, c, _hip.ptr(A), _hip.ptr(S), _hip.ptr(N) if cb else null]
+    plain = torch.full((rows, c), float("nan"), device="cuda")
+    plain_cat = torch.full((rows, c + 4), float("nan"), device="cuda")
+    tailw = [_hip.ptr(ws), _hip.ptr(bs), _hip.ptr(wb) if cb else null, _hip.ptr(bb) if cb else null, _hip.ptr(wagg), _hip.ptr(bagg)]
+    if res:
+        _hip.launch("pasnl_sa_tail_res", "sa_tail", *head, *tailw, _hip.ptr(R), _hip.ptr(plain))
+        if cat:  # (no plain entry point does both: the concat rows of the packed form are checked against its own output)
+            plain_cat = None
+    elif cat:
+        _hip.launch("pasnl_sa_tail_cat", "sa_tail", *head, *tailw, _hip.ptr(plain), _hip.ptr(xyz), _hip.ptr(plain_cat))
+    else:
+        _hip.launch("pasnl_sa_tail", "sa_tail", *head, *tailw, _hip.ptr(plain))
+    pws, pwb, pwagg = packed(ws), packed(wb) if cb else None, packed(wagg)
+    got = torch.full((rows, c), float("nan"), device="cuda")
+    got_cat = torch.full((rows, c + 4), float("nan"), device="cuda")
+    _hip.launch("pasnl_sa_tail_packed", "sa_tail", *head, _hip.ptr(pws), _hip.ptr(bs), _hip.ptr(pwb), _hip.ptr(bb) if cb else null,
+                _hip.ptr(pwagg), _hip.ptr(bagg), _hip.ptr(R) if res else null, _hip.ptr(xyz) if cat else null,
+                _hip.ptr(got_cat) if cat else null, _hip.ptr(got))
+    assert torch.equal(got, plain)
+    if cat:
+        assert torch.equal(got_cat[:, 4:], got) and torch.equal(got_cat[:, 1:4], xyz) and bool((got_cat[:, 0] == 0).all())
+        if plain_cat is not None:
+            assert torch.equal(got_cat, plain_cat)
+
+
 @pytest.mark.parametrize("rows,w,cb,c", [(10240, 35, 0, 64), (2560, 67, 0, 128), (77, 134, 64, 256), (64, 16, 0, 512), (2049, 257, 33, 96)])
 def test_sa_tail_res_is_tail_plus_residual(rows, w, cb, c):
     """pasnl_sa_tail_res (the `_res` model's residual sum, pointasnl_sem_seg_res.py:37,42,47,52, in the tail's epilogue):
