@@ -156,12 +156,12 @@ def algorithmic(symbol, ints):
         g, k, w, c1, c2 = ints
         # reads the grouped points once, writes (c2 x 32) per group; weights are LDS-resident
         return 4 * (g * k * w + g * c2 * 32 + w * c1 + c1 * c2), g * (2 * k * (w * c1 + c1 * c2 + 3 * 32) + 2 * c2 * k * 32), "mfma"
-    if symbol in ("pasnl_sa_cell", "pasnl_sa_cell_centre0"):
+    if symbol in ("pasnl_sa_cell", "pasnl_sa_cell_centre0", "pasnl_sa_cell_packed"):
         b, n, c, m, k, c1, c2 = ints
         g, w = b * m, 6 + c
         # reads the tables, the indices and the centres once; writes (c2 x 32) per group + the skip maxima
         # (centre0: no centre table to read; the centres and neighbour 0's feature rows are written instead)
-        centres = 3 * g if symbol == "pasnl_sa_cell" else 3 * g + (3 + c) * g
+        centres = 3 * g if symbol != "pasnl_sa_cell_centre0" else 3 * g + (3 + c) * g  # (_packed: the centre mode is a pointer argument)
         return (4 * (b * n * (3 + c) + g * k + centres + g * c2 * 32 + g * w + w * c1 + c1 * c2),
                 g * (2 * k * (w * c1 + c1 * c2 + 3 * 32) + 2 * c2 * k * 32), "mfma")
     if symbol in ("pasnl_sa_tail", "pasnl_sa_tail_cat", "pasnl_sa_tail_res", "pasnl_sa_tail_packed"):

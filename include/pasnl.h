@@ -249,6 +249,17 @@ int pasnl_sa_cell_centre0(int b, int n, int c, int m, int k, int c1, int c2, con
                           const float* ww, const float* bw, float* out, float* skip_max, float* new_xyz, float* new_feature,
                           pasnl_stream_t stream);
 
+/* pasnl_sa_cell / pasnl_sa_cell_centre0 (new_xyz == NULL: the centres are neighbour 0 and new_xyz_out / new_feature_out are
+ * written, else both are ignored) that ALSO get the feature rows of w0 (rows 6 .. 5 + c) and w1 in the matrix instruction's
+ * operand order -- pasnl_mlp3_pack_weights(c, c1, w0 + 6 * c1, w0_features_packed) and pasnl_mlp3_pack_weights(c1, c2, w1,
+ * w1_packed), once per variable -- for the kernels that stream their weights from L2 (one workgroup per group: c1 = c2 in
+ * {256, 512}, and 128 with few groups or one convolution): 16-byte weight loads.  The row-major matrices are still required
+ * (the first rows of w0, every other kernel); NULL packed pointers = the plain entry points; identical results. */
+int pasnl_sa_cell_packed(int b, int n, int c, int npoint, int nsample, int c1, int c2, const float* xyz, const float* feature,
+                         const int* idx, const float* new_xyz, const float* w0, const float* b0, const float* w1, const float* b1,
+                         const float* ww, const float* bw, const float* w0_features_packed, const float* w1_packed, float* out,
+                         float* skip_max, float* new_xyz_out, float* new_feature_out, pasnl_stream_t stream);
+
 /* PointNet set-abstraction pooling (pointnet_util.py:137, tf.reduce_max(new_points, axis=[2], keep_dims=True)):
  * out[b,ch] = max over the n points of x (b,n,c).  The two group_all modules of pointasnl_cls pool 67 + 34 MB. */
 int pasnl_max_pool_rows(int b, int n, int c, const float* x, float* out, pasnl_stream_t stream);

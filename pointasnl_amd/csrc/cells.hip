@@ -2559,11 +2559,15 @@ static int sa_cell16_launch(long groups, SaGatherSrc src, const float* w0, const
 //   4. G = relu(X[:, 0:3] Ww + bw) per wave (3 MFMA steps), M block v = H2^T G, stored as in the kernel above.
 //   v_mfma_f32_32x32x2_f32 throughout, D tiles chained as operands exactly as above (kappa).  k = 32 (one tile per group).
 // =============================================================================================
-template <int C, bool CONV1>
+// PACKED: the feature rows of w0 (rows 6 ..) and w1 also arrive in the matrix instruction's operand order
+// (pasnl_mlp3_pack_weights' layout: P[batch of 8 steps][h][channel][8]): two 16-byte loads per lane and batch instead of eight
+// 4-byte ones (what that is worth: EXPERIMENTS "Round 5", mlp3_pool / sa_tail).
+template <int C, bool CONV1, bool PACKED>
 __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGatherSrc src, const float* __restrict__ w0,
                                                                   const float* __restrict__ b0, const float* __restrict__ w1,
                                                                   const float* __restrict__ b1, const float* __restrict__ ww,
-                                                                  const float* __restrict__ bw, float* __restrict__ out) {
+                                                                  const float* __restrict__ bw, float* __restrict__ out,
+                                                                  const float* __restrict__ w0p, const float* __restrict__ w1p) {
   constexpr int NW = C / 32, T = NW * 64, HP = C + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int cf = w - 6, wi = 8 + cf;        // internal width (a multiple of 8: cf % 4 == 0 and the launcher asks for cf % 8 == 0)
@@ -2639,11 +2643,23 @@ __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGath
     const float* wp = w0 + (size_t)(6 + h) * C + ch;  // w0 row of internal column 8 + h
     const int nsteps = cf >> 1;                        // a multiple of BT (cf % 16 == 0), >= 2 BT
     float wa[3][BT], xb[3][BT];
+    // the weights of steps sb .. sb + BT - 1 (sb a multiple of BT) into register set `set`
+    auto load_w = [&](int set, int sb, const float* rowmajor, const float* packed) {
+      if constexpr (PACKED) {
+        const float4* q = reinterpret_cast<const float4*>(packed + ((size_t)((sb >> 3) * 2 + h) * C + ch) * 8);
+        const float4 a = q[0], b = q[1];
+        wa[set][0] = a.x; wa[set][1] = a.y; wa[set][2] = a.z; wa[set][3] = a.w;
+        wa[set][4] = b.x; wa[set][5] = b.y; wa[set][6] = b.z; wa[set][7] = b.w;
+      } else {
 #pragma unroll
-    for (int u = 0; u < BT; ++u) {
-      wa[0][u] = wp[(size_t)(2 * u) * C]; xb[0][u] = xrow[8 + 2 * u];
-      wa[1][u] = wp[(size_t)(2 * (BT + u)) * C]; xb[1][u] = xrow[8 + 2 * (BT + u)];
-    }
+        for (int u = 0; u < BT; ++u) wa[set][u] = rowmajor[(size_t)(2 * (sb + u)) * C];
+      }
+    };
+    static_assert(BT == 8, "a packed batch is eight steps");
+    load_w(0, 0, wp, w0p);
+    load_w(1, BT, wp, w0p);
+#pragma unroll
+    for (int u = 0; u < BT; ++u) { xb[0][u] = xrow[8 + 2 * u]; xb[1][u] = xrow[8 + 2 * (BT + u)]; }
     for (int s0 = 0; s0 < nsteps; s0 += 3 * BT) {
 #pragma unroll
       for (int third = 0; third < 3; ++third) {
@@ -2651,7 +2667,8 @@ __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGath
         if (sb < nsteps) {
           const int sn = min(sb + 2 * BT, nsteps - BT);  // two batches ahead (a dummy re-read at the end)
 #pragma unroll
-          for (int u = 0; u < BT; ++u) { wa[(third + 2) % 3][u] = wp[(size_t)(2 * (sn + u)) * C]; xb[(third + 2) % 3][u] = xrow[8 + 2 * (sn + u)]; }
+          for (int u = 0; u < BT; ++u) xb[(third + 2) % 3][u] = xrow[8 + 2 * (sn + u)];
+          load_w((third + 2) % 3, sn, wp, w0p);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int u = 0; u < BT; ++u) acc = mm(wa[third][u], xb[third][u], acc);
@@ -2673,15 +2690,28 @@ __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGath
     const float* hrow = H1s + ql * HP + h;
     const float* wp = w1 + (size_t)h * C + ch;
     float wa[2][BT], xb[2][BT];  // (two register sets: a third, as in conv0, gained nothing here -- H1 comes from LDS)
+    auto load_w = [&](int set, int sb) {
+      if constexpr (PACKED) {
+        const float4* q = reinterpret_cast<const float4*>(w1p + ((size_t)((sb >> 3) * 2 + h) * C + ch) * 8);
+        const float4 a = q[0], b = q[1];
+        wa[set][0] = a.x; wa[set][1] = a.y; wa[set][2] = a.z; wa[set][3] = a.w;
+        wa[set][4] = b.x; wa[set][5] = b.y; wa[set][6] = b.z; wa[set][7] = b.w;
+      } else {
 #pragma unroll
-    for (int u = 0; u < BT; ++u) { wa[0][u] = wp[(size_t)(2 * u) * C]; xb[0][u] = hrow[2 * u]; }
+        for (int u = 0; u < BT; ++u) wa[set][u] = wp[(size_t)(2 * (sb + u)) * C];
+      }
+    };
+    load_w(0, 0);
+#pragma unroll
+    for (int u = 0; u < BT; ++u) xb[0][u] = hrow[2 * u];
     for (int s0 = 0; s0 < NS; s0 += 2 * BT) {
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         const int sb = s0 + half * BT;
         const int sn = min(sb + BT, NS - BT);
 #pragma unroll
-        for (int u = 0; u < BT; ++u) { wa[half ^ 1][u] = wp[(size_t)(2 * (sn + u)) * C]; xb[half ^ 1][u] = hrow[2 * (sn + u)]; }
+        for (int u = 0; u < BT; ++u) xb[half ^ 1][u] = hrow[2 * (sn + u)];
+        load_w(half ^ 1, sn);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < BT; ++u) H2 = __builtin_amdgcn_mfma_f32_32x32x2f32(xb[half][u], wa[half][u], H2, 0, 0, 0);
@@ -2720,15 +2750,18 @@ __global__ __launch_bounds__(C / 32 * 64) void sa_cell_wide_kernel(int w, SaGath
 
 template <int C, bool CONV1>
 static int sa_cell_wide_launch(long groups, int w, SaGatherSrc src, const float* w0, const float* b0, const float* w1,
-                               const float* b1, const float* ww, const float* bw, float* out, hipStream_t st) {
+                               const float* b1, const float* ww, const float* bw, float* out, hipStream_t st,
+                               const float* w0p = nullptr, const float* w1p = nullptr) {
   const int wi = 8 + (w - 6);
   const size_t lds = ((size_t)32 * (wi + 1) + (CONV1 ? (size_t)32 * (C + 1) : 0) + 32) * sizeof(float);
   if (lds > 160 * 1024) return PASNL_EUNSUPPORTED;
-  auto kern = sa_cell_wide_kernel<C, CONV1>;
+  // packed operands: both matrices (the one convolution a layer has, when it has one), 16-byte aligned
+  const bool packed = w0p && (!CONV1 || w1p) && (reinterpret_cast<uintptr_t>(w0p) | reinterpret_cast<uintptr_t>(w1p)) % 16 == 0;
+  auto kern = packed ? sa_cell_wide_kernel<C, CONV1, true> : sa_cell_wide_kernel<C, CONV1, false>;
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(C / 32 * 64), lds, st, w, src, w0, b0, w1, b1, ww, bw, out);
+  hipLaunchKernelGGL(kern, dim3((unsigned)groups), dim3(C / 32 * 64), lds, st, w, src, w0, b0, w1, b1, ww, bw, out, w0p, w1p);
   return pasnl_launch_status();
 }
 
@@ -2769,7 +2802,7 @@ extern "C" int pasnl_sa_local_cell(int groups, int k, int w, int c1, int c2, con
 static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
                          const int* idx, const float* new_xyz, const float* w0, const float* b0, const float* w1,
                          const float* b1, const float* ww, const float* bw, float* out, float* skip_max, float* new_xyz_out,
-                         float* new_feature_out, pasnl_stream_t stream) {
+                         float* new_feature_out, pasnl_stream_t stream, const float* w0p = nullptr, const float* w1p = nullptr) {
   PASNL_REQUIRE(b >= 0 && n > 0 && c > 0 && m >= 0 && k > 0 && c1 > 0 && c2 > 0, PASNL_EINVAL);
   PASNL_REQUIRE(k % 32 == 0, PASNL_EUNSUPPORTED);
   const long groups = (long)b * m;
@@ -2794,7 +2827,7 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
     // a 128-channel layer with ONE convolution (mlp = [128, 128]: pointasnl_sem_seg_res.py layer2_2) on the wide kernel's
     // single-convolution form: 60 us at 2560 groups (86 with an identity conv1 on the persistent kernel below, which takes
     // the layer -- without the identity -- where the wide kernel's conditions do not hold)
-    return sa_cell_wide_launch<128, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
+    return sa_cell_wide_launch<128, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st, w0p, w1p);
   }
   // A 128-channel layer with FEW groups (pointasnl_sem_seg_res.py layer3_1: 640 groups, pointasnl_sem_seg.py layer3: 1024) on
   // the wide kernel as well: the persistent kernel stages 144 KB of weights into the LDS of each of 256 workgroups before a
@@ -2802,15 +2835,15 @@ static int sa_cell_entry(int b, int n, int c, int m, int k, int c1, int c2, cons
   constexpr long SA_WIDE128_MAX_GROUPS = 2048;
   if (c1 == 128 && c2 == 128 && w1 && groups <= SA_WIDE128_MAX_GROUPS && k == 32 && c % 16 == 0 && c >= 32 &&
       reinterpret_cast<uintptr_t>(feature) % 16 == 0)
-    return sa_cell_wide_launch<128, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
+    return sa_cell_wide_launch<128, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st, w0p, w1p);
   if ((c1 == 256 && c2 == 256) || (c1 == 512 && c2 == 512)) {  // the wide layers: one workgroup per group, weights from L2
     // c >= 32: the wide kernel preloads TWO batches of conv0's weight rows and of the LDS row unconditionally (nsteps = c / 2 >= 2 BT)
     PASNL_REQUIRE(k == 32 && c % 16 == 0 && c >= 32 && reinterpret_cast<uintptr_t>(feature) % 16 == 0, PASNL_EUNSUPPORTED);
     if (c1 == 256)
-      return w1 ? sa_cell_wide_launch<256, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st)
-                : sa_cell_wide_launch<256, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
-    return w1 ? sa_cell_wide_launch<512, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st)
-              : sa_cell_wide_launch<512, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st);
+      return w1 ? sa_cell_wide_launch<256, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st, w0p, w1p)
+                : sa_cell_wide_launch<256, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st, w0p, w1p);
+    return w1 ? sa_cell_wide_launch<512, true>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st, w0p, w1p)
+              : sa_cell_wide_launch<512, false>(groups, w, src, w0, b0, w1, b1, ww, bw, out, st, w0p, w1p);
   }
   if (c1 == 16 && c2 == 16) {  // the 16-channel first layer: xyz-only rows, 32 neighbours, centres from a table
     PASNL_REQUIRE(c == 3 && k == 32 && new_xyz, PASNL_EUNSUPPORTED);
@@ -2829,6 +2862,16 @@ extern "C" int pasnl_sa_cell(int b, int n, int c, int m, int k, int c1, int c2, 
                              pasnl_stream_t stream) {
   return sa_cell_entry(b, n, c, m, k, c1, c2, xyz, feature, idx, new_xyz, w0, b0, w1, b1, ww, bw, out, skip_max, nullptr,
                        nullptr, stream);
+}
+
+extern "C" int pasnl_sa_cell_packed(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,
+                                    const int* idx, const float* new_xyz, const float* w0, const float* b0, const float* w1,
+                                    const float* b1, const float* ww, const float* bw, const float* w0_features_packed,
+                                    const float* w1_packed, float* out, float* skip_max, float* new_xyz_out,
+                                    float* new_feature_out, pasnl_stream_t stream) {
+  PASNL_REQUIRE(new_xyz || (long)b * m == 0 || (new_xyz_out && new_feature_out), PASNL_ENULL);
+  return sa_cell_entry(b, n, c, m, k, c1, c2, xyz, feature, idx, new_xyz, w0, b0, w1, b1, ww, bw, out, skip_max,
+                       new_xyz ? nullptr : new_xyz_out, new_xyz ? nullptr : new_feature_out, stream, w0_features_packed, w1_packed);
 }
 
 extern "C" int pasnl_sa_cell_centre0(int b, int n, int c, int m, int k, int c1, int c2, const float* xyz, const float* feature,

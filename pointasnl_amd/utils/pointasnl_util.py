@@ -86,6 +86,7 @@ def sa_group(xyz, feature, idx, new_xyz):
 
 SA_TAIL_MIN_ROWS = 2048
 FP_HEAD_FUSED = True     # PointASNLDecodingLayer (inference, no autograd): three_weights + three_interpolate as one kernel
+SA_CELL_PACKED = True    # the wide cells (one workgroup per group, weights from L2) get their matrices packed in operand order too
 SA_TAIL_PACKED = True    # pasnl_sa_tail with its weights packed in operand order (16-byte weight loads)
 SA_TAIL_FUSED = True     # skip conv + back-projection + adds + aggregation in one kernel (pasnl_sa_tail); False = op by op
 SA_CELL_GATHER = True    # grouping fused into the local cell (pasnl_sa_cell); False = pasnl_sa_group + pasnl_sa_local_cell
@@ -164,6 +165,19 @@ def _sa_cell_weights(w_in, mlp, bn, weight_decay, native16=False, single=False):
     return st._folded[key]
 
 
+def _cell_packed(st, w, first_row):
+    """rows first_row.. of `w` (k, c) in the operand order of the one-workgroup-per-group cells (pasnl_mlp3_pack_weights' layout),
+    packed once per variable"""
+    key = "@cellpk%d:%x" % (first_row, w.data_ptr())
+    if key not in st._folded:
+        wc = w[first_row:].contiguous()
+        pk = torch.empty(int(_hip.lib().pasnl_mlp3_packed_weights_bytes(wc.shape[0], wc.shape[1])) // 4, dtype=torch.float32,
+                         device=w.device)
+        _hip.launch("pasnl_mlp3_pack_weights", "cell_pack", int(wc.shape[0]), int(wc.shape[1]), _hip.ptr(wc), _hip.ptr(pk))
+        st._folded[key] = (pk, w)  # (keeps `w` alive: the pointer in the key stays unique)
+    return st._folded[key][0]
+
+
 def sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay, bn):
     """Grouping + local cell in ONE kernel (pointasnl_util.py:63-74,248-249,258,264-274): the (B,P,K,6+C) grouped
     tensor is never materialised -- rows are gathered from the L2-resident per-cloud tables inside the MFMA
@@ -183,6 +197,22 @@ def sa_cell(xyz, feature, idx, new_xyz, mlp, is_training, bn_decay, weight_decay
     skip = torch.empty((b, p, 6 + c), dtype=torch.float32, device=xyz.device)
     c_out = mlp[0] if len(mlp) == 2 else mlp[1]
     view = out if c_out == ck else out[:, :, :c_out, :]
+    if SA_CELL_PACKED and ck in (128, 256, 512) and c % 16 == 0 and c >= 32 and k == 32:
+        # the shapes the one-workgroup-per-group kernels take: the feature rows of w0 and w1 ALSO in the matrix instruction's
+        # operand order (packed once, cached); the library uses them where its kernel reads weights from L2, ignores them elsewhere
+        st = tf_util.store()
+        w0p = _cell_packed(st, w0, 6)
+        w1p = _cell_packed(st, w1, 0) if w1 is not None else None
+        cen = nf = None
+        if new_xyz is None:
+            cen = torch.empty((b, p, 3), dtype=torch.float32, device=xyz.device)
+            nf = torch.empty((b, p, 3 + c), dtype=torch.float32, device=xyz.device)
+        else:
+            new_xyz = new_xyz.contiguous()
+        _hip.launch("pasnl_sa_cell_packed", "sa_cell", b, n, c, p, k, ck, ck, _hip.ptr(xyz), _hip.ptr(feature), _hip.ptr(idx),
+                    _hip.ptr(new_xyz), _hip.ptr(w0), _hip.ptr(b0), _hip.ptr(w1), _hip.ptr(b1), _hip.ptr(ww), _hip.ptr(bw),
+                    _hip.ptr(w0p), _hip.ptr(w1p), _hip.ptr(out), _hip.ptr(skip), _hip.ptr(cen), _hip.ptr(nf))
+        return (view, skip) if new_xyz is not None else (view, skip, cen, nf)
     if new_xyz is None:
         # the groups' centres are their neighbour 0 (as_neighbor == 0): the kernel takes them from its own tiles and also
         # returns new_xyz (B,P,3) and new_feature (B,P,3+C) = [centre | neighbour 0's feature row]

@@ -271,21 +271,39 @@ def test_sa_cell_16_channels_native_kernel(b, n, m, monkeypatch):
                                                (1, 64, 128, 7, 256, True), (1, 80, 512, 3, 512, True),
                                                (2, 320, 128, 320, 128, False), (1, 77, 64, 9, 128, False),
                                                (2, 300, 128, 77, 128, True), (1, 96, 64, 640, 128, True)])  # 128 channels, few groups
-def test_sa_cell_wide_layers(b, n, c, m, c1, conv1):
+def test_sa_cell_wide_layers(b, n, c, m, c1, conv1, monkeypatch):
     """The 256- / 512-channel layers (pointasnl_sem_seg.py:34, pointasnl_sem_seg_res.py:46-51) on pasnl_sa_cell: one workgroup per
     group, weights from L2; with conv1 (mlp [c, c, out]) and without (mlp [c, c]: the *_2 layers).  fp64 restatement to 1e-5,
-    skip maxima bit-equal."""
+    skip maxima bit-equal; the same bits with the weights packed in operand order (pasnl_sa_cell_packed, the default) and
+    row-major, with a centre table and with neighbour 0 as the centre."""
     from pointasnl_amd.utils import pointasnl_util as U
+    from pointasnl_amd import _hip
 
-    st = _store(b * 13 + c1 + m)
     rng = np.random.default_rng(n + c + m)
     xyz = clouds(25, b, n)
     feat = rng.standard_normal((b, n, c)).astype(np.float32)
     idx = rng.integers(0, n, (b, m, 32)).astype(np.int32)
     new_xyz = clouds(26, b, m)
     mlp = [c1, c1, 2 * c1] if conv1 else [c1, c1]
-    with st.scope("L"):
-        got, skip = U.sa_cell(dev(xyz), dev(feat), dev(idx), dev(new_xyz), mlp, False, None, None, True)
+    runs = {}
+    for packed in (False, True):
+        monkeypatch.setattr(U, "SA_CELL_PACKED", packed)
+        st = _store(b * 13 + c1 + m)
+        launched = []
+        real = _hip.launch
+        monkeypatch.setattr(_hip, "launch", lambda sym, *a: (launched.append(sym), real(sym, *a))[1])
+        with st.scope("L"):
+            runs[packed] = U.sa_cell(dev(xyz), dev(feat), dev(idx), dev(new_xyz), mlp, False, None, None, True)
+            centre0 = U.sa_cell(dev(xyz), dev(feat), dev(idx), None, mlp, False, None, None, True) if m <= n and (c <= 128 or c1 >= 256) else None
+        monkeypatch.setattr(_hip, "launch", real)
+        assert ("pasnl_sa_cell_packed" in launched) == (packed and c % 16 == 0 and c >= 32)
+        runs[packed] = (runs[packed], centre0)
+    for a, b_ in zip(runs[False][0], runs[True][0]):
+        assert torch.equal(a, b_)
+    if runs[False][1] is not None:
+        for a, b_ in zip(runs[False][1], runs[True][1]):
+            assert torch.equal(a, b_)
+    got, skip = runs[True][0]
     assert got.shape == (b, m, c1, 32)
     bi = np.arange(b)[:, None, None]
     gx = xyz[bi, idx]
