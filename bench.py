@@ -493,6 +493,9 @@ _FORWARD_STREAM = None
 SPLIT_PREFIX = os.environ.get('PASNL_BENCH_SPLIT_PREFIX', '1') != '0'  # tuning switch: sem_seg_res prefix as two plain branches
 FORK_AT_DEFAULT = os.environ.get("PASNL_BENCH_FORK_AT", "cell2")  # cls: where the next batch's prefix is forked (head / conv2 / cell2)
 SELF_KNN_PREFIX = os.environ.get('PASNL_BENCH_SELF_KNN', '0') != '0'    # tuning switch: cls / sem_seg prefix = sampler || self-kNN, then a row gather (measured: 1.335-1.349 vs 1.315 ms)
+# the next batch's self-kNN (large clouds: the grid-pruned search) as a background job on at most this many workgroups (0 = one wave
+# per query): its usual grid of ~20 000 workgroups leaves the forward's own small kernels waiting for slots (sa_tail: 10 -> 225 us)
+PREFETCH_KNN_WGS = int(os.environ.get('PASNL_BENCH_PREFETCH_KNN_WGS', '1024')) or None
 PREFETCH_SLOTS = tuple(int(v) for v in os.environ.get('PASNL_BENCH_PREFETCH_SLOTS', '3,4').split(','))  # side streams of the prefetch
 WORKLOADS = {
     1: dict(model="cls", AS=False, noise=0, batch=64, points=1024, name="configs[1]: ModelNet40 pointasnl_cls, 1024 pts"),
@@ -669,9 +672,10 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
                 into: the hand-over buffers of the step -- the kernels write them directly (no copy behind them)."""
                 xyz = xyz_of(t)
                 o = into if into is not None else [None, None, None]
+                mw = PREFETCH_KNN_WGS if into is not None else None  # inside a step's graph the search is a background job
                 if not res:
                     _, new_xyz = tf_sampling.farthest_point_sample_gather(npnt, xyz, out=(None, o[0]))
-                    return [new_xyz, pointasnl_util.knn_query(nsamp, xyz, new_xyz, out=o[1])]
+                    return [new_xyz, pointasnl_util.knn_query(nsamp, xyz, new_xyz, out=o[1], max_workgroups=mw)]
                 fps_idx, new_xyz = tf_sampling.farthest_point_sample_gather(N // 8, xyz, out=(None, o[1]))
                 if kf is not None:
                     k_all = kf.get()
@@ -679,7 +683,7 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
                         o[0].copy_(k_all)  # (the self-kNN ran on another branch into a buffer of its own)
                         k_all = o[0]
                 else:
-                    k_all = pointasnl_util.knn_query(32, xyz, xyz, out=o[0])
+                    k_all = pointasnl_util.knn_query(32, xyz, xyz, out=o[0], max_workgroups=mw)
                 return [k_all, new_xyz, pointasnl_util._gather_index_rows(k_all, fps_idx, out=o[2])]
 
             def as_search(t, bufs):
@@ -702,7 +706,7 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
                         # waits for another branch inside misleads the graph executor's placement (EXPERIMENTS.md, round 4)
                         # (both branches write the hand-over buffers of the next step themselves)
                         ff = pointasnl_util.Forked(lambda: tf_sampling.farthest_point_sample_gather(N // 8, xyz_of(xs[nxt]), out=(None, S[nxt][1])), slot=PREFETCH_SLOTS[0])
-                        kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt]), out=S[nxt][0]), slot=PREFETCH_SLOTS[1])
+                        kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt]), out=S[nxt][0], max_workgroups=PREFETCH_KNN_WGS), slot=PREFETCH_SLOTS[1])
                         fk.extend([ff, kf])
                         late.append((ff, kf, S[nxt][2]))
                         return
@@ -716,7 +720,7 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
                         fk.extend([ff, kf])
                         late.append((ff, kf, S[nxt][1]))
                         return
-                    kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt])), slot=PREFETCH_SLOTS[1]) \
+                    kf = pointasnl_util.Forked(lambda: pointasnl_util.knn_query(32, xyz_of(xs[nxt]), xyz_of(xs[nxt]), max_workgroups=PREFETCH_KNN_WGS), slot=PREFETCH_SLOTS[1]) \
                         if res else None
 
                     def run_prefix():

@@ -139,6 +139,14 @@ size_t pasnl_knn_workspace_bytes(int b, int n);
 int pasnl_knn_batch_ws(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
                        float* dist2, void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
 
+/* pasnl_knn_batch_ws as a BACKGROUND job: the query kernel runs on at most max_workgroups workgroups (a capped grid that walks
+ * the queries) instead of one wave per query -- for a search enqueued on a side stream beside other work (a serving loop's
+ * prefetch of the next batch's neighbour lists): a saturating grid of ~20 000 workgroups leaves the kernels of the other stream
+ * waiting for free slots (measured: a 10-us kernel of the forward stretched to 225 us beside it).  Same results.  Falls back to
+ * pasnl_knn_batch (uncapped) where the grid form does not apply. */
+int pasnl_knn_batch_ws_bg(int b, int n, int m, int K, const float* support, const float* queries, void* idx, int idx_is_i64,
+                          float* dist2, void* workspace, size_t workspace_bytes, int max_workgroups, pasnl_stream_t stream);
+
 /* The same K nearest neighbours in the REFERENCE'S order among exactly equal distances (and with the reference's choice of
  * which of several tied candidates is the K-th): nanoflann keeps candidates of equal distance in the order its KD-tree visits
  * them (nanoflann.hpp:115-134, :1351-1410; tree: divideTree / middleSplit_ / planeSplit :916-1043, leaf size 10,

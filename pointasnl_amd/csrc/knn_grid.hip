@@ -262,19 +262,21 @@ __device__ __forceinline__ unsigned long long kg_select(Scan&& scan, int k, int 
   return mykey;
 }
 
-template <int R, bool WIDE, typename IdxT>  // WIDE: two slots per run in the ring-1 fast path (runs up to 128 records)
+// LOOP: a capped grid (the background form) walks the cloud's queries with the grid's stride; without it a wave has ONE query
+// (the loop costs ten registers = a wave per SIMD: kept out of the usual form)
+template <int R, bool WIDE, typename IdxT, bool LOOP = false>  // WIDE: two slots per run in the ring-1 fast path (runs up to 128 records)
 __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, int m, int k, const float* __restrict__ queries,
                                                                      const char* __restrict__ ws_all, size_t stride,
                                                                      IdxT* __restrict__ idx, float* __restrict__ dist_out) {
   __shared__ unsigned long long cand[KG_WAVES][KG_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bi = blockIdx.y;
-  const int j = blockIdx.x * KG_WAVES + wave;
-  if (j >= m) return;  // wave-uniform; no workgroup barrier below
   const char* ws = ws_all + (size_t)bi * stride;
   const KgParams P = *kg_params(ws);
   const int* __restrict__ cells = kg_cells(ws);
   const float4* __restrict__ rec = kg_records(ws);
+  // one query per wave (pasnl_knn_batch_ws_bg: per wave and trip).  Wave-uniform; no workgroup barrier below.
+  auto one = [&](const int j) {
   const float* qp = queries + ((size_t)bi * m + j) * 3;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
   const int cx = kg_cell1(qx, P.x0, P.inv_h, P.gx), cy = kg_cell1(qy, P.y0, P.inv_h, P.gy), cz = kg_cell1(qz, P.z0, P.inv_h, P.gz);
@@ -391,6 +393,13 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, in
   if (lane < k) {
     idx[o + lane] = (IdxT)(uint32_t)mykey;
     if (dist_out) dist_out[o + lane] = __uint_as_float((uint32_t)(mykey >> 32));
+  }
+  };
+  if constexpr (LOOP) {
+    for (int j = blockIdx.x * KG_WAVES + wave; j < m; j += gridDim.x * KG_WAVES) one(j);
+  } else {
+    const int j = blockIdx.x * KG_WAVES + wave;
+    if (j < m) one(j);
   }
 }
 
@@ -535,8 +544,8 @@ extern "C" size_t pasnl_knn_workspace_bytes(int b, int n) {
   return (size_t)b * kg_stride(n);
 }
 
-extern "C" int pasnl_knn_batch_ws(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
-                                  int idx_is_i64, float* dist2, void* workspace, size_t workspace_bytes, pasnl_stream_t stream) {
+static int knn_batch_ws_entry(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
+                              float* dist2, void* workspace, size_t workspace_bytes, int max_workgroups, pasnl_stream_t stream) {
   const size_t need = pasnl_knn_workspace_bytes(b, n);
   if (need == 0 || k > 64 || k > n || m <= 0)  // small clouds / wide lists: the brute-force kernels (same results)
     return pasnl_knn_batch(b, n, m, k, support, queries, idx, idx_is_i64, dist2, stream);
@@ -556,13 +565,32 @@ extern "C" int pasnl_knn_batch_ws(int b, int n, int m, int k, const float* suppo
   hipLaunchKernelGGL(knn_grid_build_kernel, dim3(b), dim3(KG_BUILD_T), 0, st, n, rho, refine, support, static_cast<char*>(workspace),
                      stride);
   dim3 grid((m + KG_WAVES - 1) / KG_WAVES, b), block(KG_WAVES * 64);
-#define PASNL_KG(RR, WW, T) hipLaunchKernelGGL((knn_grid_query_kernel<RR, WW, T>), grid, block, 0, st, n, m, k, queries, \
-                                               static_cast<const char*>(workspace), stride, static_cast<T*>(idx), dist2)
-  if (k <= 16) { if (idx_is_i64) PASNL_KG(1, false, long long); else PASNL_KG(1, false, int); }
-  else if (k <= 32) { if (idx_is_i64) PASNL_KG(1, true, long long); else PASNL_KG(1, true, int); }
-  else { if (idx_is_i64) PASNL_KG(2, true, long long); else PASNL_KG(2, true, int); }
+  const bool bg = max_workgroups > 0;  // the background form: a capped grid that loops
+  if (bg) grid.x = (unsigned)std::max(1, std::min((int)grid.x, max_workgroups / b));
+#define PASNL_KG(RR, WW, T)                                                                                                   \
+  {                                                                                                                            \
+    if (bg) hipLaunchKernelGGL((knn_grid_query_kernel<RR, WW, T, true>), grid, block, 0, st, n, m, k, queries,                 \
+                               static_cast<const char*>(workspace), stride, static_cast<T*>(idx), dist2);                      \
+    else hipLaunchKernelGGL((knn_grid_query_kernel<RR, WW, T, false>), grid, block, 0, st, n, m, k, queries,                   \
+                            static_cast<const char*>(workspace), stride, static_cast<T*>(idx), dist2);                         \
+  }
+  if (k <= 16) { if (idx_is_i64) PASNL_KG(1, false, long long) else PASNL_KG(1, false, int) }
+  else if (k <= 32) { if (idx_is_i64) PASNL_KG(1, true, long long) else PASNL_KG(1, true, int) }
+  else { if (idx_is_i64) PASNL_KG(2, true, long long) else PASNL_KG(2, true, int) }
 #undef PASNL_KG
   return pasnl_launch_status();
+}
+
+extern "C" int pasnl_knn_batch_ws(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
+                                  int idx_is_i64, float* dist2, void* workspace, size_t workspace_bytes, pasnl_stream_t stream) {
+  return knn_batch_ws_entry(b, n, m, k, support, queries, idx, idx_is_i64, dist2, workspace, workspace_bytes, 0, stream);
+}
+
+extern "C" int pasnl_knn_batch_ws_bg(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
+                                     int idx_is_i64, float* dist2, void* workspace, size_t workspace_bytes, int max_workgroups,
+                                     pasnl_stream_t stream) {
+  PASNL_REQUIRE(max_workgroups > 0, PASNL_EINVAL);
+  return knn_batch_ws_entry(b, n, m, k, support, queries, idx, idx_is_i64, dist2, workspace, workspace_bytes, max_workgroups, stream);
 }
 
 extern "C" int pasnl_knn_distance_pick(int b, int n, int nq, int k, const float* pts, const unsigned int* rnd, long long* idx,

@@ -67,7 +67,7 @@ def _out_buffer(t, shape, dtype, device):
     return t
 
 
-def _knn_dev(pts, queries, K, i64, tie_order="index", out=None):
+def _knn_dev(pts, queries, K, i64, tie_order="index", out=None, max_workgroups=None):
     if tie_order == "nanoflann":
         if pts.dim() != 3 or pts.shape[2] != 3 or queries.dim() != 3 or queries.shape[2] != 3 or queries.shape[0] != pts.shape[0]:
             raise ValueError("knn_batch expects (B,N,3) pts and (B,M,3) queries")
@@ -84,29 +84,35 @@ def _knn_dev(pts, queries, K, i64, tie_order="index", out=None):
     nbytes = int(_hip.lib().pasnl_knn_workspace_bytes(b, n)) if GRID and K <= 64 else 0
     if nbytes:  # large clouds: grid-pruned search in a scratch workspace (bit-identical results, csrc/knn_grid.hip)
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=pts.device)
-        _hip.launch("pasnl_knn_batch_ws", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
-                    _hip.ptr(None), _hip.ptr(ws), ctypes.c_size_t(nbytes))
+        if max_workgroups:  # a background search beside other work: a capped grid (pasnl_knn_batch_ws_bg)
+            _hip.launch("pasnl_knn_batch_ws_bg", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out),
+                        int(i64), _hip.ptr(None), _hip.ptr(ws), ctypes.c_size_t(nbytes), int(max_workgroups))
+        else:
+            _hip.launch("pasnl_knn_batch_ws", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
+                        _hip.ptr(None), _hip.ptr(ws), ctypes.c_size_t(nbytes))
         return out
     _hip.launch("pasnl_knn_batch", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
                                           _hip.ptr(None))
     return out
 
 
-def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="index", out=None):
+def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="index", out=None, max_workgroups=None):
     """(B,N,3), (B,M,3) -> (B,M,K) neighbour indices (int64 like the reference; ``dtype=torch.int32`` skips
     the cast the models do at pointasnl_util.py:30).  ``omp`` is accepted and ignored.
     tie_order: "index" (default) = ascending (distance, index), the canonical order and what the models use; "nanoflann" =
     the reference's own order among EXACTLY equal distances (its KD-tree's visit order), bit-identical to cpp_knn_batch on
     lattices and duplicated points too -- slower (the tree is rebuilt per call), for exact reproduction only; K <= 64 and
     N <= 65535 (PasnlUnsupported beyond).  Captured into a HIP graph its tree-depth flag stays on the device:
-    check_deferred_flags() after the replay.  out: optional device buffer (B,M,K) of the result's dtype to write into."""
+    check_deferred_flags() after the replay.  out: optional device buffer (B,M,K) of the result's dtype to write into.
+    max_workgroups: run the search of a large cloud as a background job on at most that many workgroups (a side stream's
+    search beside other work; the same results, see pasnl_knn_batch_ws_bg)."""
     host = not isinstance(pts, torch.Tensor)
     p = _hip.as_dev(pts, torch.float32)
     q = _hip.as_dev(queries, torch.float32)
     i64 = dtype in (None, torch.int64, np.int64)
     if out is not None and host:
         raise ValueError("knn_batch: out= takes a device tensor (device inputs only)")
-    out = _knn_dev(p, q, K, i64, tie_order, out)
+    out = _knn_dev(p, q, K, i64, tie_order, out, max_workgroups)
     return out.cpu().numpy() if host else out
 
 

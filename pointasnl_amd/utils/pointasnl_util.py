@@ -27,11 +27,12 @@ KNN_TIE_ORDER = "index"  # "nanoflann": neighbour lists in the reference's own o
 #                          coordinates; slower (a tree per call).  Distinct distances: both orders are the same list.
 
 
-def knn_query(k, support_pts, query_pts, out=None):
+def knn_query(k, support_pts, query_pts, out=None, max_workgroups=None):
     """Mirror of pointasnl_util.py:22-30.  support_pts (B,N1,3), query_pts (B,N2,3) -> (B,N2,k) int32: for every query the
     indices of its k nearest support points, nearest first.  No host round trip here: the search is a gfx950 kernel.
-    out: optional (B,N2,k) int32 buffer to write into."""
-    return nearest_neighbors.knn_batch(support_pts, query_pts, k, omp=True, dtype=torch.int32, tie_order=KNN_TIE_ORDER, out=out)
+    out: optional (B,N2,k) int32 buffer to write into; max_workgroups: a background search on a capped grid (knn_batch)."""
+    return nearest_neighbors.knn_batch(support_pts, query_pts, k, omp=True, dtype=torch.int32, tie_order=KNN_TIE_ORDER, out=out,
+                                       max_workgroups=max_workgroups)
 
 
 def _gather_rows(points, idx):

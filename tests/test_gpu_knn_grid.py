@@ -78,6 +78,20 @@ def test_grid_knn_is_bit_identical_to_brute_force_and_oracle(name):
     np.testing.assert_array_equal(g[:1, sub], want)
 
 
+@pytest.mark.parametrize("name", ["kitti_10240", "k64", "n16384", "queries_outside", "k1", "duplicates"])
+@pytest.mark.parametrize("cap", [1, 7, 512])
+def test_grid_knn_background_form_gives_the_same_lists(name, cap):
+    """pasnl_knn_batch_ws_bg (a capped grid that walks the queries: the form a serving loop uses for a search beside other
+    work): the lists of the one-wave-per-query form, bit for bit, for caps below the batch size, odd caps and a usual one."""
+    import pointasnl_amd as P
+    sup, qry, k = CASES[name]
+    qry = sup if qry is None else qry
+    s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    usual = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32)
+    capped = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, max_workgroups=cap)
+    assert torch.equal(usual, capped)
+
+
 def test_grid_knn_distances_and_int64():
     from pointasnl_amd import _hip
     import ctypes
