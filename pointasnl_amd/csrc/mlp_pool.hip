@@ -5,16 +5,17 @@
 // per module: eight launches at 58-123 TF whose 256 tiles (one per CU) stretch by whatever shares a CU with them (the next
 // batch's sampler: 78 -> 141 us for the widest product).
 //
-// One workgroup of 8 waves owns a tile of 32 points of one cloud and carries it through all three convolutions:
-//   X (32 x k0) -> LDS buffer A;  H1 = relu(X W0 + b0) -> LDS buffer B;  H2 = relu(H1 W1 + b1) -> buffer A;
-//   H3 = relu(H2 W2 + b2) never leaves the registers: its column maxima over the tile's 32 rows go to partial[cloud][tile][:].
+// One workgroup of 8 waves owns a tile of 32 RB points of one cloud (RB = 2 row blocks where 64 rows of activations fit the
+// LDS -- every weight then feeds two products --, else 1) and carries it through all three convolutions:
+//   X (rows x k0) -> LDS buffer A;  H1 = relu(X W0 + b0) -> LDS buffer B;  H2 = relu(H1 W1 + b1) -> buffer A;
+//   H3 = relu(H2 W2 + b2) never leaves the registers: its column maxima over the tile's rows go to partial[cloud][tile][:].
 // v_mfma_f32_32x32x2_f32 with A = the activations (row ql of the tile, LDS, odd row pitch: conflict-free), B = the weights
 // (straight from global memory / L2, PACKED in operand order: 32 bytes per lane and batch of eight steps, see mp_mm),
 // D[m = row kappa(r, h)][n = channel]: the bias is one value per lane, the store of a block is column-contiguous, and the
 // pooled maximum is a maximum over a lane's 16 accumulators and one exchange between the wave's halves.  A wave owns the
 // 32-channel blocks wave, wave + 8, ...: one LDS operand feeds up to four products.  Operands of the NEXT eight steps are
-// requested while eight steps multiply (two register sets).  The grid has 4 (n = 128) or 16 (n = 512) tiles per cloud: more
-// workgroups than CUs, handed out by the dispatcher as CUs become free -- a CU that shares its time with the sampler simply
+// requested while eight steps multiply (two register sets).  The grid has 4 (n = 128, 32-row tiles) or 8 (n = 512, 64-row tiles) tiles
+// per cloud: more workgroups than CUs, handed out by the dispatcher as CUs become free -- a CU that shares its time with the sampler simply
 // takes fewer tiles.  fp32 MFMA: an exact fmaf chain (another summation order than the vendor GEMM's: parity 1e-5 of scale).
 #include "common.hpp"
 
