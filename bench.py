@@ -320,6 +320,8 @@ def measured_traffic(symbol, dims):
 # supervisor: progress-watched worker processes
 # ---------------------------------------------------------------------------------------------------------------
 HEARTBEAT_ENV = "PASNL_BENCH_HEARTBEAT_FD"
+# environment the supervisor / its tests use to watch the worker: not tuning switches (config.switches lists the others)
+SUPERVISOR_ENV = ("PASNL_BENCH_HEARTBEAT_FD", "PASNL_BENCH_STALL_SCALE", "PASNL_BENCH_SUPERVISE", "PASNL_BENCH_WATCHDOG", "PASNL_BENCH_FAKE_STALL")
 # seconds without a heartbeat that count as a stall, per phase the worker announces.  start: interpreter + first
 # `import torch` on a fresh box (minutes) + RCCL init; setup: eager forwards, BLAS heuristics, graph capture;
 # run: warm-up + timed steps (+ per step, see beat()); post: event-instrumented pass, the other configurations,
@@ -574,7 +576,7 @@ def run_config(cfg_index, spec, *a, **kw):
 
 
 def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, graph=True, kernel_pass=True, announce=True,
-                pipeline="serial", _switched=None):
+                pipeline="serial", extra_blocks=0, _switched=None):
     """Measure one workload on the current device -> dict.  The timed region is `steps` forwards bracketed by
     (barrier +) torch.cuda.synchronize() on both sides, max over ranks.
 
@@ -800,6 +802,25 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
             t = torch.tensor([elapsed], dtype=torch.float64, device=x.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        # ---- the spread of the figure: `extra_blocks` further blocks of K steps, each bracketed like the timed region (VERDICT r05
+        # weak 8: one 20-step block is 26 ms on boxes that differ by 15 %).  `value` stays the contract's EXACTLY-K-steps block above.
+        block_ms = [elapsed / steps * 1e3]
+        for _ in range(extra_blocks):
+            if multi:
+                dist.barrier()
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(steps + steps % max(1, len(graphs))):  # (whole rounds over the buffers: buffer 0 is next again)
+                last = step()
+            torch.cuda.synchronize()
+            if multi:
+                dist.barrier()
+            eb = time.perf_counter() - tb
+            if multi:
+                t = torch.tensor([eb], dtype=torch.float64, device=x.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                eb = float(t.item())
+            block_ms.append(eb / (steps + steps % max(1, len(graphs))) * 1e3)
         gathered_ok, shards_differ = None, None
         if gather is not None:
             # this rank's rows of the gathered logits are its own logits, and EVERY rank's rows carry that rank's logits: the
@@ -837,7 +858,7 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
         from pointasnl_amd.utils.nearest_neighbors.lib.python import nearest_neighbors as NN
         torch.cuda.synchronize()
         NN.check_deferred_flags(clear=True)  # (reference tie order inside a graph: the tree-depth flags of the replays)
-    return {"B": B, "N": N, "elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "enqueue_ms_per_step": enqueued / steps * 1e3, "clouds_per_s": world * B * steps / elapsed,
+    return {"B": B, "N": N, "elapsed": elapsed, "block_ms": block_ms, "ms_per_step": elapsed / steps * 1e3, "enqueue_ms_per_step": enqueued / steps * 1e3, "clouds_per_s": world * B * steps / elapsed,
             "graph": bool(graphs), "pipeline": pipeline if graphs else "eager", "outputs_agree": agree, "gathered_ok": gathered_ok,
             "shards_differ": shards_differ, "rows": rows, "launch_order": launch_order, "pc": pc, "store": store,
             "mode_dev": mode_dev}
@@ -930,6 +951,7 @@ def main():
     ap.add_argument("--worker", action="store_true", help="run the measurement in this process without a supervisor (the supervisor passes it; use it under profilers)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each: the first one is `value` (the contract's exactly-K-steps region), all of them go to ms_per_step_blocks")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (weak scaling); default: the BASELINE config's")
     ap.add_argument("--AS", action="store_true", help="time configs[2] (adaptive sampling on, noisy clouds) as the main workload")
@@ -1030,7 +1052,7 @@ def main():
     if args.points:
         spec["points"] = args.points
     res = run_config(main_index, spec, args.steps, args.warmup, rank=rank, world=world, multi=multi, graph=not args.no_graph,
-                     pipeline=args.pipeline)
+                     pipeline=args.pipeline, extra_blocks=max(0, args.blocks - 1))
     serial = None
     if args.pipeline != "serial" and not args.no_graph:  # the same workload without the cross-batch overlap (every rank takes part)
         # (an auxiliary figure: the better of two short runs, so that one stalled replay -- a clock ramp, an allocator sync --
@@ -1123,8 +1145,9 @@ def main():
     if multi:  # multi-rank checks (constants / nulls in a plain N = 1 run; --force-dist rehearses them with one rank)
         config.update({"rccl_ranks": rccl_ranks, "allreduce_check": allreduce_check, "gathered_rows_match_local": res["gathered_ok"],
                        "shards_differ": res["shards_differ"], "numa_node": numa_node, "cpus_bound": cpus_bound})
-    if args.set:
-        config["switches"] = ",".join(args.set)
+    # every tuning switch that was active in this process: an empty list on the driver's command line
+    config["switches"] = sorted(f"{k}={v}" for k, v in os.environ.items() if k.startswith("PASNL_BENCH_") and k not in SUPERVISOR_ENV) + \
+        [f"--set {v}" for v in (args.set or [])]
     out = {
         "metric": "point-clouds/sec fwd (Bx1024 pts, ModelNet40 cls)" if args.model == "cls" else
                   f"point-clouds/sec fwd (Bx{res['N']} pts, pointasnl_{args.model})",
@@ -1134,6 +1157,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(res["ms_per_step"], 4),
+        "ms_per_step_blocks": {"blocks": [round(v, 4) for v in res["block_ms"]], "median": round(float(np.median(res["block_ms"])), 4),
+                               "min": round(min(res["block_ms"]), 4), "max": round(max(res["block_ms"]), 4),
+                               "note": "blocks[0] is the timed region `value` is computed from; the others follow it, each of `steps` steps between synchronisations"},
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -460,6 +460,25 @@ int pasnl_grid_subsample(long n, int fdim, int ldim, const float* points, const 
                          float sample_dl, float* out_points, float* out_features, int* out_classes, int* out_count,
                          void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
 
+/* The search inside `crop_pc` (SemanticKITTI/semantic_kitti_dataset_grid.py:265-272): around ONE centre per crop, the k nearest
+ * points of a scan -- sklearn `KDTree.query(center, k=num_point+buffer)` (:271) -- or every point within a radius --
+ * `query_radius(center, r=in_radius)` (:269).  b crops; crop c searches the n points at points + c*scan_stride*3
+ * (scan_stride = 0: every crop searches the same scan) around centres[c,:].  Ranking key: the squared distance
+ * ((dx*dx)+(dy*dy))+(dz*dz) evaluated in DOUBLE on the float32 coordinates (what sklearn computes on its float64 copy of
+ * the data), so the selected set is sklearn's; a tie at the k-th distance goes to the lowest indices (sklearn: tree visit
+ * order).  radius > 0: the radius form, d2 <= radius*radius inclusive (k ignored); otherwise k[c] (device ints; NULL: kcap
+ * for every crop) nearest, clamped to [0, min(n, kcap)].
+ * -> out_idx (b,kcap) i32: the selected indices in ASCENDING INDEX order (crop_pc shuffles them at once, :274; sort by
+ * out_d2 for KDTree.query's order), entries behind the count are not written; out_d2 (b,kcap) f64 their squared
+ * distances (NULL: not wanted); out_count (b) i32: the number selected (radius form: the TRUE number within the radius,
+ * which may exceed kcap -- only the first kcap by index are stored).
+ * An exact radix selection on the 63 key bits (no tree), 8 launches, no host synchronisation.
+ * workspace: pasnl_knn_crop_workspace_bytes(b, n) bytes (8 n per crop for the keys + histograms). */
+size_t pasnl_knn_crop_workspace_bytes(int b, long n);
+int pasnl_knn_crop(int b, long n, long scan_stride, const float* points, const float* centres, const int* k, int kcap,
+                   double radius, int* out_idx, double* out_d2, int* out_count, void* workspace, size_t workspace_bytes,
+                   pasnl_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

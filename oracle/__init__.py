@@ -236,3 +236,31 @@ class ops:
         return out[0] if len(out) == 1 else tuple(out)
 
 
+
+    @staticmethod
+    def crop_d2(points, centre):
+        """sklearn EuclideanDistance.rdist on the KDTree's float64 copy of the float32 scan (what `search_tree.query` /
+        `query_radius` rank by, semantic_kitti_dataset_grid.py:269-271): d = 0; d += t*t per axis, in order, in double."""
+        p = _f32(points).astype(np.float64)
+        c = _f32(np.asarray(centre).reshape(3)).astype(np.float64)
+        d = p - c
+        return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+
+    @staticmethod
+    def knn_crop(points, centre, k):
+        """The k nearest points of a scan to one centre: indices in ASCENDING INDEX order + their squared distances (f64).
+        A tie at the k-th distance goes to the lowest indices (sklearn: tree visit order; pinned against sklearn in
+        tests/test_oracle_crop.py).  k is clamped to [0, n]."""
+        d2 = ops.crop_d2(points, centre)
+        n = d2.shape[0]
+        k = max(0, min(int(k), n))
+        order = np.lexsort((np.arange(n), d2))[:k]  # by (d2, index)
+        sel = np.sort(order).astype(np.int32)
+        return sel, d2[sel]
+
+    @staticmethod
+    def radius_crop(points, centre, radius):
+        """Every point with d2 <= radius*radius (inclusive, both in double: sklearn query_radius), ascending index."""
+        d2 = ops.crop_d2(points, centre)
+        sel = np.nonzero(d2 <= np.float64(radius) * np.float64(radius))[0].astype(np.int32)
+        return sel, d2[sel]

@@ -308,7 +308,9 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
   const int cbase2 = (int)((reinterpret_cast<char*>(cstart) - smem) >> 1);  // cstart's offset in 16-bit units
   const int rowz = gy * gx;
   // -> rs[r] = first record of run r, rl[r] = its length (0: empty, outside the grid, or beyond the ball; rs is then arbitrary
-  //    but < n: a table entry made of it is a run of zero records)
+  //    but <= min(n, BG_NMAX - 1) -- it fits the 11 position bits of a table entry, which is then a run of ZERO records.  A cell
+  //    start can equal n (an empty window in the tail of the last row of cells): at n == BG_NMAX that is 2048 = bit 11 = "one
+  //    record at position 0" in an entry, so the largest instantiation clamps it)
   auto runs_of = [&](float qx, float qy, float qz, bool live, uint32_t (&rs)[9], uint32_t (&rl)[9]) {
     const float ux = (qx - lo[0]) * inv_hx, uy = (qy - lo[1]) * inv_h, uz = (qz - lo[2]) * inv_h;
     const float uxc = fminf(fmaxf(ux, -2.f), gxf1);  // a query outside the grid looks from its border: a superset
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(BG_THREADS, NW32 <= 32 ? 6 : 4) void ball_grid_kern
         const int sv = reinterpret_cast<const unsigned short*>(smem)[cb + x0];
         const int ev = reinterpret_cast<const unsigned short*>(smem)[cb + max(x1 + 1, 0)];
         const int len = ev - sv;
-        rs[r] = (uint32_t)sv;
+        rs[r] = NW32 * 32 >= BG_NMAX ? (uint32_t)min(sv, BG_NMAX - 1) : (uint32_t)sv;  // (len <= 0 whenever sv == n)
         rl[r] = (ok && len > 0) ? (uint32_t)len : 0u;
       }
   };

@@ -174,6 +174,27 @@ def test_query_ball_point_grid_edges(P, case):
     np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
 
 
+@pytest.mark.parametrize("n", [2048, 2047, 1500])
+@pytest.mark.parametrize("r", [0.24, 0.3, 0.12])
+def test_query_ball_point_wedge_empty_tail(P, n, r):
+    """ADVICE r05 (ball_grid.hip:397): at n == 2048 an EMPTY run whose cell start equals n used to become the table entry 0x800 =
+    "one record at position 0"; as a lane's trailing entry it counted record 0 twice when record 0 lay inside the ball.  A wedge that
+    is long in x and thin in y / z, tapering so that the last rows of cells are empty, with the queries next to record 0."""
+    rng = np.random.default_rng(n * 7 + int(r * 100))
+    b, m, ns = 3, 400, 32
+    t = rng.random((b, n, 1)) ** 0.5                       # dense at the thick end
+    xyz1 = np.concatenate([10 * t, 1.5 * t * rng.random((b, n, 1)), 1.5 * t * rng.random((b, n, 1))], -1).astype(np.float32)
+    # record 0 in the grid's LAST cell (max x, max y, max z corner is empty for most draws: the wedge's cross-section is a square
+    # whose far corner few points reach), queries scattered around record 0 and around the far corner
+    xyz1[:, 0] = xyz1.max(1) - np.float32(0.05)
+    xyz2 = (xyz1[:, :1] + (rng.random((b, m, 3)).astype(np.float32) - 0.5) * np.float32(2 * r)).astype(np.float32)
+    xyz2[:, m // 2:] = xyz1[:, rng.integers(0, n, m - m // 2)][0][None]
+    want_idx, want_cnt = O.query_ball_point(r, ns, xyz1, xyz2)
+    idx, cnt = P.tf_grouping.query_ball_point(r, ns, dev(xyz1), dev(xyz2))
+    np.testing.assert_array_equal(cnt.cpu().numpy(), want_cnt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_idx)
+
+
 def test_ball_radius_boundary(P):
     # points at distances straddling sqrt: radius 0.25 exactly representable, lattice of 1/8
     xyz1 = clouds(9, 1, 2000, "lattice")
