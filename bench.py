@@ -122,7 +122,7 @@ def algorithmic(symbol, ints):
     if symbol == "pasnl_group_point":
         b, n, c, m, ns = ints
         return 4 * b * (n * c + m * ns + m * ns * c), 0, "hbm"
-    if symbol in ("pasnl_knn_batch", "pasnl_knn_batch_ws"):
+    if symbol in ("pasnl_knn_batch", "pasnl_knn_batch_ws", "pasnl_knn_batch_ws_bg", "pasnl_knn_batch_ref"):
         b, n, m, k = ints[:4]
         return 12 * b * (n + m) + 4 * b * m * k, 8 * b * n * m, "valu"  # a search: vector-issue bound
     if symbol == "pasnl_knn_batch_tree":
@@ -131,6 +131,10 @@ def algorithmic(symbol, ints):
     if symbol in ("pasnl_dense_splitk", "pasnl_dense_splitk_workspace"):
         rows, k, n = ints[:3]
         return 4 * (rows * k + k * n + n + rows * n), 2 * rows * k * n, "mfma"
+    if symbol == "pasnl_knn_crop":
+        b, n = ints[:2]
+        kcap = ints[3]
+        return 12 * b * n + 4 * b * kcap, 8 * b * n, "hbm"  # one pass over the scan; the five key passes stay in L2
     if symbol == "pasnl_query_ball_point":
         b, n, m, ns = ints
         return 12 * b * (n + m) + 4 * b * m * (ns + 1), 10 * b * n * m, "hbm"
@@ -290,7 +294,8 @@ def csrc_digests():
 
 
 # kernels that live in another file than the entry point that launches them
-EXTRA_SOURCES = {"pasnl_query_ball_point": ["ball_grid.hip", "sortnet.inc"], "pasnl_knn_batch_ws": ["grouping.hip"]}
+EXTRA_SOURCES = {"pasnl_query_ball_point": ["ball_grid.hip", "sortnet.inc"], "pasnl_knn_batch_ws": ["grouping.hip"],
+                 "pasnl_knn_batch_ref": ["grouping.hip", "knn_grid.hip", "knn_tree.hip"]}
 
 
 def measured_traffic(symbol, dims):
@@ -528,9 +533,20 @@ MODES = [
     dict(tag="bf16x3", cfg=3, switches={"tf_util.DENSE_BF16X3": True},
          what="the long GEMMs (>= 256 output tiles, K >= 512) as six bf16 matrix products of three-term operand splits, fp32 "
               "accumulation: fp32-grade (1e-5 of scale against fp64), not the fp32 chain's bits", dtype="f32 (bf16x3 products)"),
-    dict(tag="reference_tie_order", cfg=1, switches={"pointasnl_util.KNN_TIE_ORDER": "nanoflann"},
-         what="neighbour lists in the reference KD-tree's order among exactly equal distances (tree build + leaf-order search "
-              "captured in the graph, the depth flag read after the replays)", dtype="f32"),
+    dict(tag="canonical_tie_order", cfg=1, switches={"pointasnl_util.KNN_TIE_ORDER": "index"},
+         what="neighbour lists in canonical (distance, index) order: the default (the reference's order among equal distances) minus "
+              "its tie flags and the four tree kernels that return at once on tie-free clouds -- the price of the default", dtype="f32"),
+    dict(tag="canonical_tie_order_cfg3", cfg=3, switches={"pointasnl_util.KNN_TIE_ORDER": "index"},
+         what="configs[3] with canonical neighbour order: what the default's tie handling costs on 8192-point clouds", dtype="f32"),
+    dict(tag="canonical_tie_order_cfg4", cfg=4, switches={"pointasnl_util.KNN_TIE_ORDER": "index"},
+         what="configs[4] with canonical neighbour order: voxel-thinned lidar clouds have equal distances in ~0.15 % of the lists, so "
+              "the default builds the KD-tree of every cloud at the input level", dtype="f32"),
+    dict(tag="lattice_default_tie_order", cfg=1, switches={}, lattice=8,
+         what="the DEFAULT on clouds made of ties: coordinates snapped to multiples of 1/8 (SURVEY 8(d) lattice stress set) -- nearly "
+              "every query is flagged and goes through the rebuilt KD-tree (build + leaf-order search inside the graph)", dtype="f32"),
+    dict(tag="every_query_through_the_tree", cfg=1, switches={"pointasnl_util.KNN_TIE_ORDER": "nanoflann"},
+         what="the checker of the default: EVERY query of every cloud through the rebuilt KD-tree (round 5's reference_tie_order "
+              "mode)", dtype="f32"),
 ]
 
 
@@ -543,6 +559,8 @@ def make_input(cfg_index, spec, rank):
     pc = synth_clouds(seed, spec["batch"], spec["points"])
     if spec["AS"]:
         pc = add_noise(pc, spec["noise"], seed)
+    if spec.get("lattice"):  # (modes) the lattice stress set: distance ties everywhere
+        pc = (np.round(pc * spec["lattice"]) / spec["lattice"]).astype(np.float32)
     return pc
 
 
@@ -627,7 +645,7 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
     if announce:
         beat("setup")
     mode_dev = None
-    if spec.get("switches"):  # a MODE: the default mode's eager logits first, then the switches (restored on the way out)
+    if spec.get("switches") is not None:  # a MODE: the default mode's eager logits first, then the switches (restored on the way out)
         with torch.no_grad():
             ref_default = forward().clone()
         for target, value in spec["switches"].items():
@@ -854,10 +872,9 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
             per_fwd = len(_hip.PROFILE) // max(1, reps)
             launch_order = [[sym, list(ints)] for sym, ints, _, _ in _hip.PROFILE[:per_fwd]]
             _hip.PROFILE = None
-    if spec.get("switches"):
-        from pointasnl_amd.utils.nearest_neighbors.lib.python import nearest_neighbors as NN
-        torch.cuda.synchronize()
-        NN.check_deferred_flags(clear=True)  # (reference tie order inside a graph: the tree-depth flags of the replays)
+    from pointasnl_amd.utils.nearest_neighbors.lib.python import nearest_neighbors as NN
+    torch.cuda.synchronize()
+    NN.check_deferred_flags(clear=True)  # (the reference's tie order is the default: the sticky tree-depth flag of every search so far)
     return {"B": B, "N": N, "elapsed": elapsed, "block_ms": block_ms, "ms_per_step": elapsed / steps * 1e3, "enqueue_ms_per_step": enqueued / steps * 1e3, "clouds_per_s": world * B * steps / elapsed,
             "graph": bool(graphs), "pipeline": pipeline if graphs else "eager", "outputs_agree": agree, "gathered_ok": gathered_ok,
             "shards_differ": shards_differ, "rows": rows, "launch_order": launch_order, "pc": pc, "store": store,
@@ -1099,7 +1116,7 @@ def main():
         for md in MODES:
             if args.no_graph:
                 break
-            mspec = dict(WORKLOADS[md["cfg"]], switches=md["switches"])
+            mspec = dict(WORKLOADS[md["cfg"]], switches=md["switches"], lattice=md.get("lattice"))
             r = run_config(md["cfg"], mspec, args.other_steps, 4, graph=True, kernel_pass=False, announce=False, pipeline=args.pipeline)
             beat("post")
             base = res if md["cfg"] == main_index else None

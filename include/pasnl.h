@@ -161,6 +161,22 @@ size_t pasnl_knn_tree_workspace_bytes(int b, int n, int m, int k);
 int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
                          void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
 
+/* cpp_knn_batch's RESULT, ties included, at the canonical kernels' price -- what the Python mirror calls by default.
+ * replaces cpp_knn_batch / cpp_knn_batch_omp  knn_.cxx:72-135 (result-set order: nanoflann.hpp:115-134).
+ * nanoflann's list can differ from the (distance, index) list only where distances are EQUAL -- two of them inside a query's
+ * K-list, or a candidate beyond the list at exactly the K-th distance.  So: the canonical search (pasnl_knn_batch_ws's choice
+ * of kernel) writes every row and, from the sorted keys it already holds, lists the queries with such a tie; then the KD-tree
+ * of every cloud that has a listed query is built and searched for THOSE queries (pasnl_knn_batch_tree's kernels), whose rows
+ * are overwritten.  All counts stay on the device: every kernel is launched and returns at once where nothing is listed -- no
+ * host synchronisation, capturable.  Tie-free clouds pay four empty launches; output == pasnl_knn_batch_tree's bit for bit.
+ * depth_flag (device int, required): set to 1 -- never cleared by the library -- if a listed query's tree or search was deeper
+ * than 96 levels; such rows KEEP the canonical order (valid neighbours, canonical order among equals).
+ * max_workgroups > 0: the grid-pruned canonical search as a background job (pasnl_knn_batch_ws_bg); 0: the usual grid.
+ * k <= n, k <= 64, n <= 65535 (else PASNL_EUNSUPPORTED).  workspace: pasnl_knn_batch_ref_workspace_bytes(b, n, m, k). */
+size_t pasnl_knn_batch_ref_workspace_bytes(int b, int n, int m, int k);
+int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
+                        int* depth_flag, void* workspace, size_t workspace_bytes, int max_workgroups, pasnl_stream_t stream);
+
 /* ------------------------------------------------------- interpolation (tf_ops/3d_interpolation) */
 
 /* Three nearest known points, squared distances ascending, lowest index first on ties.

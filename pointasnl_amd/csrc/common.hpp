@@ -187,6 +187,28 @@ __device__ __forceinline__ void wave_bitonic_sort(KeyT (&v)[NREG], int lane) {
   }
 }
 
+// ---- kNN in the reference's order (pasnl_knn_batch_ref): which queries need the KD-tree search at all.
+// nanoflann's result can differ from the canonical (distance, index) list only where distances are EQUAL: inside the K-list
+// (its order among equals is the tree's visit order) or at its end (which of several candidates at the K-th distance is kept).
+// A query with neither has ONE possible answer, and the canonical kernels have already written it.
+struct KnnTieFlags {
+  int* nflag;   // [b] flagged queries per cloud (zeroed before the launch); nullptr: no flagging
+  int* flist;   // [b][m] their numbers, in arrival order (the order does not matter: rows are independent)
+};
+// sorted ascending keys (distance bits << 32 | index): rank l in lane l of key0, rank 64 + l in lane l of key1 (absent: ~0).
+// True (wave-uniform) if two of the first k distances are equal or the (k+1)-th candidate ties with the k-th.  1 <= k <= 64.
+__device__ __forceinline__ bool knn_sorted_has_tie(unsigned long long key0, unsigned long long key1, int k, int lane) {
+  const uint32_t d = (uint32_t)(key0 >> 32);
+  const uint32_t prev = (uint32_t)wave_shr1_i((int)d);  // lane l: rank l - 1 (lane 0: its own, excluded below)
+  const uint32_t dnext = k < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)d, k & 63)
+                                : (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key1 >> 32), 0);
+  const uint32_t dlast = (uint32_t)__builtin_amdgcn_readlane((int)d, (k - 1) & 63);
+  return __builtin_amdgcn_ballot_w64(lane >= 1 && lane < k && d == prev) != 0ull || dnext == dlast;
+}
+__device__ __forceinline__ void knn_flag_query(const KnnTieFlags f, int bi, int m, int j, int lane) {
+  if (lane == 0) f.flist[(size_t)bi * m + atomicAdd(&f.nflag[bi], 1)] = j;
+}
+
 // Tuning / A-B switches read from the environment exist ONLY in the diagnostic build (make tuning ->
 // libpasnl_hip_tuning.so, never loaded by the package): the product library reads no environment variable and
 // keeps no global state (include/pasnl.h), so a launch is a pure function of its arguments.
@@ -196,4 +218,14 @@ inline const char* tune_env(const char* name) { return getenv(name); }
 constexpr const char* tune_env(const char*) { return nullptr; }
 #endif
 
+
+// internal launchers behind pasnl_knn_batch / _ws / _tree / _ref (host side; defined in grouping.hip, knn_grid.hip, knn_tree.hip)
+int knn_brute_launch(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64, float* dist2,
+                     KnnTieFlags flags, hipStream_t st);
+size_t knn_grid_ws_bytes(int b, int n);
+int knn_grid_launch(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64, float* dist2,
+                    void* workspace, size_t workspace_bytes, int max_workgroups, KnnTieFlags flags, hipStream_t st);
+size_t knn_tree_ws_bytes(int b, int n, int m, int k);
+int knn_tree_launch(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64, void* workspace,
+                    size_t workspace_bytes, KnnTieFlags only, int* depth_flag, hipStream_t st);
 }  // namespace pasnl

@@ -148,7 +148,7 @@ __device__ __forceinline__ void knn_insert(KnnList<SLOTS>& L, float cd, int ck, 
 template <int SLOTS, int QW, typename IdxT>
 __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn_kernel(int n, int m, int k, const float* __restrict__ support,
                                                                const float* __restrict__ queries, IdxT* __restrict__ idx,
-                                                               float* __restrict__ dist_out) {
+                                                               float* __restrict__ dist_out, const KnnTieFlags flags) {
   __shared__ float sx[SEARCH_TILE], sy[SEARCH_TILE], sz[SEARCH_TILE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bi = blockIdx.y;
@@ -156,6 +156,11 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn_kernel(int n, int m, in
   const int q0 = (blockIdx.x * SEARCH_WAVES + wave) * QW;
 
   float qx[QW], qy[QW], qz[QW], tau[QW];
+  // (flagging for pasnl_knn_batch_ref) the value of tau at which a point that is NOT in the list was last seen at exactly the
+  // K-th distance -- a candidate refused with d == tau, or the old K-th entry pushed out by an insertion that left an equal
+  // distance in its place.  tau only falls: the K-list ends on a tie iff this equals the final tau.
+  float tie_tau[QW];
+  const bool flagging = flags.nflag != nullptr;
   KnnList<SLOTS> L[QW];
   const int ks = (k - 1) >> 6, kl = (k - 1) & 63;  // slot / lane of the K-th entry
 #pragma unroll
@@ -164,6 +169,7 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn_kernel(int n, int m, in
     const float* p = queries + ((size_t)bi * m + j) * 3;
     qx[q] = p[0]; qy[q] = p[1]; qz[q] = p[2];
     tau[q] = INFINITY;
+    tie_tau[q] = -1.f;
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) { L[q].d[s] = INFINITY; L[q].i[s] = 0; }
   }
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn_kernel(int n, int m, in
       for (int q = 0; q < QW; ++q) {
         float d = dq[q];
         unsigned long long mask = __ballot(in && d < tau[q]);
+        if (flagging && __ballot(in && d == tau[q]) != 0ull) tie_tau[q] = tau[q];
         while (mask) {
           int src = (int)__builtin_ctzll(mask);
           mask &= mask - 1;
@@ -193,7 +200,10 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn_kernel(int n, int m, in
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s)
               if (s == ks) t = readlane_f(L[q].d[s], kl);
+            if (t == tau[q]) tie_tau[q] = t;  // the entry that fell off the end had the distance the new K-th has
             tau[q] = t;
+          } else if (cd == tau[q]) {
+            tie_tau[q] = cd;
           }
         }
       }
@@ -204,6 +214,7 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn_kernel(int n, int m, in
     int j = q0 + q;
     if (j >= m) continue;
     size_t o = ((size_t)bi * m + j) * k;
+    bool tie = flagging && tie_tau[q] == tau[q];
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       int r = s * 64 + lane;
@@ -211,7 +222,13 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn_kernel(int n, int m, in
         idx[o + r] = (IdxT)L[q].i[s];
         if (dist_out) dist_out[o + r] = L[q].d[s];
       }
+      if (flagging) {  // two equal distances next to each other inside the list (rank r - 1 sits in the lane below, or in lane 63 of the slot below)
+        float prev = wave_shr1_f(L[q].d[s]);
+        if (lane == 0) prev = s > 0 ? readlane_f(L[q].d[s > 0 ? s - 1 : 0], 63) : -1.f;
+        tie = tie || __ballot(r >= 1 && r < k && L[q].d[s] == prev) != 0ull;
+      }
     }
+    if (tie) knn_flag_query(flags, bi, m, j, lane);
   }
 }
 
@@ -244,7 +261,7 @@ __device__ unsigned long long knn_probe[8];
 template <int R, int QW, typename IdxT>
 __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, int k, const float* __restrict__ support,
                                                                 const float* __restrict__ queries, IdxT* __restrict__ idx,
-                                                                float* __restrict__ dist_out) {
+                                                                float* __restrict__ dist_out, const KnnTieFlags flags) {
   __shared__ float sx[SEARCH_TILE], sy[SEARCH_TILE], sz[SEARCH_TILE];
   __shared__ unsigned long long cand[SEARCH_WAVES * QW][KNN2_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -351,6 +368,8 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
         idx[o + lane] = (IdxT)(uint32_t)key[0];
         if (dist_out) dist_out[o + lane] = __uint_as_float((uint32_t)(key[0] >> 32));
       }
+      // (every point at the K-th distance is among the candidates: they were collected with d <= U and U bounds it from above)
+      if (flags.nflag && knn_sorted_has_tie(key[0], ~0ull, k, lane)) knn_flag_query(flags, bi, m, j, lane);
     } else {
       unsigned long long key[2];
       key[0] = cb[lane];
@@ -360,6 +379,7 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
         idx[o + lane] = (IdxT)(uint32_t)key[0];
         if (dist_out) dist_out[o + lane] = __uint_as_float((uint32_t)(key[0] >> 32));
       }
+      if (flags.nflag && knn_sorted_has_tie(key[0], key[1], k, lane)) knn_flag_query(flags, bi, m, j, lane);
     }
   }
 #ifdef PASNL_KNN_PROBE
@@ -415,6 +435,7 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
       idx[o + lane] = (IdxT)L[q].i[0];
       if (dist_out) dist_out[o + lane] = L[q].d[0];
     }
+    if (flags.nflag) knn_flag_query(flags, bi, m, q0 + q, lane);  // > 128 candidates under the bound: ties by the dozen
   }
 }
 
@@ -783,15 +804,15 @@ extern "C" int pasnl_query_ball_point(int b, int n, int m, float radius, int nsa
 
 template <int SLOTS, int QW>
 static int knn_launch(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
-                      float* dist2, hipStream_t st) {
+                      float* dist2, pasnl::KnnTieFlags flags, hipStream_t st) {
   int qpb = SEARCH_WAVES * QW;
   dim3 grid((m + qpb - 1) / qpb, b), block(SEARCH_WAVES * 64);
   if (idx_is_i64)
     hipLaunchKernelGGL((knn_kernel<SLOTS, QW, long long>), grid, block, 0, st, n, m, k, support, queries,
-                       static_cast<long long*>(idx), dist2);
+                       static_cast<long long*>(idx), dist2, flags);
   else
     hipLaunchKernelGGL((knn_kernel<SLOTS, QW, int>), grid, block, 0, st, n, m, k, support, queries, static_cast<int*>(idx),
-                       dist2);
+                       dist2, flags);
   return pasnl_launch_status();
 }
 
@@ -806,13 +827,18 @@ extern "C" int pasnl_knn_probe_read(unsigned long long* host8) {
 
 extern "C" int pasnl_knn_batch(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
                                int idx_is_i64, float* dist2, pasnl_stream_t stream) {
+  return pasnl::knn_brute_launch(b, n, m, k, support, queries, idx, idx_is_i64, dist2, pasnl::KnnTieFlags{nullptr, nullptr},
+                                 pasnl_hip_stream(stream));
+}
+
+int pasnl::knn_brute_launch(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
+                            float* dist2, pasnl::KnnTieFlags flags, hipStream_t st) {
   PASNL_REQUIRE(b >= 0 && n > 0 && m >= 0 && k > 0, PASNL_EINVAL);
   PASNL_REQUIRE(k <= n, PASNL_EINVAL);  // nanoflann leaves slots uninitialised when K > npts; refuse instead
   PASNL_REQUIRE(k <= PASNL_KNN_MAX_K, PASNL_EUNSUPPORTED);
   if (b == 0 || m == 0) return PASNL_OK;
   PASNL_REQUIRE(support && queries && idx, PASNL_ENULL);
   PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
-  hipStream_t st = pasnl_hip_stream(stream);
   // Two-pass selection wins wherever selection dominates (measured: 2.6x at N=1024,K=32; 3.7x at N=512,K=64); for
   // small K over large clouds both kernels are bound by the distance loop and the single pass is ahead
   // (N=8192,K=16: 795 vs 982 us).  PASNL_KNN_INSERTION=1 forces the insertion kernel (A/B measurements).
@@ -826,7 +852,7 @@ extern "C" int pasnl_knn_batch(int b, int n, int m, int k, const float* support,
 #endif
     const int qw = nq >= 4L * PASNL_KNN2_MIN_WAVES ? 4 : (nq >= 2L * PASNL_KNN2_MIN_WAVES ? 2 : 1);
     dim3 grid((m + SEARCH_WAVES * qw - 1) / (SEARCH_WAVES * qw), b), block(SEARCH_WAVES * 64);
-#define PASNL_KNN2Q(RR, Q, T) hipLaunchKernelGGL((knn2_kernel<RR, Q, T>), grid, block, 0, st, n, m, k, support, queries, static_cast<T*>(idx), dist2)
+#define PASNL_KNN2Q(RR, Q, T) hipLaunchKernelGGL((knn2_kernel<RR, Q, T>), grid, block, 0, st, n, m, k, support, queries, static_cast<T*>(idx), dist2, flags)
 #define PASNL_KNN2(RR, T) { if (qw == 4) PASNL_KNN2Q(RR, 4, T); else if (qw == 2) PASNL_KNN2Q(RR, 2, T); else PASNL_KNN2Q(RR, 1, T); }
     if (k <= 32) { if (idx_is_i64) PASNL_KNN2(1, long long) else PASNL_KNN2(1, int) }
     else { if (idx_is_i64) PASNL_KNN2(2, long long) else PASNL_KNN2(2, int) }
@@ -834,9 +860,9 @@ extern "C" int pasnl_knn_batch(int b, int n, int m, int k, const float* support,
 #undef PASNL_KNN2
     return pasnl_launch_status();
   }
-  if (k <= 64) return knn_launch<1, 4>(b, n, m, k, support, queries, idx, idx_is_i64, dist2, st);
-  if (k <= 128) return knn_launch<2, 2>(b, n, m, k, support, queries, idx, idx_is_i64, dist2, st);
-  return knn_launch<4, 1>(b, n, m, k, support, queries, idx, idx_is_i64, dist2, st);
+  if (k <= 64) return knn_launch<1, 4>(b, n, m, k, support, queries, idx, idx_is_i64, dist2, flags, st);
+  if (k <= 128) return knn_launch<2, 2>(b, n, m, k, support, queries, idx, idx_is_i64, dist2, flags, st);
+  return knn_launch<4, 1>(b, n, m, k, support, queries, idx, idx_is_i64, dist2, flags, st);
 }
 
 extern "C" int pasnl_group_point(int b, int n, int c, int m, int nsample, const float* points, const int* idx, float* out,

@@ -205,8 +205,9 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // Selection over the candidates `scan` enumerates for this lane (scan(f) calls f(distance bits, key) once per candidate;
 // it may be called several times and must enumerate the same candidates each time).  Returns the wave's K nearest as keys
 // (distance bits << 32 | index), ascending, lane t < k holding the t-th.
+// tie (out, wave-uniform; for pasnl_knn_batch_ref): two equal distances among the K, or a candidate beyond them at the K-th distance
 template <int R, typename Scan>
-__device__ __forceinline__ unsigned long long kg_select(Scan&& scan, int k, int lane, unsigned long long* cb) {
+__device__ __forceinline__ unsigned long long kg_select(Scan&& scan, int k, int lane, unsigned long long* cb, bool& tie) {
   constexpr uint32_t INF_BITS = 0x7f800000u;
   // ---- pass 1: per-lane smallest distance(s) -> U = the K-th smallest of the lane minima bounds the K-th neighbour
   uint32_t m1 = INF_BITS, m2 = INF_BITS;
@@ -239,6 +240,7 @@ __device__ __forceinline__ unsigned long long kg_select(Scan&& scan, int k, int 
     unsigned long long key[1];
     key[0] = lane < cnt ? cb[lane] : ~0ull;
     wave_bitonic_sort<1, unsigned long long>(key, lane);
+    tie = knn_sorted_has_tie(key[0], ~0ull, k, lane);
     return key[0];
   }
   if (cnt <= KG_CAP) {
@@ -246,8 +248,10 @@ __device__ __forceinline__ unsigned long long kg_select(Scan&& scan, int k, int 
     key[0] = cb[lane];
     key[1] = 64 + lane < cnt ? cb[64 + lane] : ~0ull;
     wave_bitonic_sort<2, unsigned long long>(key, lane);
+    tie = knn_sorted_has_tie(key[0], key[1], k, lane);
     return key[0];
   }
+  tie = true;  // more candidates under the bound than the network holds: ties by the dozen
   // heavy ties: K rounds of "smallest key not below `lower`"
   unsigned long long mykey = ~0ull, lower = 0;
   for (int t = 0; t < k; ++t) {
@@ -267,7 +271,8 @@ __device__ __forceinline__ unsigned long long kg_select(Scan&& scan, int k, int 
 template <int R, bool WIDE, typename IdxT, bool LOOP = false>  // WIDE: two slots per run in the ring-1 fast path (runs up to 128 records)
 __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, int m, int k, const float* __restrict__ queries,
                                                                      const char* __restrict__ ws_all, size_t stride,
-                                                                     IdxT* __restrict__ idx, float* __restrict__ dist_out) {
+                                                                     IdxT* __restrict__ idx, float* __restrict__ dist_out,
+                                                                     const KnnTieFlags flags) {
   __shared__ unsigned long long cand[KG_WAVES][KG_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bi = blockIdx.y;
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, in
   };
 
   unsigned long long mykey = ~0ull;  // lane t < k ends up with the t-th neighbour's key
-  bool done = false;
+  bool done = false, tie = false;    // tie: of the selection that was accepted (the last one)
   int r = 1;
   // ---- ring 1, the common case: the nine runs' bounds, then their records, are requested together (ONE memory latency
   // instead of one per run and pass), and both selection passes work from registers
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, in
       };
       // (dead slots carry 0xffffffff: kg_select's pass 1 sees them as > INF, pass 2 never collects them unless U is
       // 0xffffffff itself, which cannot happen: U is a lane minimum <= INF_BITS or INF_BITS)
-      mykey = kg_select<R>(scan, k, lane, cb);
+      mykey = kg_select<R>(scan, k, lane, cb, tie);
       const uint32_t dk = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mykey >> 32), k - 1);
       const float bnd = bound_of(xl, xh, max(cy - 1, 0), min(cy + 1, P.gy - 1), max(cz - 1, 0), min(cz + 1, P.gz - 1));
       done = __uint_as_float(dk) < bnd || bnd == INFINITY;
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, in
           run(cells[base + xl], cells[base + xh + 1]);
         }
     };
-    mykey = kg_select<R>(scan, k, lane, cb);
+    mykey = kg_select<R>(scan, k, lane, cb, tie);
     const uint32_t dk = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mykey >> 32), k - 1);
     done = whole || __uint_as_float(dk) < bnd;
   }
@@ -394,6 +399,9 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_query_kernel(int n, in
     idx[o + lane] = (IdxT)(uint32_t)mykey;
     if (dist_out) dist_out[o + lane] = __uint_as_float((uint32_t)(mykey >> 32));
   }
+  // (a point outside the examined block is farther than the bound, which the K-th distance is strictly below: every point that
+  // ties with the K-th was among the candidates)
+  if (flags.nflag && tie) knn_flag_query(flags, bi, m, j, lane);
   };
   if constexpr (LOOP) {
     for (int j = blockIdx.x * KG_WAVES + wave; j < m; j += gridDim.x * KG_WAVES) one(j);
@@ -539,22 +547,23 @@ static int kg_min_n() {
   return PASNL_KNN_GRID_MIN_N;
 }
 
-extern "C" size_t pasnl_knn_workspace_bytes(int b, int n) {
+size_t pasnl::knn_grid_ws_bytes(int b, int n) {
   if (b <= 0 || n < kg_min_n() || n > KG_BUILD_T * KG_PPT) return 0;
   return (size_t)b * kg_stride(n);
 }
+extern "C" size_t pasnl_knn_workspace_bytes(int b, int n) { return pasnl::knn_grid_ws_bytes(b, n); }
 
-static int knn_batch_ws_entry(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
-                              float* dist2, void* workspace, size_t workspace_bytes, int max_workgroups, pasnl_stream_t stream) {
-  const size_t need = pasnl_knn_workspace_bytes(b, n);
+int pasnl::knn_grid_launch(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
+                           float* dist2, void* workspace, size_t workspace_bytes, int max_workgroups, pasnl::KnnTieFlags flags,
+                           hipStream_t st) {
+  const size_t need = knn_grid_ws_bytes(b, n);
   if (need == 0 || k > 64 || k > n || m <= 0)  // small clouds / wide lists: the brute-force kernels (same results)
-    return pasnl_knn_batch(b, n, m, k, support, queries, idx, idx_is_i64, dist2, stream);
+    return knn_brute_launch(b, n, m, k, support, queries, idx, idx_is_i64, dist2, flags, st);
   PASNL_REQUIRE(b >= 0 && n > 0 && m >= 0 && k > 0, PASNL_EINVAL);
   PASNL_REQUIRE(support && queries && idx, PASNL_ENULL);
   PASNL_REQUIRE(workspace != nullptr, PASNL_ENULL);
   PASNL_REQUIRE(workspace_bytes >= need, PASNL_EWORKSPACE);
   PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
-  hipStream_t st = pasnl_hip_stream(stream);
   const size_t stride = kg_stride(n);
   // ~0.4 K records per cell: the sphere of radius h around a query (what ring 1 certifies) then holds ~1.7 K of them
   // target: ~0.7 K records in the cell of a point (measured optimum on uniform-box, ball and lidar-like clouds, K = 16 / 32)
@@ -570,9 +579,9 @@ static int knn_batch_ws_entry(int b, int n, int m, int k, const float* support, 
 #define PASNL_KG(RR, WW, T)                                                                                                   \
   {                                                                                                                            \
     if (bg) hipLaunchKernelGGL((knn_grid_query_kernel<RR, WW, T, true>), grid, block, 0, st, n, m, k, queries,                 \
-                               static_cast<const char*>(workspace), stride, static_cast<T*>(idx), dist2);                      \
+                               static_cast<const char*>(workspace), stride, static_cast<T*>(idx), dist2, flags);               \
     else hipLaunchKernelGGL((knn_grid_query_kernel<RR, WW, T, false>), grid, block, 0, st, n, m, k, queries,                   \
-                            static_cast<const char*>(workspace), stride, static_cast<T*>(idx), dist2);                         \
+                            static_cast<const char*>(workspace), stride, static_cast<T*>(idx), dist2, flags);                  \
   }
   if (k <= 16) { if (idx_is_i64) PASNL_KG(1, false, long long) else PASNL_KG(1, false, int) }
   else if (k <= 32) { if (idx_is_i64) PASNL_KG(1, true, long long) else PASNL_KG(1, true, int) }
@@ -583,14 +592,16 @@ static int knn_batch_ws_entry(int b, int n, int m, int k, const float* support, 
 
 extern "C" int pasnl_knn_batch_ws(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
                                   int idx_is_i64, float* dist2, void* workspace, size_t workspace_bytes, pasnl_stream_t stream) {
-  return knn_batch_ws_entry(b, n, m, k, support, queries, idx, idx_is_i64, dist2, workspace, workspace_bytes, 0, stream);
+  return pasnl::knn_grid_launch(b, n, m, k, support, queries, idx, idx_is_i64, dist2, workspace, workspace_bytes, 0,
+                                pasnl::KnnTieFlags{nullptr, nullptr}, pasnl_hip_stream(stream));
 }
 
 extern "C" int pasnl_knn_batch_ws_bg(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
                                      int idx_is_i64, float* dist2, void* workspace, size_t workspace_bytes, int max_workgroups,
                                      pasnl_stream_t stream) {
   PASNL_REQUIRE(max_workgroups > 0, PASNL_EINVAL);
-  return knn_batch_ws_entry(b, n, m, k, support, queries, idx, idx_is_i64, dist2, workspace, workspace_bytes, max_workgroups, stream);
+  return pasnl::knn_grid_launch(b, n, m, k, support, queries, idx, idx_is_i64, dist2, workspace, workspace_bytes, max_workgroups,
+                                pasnl::KnnTieFlags{nullptr, nullptr}, pasnl_hip_stream(stream));
 }
 
 extern "C" int pasnl_knn_distance_pick(int b, int n, int nq, int k, const float* pts, const unsigned int* rnd, long long* idx,

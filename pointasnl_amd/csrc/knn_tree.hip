@@ -18,6 +18,7 @@
 //   kernels take 62 us -- an exactness mode that is usable, not a fast path.
 // Trees or searches deeper than KT_DEPTH levels (pathological, exponentially clustered data) raise a flag in the workspace,
 // which the Python wrapper turns into PasnlUnsupported.
+#include <algorithm>
 #include "common.hpp"
 
 namespace pasnl {
@@ -46,6 +47,20 @@ struct KtWork {  // an inner node waiting for its split (parallel build): the ac
   unsigned left, right;
   float box[6];
 };
+// A queue entry written by another wave of the workgroup one level ago, read by a whole wave: its nine words by nine LANES in ONE
+// load (volatile: never the scalar cache, never a stale line), handed round by readlane.  Lane-uniform volatile loads of the
+// struct compiled to nine system-coherent loads each waited for in turn -- most of the "3.5 us of fixed cost per node".
+static_assert(sizeof(KtWork) == 36, "nine words");
+__device__ __forceinline__ KtWork kt_load_work(const KtWork* qe, const int lane) {
+  const uint32_t v = reinterpret_cast<const volatile uint32_t*>(qe)[lane < 9 ? lane : 0];
+  KtWork wk;
+  wk.node = __builtin_amdgcn_readlane((int)v, 0);
+  wk.left = (unsigned)__builtin_amdgcn_readlane((int)v, 1);
+  wk.right = (unsigned)__builtin_amdgcn_readlane((int)v, 2);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) wk.box[i] = __int_as_float(__builtin_amdgcn_readlane((int)v, 3 + i));
+  return wk;
+}
 constexpr int KT_HDR = 32;   // header bytes: [flag, root, nodes used, depth, deep work items, the queue they are in, -, -]
 #define KT_NNODES(n) (2 * (n) + 32)  // node slots: the two-phase build hands every deep subtree its own id range (32 + 2 left ..)
 constexpr int KTD_MAXWORK = 16;   // subtrees handed to the second phase: the queue after KTD_TOP levels
@@ -63,11 +78,10 @@ static inline size_t kt_recs_offset(int n) {
 }
 static inline size_t kt_cloud_bytes(int n) { return kt_recs_offset(n) + kt_align_h((size_t)n * 16); }
 
-__global__ __launch_bounds__(64) void knn_tree_build_kernel(int n, const float* __restrict__ pts_all, char* __restrict__ ws_all,
-                                                           size_t stride, size_t recs_off) {
-  if (threadIdx.x != 0) return;
-  const float* pts = pts_all + (size_t)blockIdx.x * n * 3;
-  char* ws = ws_all + (size_t)blockIdx.x * stride;
+__device__ void knn_tree_build_body(int cloud, int n, const float* __restrict__ pts_all, char* __restrict__ ws_all,
+                                    size_t stride, size_t recs_off) {
+  const float* pts = pts_all + (size_t)cloud * n * 3;
+  char* ws = ws_all + (size_t)cloud * stride;
   int* hdr = reinterpret_cast<int*>(ws);
   unsigned* vind = reinterpret_cast<unsigned*>(ws + kt_align(KT_HDR));
   KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
@@ -215,6 +229,16 @@ __global__ __launch_bounds__(64) void knn_tree_build_kernel(int n, const float* 
   hdr[2] = nnodes;
   hdr[3] = maxdepth;
 }
+// A grid of at most `b` workgroups walks the clouds.  nflag (pasnl_knn_batch_ref): only the clouds with flagged queries get a
+// tree -- on tie-free batches every workgroup reads a few counters and returns, so the launch has to be CHEAP TO PLACE: a capped
+// grid (the kernels of a forward running beside it hold the LDS these workgroups ask for; one workgroup per cloud of a large
+// batch queued behind them and held the side stream for ~50 us per search, measured: +8 % on the classifier's step)
+__global__ __launch_bounds__(64) void knn_tree_build_kernel(int b, int n, const float* __restrict__ pts_all, char* __restrict__ ws_all,
+                                                           size_t stride, size_t recs_off, const int* __restrict__ nflag) {
+  if (threadIdx.x != 0) return;
+  for (int cloud = blockIdx.x; cloud < b; cloud += gridDim.x)
+    if (!nflag || nflag[cloud] != 0) knn_tree_build_body(cloud, n, pts_all, ws_all, stride, recs_off);
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The same tree, built by a WORKGROUP per cloud (n <= KTB_NMAX).  What makes the serial build slow is not its arithmetic
@@ -241,8 +265,8 @@ __device__ __forceinline__ void ktb_wave_sync() {  // LDS operations of a wave e
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int n, const float* __restrict__ pts_all,
-                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off, int stop_level) {
+__device__ void knn_tree_build_par_body(int cloud, int n, const float* __restrict__ pts_all, char* __restrict__ ws_all, size_t stride,
+                                        size_t recs_off, int stop_level) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   unsigned* vind = reinterpret_cast<unsigned*>(smem);                       // [n]
   float* vals = reinterpret_cast<float*>(vind + n);                          // [n] cut coordinate of vind[i] (current node)
@@ -250,8 +274,8 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
   float* part = reinterpret_cast<float*>(sc + ((n + 1) & ~1));               // [KTB_WAVES][6] root-box partials
   int* ctr = reinterpret_cast<int*>(part + KTB_WAVES * 6);                   // [0], [1]: queue lengths; [2]: nodes used; [3]: flag
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* pts = pts_all + (size_t)blockIdx.x * n * 3;
-  char* ws = ws_all + (size_t)blockIdx.x * stride;
+  const float* pts = pts_all + (size_t)cloud * n * 3;
+  char* ws = ws_all + (size_t)cloud * stride;
   int* hdr = reinterpret_cast<int*>(ws);
   unsigned* gvind = reinterpret_cast<unsigned*>(ws + kt_align(KT_HDR));
   KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
@@ -324,12 +348,7 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
     }
     if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }  // deeper than the search's stack: flagged, not built
     for (int e = wave; e < nq; e += KTB_WAVES) {
-      KtWork wk;  // the same address in every lane; written by another wave one level ago: plain vector loads, never the scalar cache
-      {
-        const volatile KtWork* qe = queue[cur] + e;
-        wk.node = qe->node; wk.left = qe->left; wk.right = qe->right;
-        for (int i = 0; i < 6; ++i) wk.box[i] = qe->box[i];
-      }
+      const KtWork wk = kt_load_work(queue[cur] + e, lane);
       const unsigned left = wk.left, right = wk.right, count = right - left;
       // ---- middleSplit_ (:966-1005)
       const float EPS = 0.00001f;
@@ -459,6 +478,15 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
   }
   if (tid == 0) { hdr[0] = ctr[3] & 1; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; hdr[4] = (ctr[3] & 1) || stop_level == 0 ? 0 : ctr[cur]; hdr[5] = cur; }
 }
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int b, int n, const float* __restrict__ pts_all,
+                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off, int stop_level,
+                                                                           const int* __restrict__ nflag) {
+  for (int cloud = blockIdx.x; cloud < b; cloud += gridDim.x) {  // (a capped grid walks the clouds: knn_tree_build_kernel's note)
+    if (nflag && nflag[cloud] == 0) continue;
+    knn_tree_build_par_body(cloud, n, pts_all, ws_all, stride, recs_off, stop_level);
+    __syncthreads();  // the next cloud re-uses the LDS
+  }
+}
 
 // The same build with the POINTS in LDS (n <= KTB_LDS_NMAX): records {x, y, z, index} that move with the index list, so every
 // pass over a node is a sequential LDS read.  In the kernel above a pass gathers pts[vind[i]] from global memory, one dependent
@@ -467,9 +495,92 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int 
 // One inner node of the build with the points in LDS (middleSplit_ + planeSplit + the children's tight bounds), by one wave:
 // rec / sc positions `left .. right` are LDS positions.  -> cutfeat, cutval, index (the left child's size), divlow, divhigh
 struct KtSplit { int cutfeat; float cutval; unsigned index; float dl, dh; };
+// A node of at most 64 points (the thousands of nodes at the deep levels; ~3.5 us each through the general form below, whose ten
+// passes are LDS round trips for one trip's worth of data): ONE POINT PER LANE, held in registers through both partition passes.
+// The same closed form of planeSplit (header): with cnt satisfiers in [lo, count), the i-th violator among positions
+// [lo, lo + cnt) (ascending) and the i-th satisfier at or behind lo + cnt (descending) exchange places -- ranks by ballot +
+// popcount, the partner's lane through 64 bytes of scratch, the exchange itself by four ds_bpermute.  ~0.5 us.
+__device__ __forceinline__ KtSplit ktb_split_node_small(float4* rec, unsigned short* sc, const KtWork& wk, const unsigned left,
+                                                        const unsigned count, const int lane, const unsigned long long lt_mask) {
+  const bool in = (unsigned)lane < count;
+  float4 r = rec[left + (in ? lane : 0)];
+  // ---- middleSplit_ (:966-1005)
+  const float EPS = 0.00001f;
+  float max_span = wk.box[1] - wk.box[0];
+  for (int d = 1; d < 3; ++d) {
+    const float span = wk.box[2 * d + 1] - wk.box[2 * d];
+    if (span > max_span) max_span = span;
+  }
+  float mn3[3], mx3[3];
+  {
+    const float c[3] = {r.x, r.y, r.z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { mn3[d] = wave_min_f32(in ? c[d] : INFINITY); mx3[d] = wave_max_f32(in ? c[d] : -INFINITY); }
+  }
+  float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
+  int cutfeat = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float span = wk.box[2 * d + 1] - wk.box[2 * d];
+    if (span > (1 - EPS) * max_span) {
+      const float spread = mx3[d] - mn3[d];
+      if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn3[d]; mx_c = mx3[d]; }
+    }
+  }
+  const float blo = cutfeat == 0 ? wk.box[0] : (cutfeat == 1 ? wk.box[2] : wk.box[4]);
+  const float bhi = cutfeat == 0 ? wk.box[1] : (cutfeat == 1 ? wk.box[3] : wk.box[5]);
+  const float split_val = (blo + bhi) / 2;
+  float cutval;
+  if (split_val < mn_c) cutval = mn_c;
+  else if (split_val > mx_c) cutval = mx_c;
+  else cutval = split_val;
+  // ---- planeSplit (:1016-1043), both passes on registers
+  unsigned lim[2];
+  unsigned lo_p = 0;
+  unsigned short* scr = sc + left;  // >= count entries of scratch: partner lanes by rank (violators from the front, satisfiers from the back)
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const float v = cutfeat == 0 ? r.x : (cutfeat == 1 ? r.y : r.z);
+    const bool inr = in && (unsigned)lane >= lo_p;
+    const bool sat = inr && (pass == 0 ? v < cutval : v <= cutval);
+    const unsigned cnt = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sat));
+    const unsigned mid = lo_p + cnt;
+    const bool viol = inr && (unsigned)lane < mid && !sat;       // a violator among the first cnt positions
+    const bool rsat = sat && (unsigned)lane >= mid;              // a satisfier among the rest
+    const unsigned long long mv = __builtin_amdgcn_ballot_w64(viol), mr = __builtin_amdgcn_ballot_w64(rsat);
+    if (mv != 0ull) {  // (uniform) popcount(mv) == popcount(mr)
+      const unsigned vrank = (unsigned)__builtin_popcountll(mv & lt_mask);                                   // ascending
+      const unsigned rrank = (unsigned)__builtin_popcountll(mr & ~lt_mask & ~(1ull << lane));                // descending: set bits above this lane
+      if (viol) scr[vrank] = (unsigned short)lane;
+      if (rsat) scr[count - 1 - rrank] = (unsigned short)lane;
+      ktb_wave_sync();
+      int partner = lane;
+      if (viol) partner = scr[count - 1 - vrank];
+      if (rsat) partner = scr[rrank];
+      ktb_wave_sync();
+      r.x = __shfl(r.x, partner); r.y = __shfl(r.y, partner); r.z = __shfl(r.z, partner); r.w = __shfl(r.w, partner);
+    }
+    lim[pass] = mid;
+    lo_p = mid;
+  }
+  unsigned index;
+  if (lim[0] > count / 2) index = lim[0];
+  else if (lim[1] < count / 2) index = lim[1];
+  else index = count / 2;
+  const float v = cutfeat == 0 ? r.x : (cutfeat == 1 ? r.y : r.z);
+  const float dl = wave_max_f32(in && (unsigned)lane < index ? v : -INFINITY);
+  const float dh = wave_min_f32(in && (unsigned)lane >= index ? v : INFINITY);
+  if (in) rec[left + lane] = r;
+  ktb_wave_sync();
+  KtSplit o;
+  o.cutfeat = cutfeat; o.cutval = cutval; o.index = index; o.dl = dl; o.dh = dh;
+  return o;
+}
+
 __device__ __forceinline__ KtSplit ktb_split_node(float4* rec, unsigned short* sc, const KtWork& wk, const unsigned left,
                                                   const unsigned right, const int lane, const unsigned long long lt_mask) {
   const unsigned count = right - left;
+  if (count <= 64u) return ktb_split_node_small(rec, sc, wk, left, count, lane, lt_mask);  // (wave-uniform)
   // ---- middleSplit_ (:966-1005)
   const float EPS = 0.00001f;
   float max_span = wk.box[1] - wk.box[0];
@@ -566,16 +677,16 @@ __device__ __forceinline__ KtSplit ktb_split_node(float4* rec, unsigned short* s
   return r;
 }
 
-__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int n, const float* __restrict__ pts_all,
-                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off, int stop_level) {
+__device__ void knn_tree_build_lds_body(int cloud, int n, const float* __restrict__ pts_all, char* __restrict__ ws_all, size_t stride,
+                                        size_t recs_off, int stop_level) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* rec = reinterpret_cast<float4*>(smem);                             // [n] {x, y, z, index bits}: the points move with the index list
   unsigned short* sc = reinterpret_cast<unsigned short*>(rec + n);           // [n] positions of misplaced elements
   float* part = reinterpret_cast<float*>(sc + ((n + 1) & ~1));               // [KTB_WAVES][6] root-box partials
   int* ctr = reinterpret_cast<int*>(part + KTB_WAVES * 6);                   // [0], [1]: queue lengths; [2]: nodes used; [3]: flag
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* pts = pts_all + (size_t)blockIdx.x * n * 3;
-  char* ws = ws_all + (size_t)blockIdx.x * stride;
+  const float* pts = pts_all + (size_t)cloud * n * 3;
+  char* ws = ws_all + (size_t)cloud * stride;
   int* hdr = reinterpret_cast<int*>(ws);
   unsigned* gvind = reinterpret_cast<unsigned*>(ws + kt_align(KT_HDR));
   KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
@@ -634,12 +745,7 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int 
     if (stop_level > 0 && level >= stop_level) break;  // the pending subtrees go to knn_tree_build_deep_kernel, one workgroup each
     if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }  // deeper than the search's stack: flagged, not built
     for (int e = wave; e < nq; e += KTB_WAVES) {
-      KtWork wk;  // the same address in every lane; written by another wave one level ago: plain vector loads, never the scalar cache
-      {
-        const volatile KtWork* qe = queue[cur] + e;
-        wk.node = qe->node; wk.left = qe->left; wk.right = qe->right;
-        for (int i = 0; i < 6; ++i) wk.box[i] = qe->box[i];
-      }
+      const KtWork wk = kt_load_work(queue[cur] + e, lane);
       const unsigned left = wk.left, right = wk.right;
       const KtSplit sp_ = ktb_split_node(rec, sc, wk, left, right, lane, lt_mask);
       const int cutfeat = sp_.cutfeat;
@@ -687,6 +793,15 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int 
   }
   if (tid == 0) { hdr[0] = ctr[3]; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; hdr[4] = ctr[3] ? 0 : ctr[cur]; hdr[5] = cur; }
 }
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int b, int n, const float* __restrict__ pts_all,
+                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off, int stop_level,
+                                                                           const int* __restrict__ nflag) {
+  for (int cloud = blockIdx.x; cloud < b; cloud += gridDim.x) {  // (a capped grid walks the clouds: knn_tree_build_kernel's note)
+    if (nflag && nflag[cloud] == 0) continue;
+    knn_tree_build_lds_body(cloud, n, pts_all, ws_all, stride, recs_off, stop_level);
+    __syncthreads();  // the next cloud re-uses the LDS
+  }
+}
 
 // Second phase of the two-phase build: one workgroup per subtree the first phase left pending after KTD_TOP levels (<= 16 per
 // cloud).  The deep levels are thousands of small nodes with ~3.5 us of fixed cost each; one workgroup per cloud worked them off
@@ -694,13 +809,12 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int 
 // (32 + 2 left ..: a subtree of c points has < 2 c nodes) and its level queues in LDS (or, for a subtree too large for that --
 // then the only one of its size in the cloud -- in the workspace).
 constexpr int KTD_LDSQ_MAX = 6000;  // points of a subtree whose two level queues still fit in LDS behind its records
-__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_deep_kernel(int n, char* __restrict__ ws_all, size_t stride,
-                                                                            size_t recs_off) {
+__device__ void knn_tree_build_deep_body(int cloud, int item, int n, char* __restrict__ ws_all, size_t stride, size_t recs_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  char* ws = ws_all + (size_t)blockIdx.y * stride;
+  char* ws = ws_all + (size_t)cloud * stride;
   int* hdr = reinterpret_cast<int*>(ws);
-  if ((int)blockIdx.x >= hdr[4]) return;
+  if (item >= hdr[4]) return;
   unsigned* gvind = reinterpret_cast<unsigned*>(ws + kt_align(KT_HDR));
   KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
   KtFrame* fr = reinterpret_cast<KtFrame*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4) + kt_align((size_t)KT_NNODES(n) * sizeof(KtNode)));
@@ -712,7 +826,7 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_deep_kernel(int
   g2[0] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(q1[1]) + kt_align((size_t)qcap * sizeof(KtWork)));
   g2[1] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(g2[0]) + kt_align((size_t)(qcap + 3 * KTD_MAXWORK) * sizeof(KtWork)));
   float4* grecs = reinterpret_cast<float4*>(ws + recs_off);
-  const KtWork w0 = q1[hdr[5]][blockIdx.x];  // written by the previous kernel
+  const KtWork w0 = q1[hdr[5]][item];  // written by the previous kernel
   const unsigned left0 = w0.left, count0 = w0.right - w0.left;
 
   float4* rec = reinterpret_cast<float4*>(smem);                                  // [count0]
@@ -742,12 +856,7 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_deep_kernel(int
     if (nq == 0) break;
     if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }
     for (int e = wave; e < nq; e += KTB_WAVES) {
-      KtWork wk;
-      {
-        const volatile KtWork* qe = (cur ? qb : qa) + e;
-        wk.node = qe->node; wk.left = qe->left; wk.right = qe->right;
-        for (int i = 0; i < 6; ++i) wk.box[i] = qe->box[i];
-      }
+      const KtWork wk = kt_load_work((cur ? qb : qa) + e, lane);
       const unsigned left = wk.left, right = wk.right;
       const KtSplit sp_ = ktb_split_node(rec, sc, wk, left, right, lane, lt_mask);
       const int cutfeat = sp_.cutfeat;
@@ -796,6 +905,16 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_deep_kernel(int
     atomicMax(&hdr[3], level);
   }
 }
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_deep_kernel(int b, int n, char* __restrict__ ws_all, size_t stride,
+                                                                            size_t recs_off, const int* __restrict__ nflag) {
+  // (cloud, pending subtree) pairs, walked by a capped grid (knn_tree_build_kernel's note)
+  for (int w = blockIdx.x; w < b * KTD_MAXWORK; w += gridDim.x) {
+    const int cloud = w / KTD_MAXWORK, item = w - cloud * KTD_MAXWORK;
+    if (nflag && nflag[cloud] == 0) continue;  // (the first phase did not run: the header is stale)
+    knn_tree_build_deep_body(cloud, item, n, ws_all, stride, recs_off);
+    __syncthreads();
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The search: one lane per query, nanoflann's searchLevel (:1351-1410) as a FLAT state machine.  Sixty-four lanes walk
@@ -819,19 +938,21 @@ constexpr int KT_LDS_DEPTH = 32;
 constexpr float KT_FLT_MAX = 3.402823466e+38f;
 
 template <typename IdxT>
-__global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k, const float* __restrict__ queries,
-                                                            const char* __restrict__ ws_all, size_t stride, size_t recs_off,
-                                                            IdxT* __restrict__ out, int* __restrict__ flag) {
-  const int j = blockIdx.x * 64 + threadIdx.x;
-  const int bi = blockIdx.y;
+__device__ void knn_tree_search_body(int bi, int blk, int n, int m, int k, const float* __restrict__ queries,
+                                     const char* __restrict__ ws_all, size_t stride, size_t recs_off, IdxT* __restrict__ out,
+                                     int* __restrict__ flag, const int* __restrict__ nflag, const int* __restrict__ flist) {
+  // every query of the cloud, or (pasnl_knn_batch_ref) only the ones the canonical kernels flagged: entry `slot` of the cloud's list
+  const int slot = blk * 64 + threadIdx.x;
+  const int nq = nflag ? nflag[bi] : m;
+  const bool live = slot < nq;
+  const int j = nflag ? flist[(size_t)bi * m + (live ? slot : 0)] : slot;
   const char* ws = ws_all + (size_t)bi * stride;
   const int* hdr = reinterpret_cast<const int*>(ws);
-  if (hdr[0] != 0) { if (j == 0) atomicExch(flag, 1); return; }
+  if (hdr[0] != 0) { if (slot == 0) atomicExch(flag, 1); return; }  // (the rows keep what was in them: the canonical order under _ref)
   const KtNode* nodes = reinterpret_cast<const KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
   const KtFrame* bst = reinterpret_cast<const KtFrame*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4) + kt_align((size_t)KT_NNODES(n) * sizeof(KtNode)));
   const float4* recs = reinterpret_cast<const float4*>(ws + recs_off);
   const float* rootbox = bst[1].bbox;
-  const bool live = j < m;
   const float* qp = queries + ((size_t)bi * m + (live ? j : 0)) * 3;
   const float vec[3] = {qp[0], qp[1], qp[2]};
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -977,7 +1098,7 @@ __global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k
     }
   }
   if (overflow) atomicExch(flag, 1);
-  if (!live) return;
+  if (!live || overflow) return;  // (an overflowing search writes nothing: under _ref the row keeps the canonical order)
   // the set in the reference's order: ascending (distance, arrival).  k <= n: the set is full.
   IdxT* o = out + ((size_t)bi * m + j) * k;
   for (int s0 = k; s0 < kp; ++s0) { rd[s0 * 64] = __uint_as_float(0xFFFFFFFFu); rk[s0 * 64] = 0xFFFFFFFFu; }  // padding: never the minimum
@@ -999,6 +1120,306 @@ __global__ __launch_bounds__(64) void knn_tree_search_kernel(int n, int m, int k
     rk[bp * 64] = 0xFFFFFFFFu;
   }
 }
+// one wave per workgroup; a capped grid walks the (cloud, block of 64 queries) pairs (knn_tree_build_kernel's note)
+template <typename IdxT>
+__global__ __launch_bounds__(64) void knn_tree_search_kernel(int b, int n, int m, int k, const float* __restrict__ queries,
+                                                            const char* __restrict__ ws_all, size_t stride, size_t recs_off,
+                                                            IdxT* __restrict__ out, int* __restrict__ flag,
+                                                            const int* __restrict__ nflag, const int* __restrict__ flist) {
+  const int mblk = (m + 63) / 64;
+  for (int w = blockIdx.x; w < b * mblk; w += gridDim.x) {
+    const int bi = w / mblk, blk = w - bi * mblk;
+    if (blk * 64 >= (nflag ? nflag[bi] : m)) continue;
+    knn_tree_search_body<IdxT>(bi, blk, n, m, k, queries, ws_all, stride, recs_off, out, flag, nflag, flist);
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The search for FEW queries (pasnl_knn_batch_ref's flagged ones): ONE WAVE PER QUERY.  The lane-per-query kernel above is
+// the throughput form -- a lone query walks ~250 dependent steps in one lane, 130 us for K = 32 in 1024 points, 0.5 ms in
+// 8192, which is the whole price of a single chance tie in a batch.  Here the walk itself is wave-uniform (node, stack,
+// running side distances: one copy, the stack in LDS), a leaf's <= 10 candidates are evaluated by ten lanes at once against the
+// worst distance read at the leaf's entry (nanoflann.hpp:1357-1368 reads it once per leaf too), and the result set is
+// nanoflann's sorted list itself, rank l in lane l: a candidate's place is the number of entries with distance <= its own (ballot
+// + popcount: behind its equals, :115-134), the tail shifts by one lane (DPP).  Dependent steps: one per node and one per leaf.
+// Tree: node / record accessors over global memory (the builds above) or LDS (knn_tree_small_kernel below).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename IdxT, typename NodeP, typename RecP>
+__device__ __forceinline__ bool knn_tree_search_wave(const float qx, const float qy, const float qz, const int k, const int root,
+                                                     NodeP nodes, RecP recs, const float* rootbox, uint32_t* stk /* [KT_DEPTH * 3] */,
+                                                     IdxT* __restrict__ orow, const int lane) {
+  const float vec[3] = {qx, qy, qz};
+  // computeInitialDistances (:1045-1061)
+  float dists[3] = {0.f, 0.f, 0.f};
+  float distsq = 0.f;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (vec[d] < rootbox[2 * d]) { dists[d] = (vec[d] - rootbox[2 * d]) * (vec[d] - rootbox[2 * d]); distsq += dists[d]; }
+    if (vec[d] > rootbox[2 * d + 1]) { dists[d] = (vec[d] - rootbox[2 * d + 1]) * (vec[d] - rootbox[2 * d + 1]); distsq += dists[d]; }
+  }
+  const float epsError = 1.f;
+  float ld = KT_FLT_MAX;   // KNNResultSet::init: dists[capacity - 1] = max (:84-90); rank `lane` of the sorted list
+  int li = 0;
+  float worst = KT_FLT_MAX;
+  int node = root, sp = 0;
+  float mindistsq = distsq;
+  bool descending = true;
+  for (;;) {
+    if (descending) {
+      const KtNode nd = nodes[node];
+      if (nd.child1 < 0) {  // leaf (:1355-1369): every point against the worst distance as it is NOW
+        const int left = nd.a, right = __float_as_int(nd.divlow);
+        for (int p0 = left; p0 < right; p0 += 64) {  // (<= KT_LEAF points: one trip)
+          const bool in = p0 + lane < right;
+          const float4 c = recs[in ? p0 + lane : left];
+          float dist = 0.f;  // L2_Adaptor::evalMetric, dim 3: the tail loop (:343-346)
+          { const float diff = vec[0] - c.x; dist += diff * diff; }
+          { const float diff = vec[1] - c.y; dist += diff * diff; }
+          { const float diff = vec[2] - c.z; dist += diff * diff; }
+          unsigned long long mask = __builtin_amdgcn_ballot_w64(in && dist < worst);
+          while (mask != 0ull) {
+            const int src = (int)__builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const float cd = readlane_f(dist, src);
+            const int ci = __builtin_amdgcn_readlane(__float_as_int(c.w), src);
+            // addPoint (:115-134): behind every entry with distance <= cd; beyond the capacity: dropped
+            const int pos = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < k && ld <= cd));
+            if (pos < k) {
+              const float sd = wave_shr1_f(ld);
+              const int si = wave_shr1_i(li);
+              if (lane > pos) { ld = sd; li = si; }
+              if (lane == pos) { ld = cd; li = ci; }
+            }
+          }
+        }
+        worst = readlane_f(ld, k - 1);
+        descending = false;
+      } else {
+        const int idx = nd.a;
+        const float val = idx == 0 ? vec[0] : (idx == 1 ? vec[1] : vec[2]);
+        const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+        int best, other;
+        float cut;
+        if ((diff1 + diff2) < 0) { best = nd.child1; other = nd.child2; cut = (val - nd.divhigh) * (val - nd.divhigh); }
+        else { best = nd.child2; other = nd.child1; cut = (val - nd.divlow) * (val - nd.divlow); }
+        if (sp + 1 >= KT_DEPTH) return false;
+        stk[sp * 3] = (uint32_t)other | ((uint32_t)idx << 28) | (1u << 30);
+        stk[sp * 3 + 1] = __float_as_uint(mindistsq);
+        stk[sp * 3 + 2] = __float_as_uint(cut);
+        ++sp;
+        node = best;  // (the near child inherits mindistsq, :1396)
+      }
+    } else {
+      if (sp == 0) break;
+      const uint32_t w0 = stk[(sp - 1) * 3];
+      const int feat = (int)((w0 >> 28) & 3u);
+      if ((w0 >> 30) == 1u) {  // the near child is done (:1397-1405)
+        const float fmind = __uint_as_float(stk[(sp - 1) * 3 + 1]), cut = __uint_as_float(stk[(sp - 1) * 3 + 2]);
+        const float dst = feat == 0 ? dists[0] : (feat == 1 ? dists[1] : dists[2]);
+        const float mind = fmind + cut - dst;
+        if (mind * epsError <= worst) {
+          if (feat == 0) dists[0] = cut; else if (feat == 1) dists[1] = cut; else dists[2] = cut;
+          stk[(sp - 1) * 3] = (w0 & 0x3FFFFFFFu) | (2u << 30);
+          stk[(sp - 1) * 3 + 2] = __float_as_uint(dst);
+          node = (int)(w0 & 0x0FFFFFFFu);
+          mindistsq = mind;
+          descending = true;
+        } else {
+          --sp;
+        }
+      } else {  // the far child is done: dists[idx] = dst (:1404)
+        const float dst = __uint_as_float(stk[(sp - 1) * 3 + 2]);
+        if (feat == 0) dists[0] = dst; else if (feat == 1) dists[1] = dst; else dists[2] = dst;
+        --sp;
+      }
+    }
+  }
+  if (lane < k) orow[lane] = (IdxT)li;
+  return true;
+}
+
+// waves of a capped grid walk the flagged queries of all clouds (global tree: the builds above)
+constexpr int KTW_WAVES = 4;
+template <typename IdxT>
+__global__ __launch_bounds__(KTW_WAVES * 64) void knn_tree_search_wave_kernel(int b, int n, int m, int k, const float* __restrict__ queries,
+                                                                             const char* __restrict__ ws_all, size_t stride, size_t recs_off,
+                                                                             IdxT* __restrict__ out, int* __restrict__ flag,
+                                                                             const int* __restrict__ nflag, const int* __restrict__ flist) {
+  __shared__ uint32_t stacks[KTW_WAVES][KT_DEPTH * 3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long gw = (long)blockIdx.x * KTW_WAVES + wave, nw = (long)gridDim.x * KTW_WAVES;
+  long base = 0;  // flagged queries of the clouds before `bi`
+  for (int bi = 0; bi < b; ++bi) {
+    const int nq = nflag[bi];
+    if (nq == 0) continue;
+    const char* ws = ws_all + (size_t)bi * stride;
+    const int* hdr = reinterpret_cast<const int*>(ws);
+    const KtNode* nodes = reinterpret_cast<const KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
+    const KtFrame* bst = reinterpret_cast<const KtFrame*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4) + kt_align((size_t)KT_NNODES(n) * sizeof(KtNode)));
+    const float4* recs = reinterpret_cast<const float4*>(ws + recs_off);
+    // wave gw takes the entries e of this cloud with (base + e) % nw == gw
+    long e = (gw - base % nw + nw) % nw;
+    for (; e < nq; e += nw) {
+      if (hdr[0] != 0) { if (lane == 0) atomicExch(flag, 1); break; }  // the tree is not complete: the rows keep the canonical order
+      const int j = flist[(size_t)bi * m + e];
+      const float* qp = queries + ((size_t)bi * m + j) * 3;
+      if (!knn_tree_search_wave<IdxT>(qp[0], qp[1], qp[2], k, hdr[1], nodes, recs, bst[1].bbox, stacks[wave],
+                                      out + ((size_t)bi * m + j) * k, lane) && lane == 0)
+        atomicExch(flag, 1);
+    }
+    base += nq;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small clouds (n <= KTS_NMAX: the classifier's, the deep levels of the segmentation models): tree AND searches of a flagged
+// cloud in ONE workgroup, everything in LDS -- records, nodes, level queues, the searching waves' stacks.  One launch instead of
+// three, no global round trip inside the build's level loop or the walk: a single chance tie in a batch of 64 x 1024 points
+// costs ~40 us here where build + deep + lane search took 184.  The build is knn_tree_build_lds_kernel's (same split code).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int KTS_NMAX = 2048;
+#ifdef PASNL_TUNING
+// phase probe of the FIRST flagged cloud a workgroup takes (tools/knn_small_probe.py): s_memtime at [0] entry, [1] records + box in
+// LDS, [2 + l] level l done (l < 20), [30] build done, [31] searches done
+__device__ unsigned long long kts_probe[32];
+#define KTS_MARK(i) do { if (tid == 0 && blockIdx.x == kts_first) kts_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KTS_MARK(i) do { } while (0)
+#endif
+__host__ __device__ inline size_t kts_lds_bytes(int n) {
+  const size_t lq = (size_t)(n / (KT_LEAF + 1)) + 2;
+  return (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15) + (size_t)KT_NNODES(n) * sizeof(KtNode) + 2 * lq * sizeof(KtWork) + 64 +
+         KTB_WAVES * 6 * 4 + (size_t)KTB_WAVES * KT_DEPTH * 3 * 4;
+}
+template <typename IdxT>
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, int n, int m, int k, const float* __restrict__ pts_all,
+                                                                       const float* __restrict__ queries, IdxT* __restrict__ out,
+                                                                       int* __restrict__ flag, const int* __restrict__ nflag,
+                                                                       const int* __restrict__ flist) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* rec = reinterpret_cast<float4*>(smem);                                          // [n]
+  unsigned short* sc = reinterpret_cast<unsigned short*>(rec + n);                        // [n]
+  KtNode* nodes = reinterpret_cast<KtNode*>(smem + (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15));  // [KT_NNODES(n)]
+  const int lq = n / (KT_LEAF + 1) + 2;
+  KtWork* const qa = reinterpret_cast<KtWork*>(nodes + KT_NNODES(n));
+  KtWork* const qb = qa + lq;
+  int* ctr = reinterpret_cast<int*>(qb + lq);                                             // [0], [1] queue lengths, [2] nodes used, [3] flag; then the root box
+  float* rootbox = reinterpret_cast<float*>(ctr + 4);                                     // [6] (+ padding to 64 bytes)
+  float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ctr) + 64);              // [KTB_WAVES][6]
+  uint32_t* stacks = reinterpret_cast<uint32_t*>(part + KTB_WAVES * 6);                   // [KTB_WAVES][KT_DEPTH * 3]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#ifdef PASNL_TUNING
+  int kts_first = -1;
+  for (int c = 0; c < b && kts_first < 0; ++c) if (nflag[c] != 0) kts_first = c % gridDim.x;
+#endif
+  for (int cloud = blockIdx.x; cloud < b; cloud += gridDim.x) {
+    const int nq = nflag[cloud];
+    if (nq == 0) continue;  // (uniform)
+    KTS_MARK(0);
+    const float* pts = pts_all + (size_t)cloud * n * 3;
+    // init_vind (:1318), computeBoundingBox (:1321-1346)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < n; i += KTB_WAVES * 64) {
+      const float c[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
+      rec[i] = make_float4(c[0], c[1], c[2], __int_as_float(i));
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = c[d] < lo[d] ? c[d] : lo[d];
+        hi[d] = c[d] > hi[d] ? c[d] : hi[d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = wave_min_f32(lo[d]); hi[d] = wave_max_f32(hi[d]); }
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { part[wave * 6 + 2 * d] = lo[d]; part[wave * 6 + 2 * d + 1] = hi[d]; }
+    }
+    if (tid < 4) ctr[tid] = 0;
+    __syncthreads();
+    if (tid == 0) {
+      float root[6];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float l = part[2 * d], h = part[2 * d + 1];
+        for (int w = 1; w < KTB_WAVES; ++w) { l = fminf(l, part[w * 6 + 2 * d]); h = fmaxf(h, part[w * 6 + 2 * d + 1]); }
+        root[2 * d] = l; root[2 * d + 1] = h;
+      }
+      for (int i = 0; i < 6; ++i) rootbox[i] = root[i];  // root_bbox after divideTree = the tight box of all points (what the search reads)
+      ctr[2] = 1;  // node 0 = the root
+      if (n <= KT_LEAF) {
+        nodes[0].child1 = nodes[0].child2 = -1; nodes[0].a = 0; nodes[0].divlow = __int_as_float(n); nodes[0].divhigh = 0.f;
+      } else {
+        KtWork w0; w0.node = 0; w0.left = 0; w0.right = (unsigned)n;
+        for (int i = 0; i < 6; ++i) w0.box[i] = root[i];
+        qa[0] = w0;
+        ctr[0] = 1;
+      }
+    }
+    __syncthreads();
+    KTS_MARK(1);
+    int cur = 0, level = 0;
+    for (;;) {
+      const int nqn = ctr[cur];
+      if (nqn == 0) break;
+      if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }
+      for (int e = wave; e < nqn; e += KTB_WAVES) {
+        const KtWork wk = kt_load_work((cur ? qb : qa) + e, lane);
+        const unsigned left = wk.left, right = wk.right;
+        const KtSplit sp_ = ktb_split_node(rec, sc, wk, left, right, lane, lt_mask);
+        const int cutfeat = sp_.cutfeat;
+        const float cutval = sp_.cutval;
+        const unsigned index = sp_.index;
+        if (lane == 0) {
+          int child[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const unsigned cl = c == 0 ? left : left + index, cr = c == 0 ? left + index : right;
+            const int id = atomicAdd(&ctr[2], 1);
+            child[c] = id;
+            if (cr - cl <= (unsigned)KT_LEAF) {  // leaf (:921-936)
+              nodes[id].child1 = nodes[id].child2 = -1;
+              nodes[id].a = (int)cl;
+              nodes[id].divlow = __int_as_float((int)cr);
+              nodes[id].divhigh = 0.f;
+            } else {
+              KtWork w;
+              w.node = id; w.left = cl; w.right = cr;
+#pragma unroll
+              for (int i = 0; i < 6; ++i) w.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : wk.box[i];
+              (cur ? qa : qb)[atomicAdd(&ctr[cur ^ 1], 1)] = w;
+            }
+          }
+          KtNode nd;
+          nd.child1 = child[0]; nd.child2 = child[1]; nd.a = cutfeat; nd.divlow = sp_.dl; nd.divhigh = sp_.dh;
+          nodes[wk.node] = nd;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) ctr[cur] = 0;
+      cur ^= 1;
+      ++level;
+      __syncthreads();
+      if (level < 20) KTS_MARK(1 + level);
+    }
+    __syncthreads();
+    KTS_MARK(30);
+    if (ctr[3] != 0) {  // deeper than the search's stack: flagged, the rows keep the canonical order
+      if (tid == 0) atomicExch(flag, 1);
+    } else {
+      for (int e = wave; e < nq; e += KTB_WAVES) {
+        const int j = flist[(size_t)cloud * m + e];
+        const float* qp = queries + ((size_t)cloud * m + j) * 3;
+        if (!knn_tree_search_wave<IdxT>(qp[0], qp[1], qp[2], k, 0, nodes, rec, rootbox, stacks + wave * (KT_DEPTH * 3),
+                                        out + ((size_t)cloud * m + j) * k, lane) && lane == 0)
+          atomicExch(flag, 1);
+      }
+    }
+    KTS_MARK(31);
+    __syncthreads();  // the next cloud re-uses the LDS
+  }
+}
 
 }  // namespace pasnl
 
@@ -1007,7 +1428,8 @@ using namespace pasnl;
 // LDS of a subtree's workgroup: records + scratch positions (18 bytes per point) for a subtree of up to min(n, KTB_LDS_NMAX)
 // points (the first phase keeps larger ones to itself), or those of KTD_LDSQ_MAX points plus their two level queues --
 // whichever is larger
-static int knn_tree_deep_launch(int b, int n, char* clouds, size_t stride, size_t recs_off, hipStream_t st) {
+static int knn_tree_deep_launch(int b, int n, char* clouds, size_t stride, size_t recs_off, const int* nflag, hipStream_t st) {
+  const int grid = nflag ? std::min(b * pasnl::KTD_MAXWORK, 64) : b * pasnl::KTD_MAXWORK;  // (capped under _ref: knn_tree_build_kernel's note)
   using namespace pasnl;
   const size_t cmax = (size_t)(n < KTB_LDS_NMAX ? n : KTB_LDS_NMAX);
   const size_t c = cmax < (size_t)KTD_LDSQ_MAX ? cmax : (size_t)KTD_LDSQ_MAX;
@@ -1018,7 +1440,7 @@ static int knn_tree_deep_launch(int b, int n, char* clouds, size_t stride, size_
   if (lds2 > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_tree_build_deep_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
     return PASNL_ELAUNCH;
-  hipLaunchKernelGGL(knn_tree_build_deep_kernel, dim3(KTD_MAXWORK, b), dim3(KTB_WAVES * 64), lds2, st, n, clouds, stride, recs_off);
+  hipLaunchKernelGGL(knn_tree_build_deep_kernel, dim3(grid), dim3(KTB_WAVES * 64), lds2, st, b, n, clouds, stride, recs_off, nflag);
   return PASNL_OK;
 }
 
@@ -1027,40 +1449,51 @@ static int knn_tree_deep_launch(int b, int n, char* clouds, size_t stride, size_
 // the reference tie order has to work inside a captured forward
 __global__ void knn_tree_clear_kernel(int* __restrict__ flag) { flag[threadIdx.x] = 0; }
 
-extern "C" size_t pasnl_knn_tree_workspace_bytes(int b, int n, int m, int k) {
+size_t pasnl::knn_tree_ws_bytes(int b, int n, int m, int k) {
   if (b <= 0 || n <= 0 || m <= 0 || k <= 0) return 0;
   return 256 + (size_t)b * kt_cloud_bytes(n);  // (the search keeps its result sets in LDS)
 }
+extern "C" size_t pasnl_knn_tree_workspace_bytes(int b, int n, int m, int k) { return pasnl::knn_tree_ws_bytes(b, n, m, k); }
 
-extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
-                                    int idx_is_i64, void* workspace, size_t workspace_bytes, pasnl_stream_t stream) {
+// Build + search.  only.nflag == nullptr: every cloud, every query.  Otherwise (pasnl_knn_batch_ref): the trees of the clouds with
+// flagged queries and the rows of those queries; every kernel is launched whatever the counts are (they live on the device: no
+// host synchronisation, capturable) and returns at once where there is nothing to do.
+// depth_flag: set to 1 (never cleared here) when a tree or a search was deeper than KT_DEPTH; nullptr: the workspace's first word,
+// cleared first (the contract of pasnl_knn_batch_tree).
+int pasnl::knn_tree_launch(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
+                           void* workspace, size_t workspace_bytes, pasnl::KnnTieFlags only, int* depth_flag, hipStream_t st) {
   PASNL_REQUIRE(b >= 0 && n > 0 && m >= 0 && k > 0, PASNL_EINVAL);
   PASNL_REQUIRE(k <= n, PASNL_EINVAL);
   if (b == 0 || m == 0) return PASNL_OK;
   PASNL_REQUIRE(support && queries && idx && workspace, PASNL_ENULL);
   PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
   PASNL_REQUIRE(k <= 64 && n <= 65535, PASNL_EUNSUPPORTED);  // the search's result set: 16-bit arrival numbers / indices, k slots of LDS per lane
-  PASNL_REQUIRE(workspace_bytes >= pasnl_knn_tree_workspace_bytes(b, n, m, k), PASNL_EWORKSPACE);
-  hipStream_t st = pasnl_hip_stream(stream);
+  PASNL_REQUIRE(workspace_bytes >= knn_tree_ws_bytes(b, n, m, k), PASNL_EWORKSPACE);
   char* base = static_cast<char*>(workspace);
-  int* flag = reinterpret_cast<int*>(base);  // first word: set when a tree or a search was deeper than KT_DEPTH
-  hipLaunchKernelGGL(knn_tree_clear_kernel, dim3(1), dim3(64), 0, st, flag);
+  int* flag = depth_flag;
+  if (!flag) {
+    flag = reinterpret_cast<int*>(base);  // first word: set when a tree or a search was deeper than KT_DEPTH
+    hipLaunchKernelGGL(knn_tree_clear_kernel, dim3(1), dim3(64), 0, st, flag);
+  }
+  const int* nflag = only.nflag;
+  // under _ref the kernels are launched whatever the counts are: capped grids that walk the work (knn_tree_build_kernel's note)
+  const int bgrid = nflag ? std::min(b, 32) : b;
   char* clouds = base + 256;
   const size_t stride = kt_cloud_bytes(n);
   const bool serial = n > KTB_NMAX || tune_env("PASNL_KNN_TREE_SERIAL") != nullptr;  // (tuning build: the checker of the parallel build)
   const size_t recs_off = kt_recs_offset(n);
   if (serial) {
-    hipLaunchKernelGGL(knn_tree_build_kernel, dim3(b), dim3(64), 0, st, n, support, clouds, stride, recs_off);
+    hipLaunchKernelGGL(knn_tree_build_kernel, dim3(bgrid), dim3(64), 0, st, b, n, support, clouds, stride, recs_off, nflag);
   } else if (n <= KTB_LDS_NMAX && tune_env("PASNL_KNN_TREE_GATHER") == nullptr) {  // (tuning build: A/B against the gathering build)
     const size_t lds = (size_t)n * 16 + (size_t)((n + 1) & ~1) * 2 + (KTB_WAVES * 6 + 4) * 4;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_tree_build_lds_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return PASNL_ELAUNCH;
     const int two_phase = tune_env("PASNL_KNN_TREE_ONE_PHASE") == nullptr;  // (tuning build: A/B)
-    hipLaunchKernelGGL(knn_tree_build_lds_kernel, dim3(b), dim3(KTB_WAVES * 64), lds, st, n, support, clouds, stride, recs_off,
-                       two_phase ? KTD_TOP : 0);
+    hipLaunchKernelGGL(knn_tree_build_lds_kernel, dim3(bgrid), dim3(KTB_WAVES * 64), lds, st, b, n, support, clouds, stride, recs_off,
+                       two_phase ? KTD_TOP : 0, nflag);
     if (two_phase) {
-      const int rc = knn_tree_deep_launch(b, n, clouds, stride, recs_off, st);
+      const int rc = knn_tree_deep_launch(b, n, clouds, stride, recs_off, nflag, st);
       if (rc != PASNL_OK) return rc;
     }
   } else {
@@ -1069,14 +1502,23 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return PASNL_ELAUNCH;
     const int two_phase = tune_env("PASNL_KNN_TREE_ONE_PHASE") == nullptr;  // (tuning build: A/B)
-    hipLaunchKernelGGL(knn_tree_build_par_kernel, dim3(b), dim3(KTB_WAVES * 64), lds, st, n, support, clouds, stride, recs_off,
-                       two_phase ? KTD_TOP : 0);
+    hipLaunchKernelGGL(knn_tree_build_par_kernel, dim3(bgrid), dim3(KTB_WAVES * 64), lds, st, b, n, support, clouds, stride, recs_off,
+                       two_phase ? KTD_TOP : 0, nflag);
     if (two_phase) {
-      const int rc = knn_tree_deep_launch(b, n, clouds, stride, recs_off, st);
+      const int rc = knn_tree_deep_launch(b, n, clouds, stride, recs_off, nflag, st);
       if (rc != PASNL_OK) return rc;
     }
   }
-  dim3 grid((m + 63) / 64, b);
+  if (nflag) {  // few queries: one wave each (knn_tree_search_wave_kernel), a capped grid
+#define PASNL_KT_WAVE(T)                                                                                                          \
+    hipLaunchKernelGGL(knn_tree_search_wave_kernel<T>, dim3(256), dim3(KTW_WAVES * 64), 0, st, b, n, m, k, queries, clouds, stride,  \
+                       recs_off, static_cast<T*>(idx), flag, nflag, only.flist)
+    if (idx_is_i64) PASNL_KT_WAVE(long long); else PASNL_KT_WAVE(int);
+#undef PASNL_KT_WAVE
+    return pasnl_launch_status();
+  }
+  const long sblocks = (long)((m + 63) / 64) * b;
+  dim3 grid((unsigned)(nflag ? std::min(sblocks, 512L) : sblocks));
   const size_t lds = (size_t)KT_LDS_DEPTH * 3 * 64 * 4 + (size_t)((k + 7) & ~7) * 64 * 8;
 #define PASNL_KT_SEARCH(T)                                                                                                        \
   {                                                                                                                               \
@@ -1084,9 +1526,91 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                                (int)lds) != hipSuccess)                                                           \
       return PASNL_ELAUNCH;                                                                                                       \
-    hipLaunchKernelGGL(kern, grid, dim3(64), lds, st, n, m, k, queries, clouds, stride, recs_off, static_cast<T*>(idx), flag);      \
+    hipLaunchKernelGGL(kern, grid, dim3(64), lds, st, b, n, m, k, queries, clouds, stride, recs_off, static_cast<T*>(idx), flag,    \
+                       nflag, only.flist);                                                                                        \
   }
   if (idx_is_i64) PASNL_KT_SEARCH(long long) else PASNL_KT_SEARCH(int)
 #undef PASNL_KT_SEARCH
   return pasnl_launch_status();
 }
+
+extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
+                                    int idx_is_i64, void* workspace, size_t workspace_bytes, pasnl_stream_t stream) {
+  return pasnl::knn_tree_launch(b, n, m, k, support, queries, idx, idx_is_i64, workspace, workspace_bytes,
+                                pasnl::KnnTieFlags{nullptr, nullptr}, nullptr, pasnl_hip_stream(stream));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pasnl_knn_batch_ref: the reference's result -- nanoflann's order among equal distances included -- at the canonical
+// kernels' price wherever distances are distinct.  (1) the flag counters are cleared; (2) the canonical search (grid-pruned
+// or brute force, as pasnl_knn_batch_ws would choose) writes every row and lists the queries whose K-list contains two equal
+// distances or ends on a tie (common.hpp knn_sorted_has_tie); (3) the KD-tree of every cloud with a listed query is built
+// and (4) searched for exactly those queries, whose rows are overwritten.  A query that is not listed has a single possible
+// answer under both orders, so the output is cpp_knn_batch's bit for bit (knn_.cxx:72-135, nanoflann.hpp:119-123).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void knn_ref_clear_kernel(int b, int* __restrict__ nflag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b) nflag[i] = 0;
+}
+
+namespace {
+struct RefLayout { size_t nflag, flist, grid, tree, total; };
+RefLayout ref_layout(int b, int n, int m, int k) {
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  RefLayout L;
+  L.nflag = 0;
+  L.flist = al((size_t)b * 4);
+  L.grid = L.flist + al((size_t)b * m * 4);
+  L.tree = L.grid + al(k <= 64 ? pasnl::knn_grid_ws_bytes(b, n) : 0);
+  L.total = L.tree + al(pasnl::knn_tree_ws_bytes(b, n, m, k));
+  return L;
+}
+}  // namespace
+
+extern "C" size_t pasnl_knn_batch_ref_workspace_bytes(int b, int n, int m, int k) {
+  if (b <= 0 || n <= 0 || m <= 0 || k <= 0) return 0;
+  return ref_layout(b, n, m, k).total;
+}
+
+extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* support, const float* queries, void* idx,
+                                   int idx_is_i64, int* depth_flag, void* workspace, size_t workspace_bytes, int max_workgroups,
+                                   pasnl_stream_t stream) {
+  PASNL_REQUIRE(b >= 0 && n > 0 && m >= 0 && k > 0 && max_workgroups >= 0, PASNL_EINVAL);
+  PASNL_REQUIRE(k <= n, PASNL_EINVAL);
+  if (b == 0 || m == 0) return PASNL_OK;
+  PASNL_REQUIRE(support && queries && idx && workspace && depth_flag, PASNL_ENULL);
+  PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE(k <= 64 && n <= 65535, PASNL_EUNSUPPORTED);
+  const RefLayout L = ref_layout(b, n, m, k);
+  PASNL_REQUIRE(workspace_bytes >= L.total, PASNL_EWORKSPACE);
+  hipStream_t st = pasnl_hip_stream(stream);
+  char* base = static_cast<char*>(workspace);
+  pasnl::KnnTieFlags flags{reinterpret_cast<int*>(base + L.nflag), reinterpret_cast<int*>(base + L.flist)};
+  hipLaunchKernelGGL(knn_ref_clear_kernel, dim3((b + 255) / 256), dim3(256), 0, st, b, flags.nflag);
+  int rc = pasnl::knn_grid_launch(b, n, m, k, support, queries, idx, idx_is_i64, nullptr, base + L.grid, L.tree - L.grid,
+                                  max_workgroups, flags, st);
+  if (rc != PASNL_OK) return rc;
+  if (n <= pasnl::KTS_NMAX) {  // tree + searches of a flagged cloud in one workgroup, all in LDS
+    const size_t lds = pasnl::kts_lds_bytes(n);
+    const int grid = std::min(b, 64);
+#define PASNL_KTS(T)                                                                                                             \
+    {                                                                                                                             \
+      auto kern = pasnl::knn_tree_small_kernel<T>;                                                                                \
+      if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                 (int)lds) != hipSuccess)                                                         \
+        return PASNL_ELAUNCH;                                                                                                     \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(pasnl::KTB_WAVES * 64), lds, st, b, n, m, k, support, queries, static_cast<T*>(idx), \
+                         depth_flag, flags.nflag, flags.flist);                                                                   \
+    }
+    if (idx_is_i64) PASNL_KTS(long long) else PASNL_KTS(int)
+#undef PASNL_KTS
+    return pasnl_launch_status();
+  }
+  return pasnl::knn_tree_launch(b, n, m, k, support, queries, idx, idx_is_i64, base + L.tree, L.total - L.tree, flags, depth_flag, st);
+}
+
+#ifdef PASNL_TUNING
+extern "C" int pasnl_knn_small_probe_read(unsigned long long* host32) {
+  return hipMemcpyFromSymbol(host32, HIP_SYMBOL(pasnl::kts_probe), sizeof(pasnl::kts_probe)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -2,9 +2,11 @@
 imported by the models as ``nearest_neighbors.lib.python.nearest_neighbors`` (pointasnl_util.py:19).
 
 The reference builds a nanoflann KD-tree per cloud on the host (OpenMP over the batch) and is reached through
-tf.py_func, i.e. a device->host->device round trip per layer.  Here the search is an exact brute-force gfx950
-kernel; results are the K nearest in ascending (squared distance, index) order -- identical to nanoflann
-whenever distances are distinct (nanoflann's order among exactly equal distances is traversal dependent).
+tf.py_func, i.e. a device->host->device round trip per layer.  Here the search is an exact gfx950 kernel (brute force, or
+grid-pruned for large clouds) that returns the K nearest in ascending (squared distance, index) order -- nanoflann's list
+whenever a query's distances are distinct -- and, by default (tie_order="reference"), a GPU rebuild of nanoflann's own tree
+and search for exactly the queries whose list contains or ends on EQUAL distances (there nanoflann's order is its tree's
+visit order): the result is cpp_knn_batch's bit for bit, ties included, at the plain search's price on tie-free clouds.
 
 numpy in -> numpy int64 out like the reference (host buffers cross PCIe); torch CUDA tensors in -> torch CUDA
 tensors out (no copies), which is what utils/pointasnl_util.py uses.
@@ -19,29 +21,43 @@ from pointasnl_amd import _hip
 GRID = True  # False: brute-force kernels for every size (A/B, and the reference point of the grid kernel's parity test)
 
 
-# Tree-depth flags of tie_order="nanoflann" searches that were CAPTURED into a HIP graph: the flag (first word of the search's
-# workspace) cannot be read while capturing, so it stays on the device -- the workspace is kept alive here -- and
-# check_deferred_flags() reads them after a replay (one synchronisation per step instead of one per search).
-_DEFERRED_FLAGS = []
-_DEPTH_MSG = "knn_batch(tie_order='nanoflann'): a KD-tree deeper than 96 levels (pathologically clustered cloud)"
+# Tree-depth flag of the KD-tree searches (tie_order "reference" / "nanoflann"): ONE sticky int32 per device that the kernels
+# only ever set.  It cannot be read while a HIP graph is being captured (and reading it costs a synchronisation), so eager
+# tie_order="nanoflann" calls check it at once and everything else leaves it to check_deferred_flags().
+_DEPTH_FLAG = {}
+_DEPTH_MSG = ("knn_batch: a KD-tree deeper than 96 levels (pathologically clustered cloud); the affected rows hold valid neighbours in "
+              "canonical (distance, index) order instead of nanoflann's order among equal distances")
+
+
+def _depth_flag(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _DEPTH_FLAG:
+        _DEPTH_FLAG[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+    return _DEPTH_FLAG[key]
 
 
 def check_deferred_flags(clear=False):
-    """Raise PasnlUnsupported if any captured tie_order="nanoflann" search met a tree deeper than its stack (its rows are then
-    undefined).  Call it after replaying the graph; synchronises with the device.  clear=True forgets the captured searches
-    (their graph is gone)."""
-    bad = any(int(f.item()) != 0 for f in _DEFERRED_FLAGS)
+    """Raise PasnlUnsupported if any KD-tree search since the last cleared check (eager or replayed from a HIP graph) met a tree
+    deeper than its stack.  Synchronises with the device.  clear=True resets the flags."""
+    bad = any(int(f.item()) != 0 for f in _DEPTH_FLAG.values())
     if clear:
-        _DEFERRED_FLAGS.clear()
+        for f in _DEPTH_FLAG.values():
+            f.zero_()
     if bad:
         raise _hip.PasnlUnsupported(_DEPTH_MSG)
 
 
+def _check_args(pts, queries):
+    if pts.dim() != 3 or pts.shape[2] != 3 or queries.dim() != 3 or queries.shape[2] != 3:
+        raise ValueError("knn_batch expects (B,N,3) pts and (B,M,3) queries")
+    if queries.shape[0] != pts.shape[0]:
+        raise ValueError("knn_batch expects the same batch size for pts and queries")
+
+
 def _knn_tree_dev(pts, queries, K, i64, out=None):
-    """The reference's own order among equal distances (csrc/knn_tree.hip): nanoflann's tree and search rebuilt on the GPU.
+    """EVERY query through the GPU rebuild of nanoflann's tree and search (csrc/knn_tree.hip): the checker of the default path.
     Limits of the kernels (16-bit arrival / index packing, result sets in LDS): K <= 64, N <= 65535 -- beyond them the launcher
-    answers PASNL_EUNSUPPORTED and this raises PasnlUnsupported (use the canonical order there: it differs only inside runs of
-    exactly equal distances)."""
+    answers PASNL_EUNSUPPORTED and this raises PasnlUnsupported."""
     b, n, _ = pts.shape
     m = queries.shape[1]
     if K > n:
@@ -53,9 +69,24 @@ def _knn_tree_dev(pts, queries, K, i64, out=None):
                 _hip.ptr(ws), ctypes.c_size_t(nbytes))
     flag = ws[:4].view(torch.int32)
     if torch.cuda.is_current_stream_capturing():
-        _DEFERRED_FLAGS.append(flag)  # stays on the device: check_deferred_flags() after the replay
+        _depth_flag(pts.device).bitwise_or_(flag)  # (captured with the search: the sticky flag is read after the replays)
     elif int(flag.item()) != 0:  # eager: checked at once (a synchronisation: this mode is about exactness, not speed)
         raise _hip.PasnlUnsupported(_DEPTH_MSG)
+    return out
+
+
+def _knn_ref_dev(pts, queries, K, i64, out=None, max_workgroups=None, stats=None):
+    """The default: canonical search + nanoflann's tree for the queries whose K-list contains or ends on equal distances
+    (pasnl_knn_batch_ref).  No synchronisation; the depth flag is sticky (check_deferred_flags)."""
+    b, n, _ = pts.shape
+    m = queries.shape[1]
+    out = _out_buffer(out, (b, m, int(K)), torch.int64 if i64 else torch.int32, pts.device)
+    nbytes = int(_hip.lib().pasnl_knn_batch_ref_workspace_bytes(b, n, m, int(K)))
+    ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=pts.device)
+    _hip.launch("pasnl_knn_batch_ref", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
+                _hip.ptr(_depth_flag(pts.device)), _hip.ptr(ws), ctypes.c_size_t(nbytes), int(max_workgroups or 0))
+    if stats is not None:  # (tests, bench) the per-cloud numbers of queries that went through the tree: the workspace's first b ints
+        stats.append(ws[:4 * b].view(torch.int32))
     return out
 
 
@@ -67,19 +98,25 @@ def _out_buffer(t, shape, dtype, device):
     return t
 
 
-def _knn_dev(pts, queries, K, i64, tie_order="index", out=None, max_workgroups=None):
+TIE_ORDERS = ("reference", "index", "nanoflann")
+REF_MAX_K, REF_MAX_N = 64, 65535  # limits of the KD-tree kernels (include/pasnl.h: pasnl_knn_batch_ref)
+
+
+def _knn_dev(pts, queries, K, i64, tie_order="reference", out=None, max_workgroups=None, stats=None):
+    if tie_order not in TIE_ORDERS:
+        raise ValueError("tie_order is 'reference' (cpp_knn_batch's result, ties included; the default), 'index' (canonical "
+                         "(distance, index) order) or 'nanoflann' (every query through the rebuilt KD-tree: the checker)")
+    _check_args(pts, queries)
     if tie_order == "nanoflann":
-        if pts.dim() != 3 or pts.shape[2] != 3 or queries.dim() != 3 or queries.shape[2] != 3 or queries.shape[0] != pts.shape[0]:
-            raise ValueError("knn_batch expects (B,N,3) pts and (B,M,3) queries")
         return _knn_tree_dev(pts, queries, K, i64, out)
-    if tie_order != "index":
-        raise ValueError("tie_order is 'index' (canonical (distance, index) order) or 'nanoflann' (the reference's visit order)")
-    if pts.dim() != 3 or pts.shape[2] != 3 or queries.dim() != 3 or queries.shape[2] != 3:
-        raise ValueError("knn_batch expects (B,N,3) pts and (B,M,3) queries")
-    if queries.shape[0] != pts.shape[0]:
-        raise ValueError("knn_batch expects the same batch size for pts and queries")
     b, n, _ = pts.shape
     m = queries.shape[1]
+    if tie_order == "reference" and b > 0 and m > 0 and 0 < K <= n:
+        if K > REF_MAX_K or n > REF_MAX_N:
+            raise _hip.PasnlUnsupported(
+                f"knn_batch(tie_order='reference') covers K <= {REF_MAX_K} and N <= {REF_MAX_N} (got K={K}, N={n}): pass "
+                "tie_order='index' for the canonical (distance, index) order, which differs only among exactly equal distances")
+        return _knn_ref_dev(pts, queries, K, i64, out, max_workgroups, stats)
     out = _out_buffer(out, (b, m, int(K)), torch.int64 if i64 else torch.int32, pts.device)
     nbytes = int(_hip.lib().pasnl_knn_workspace_bytes(b, n)) if GRID and K <= 64 else 0
     if nbytes:  # large clouds: grid-pruned search in a scratch workspace (bit-identical results, csrc/knn_grid.hip)
@@ -96,14 +133,17 @@ def _knn_dev(pts, queries, K, i64, tie_order="index", out=None, max_workgroups=N
     return out
 
 
-def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="index", out=None, max_workgroups=None):
+def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="reference", out=None, max_workgroups=None, stats=None):
     """(B,N,3), (B,M,3) -> (B,M,K) neighbour indices (int64 like the reference; ``dtype=torch.int32`` skips
     the cast the models do at pointasnl_util.py:30).  ``omp`` is accepted and ignored.
-    tie_order: "index" (default) = ascending (distance, index), the canonical order and what the models use; "nanoflann" =
-    the reference's own order among EXACTLY equal distances (its KD-tree's visit order), bit-identical to cpp_knn_batch on
-    lattices and duplicated points too -- slower (the tree is rebuilt per call), for exact reproduction only; K <= 64 and
-    N <= 65535 (PasnlUnsupported beyond).  Captured into a HIP graph its tree-depth flag stays on the device:
-    check_deferred_flags() after the replay.  out: optional device buffer (B,M,K) of the result's dtype to write into.
+    tie_order: "reference" (default, what the models use) = cpp_knn_batch's result bit for bit, its order among EXACTLY equal
+    distances (nanoflann's KD-tree visit order) included: the canonical search, then the rebuilt tree for the queries whose list
+    contains or ends on a tie (none on clouds with distinct distances: the plain search's price); K <= 64 and N <= 65535
+    (PasnlUnsupported beyond: ask for "index" there).  "index" = ascending (distance, index), the canonical order: the same list
+    wherever distances are distinct.  "nanoflann" = every query through the rebuilt tree (same result as "reference", slower:
+    the checker).  A tree deeper than 96 levels raises a sticky flag: check_deferred_flags().
+    out: optional device buffer (B,M,K) of the result's dtype to write into.  stats: a list that receives, per "reference"
+    search, the (B,) int32 device tensor of how many queries of each cloud went through the tree.
     max_workgroups: run the search of a large cloud as a background job on at most that many workgroups (a side stream's
     search beside other work; the same results, see pasnl_knn_batch_ws_bg)."""
     host = not isinstance(pts, torch.Tensor)
@@ -112,8 +152,13 @@ def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="index", out=Non
     i64 = dtype in (None, torch.int64, np.int64)
     if out is not None and host:
         raise ValueError("knn_batch: out= takes a device tensor (device inputs only)")
-    out = _knn_dev(p, q, K, i64, tie_order, out, max_workgroups)
+    out = _knn_dev(p, q, K, i64, tie_order, out, max_workgroups, stats)
     return out.cpu().numpy() if host else out
+
+
+def _default_order(p, K):
+    """single-cloud / legacy entry points: the reference's order where the tree kernels cover the shape, else canonical"""
+    return "reference" if K <= REF_MAX_K and p.shape[-2] <= REF_MAX_N else "index"
 
 
 def knn(pts, queries, K, omp=False):
@@ -121,7 +166,7 @@ def knn(pts, queries, K, omp=False):
     host = not isinstance(pts, torch.Tensor)
     p = _hip.as_dev(pts, torch.float32)[None]
     q = _hip.as_dev(queries, torch.float32)[None]
-    out = _knn_dev(p, q, K, True)[0]
+    out = _knn_dev(p, q, K, True, _default_order(p, K))[0]
     return out.cpu().numpy() if host else out
 
 

@@ -22,9 +22,10 @@ from pointasnl_amd.utils import tf_util
 NL_VARIANT = 0  # 0 auto / 1 vector-FMA / 2 MFMA  (pasnl_nl_attention); bench.py --ops sweeps it
 
 
-KNN_TIE_ORDER = "index"  # "nanoflann": neighbour lists in the reference's own order among exactly equal distances (its KD-tree's
-#                          visit order, csrc/knn_tree.hip) -- for bit-exact reproduction on clouds with duplicated / lattice
-#                          coordinates; slower (a tree per call).  Distinct distances: both orders are the same list.
+KNN_TIE_ORDER = "reference"  # nearest_neighbors.knn_batch's tie_order for every search of the models: "reference" = cpp_knn_batch's
+#                              result bit for bit, nanoflann's order among exactly equal distances included (the canonical search +
+#                              the rebuilt KD-tree for the queries that have such a tie; free on tie-free clouds); "index" = the
+#                              canonical (distance, index) order (A/B); "nanoflann" = every query through the tree (the checker).
 
 
 def knn_query(k, support_pts, query_pts, out=None, max_workgroups=None):

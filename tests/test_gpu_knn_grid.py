@@ -20,10 +20,10 @@ def both(sup, qry, k, dist=False):
 
     s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
     NN.GRID = True
-    g = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32).cpu().numpy()
+    g = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="index").cpu().numpy()
     NN.GRID = False
     try:
-        bf = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32).cpu().numpy()
+        bf = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="index").cpu().numpy()
     finally:
         NN.GRID = True
     return g, bf
@@ -87,9 +87,10 @@ def test_grid_knn_background_form_gives_the_same_lists(name, cap):
     sup, qry, k = CASES[name]
     qry = sup if qry is None else qry
     s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
-    usual = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32)
-    capped = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, max_workgroups=cap)
-    assert torch.equal(usual, capped)
+    for order in ("index", "reference"):
+        usual = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order=order)
+        capped = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, max_workgroups=cap, tie_order=order)
+        assert torch.equal(usual, capped)
 
 
 def test_grid_knn_distances_and_int64():
@@ -140,8 +141,15 @@ def test_knn_nanoflann_tie_order_matches_the_reference(case):
     np.testing.assert_array_equal(got, want)
     got64 = P.nearest_neighbors.knn_batch(s, q, k, tie_order="nanoflann")
     assert got64.dtype == torch.int64 and np.array_equal(got64.cpu().numpy(), want)
-    # the default order: the same distances position by position, a different order only inside runs of equal distance
-    canon = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32).cpu().numpy()
+    # THE DEFAULT PATH (canonical search + the tree for the flagged queries only): the reference's lists, index for index
+    stats = []
+    dflt = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, stats=stats)
+    np.testing.assert_array_equal(dflt.cpu().numpy(), want)
+    assert int(stats[0].max()) <= m and (int(stats[0].sum()) > 0 or kind not in ("lattice", "lattice16", "dup", "same", "line", "lattice_q_off"))
+    d64 = P.nearest_neighbors.knn_batch(s, q, k)
+    assert d64.dtype == torch.int64 and np.array_equal(d64.cpu().numpy(), want)
+    # the canonical order: the same distances position by position, a different order only inside runs of equal distance
+    canon = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="index").cpu().numpy()
     d = lambda idx: ((qry[:, :, None, :] - np.take_along_axis(sup[:, None, :, :], idx[..., None].astype(np.int64), axis=2)) ** 2).sum(-1)
     np.testing.assert_array_equal(d(canon), d(want))
     if kind in ("lattice", "lattice16", "dup", "same", "line", "lattice_q_off"):
@@ -157,6 +165,8 @@ def test_knn_nanoflann_matches_live_reference_when_built():
     want = ref.knn_batch(sup, qry, 24)
     got = P.nearest_neighbors.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), 24, tie_order="nanoflann")
     np.testing.assert_array_equal(got.cpu().numpy(), want)
+    dflt = P.nearest_neighbors.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), 24)
+    np.testing.assert_array_equal(dflt.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("n,m,k,kind", [(8192, 300, 32, "lattice"), (10240, 200, 16, "dup"), (37, 20, 8, "lattice"), (11, 5, 3, "lattice"),
@@ -182,3 +192,83 @@ def test_knn_nanoflann_parallel_build_matches_live_reference(n, m, k, kind):
     want = ref.knn_batch(sup, qry, k)
     got = P.nearest_neighbors.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), k, tie_order="nanoflann")
     np.testing.assert_array_equal(got.cpu().numpy(), want)
+    stats = []
+    dflt = P.nearest_neighbors.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), k, stats=stats)
+    np.testing.assert_array_equal(dflt.cpu().numpy(), want)   # the default path: only the flagged queries went through the tree
+    assert int(stats[0].sum()) <= 3 * m and (int(stats[0].sum()) > 0 or n < 100)
+
+
+# ---- the default path (pasnl_knn_batch_ref): which queries it sends through the tree
+@pytest.mark.parametrize("name", ["ball_8192_self", "scannet_8192", "kitti_10240", "k64", "queries_outside", "translated_1e4"])
+def test_default_order_on_tie_free_clouds_flags_nothing_and_is_the_canonical_list(name):
+    """Clouds whose distances are distinct: no query is flagged (the four tree kernels return at once), the result is the
+    canonical list bit for bit -- and the reference library's where it is here."""
+    from oracle import ref
+    sup, qry, k = CASES[name]
+    qry = sup if qry is None else qry
+    s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    stats = []
+    dflt = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, stats=stats)
+    canon = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="index")
+    nflag = int(stats[0].sum())
+    # (a pair of exactly equal fp32 distances occurs by chance: about one query in 30 000 at K = 32 on unit-ball clouds, more where
+    # the coordinates are large against the distances -- translated clouds -- and few of the mantissa's bits are left to differ)
+    assert nflag <= max(3, qry.shape[0] * qry.shape[1] // 300), nflag
+    if nflag == 0:
+        assert torch.equal(dflt, canon)
+    if ref.available("libref_knn.so"):
+        sub = slice(0, min(qry.shape[1], 1500))
+        np.testing.assert_array_equal(dflt[:, sub].cpu().numpy(), ref.knn_batch(sup, qry[:, sub].copy(), k))
+
+
+@pytest.mark.parametrize("name", ["lattice", "duplicates", "all_identical", "flat_plane", "line"])
+def test_default_order_equals_the_full_tree_search_on_clouds_made_of_ties(name):
+    """default (flagged queries only) == tie_order="nanoflann" (every query through the tree) == the reference library, on the
+    grid-pruned path's tie cases (n >= 4096: knn_grid's flags) -- and on a brute-force-sized slice of them (knn2's flags)."""
+    from oracle import ref
+    sup, qry, k = CASES[name]
+    for n in (sup.shape[1], 1500):
+        sp = np.ascontiguousarray(sup[:, :n])
+        qr = np.ascontiguousarray(sp[:, :700])
+        s, q = torch.from_numpy(sp).cuda(), torch.from_numpy(qr).cuda()
+        stats = []
+        dflt = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, stats=stats)
+        full = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="nanoflann")
+        assert torch.equal(dflt, full), (name, n)
+        if ref.available("libref_knn.so"):
+            np.testing.assert_array_equal(dflt.cpu().numpy(), ref.knn_batch(sp, qr, k))
+
+
+def test_default_order_mixed_batch_only_builds_the_trees_it_needs():
+    """A batch where ONE cloud has ties: its flagged queries go through the tree, the other clouds' counts stay zero."""
+    from oracle import ref
+    sup = B.synth_clouds(31, 4, 1024)
+    sup[2] = (np.round(sup[2] * 8) / 8).astype(np.float32)
+    qry = np.ascontiguousarray(sup[:, :512])
+    stats = []
+    dflt = P.nearest_neighbors.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), 32, dtype=torch.int32, stats=stats)
+    counts = stats[0].cpu().numpy()
+    assert counts[2] > 400 and counts[[0, 1, 3]].sum() <= 2, counts
+    if ref.available("libref_knn.so"):
+        np.testing.assert_array_equal(dflt.cpu().numpy(), ref.knn_batch(sup, qry, 32))
+
+
+@pytest.mark.parametrize("k,n", [(1, 300), (5, 2500), (16, 3000), (16, 9000), (33, 600), (64, 64), (64, 5000), (7, 7)])
+def test_default_order_random_lattices_vs_live_reference(k, n):
+    """sweeps over K (both selection widths, the insertion kernel for K <= 16 on clouds above 2048 points, K = n) on half-snapped
+    clouds: some queries tie inside the list, some only at its end, some not at all."""
+    from oracle import ref
+    if not ref.available("libref_knn.so"):
+        pytest.skip("oracle/_ref/libref_knn.so not built here")
+    rng = np.random.default_rng(k * 1000 + n)
+    sup = rng.random((3, n, 3))
+    snap = rng.random((3, n)) < 0.5
+    sup[snap] = np.round(sup[snap] * 6) / 6
+    sup = sup.astype(np.float32)
+    m = min(n, 400)
+    qry = np.concatenate([sup[:, : m // 2], rng.random((3, m - m // 2, 3)).astype(np.float32)], axis=1)
+    stats = []
+    dflt = P.nearest_neighbors.knn_batch(torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda(), k, stats=stats)
+    np.testing.assert_array_equal(dflt.cpu().numpy(), ref.knn_batch(sup, qry, k))
+    if k > 1 and n > 64:
+        assert 0 < int(stats[0].sum()) <= 3 * m
