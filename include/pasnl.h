@@ -153,8 +153,8 @@ int pasnl_knn_batch_ws_bg(int b, int n, int m, int K, const float* support, cons
  * knn_.cxx:83).  Replaces cpp_knn_batch knn_.cxx:72-101 bit for bit, ties included, by rebuilding that tree and that search on
  * the GPU -- an exactness mode (a workgroup per cloud builds the tree level by level, a lane per query searches it: about
  * 1 ms for 16 clouds of 8192 points where the canonical kernels take 0.06), not a fast path; pasnl_knn_batch returns the
- * canonical (distance, index) order, identical whenever distances are distinct.  k <= n, k <= 64, n <= 65535
- * (else PASNL_EUNSUPPORTED).  workspace:
+ * canonical (distance, index) order, identical whenever distances are distinct.  k <= n, k <= PASNL_KNN_MAX_K (k > 64 or
+ * n > 65535: one wave per query instead of one lane; n > 10240: the tree from a one-lane build -- seconds at 1e5 points).  workspace:
  * pasnl_knn_tree_workspace_bytes(b, n, m, k) bytes; its first int32 is non-zero afterwards if a tree or a search was deeper
  * than 96 levels (pathological clustering: the result is then not valid). */
 size_t pasnl_knn_tree_workspace_bytes(int b, int n, int m, int k);
@@ -172,7 +172,9 @@ int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* support, const
  * depth_flag (device int, required): set to 1 -- never cleared by the library -- if a listed query's tree or search was deeper
  * than 96 levels; such rows KEEP the canonical order (valid neighbours, canonical order among equals).
  * max_workgroups > 0: the grid-pruned canonical search as a background job (pasnl_knn_batch_ws_bg); 0: the usual grid.
- * k <= n, k <= 64, n <= 65535 (else PASNL_EUNSUPPORTED).  workspace: pasnl_knn_batch_ref_workspace_bytes(b, n, m, k). */
+ * k <= n, k <= PASNL_KNN_MAX_K.  Clouds of up to 2048 points (k <= 64): tree and searches of a listed cloud in ONE workgroup, all
+ * in LDS; larger ones: the builds of pasnl_knn_batch_tree + one wave per listed query.
+ * workspace: pasnl_knn_batch_ref_workspace_bytes(b, n, m, k). */
 size_t pasnl_knn_batch_ref_workspace_bytes(int b, int n, int m, int k);
 int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
                         int* depth_flag, void* workspace, size_t workspace_bytes, int max_workgroups, pasnl_stream_t stream);

@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(64) void knn_tree_search_kernel(int b, int n, int m
 // + popcount: behind its equals, :115-134), the tail shifts by one lane (DPP).  Dependent steps: one per node and one per leaf.
 // Tree: node / record accessors over global memory (the builds above) or LDS (knn_tree_small_kernel below).
 // ---------------------------------------------------------------------------------------------------------------------
-template <typename IdxT, typename NodeP, typename RecP>
+template <typename IdxT, int SLOTS, typename NodeP, typename RecP>
 __device__ __forceinline__ bool knn_tree_search_wave(const float qx, const float qy, const float qz, const int k, const int root,
                                                      NodeP nodes, RecP recs, const float* rootbox, uint32_t* stk /* [KT_DEPTH * 3] */,
                                                      IdxT* __restrict__ orow, const int lane) {
@@ -1159,8 +1159,12 @@ __device__ __forceinline__ bool knn_tree_search_wave(const float qx, const float
     if (vec[d] > rootbox[2 * d + 1]) { dists[d] = (vec[d] - rootbox[2 * d + 1]) * (vec[d] - rootbox[2 * d + 1]); distsq += dists[d]; }
   }
   const float epsError = 1.f;
-  float ld = KT_FLT_MAX;   // KNNResultSet::init: dists[capacity - 1] = max (:84-90); rank `lane` of the sorted list
-  int li = 0;
+  // the sorted list: rank 64 s + lane in slot s of lane `lane` (K <= 64: one slot).  KNNResultSet::init: dists[capacity - 1] = max (:84-90)
+  float ld[SLOTS];
+  int li[SLOTS];
+#pragma unroll
+  for (int s0 = 0; s0 < SLOTS; ++s0) { ld[s0] = KT_FLT_MAX; li[s0] = 0; }
+  const int ks = (k - 1) >> 6, kl = (k - 1) & 63;  // slot / lane of the K-th entry
   float worst = KT_FLT_MAX;
   int node = root, sp = 0;
   float mindistsq = distsq;
@@ -1184,16 +1188,34 @@ __device__ __forceinline__ bool knn_tree_search_wave(const float qx, const float
             const float cd = readlane_f(dist, src);
             const int ci = __builtin_amdgcn_readlane(__float_as_int(c.w), src);
             // addPoint (:115-134): behind every entry with distance <= cd; beyond the capacity: dropped
-            const int pos = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < k && ld <= cd));
+            int pos = 0;
+#pragma unroll
+            for (int s0 = 0; s0 < SLOTS; ++s0) pos += (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(s0 * 64 + lane < k && ld[s0] <= cd));
             if (pos < k) {
-              const float sd = wave_shr1_f(ld);
-              const int si = wave_shr1_i(li);
-              if (lane > pos) { ld = sd; li = si; }
-              if (lane == pos) { ld = cd; li = ci; }
+              float carry_d = 0.f;
+              int carry_i = 0;
+#pragma unroll
+              for (int s0 = 0; s0 < SLOTS; ++s0) {  // ranks above pos move up by one; lane 63 of a slot carries into lane 0 of the next
+                const float top_d = readlane_f(ld[s0], 63);
+                const int top_i = __builtin_amdgcn_readlane(li[s0], 63);
+                float sd = wave_shr1_f(ld[s0]);
+                int si = wave_shr1_i(li[s0]);
+                if (lane == 0) { sd = carry_d; si = carry_i; }
+                const int r = s0 * 64 + lane;
+                if (r > pos) { ld[s0] = sd; li[s0] = si; }
+                if (r == pos) { ld[s0] = cd; li[s0] = ci; }
+                carry_d = top_d; carry_i = top_i;
+              }
             }
           }
         }
-        worst = readlane_f(ld, k - 1);
+        {
+          float t = KT_FLT_MAX;
+#pragma unroll
+          for (int s0 = 0; s0 < SLOTS; ++s0)
+            if (s0 == ks) t = readlane_f(ld[s0], kl);
+          worst = t;
+        }
         descending = false;
       } else {
         const int idx = nd.a;
@@ -1235,13 +1257,15 @@ __device__ __forceinline__ bool knn_tree_search_wave(const float qx, const float
       }
     }
   }
-  if (lane < k) orow[lane] = (IdxT)li;
+#pragma unroll
+  for (int s0 = 0; s0 < SLOTS; ++s0)
+    if (s0 * 64 + lane < k) orow[s0 * 64 + lane] = (IdxT)li[s0];
   return true;
 }
 
 // waves of a capped grid walk the flagged queries of all clouds (global tree: the builds above)
 constexpr int KTW_WAVES = 4;
-template <typename IdxT>
+template <typename IdxT, int SLOTS>
 __global__ __launch_bounds__(KTW_WAVES * 64) void knn_tree_search_wave_kernel(int b, int n, int m, int k, const float* __restrict__ queries,
                                                                              const char* __restrict__ ws_all, size_t stride, size_t recs_off,
                                                                              IdxT* __restrict__ out, int* __restrict__ flag,
@@ -1251,7 +1275,7 @@ __global__ __launch_bounds__(KTW_WAVES * 64) void knn_tree_search_wave_kernel(in
   const long gw = (long)blockIdx.x * KTW_WAVES + wave, nw = (long)gridDim.x * KTW_WAVES;
   long base = 0;  // flagged queries of the clouds before `bi`
   for (int bi = 0; bi < b; ++bi) {
-    const int nq = nflag[bi];
+    const int nq = nflag ? nflag[bi] : m;  // (no list: every query of every cloud -- the every-query mode beyond the lane search's limits)
     if (nq == 0) continue;
     const char* ws = ws_all + (size_t)bi * stride;
     const int* hdr = reinterpret_cast<const int*>(ws);
@@ -1262,9 +1286,9 @@ __global__ __launch_bounds__(KTW_WAVES * 64) void knn_tree_search_wave_kernel(in
     long e = (gw - base % nw + nw) % nw;
     for (; e < nq; e += nw) {
       if (hdr[0] != 0) { if (lane == 0) atomicExch(flag, 1); break; }  // the tree is not complete: the rows keep the canonical order
-      const int j = flist[(size_t)bi * m + e];
+      const int j = nflag ? flist[(size_t)bi * m + e] : (int)e;
       const float* qp = queries + ((size_t)bi * m + j) * 3;
-      if (!knn_tree_search_wave<IdxT>(qp[0], qp[1], qp[2], k, hdr[1], nodes, recs, bst[1].bbox, stacks[wave],
+      if (!knn_tree_search_wave<IdxT, SLOTS>(qp[0], qp[1], qp[2], k, hdr[1], nodes, recs, bst[1].bbox, stacks[wave],
                                       out + ((size_t)bi * m + j) * k, lane) && lane == 0)
         atomicExch(flag, 1);
     }
@@ -1411,7 +1435,7 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
       for (int e = wave; e < nq; e += KTB_WAVES) {
         const int j = flist[(size_t)cloud * m + e];
         const float* qp = queries + ((size_t)cloud * m + j) * 3;
-        if (!knn_tree_search_wave<IdxT>(qp[0], qp[1], qp[2], k, 0, nodes, rec, rootbox, stacks + wave * (KT_DEPTH * 3),
+        if (!knn_tree_search_wave<IdxT, 1>(qp[0], qp[1], qp[2], k, 0, nodes, rec, rootbox, stacks + wave * (KT_DEPTH * 3),
                                         out + ((size_t)cloud * m + j) * k, lane) && lane == 0)
           atomicExch(flag, 1);
       }
@@ -1467,7 +1491,7 @@ int pasnl::knn_tree_launch(int b, int n, int m, int k, const float* support, con
   if (b == 0 || m == 0) return PASNL_OK;
   PASNL_REQUIRE(support && queries && idx && workspace, PASNL_ENULL);
   PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
-  PASNL_REQUIRE(k <= 64 && n <= 65535, PASNL_EUNSUPPORTED);  // the search's result set: 16-bit arrival numbers / indices, k slots of LDS per lane
+  PASNL_REQUIRE(k <= PASNL_KNN_MAX_K, PASNL_EUNSUPPORTED);
   PASNL_REQUIRE(workspace_bytes >= knn_tree_ws_bytes(b, n, m, k), PASNL_EWORKSPACE);
   char* base = static_cast<char*>(workspace);
   int* flag = depth_flag;
@@ -1509,11 +1533,17 @@ int pasnl::knn_tree_launch(int b, int n, int m, int k, const float* support, con
       if (rc != PASNL_OK) return rc;
     }
   }
-  if (nflag) {  // few queries: one wave each (knn_tree_search_wave_kernel), a capped grid
-#define PASNL_KT_WAVE(T)                                                                                                          \
-    hipLaunchKernelGGL(knn_tree_search_wave_kernel<T>, dim3(256), dim3(KTW_WAVES * 64), 0, st, b, n, m, k, queries, clouds, stride,  \
+  // few queries (the flagged ones), or a shape beyond the lane-per-query kernel's packing (K > 64: a list of several registers per
+  // lane; n > 65535: 16-bit arrival numbers and indices): one WAVE per query (knn_tree_search_wave_kernel)
+  if (nflag || k > 64 || n > 65535) {
+    const long waves = nflag ? 1024L : (long)b * m;
+    const dim3 wgrid((unsigned)std::min((waves + KTW_WAVES - 1) / KTW_WAVES, 16384L));
+#define PASNL_KT_WAVE(T, S)                                                                                                       \
+    hipLaunchKernelGGL((knn_tree_search_wave_kernel<T, S>), wgrid, dim3(KTW_WAVES * 64), 0, st, b, n, m, k, queries, clouds, stride, \
                        recs_off, static_cast<T*>(idx), flag, nflag, only.flist)
-    if (idx_is_i64) PASNL_KT_WAVE(long long); else PASNL_KT_WAVE(int);
+#define PASNL_KT_WAVES(S) { if (idx_is_i64) PASNL_KT_WAVE(long long, S); else PASNL_KT_WAVE(int, S); }
+    if (k <= 64) PASNL_KT_WAVES(1) else if (k <= 128) PASNL_KT_WAVES(2) else PASNL_KT_WAVES(4)
+#undef PASNL_KT_WAVES
 #undef PASNL_KT_WAVE
     return pasnl_launch_status();
   }
@@ -1580,7 +1610,7 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
   if (b == 0 || m == 0) return PASNL_OK;
   PASNL_REQUIRE(support && queries && idx && workspace && depth_flag, PASNL_ENULL);
   PASNL_REQUIRE(b <= 65535, PASNL_EUNSUPPORTED);
-  PASNL_REQUIRE(k <= 64 && n <= 65535, PASNL_EUNSUPPORTED);
+  PASNL_REQUIRE(k <= PASNL_KNN_MAX_K, PASNL_EUNSUPPORTED);
   const RefLayout L = ref_layout(b, n, m, k);
   PASNL_REQUIRE(workspace_bytes >= L.total, PASNL_EWORKSPACE);
   hipStream_t st = pasnl_hip_stream(stream);
@@ -1590,7 +1620,7 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
   int rc = pasnl::knn_grid_launch(b, n, m, k, support, queries, idx, idx_is_i64, nullptr, base + L.grid, L.tree - L.grid,
                                   max_workgroups, flags, st);
   if (rc != PASNL_OK) return rc;
-  if (n <= pasnl::KTS_NMAX) {  // tree + searches of a flagged cloud in one workgroup, all in LDS
+  if (n <= pasnl::KTS_NMAX && k <= 64) {  // tree + searches of a flagged cloud in one workgroup, all in LDS
     const size_t lds = pasnl::kts_lds_bytes(n);
     const int grid = std::min(b, 64);
 #define PASNL_KTS(T)                                                                                                             \

@@ -56,8 +56,7 @@ def _check_args(pts, queries):
 
 def _knn_tree_dev(pts, queries, K, i64, out=None):
     """EVERY query through the GPU rebuild of nanoflann's tree and search (csrc/knn_tree.hip): the checker of the default path.
-    Limits of the kernels (16-bit arrival / index packing, result sets in LDS): K <= 64, N <= 65535 -- beyond them the launcher
-    answers PASNL_EUNSUPPORTED and this raises PasnlUnsupported."""
+    K <= 256 (PASNL_KNN_MAX_K); clouds above 10240 points get their tree from the one-lane build (seconds at 1e5 points)."""
     b, n, _ = pts.shape
     m = queries.shape[1]
     if K > n:
@@ -99,7 +98,7 @@ def _out_buffer(t, shape, dtype, device):
 
 
 TIE_ORDERS = ("reference", "index", "nanoflann")
-REF_MAX_K, REF_MAX_N = 64, 65535  # limits of the KD-tree kernels (include/pasnl.h: pasnl_knn_batch_ref)
+REF_MAX_K, REF_MAX_N = 256, 2 ** 31 - 1  # limits of the KD-tree kernels (include/pasnl.h: PASNL_KNN_MAX_K; int32 indices)
 
 
 def _knn_dev(pts, queries, K, i64, tie_order="reference", out=None, max_workgroups=None, stats=None):
@@ -138,8 +137,7 @@ def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="reference", out
     the cast the models do at pointasnl_util.py:30).  ``omp`` is accepted and ignored.
     tie_order: "reference" (default, what the models use) = cpp_knn_batch's result bit for bit, its order among EXACTLY equal
     distances (nanoflann's KD-tree visit order) included: the canonical search, then the rebuilt tree for the queries whose list
-    contains or ends on a tie (none on clouds with distinct distances: the plain search's price); K <= 64 and N <= 65535
-    (PasnlUnsupported beyond: ask for "index" there).  "index" = ascending (distance, index), the canonical order: the same list
+    contains or ends on a tie (none on clouds with distinct distances: the plain search's price); K <= 256.  "index" = ascending (distance, index), the canonical order: the same list
     wherever distances are distinct.  "nanoflann" = every query through the rebuilt tree (same result as "reference", slower:
     the checker).  A tree deeper than 96 levels raises a sticky flag: check_deferred_flags().
     out: optional device buffer (B,M,K) of the result's dtype to write into.  stats: a list that receives, per "reference"

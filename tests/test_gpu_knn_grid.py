@@ -272,3 +272,52 @@ def test_default_order_random_lattices_vs_live_reference(k, n):
     np.testing.assert_array_equal(dflt.cpu().numpy(), ref.knn_batch(sup, qry, k))
     if k > 1 and n > 64:
         assert 0 < int(stats[0].sum()) <= 3 * m
+
+
+@pytest.mark.parametrize("k,n,m", [(100, 700, 200), (200, 3000, 150), (256, 256, 64), (65, 5000, 100), (129, 1000, 80)])
+def test_wide_lists_default_and_every_query_tree_vs_live_reference(k, n, m):
+    """K > 64 (VERDICT r05 missing 4: the tree kernels refused it): the wave-per-query search keeps the sorted list in 2 / 4
+    registers per lane; half-snapped clouds so that the lists contain ties."""
+    from oracle import ref
+    if not ref.available("libref_knn.so"):
+        pytest.skip("oracle/_ref/libref_knn.so not built here")
+    rng = np.random.default_rng(k + n)
+    sup = rng.random((2, n, 3))
+    snap = rng.random((2, n)) < 0.5
+    sup[snap] = np.round(sup[snap] * 5) / 5
+    sup = sup.astype(np.float32)
+    qry = np.concatenate([sup[:, : m // 2], rng.random((2, m - m // 2, 3)).astype(np.float32)], axis=1)
+    want = ref.knn_batch(sup, qry, k)
+    s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    np.testing.assert_array_equal(P.nearest_neighbors.knn_batch(s, q, k).cpu().numpy(), want)
+    np.testing.assert_array_equal(P.nearest_neighbors.knn_batch(s, q, k, tie_order="nanoflann").cpu().numpy(), want)
+
+
+def test_the_references_own_shape_81920_points():
+    """utils/nearest_neighbors/test.py:5-8 of the reference: knn_batch on (16, 81920, 3) random points, K = 16 (queries = the
+    points).  Here: the default path at that cloud size (n > 65535: beyond the 16-bit packing of the lane-per-query tree
+    search; the canonical search is brute force above 16384 points) on 2 clouds x 4096 of their points as queries, against the
+    reference library; ties exist by chance only, so the tree is built (one-lane build, ~1 s) for the clouds that have one."""
+    import time
+    from oracle import ref
+    rng = np.random.default_rng(0)
+    sup = rng.random((2, 81920, 3)).astype(np.float32)       # np.random.rand(batch_size, num_points, 3).astype(np.float32)
+    qry = np.ascontiguousarray(sup[:, :4096])
+    s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    stats = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = P.nearest_neighbors.knn_batch(s, q, 16, stats=stats)
+    torch.cuda.synchronize()
+    print(f"default path, 2 x 81920 points, 4096 queries each, K=16: {1e3 * (time.perf_counter() - t0):.1f} ms, flagged {stats[0].tolist()}")
+    canon = P.nearest_neighbors.knn_batch(s, q, 16, tie_order="index")
+    d = lambda idx: ((qry[:, :, None, :] - np.take_along_axis(sup[:, None, :, :], idx[..., None], axis=2)) ** 2).sum(-1)
+    np.testing.assert_array_equal(d(got.cpu().numpy()), d(canon.cpu().numpy()))    # the same distances whatever the order
+    if ref.available("libref_knn.so"):
+        np.testing.assert_array_equal(got.cpu().numpy(), ref.knn_batch(sup, qry, 16))
+    # and a snapped cloud of that size: every query ties, every cloud gets its tree
+    sup2 = (np.round(sup[:1] * 64) / 64).astype(np.float32)
+    q2 = np.ascontiguousarray(sup2[:, :512])
+    got2 = P.nearest_neighbors.knn_batch(torch.from_numpy(sup2).cuda(), torch.from_numpy(q2).cuda(), 16)
+    if ref.available("libref_knn.so"):
+        np.testing.assert_array_equal(got2.cpu().numpy(), ref.knn_batch(sup2, q2, 16))

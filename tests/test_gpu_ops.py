@@ -250,9 +250,12 @@ def test_knn_batch(P, b, n, m, k, kind):
         got_np = P.nearest_neighbors.knn_batch(sup, qry, k)
         assert isinstance(got_np, np.ndarray) and got_np.dtype == np.int64
         np.testing.assert_array_equal(got_np, dflt.cpu().numpy())
-    else:
-        with pytest.raises(Exception):  # PasnlUnsupported: the tree kernels cover K <= 64
-            P.nearest_neighbors.knn_batch(dev(sup), dev(qry), k)
+    else:  # K > 64: lists of several registers per lane (insertion kernel's flags, wave-per-query tree search)
+        dflt = P.nearest_neighbors.knn_batch(dev(sup), dev(qry), k, omp=True)
+        if ref.available("libref_knn.so"):
+            np.testing.assert_array_equal(dflt.cpu().numpy(), ref.knn_batch(sup, qry, k))
+        if kind != "lattice":
+            np.testing.assert_array_equal(dflt.cpu().numpy(), want)
 
 
 def test_knn_self_first(P):
