@@ -222,6 +222,15 @@ int pasnl_fp_interpolate_cat(int b, int m, int c2, int n, int c1, const float* p
  * anything else: PASNL_EUNSUPPORTED (the Python mirror then takes the op-by-op path on the vendor BLAS). */
 int pasnl_nl_attention(int b, int p, int n, int cb, const float* q, const float* kv, float* out, int variant,
                        pasnl_stream_t stream);
+/* pasnl_nl_attention with a scratch workspace: where b * ceil(p / 64) workgroups would leave CUs empty (cb = 32; the
+ * SemanticKITTI model's layer 1_1: 8 x 1280 queries = 160 workgroups for 256 CUs) the KEYS are split over workgroups too
+ * ("flash-decoding"): every part leaves its un-normalised (O, m, l) in the workspace and a second small kernel combines the
+ * parts in ascending key order -- a fixed order: the result is a pure function of the inputs -- and normalises.  Same 1e-5
+ * contract; not the bits of the one-workgroup form (another association of the running rescalings).
+ * pasnl_nl_attention_workspace_bytes: the bytes that form needs for the shape, 0 where it is not used (workspace may be NULL). */
+size_t pasnl_nl_attention_workspace_bytes(int b, int p, int n, int cb);
+int pasnl_nl_attention_ws(int b, int p, int n, int cb, const float* q, const float* kv, float* out, int variant,
+                          void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
 
 /* Adaptive-Sampling micro self-attention over the first `as` neighbours of each query
  * (SampleWeights, pointasnl_util.py:136-146):  g groups, each q,k,v (as,cb):

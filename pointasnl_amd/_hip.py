@@ -19,7 +19,7 @@ SYMBOLS = [
     "pasnl_farthest_point_sample", "pasnl_farthest_point_sample_gather", "pasnl_gather_point", "pasnl_gather_point_grad", "pasnl_prob_sample",
     "pasnl_query_ball_point", "pasnl_sa_group", "pasnl_group_point", "pasnl_group_point_grad", "pasnl_select_top_k", "pasnl_knn_batch", "pasnl_knn_workspace_bytes", "pasnl_knn_batch_ws", "pasnl_knn_batch_ws_bg", "pasnl_knn_tree_workspace_bytes", "pasnl_knn_batch_tree", "pasnl_knn_batch_ref_workspace_bytes", "pasnl_knn_batch_ref", "pasnl_knn_distance_pick",
     "pasnl_three_nn", "pasnl_three_interpolate", "pasnl_three_interpolate_grad", "pasnl_three_weights", "pasnl_fp_interpolate_cat",
-    "pasnl_nl_attention", "pasnl_as_attention", "pasnl_as_reweight", "pasnl_sa_local_cell", "pasnl_sa_cell", "pasnl_sa_cell_centre0", "pasnl_sa_cell_packed", "pasnl_sa_tail", "pasnl_sa_tail_cat", "pasnl_sa_tail_res", "pasnl_sa_tail_packed_weights_bytes", "pasnl_sa_tail_pack_weights", "pasnl_sa_tail_packed", "pasnl_decode_cell", "pasnl_decode_cell_tiled", "pasnl_decode_cell_tiled_v4", "pasnl_max_pool_rows", "pasnl_max_pool_rows_strided", "pasnl_mlp3_max_pool_workspace_bytes", "pasnl_mlp3_max_pool", "pasnl_mlp3_packed_weights_bytes", "pasnl_mlp3_pack_weights", "pasnl_dense_rows_workspace_bytes", "pasnl_dense_rows", "pasnl_dense_splitk_workspace_bytes", "pasnl_dense_splitk", "pasnl_bf16x3_weights_bytes", "pasnl_bf16x3_split_weights", "pasnl_dense_bf16x3", "pasnl_narrow_project2", "pasnl_take_neighbor0", "pasnl_as_gather", "pasnl_as_attention_qkv", "pasnl_as_attention_proj", "pasnl_as_cell_narrow", "pasnl_as_cell_wide", "pasnl_as_cell_wide_ld", "pasnl_as_reweight_x", "pasnl_grid_subsample_workspace_bytes", "pasnl_grid_subsample", "pasnl_knn_crop_workspace_bytes", "pasnl_knn_crop",
+    "pasnl_nl_attention", "pasnl_nl_attention_workspace_bytes", "pasnl_nl_attention_ws", "pasnl_as_attention", "pasnl_as_reweight", "pasnl_sa_local_cell", "pasnl_sa_cell", "pasnl_sa_cell_centre0", "pasnl_sa_cell_packed", "pasnl_sa_tail", "pasnl_sa_tail_cat", "pasnl_sa_tail_res", "pasnl_sa_tail_packed_weights_bytes", "pasnl_sa_tail_pack_weights", "pasnl_sa_tail_packed", "pasnl_decode_cell", "pasnl_decode_cell_tiled", "pasnl_decode_cell_tiled_v4", "pasnl_max_pool_rows", "pasnl_max_pool_rows_strided", "pasnl_mlp3_max_pool_workspace_bytes", "pasnl_mlp3_max_pool", "pasnl_mlp3_packed_weights_bytes", "pasnl_mlp3_pack_weights", "pasnl_dense_rows_workspace_bytes", "pasnl_dense_rows", "pasnl_dense_splitk_workspace_bytes", "pasnl_dense_splitk", "pasnl_bf16x3_weights_bytes", "pasnl_bf16x3_split_weights", "pasnl_dense_bf16x3", "pasnl_narrow_project2", "pasnl_take_neighbor0", "pasnl_as_gather", "pasnl_as_attention_qkv", "pasnl_as_attention_proj", "pasnl_as_cell_narrow", "pasnl_as_cell_wide", "pasnl_as_cell_wide_ld", "pasnl_as_reweight_x", "pasnl_grid_subsample_workspace_bytes", "pasnl_grid_subsample", "pasnl_knn_crop_workspace_bytes", "pasnl_knn_crop",
     "pasnl_grad_workspace_bytes", "pasnl_gather_point_grad_det", "pasnl_group_point_grad_det", "pasnl_three_interpolate_grad_det",
 ]
 
@@ -58,6 +58,7 @@ def lib():
         _lib.pasnl_dense_splitk_workspace_bytes.restype = ctypes.c_size_t
         _lib.pasnl_grid_subsample_workspace_bytes.restype = ctypes.c_size_t
         _lib.pasnl_knn_crop_workspace_bytes.restype = ctypes.c_size_t
+        _lib.pasnl_nl_attention_workspace_bytes.restype = ctypes.c_size_t
         for s in SYMBOLS:
             getattr(_lib, s)  # AttributeError here == header / library mismatch
     return _lib

@@ -467,9 +467,14 @@ __global__ __launch_bounds__(SPLIT * 64, CB == 64 ? 2 : 1) void nl_attention_dir
 // key blocks per wave, same merge order).  cls layer 1 64.6 -> 55 us, ScanNet layer 1 202 -> 178, KITTI layer 1_1 222 -> 200
 // (profiles/r04_q_nl_pair.txt); without its refills the loop runs 2-3 % faster: it is not waiting for memory.
 // =============================================================================================
-template <int SPLIT>
+// PART ("flash-decoding"): where b * ceil(p / 64) workgroups leave CUs empty (KITTI layer 1_1: 160 for 256 CUs),
+// the KEYS are split over gridDim.z workgroups as well: workgroup z owns the key blocks [z * bpz, (z + 1) * bpz), merges its waves
+// as before and leaves (O, m, l) un-normalised in a workspace; nl_attention_merge_kernel combines the parts in ascending z -- a
+// fixed order, so the result is a pure function of the inputs -- and normalises.
+template <int SPLIT, bool PART = false>
 __global__ __launch_bounds__(SPLIT * 64, 2) void nl_attention_pair_kernel(int p, int n, float qscale, const float* __restrict__ q,
-                                                                     const float* __restrict__ kv, float* __restrict__ out) {
+                                                                     const float* __restrict__ kv, float* __restrict__ out,
+                                                                     int bpz = 0, float* __restrict__ part = nullptr) {
   constexpr int CB = 32, HC = 16;
   constexpr int PARK = (CB / 2 + 2) * 64;  // floats a wave parks per tile for the merge
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -502,8 +507,11 @@ __global__ __launch_bounds__(SPLIT * 64, 2) void nl_attention_pair_kernel(int p,
   // n is a multiple of the 32-key block here (the launcher's condition): no ragged block, so a block's rows are ONE lane
   // pointer each for K and V plus compile-time offsets (V: rows kappa(t, h) - 14 around row 14, inside the load's 13-bit
   // immediate), advanced by a uniform stride per block -- 4 address registers instead of 40
-  const float* kp = kvb + (size_t)(wave * NL_KB + ql) * 2 * CB + HC * h;
-  const float* vp = kvb + (size_t)(wave * NL_KB + 4 * h + 14) * 2 * CB + CB + ql;
+  // the key blocks of this workgroup: all of them, or (PART) its slice
+  const int kfirst = PART ? (int)blockIdx.z * bpz * NL_KB : 0;
+  const int kend = PART ? min(n, kfirst + bpz * NL_KB) : n;
+  const float* kp = kvb + (size_t)(kfirst + wave * NL_KB + ql) * 2 * CB + HC * h;
+  const float* vp = kvb + (size_t)(kfirst + wave * NL_KB + 4 * h + 14) * 2 * CB + CB + ql;
   auto load_k = [&]() {
 #pragma unroll
     for (int g = 0; g < HC / 4; ++g) {
@@ -546,16 +554,16 @@ __global__ __launch_bounds__(SPLIT * 64, 2) void nl_attention_pair_kernel(int p,
     }
   };
 
-  const int first = wave * NL_KB;
+  const int first = kfirst + wave * NL_KB;
   constexpr size_t STRIDE = (size_t)SPLIT * NL_KB * 2 * CB;  // floats between a wave's consecutive key blocks
-  if (first < n) {
+  if (first < kend) {
     load_k();
     __builtin_amdgcn_sched_barrier(0);
     load_v();
     __builtin_amdgcn_sched_barrier(0);
   }
-  for (int base = first; base < n; base += SPLIT * NL_KB) {
-    if (base + SPLIT * NL_KB < n) { kp += STRIDE; vp += STRIDE; }  // (uniform) the last refill of a wave re-reads its block
+  for (int base = first; base < kend; base += SPLIT * NL_KB) {
+    if (base + SPLIT * NL_KB < kend) { kp += STRIDE; vp += STRIDE; }  // (uniform) the last refill of a wave re-reads its block
     f32x16 S0, S1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { S0[r] = 0.f; S1[r] = 0.f; }
@@ -619,6 +627,19 @@ __global__ __launch_bounds__(SPLIT * 64, 2) void nl_attention_pair_kernel(int p,
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[u][r] = O[u][r] * a0 + pw[r * 64 + lane] * a1;
       }
+  } else if (wave > 0) {
+    return;
+  }
+  if constexpr (PART) {  // (wave 0) this slice's running state, in the layout the waves park theirs: [tile][16 O rows, m, l][lane]
+    float* pz = part + (((size_t)bi * gridDim.x + qt) * gridDim.z + blockIdx.z) * 2 * PARK;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) pz[u * PARK + r * 64 + lane] = O[u][r];
+      pz[u * PARK + 16 * 64 + lane] = mrun[u];
+      pz[u * PARK + 17 * 64 + lane] = lrun[u];
+    }
+    return;
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -631,6 +652,41 @@ __global__ __launch_bounds__(SPLIT * 64, 2) void nl_attention_pair_kernel(int p,
         *reinterpret_cast<float4*>(op + 8 * g + 4 * h) = v;
       }
     }
+}
+
+// the parts of nl_attention_pair_kernel<., true> combined in ascending z (the same rescaling as the merge of a workgroup's waves),
+// normalised and written: one wave per pair of query tiles; grid = (ceil(p / 64), b)
+__global__ __launch_bounds__(64) void nl_attention_merge_kernel(int p, int kparts, const float* __restrict__ part, float* __restrict__ out) {
+  constexpr int CB = 32, PARK = (CB / 2 + 2) * 64;
+  const int lane = threadIdx.x, h = lane >> 5, ql = lane & 31;
+  const int bi = blockIdx.y, qt = blockIdx.x, q0 = qt * 64;
+  const float* pb = part + (((size_t)bi * gridDim.x + qt) * kparts) * 2 * PARK;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    float O[16], mrun = pb[u * PARK + 16 * 64 + lane], lrun = pb[u * PARK + 17 * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[r] = pb[u * PARK + r * 64 + lane];
+    for (int z = 1; z < kparts; ++z) {
+      const float* pw = pb + (size_t)z * 2 * PARK + u * PARK;
+      const float mw = pw[16 * 64 + lane], lw = pw[17 * 64 + lane];
+      const float mnew = fmaxf(mrun, mw);  // a part that saw no key block has m = -inf, l = 0, O = 0
+      const float a0 = mrun == -INFINITY ? 0.f : fast_exp2(mrun - mnew);
+      const float a1 = mw == -INFINITY ? 0.f : fast_exp2(mw - mnew);
+      lrun = lrun * a0 + lw * a1;
+      mrun = mnew;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O[r] = O[r] * a0 + pw[r * 64 + lane] * a1;
+    }
+    if (q0 + 32 * u + ql < p) {
+      const float inv = 1.0f / lrun;
+      float* op = out + ((size_t)bi * p + q0 + 32 * u + ql) * CB;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(O[4 * g] * inv, O[4 * g + 1] * inv, O[4 * g + 2] * inv, O[4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + 8 * g + 4 * h) = v;
+      }
+    }
+  }
 }
 
 // =============================================================================================
@@ -1689,7 +1745,49 @@ static int nl_pair_launch(int b, int p, int n, float qscale, const float* q, con
   if (lds > 48 * 1024 &&
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return PASNL_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3((p + 63) / 64, b), dim3(SPLIT * 64), lds, st, p, n, qscale, q, kv, out);
+  hipLaunchKernelGGL(kern, dim3((p + 63) / 64, b), dim3(SPLIT * 64), lds, st, p, n, qscale, q, kv, out, 0, static_cast<float*>(nullptr));
+  return pasnl_launch_status();
+}
+
+// Keys over workgroups (nl_attention_pair_kernel<., true>): for cb = 32 shapes whose b * ceil(p / 64) workgroups leave CUs empty
+// and whose key loops are long (n >= 4096).  -> kparts (1: not used) and the waves per workgroup.  Measured on the shapes of the
+// models (tools/nl_parts_sweep.py): four waves per workgroup; the number of parts that deals the workgroups evenly to the 256
+// CUs -- the smallest k that minimises ceil(pairs k / 256) / k -- with >= 4 key blocks per wave: [8,1280,10240] 198 -> 128 us
+// at k = 8 (1280 workgroups = 5 per CU), [4,1024,8192] 90 -> 49 us at k = 4; key sets of 40 blocks ([8,320,1280], 18 us) gain
+// nothing and keep the plain form.
+struct NlParts { int kparts, split; };
+static NlParts nl_parts(int b, int p, int n, int cb) {
+  NlParts r{1, 1};
+  if (cb != 32 || n % NL_KB != 0) return r;
+  const long pairs = (long)b * ((p + 63) / 64), blocks = n / NL_KB;
+  if (pairs >= 224 || pairs <= 0 || blocks < 128) return r;  // (the plain form has a workgroup for ~every CU / short key loops)
+  const int split = 4;
+  double best = 1.0;  // the plain form: one round of whole pairs
+  for (int k = 2; k <= 32 && (long)k * split * 4 <= blocks; ++k) {
+    const double t = (double)((pairs * k + 255) / 256) / (double)k;
+    if (t < best - 1e-9) { best = t; r.kparts = k; r.split = split; }
+  }
+  if (const char* e = tune_env("PASNL_NL_PARTS")) {  // tuning build only: "kparts,split"
+    int k = 1, sp = 8;
+    if (sscanf(e, "%d,%d", &k, &sp) == 2 && k >= 1 && (long)k * sp <= blocks) { r.kparts = k; r.split = sp; }
+  }
+  return r;
+}
+static size_t nl_parts_bytes(int b, int p, int kparts) {
+  return (size_t)b * ((p + 63) / 64) * kparts * 2 * (32 / 2 + 2) * 64 * sizeof(float);
+}
+
+template <int SPLIT>
+static int nl_pair_parts_launch(int b, int p, int n, float qscale, const float* q, const float* kv, float* out, int kparts, float* part,
+                                hipStream_t st) {
+  const size_t lds = (size_t)SPLIT * 2 * (32 / 2 + 2) * 64 * sizeof(float);
+  auto kern = nl_attention_pair_kernel<SPLIT, true>;
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return PASNL_ELAUNCH;
+  const int blocks = n / NL_KB, bpz = (blocks + kparts - 1) / kparts;
+  hipLaunchKernelGGL(kern, dim3((p + 63) / 64, b, kparts), dim3(SPLIT * 64), lds, st, p, n, qscale, q, kv, out, bpz, part);
+  hipLaunchKernelGGL(nl_attention_merge_kernel, dim3((p + 63) / 64, b), dim3(64), 0, st, p, kparts, part, out);
   return pasnl_launch_status();
 }
 
@@ -1740,8 +1838,23 @@ static int nl_valu_launch(int b, int p, int n, float qscale, const float* q, con
   return pasnl_launch_status();
 }
 
+static int nl_attention_entry(int b, int p, int n, int cb, const float* q, const float* kv, float* out, int variant,
+                              void* workspace, size_t workspace_bytes, pasnl_stream_t stream);
 extern "C" int pasnl_nl_attention(int b, int p, int n, int cb, const float* q, const float* kv, float* out, int variant,
                                   pasnl_stream_t stream) {
+  return nl_attention_entry(b, p, n, cb, q, kv, out, variant, nullptr, 0, stream);
+}
+extern "C" size_t pasnl_nl_attention_workspace_bytes(int b, int p, int n, int cb) {
+  if (b <= 0 || p <= 0 || n <= 0) return 0;
+  const NlParts np = nl_parts(b, p, n, cb);
+  return np.kparts > 1 ? nl_parts_bytes(b, p, np.kparts) : 0;
+}
+extern "C" int pasnl_nl_attention_ws(int b, int p, int n, int cb, const float* q, const float* kv, float* out, int variant,
+                                     void* workspace, size_t workspace_bytes, pasnl_stream_t stream) {
+  return nl_attention_entry(b, p, n, cb, q, kv, out, variant, workspace, workspace_bytes, stream);
+}
+static int nl_attention_entry(int b, int p, int n, int cb, const float* q, const float* kv, float* out, int variant,
+                              void* workspace, size_t workspace_bytes, pasnl_stream_t stream) {
   PASNL_REQUIRE(b >= 0 && p >= 0 && n > 0 && cb > 0, PASNL_EINVAL);
   PASNL_REQUIRE(variant >= 0 && variant <= 3, PASNL_EINVAL);
   PASNL_REQUIRE(cb == 32 || cb == 64 || cb == 128, PASNL_EUNSUPPORTED);
@@ -1756,6 +1869,18 @@ extern "C" int pasnl_nl_attention(int b, int p, int n, int cb, const float* q, c
     if (cb == 32) return nl_valu_launch<32>(b, p, n, qscale, q, kv, out, st);
     if (cb == 64) return nl_valu_launch<64>(b, p, n, qscale, q, kv, out, st);
     return PASNL_EUNSUPPORTED;  // cb=128 does not fit the one-query-per-lane register budget
+  }
+  if (cb == 32 && variant == 0 && workspace != nullptr) {  // keys over workgroups where the plain form leaves CUs empty
+    const NlParts np = nl_parts(b, p, n, cb);
+    if (np.kparts > 1) {
+      PASNL_REQUIRE(workspace_bytes >= nl_parts_bytes(b, p, np.kparts), PASNL_EWORKSPACE);
+      PASNL_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, PASNL_EUNSUPPORTED);
+      float* part = static_cast<float*>(workspace);
+      if (np.split >= 8) return nl_pair_parts_launch<8>(b, p, n, qscale, q, kv, out, np.kparts, part, st);
+      if (np.split >= 4) return nl_pair_parts_launch<4>(b, p, n, qscale, q, kv, out, np.kparts, part, st);
+      if (np.split >= 2) return nl_pair_parts_launch<2>(b, p, n, qscale, q, kv, out, np.kparts, part, st);
+      return nl_pair_parts_launch<1>(b, p, n, qscale, q, kv, out, np.kparts, part, st);
+    }
   }
   if (cb == 32) return nl_mfma_dispatch<32>(b, p, n, qscale, q, kv, out, variant == 3, st);
   if (cb == 64) return nl_mfma_dispatch<64>(b, p, n, qscale, q, kv, out, variant == 3, st);

@@ -391,13 +391,14 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
 #endif
   // ---- fallback (rare): sorted-list insertion for the flagged queries; every wave helps staging the tiles
   if (!__syncthreads_or(overflow ? 1 : 0)) return;
-  float tau[QW];
+  float tau[QW], tie_tau[QW];  // (tie_tau: knn_kernel's note)
   KnnList<1> L[QW];
   bool todo[QW];
 #pragma unroll
   for (int q = 0; q < QW; ++q) {
     todo[q] = cnt[q] > KNN2_CAP && (q0 + q) < m;
     tau[q] = INFINITY;
+    tie_tau[q] = -1.f;
     L[q].d[0] = INFINITY;
     L[q].i[0] = 0;
   }
@@ -415,13 +416,18 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
         if (!todo[q]) continue;  // wave-uniform
         float d = dist2(qx[q], qy[q], qz[q], x, y, z);
         unsigned long long mask = __ballot(in && d < tau[q]);
+        if (__ballot(in && d == tau[q]) != 0ull) tie_tau[q] = tau[q];
         while (mask) {
           int src = (int)__builtin_ctzll(mask);
           mask &= mask - 1;
           float cd = readlane_f(d, src);
           if (cd < tau[q]) {
             knn_insert<1>(L[q], cd, base + it + src, lane);
-            tau[q] = readlane_f(L[q].d[0], k - 1);
+            const float t = readlane_f(L[q].d[0], k - 1);
+            if (t == tau[q]) tie_tau[q] = t;
+            tau[q] = t;
+          } else if (cd == tau[q]) {
+            tie_tau[q] = cd;
           }
         }
       }
@@ -435,7 +441,10 @@ __global__ __launch_bounds__(SEARCH_WAVES * 64) void knn2_kernel(int n, int m, i
       idx[o + lane] = (IdxT)L[q].i[0];
       if (dist_out) dist_out[o + lane] = L[q].d[0];
     }
-    if (flags.nflag) knn_flag_query(flags, bi, m, q0 + q, lane);  // > 128 candidates under the bound: ties by the dozen
+    if (flags.nflag) {  // (more than 128 candidates under the bound is not yet a tie: the same test as knn_kernel's)
+      const float prev = wave_shr1_f(L[q].d[0]);
+      if (tie_tau[q] == tau[q] || __ballot(lane >= 1 && lane < k && L[q].d[0] == prev) != 0ull) knn_flag_query(flags, bi, m, q0 + q, lane);
+    }
   }
 }
 

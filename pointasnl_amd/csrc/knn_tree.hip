@@ -62,12 +62,16 @@ __device__ __forceinline__ KtWork kt_load_work(const KtWork* qe, const int lane)
   return wk;
 }
 constexpr int KT_HDR = 32;   // header bytes: [flag, root, nodes used, depth, deep work items, the queue they are in, -, -]
-#define KT_NNODES(n) (2 * (n) + 32)  // node slots: the two-phase build hands every deep subtree its own id range (32 + 2 left ..)
-constexpr int KTD_MAXWORK = 16;   // subtrees handed to the second phase: the queue after KTD_TOP levels
+constexpr int KT_TOPIDS = 1024;  // node ids of the first phase of a two-phase build; a deep subtree at leaf position `left` owns the ids
+                                 // KT_TOPIDS + 2 left .. (a subtree of c points has < 2 c nodes)
+#define KT_NNODES(n) (2 * (n) + KT_TOPIDS)
+constexpr int KTD_MAXWORK = 128;  // subtrees handed to the second phase at most (16 after KTD_TOP levels; clouds above 8192 points: every
+                                  // subtree that fits a workgroup's LDS)
 constexpr int KTD_TOP = 4;
 constexpr int KTB_WAVES = 16;          // waves of the parallel build's workgroup (one workgroup per cloud)
 constexpr int KTB_LDS_NMAX = 8192;     // points (of a cloud, of a subtree) whose 18-byte records + positions fit the LDS (147 KB)
 constexpr int KTB_LDS_NMAX_ = KTB_LDS_NMAX;
+constexpr int KTD_LDSQ_MAX = 6000;  // points of a subtree whose two level queues still fit in LDS behind its records
 constexpr int KTB_NMAX = 10240;        // points per cloud it holds in LDS (vind + the cut coordinate + a scratch slice)
 static inline int kt_queue_cap(int n) { return n / (KT_LEAF + 1) + 2; }  // inner nodes of one level: more than KT_LEAF points each
 // workspace of one cloud: [flag, root, nodes used, depth] | vind[n] | nodes[2n] | build frames[KT_DEPTH] | 2 level queues |
@@ -476,7 +480,7 @@ __device__ void knn_tree_build_par_body(int cloud, int n, const float* __restric
     gvind[i] = v;
     recs[i] = make_float4(pts[(size_t)v * 3], pts[(size_t)v * 3 + 1], pts[(size_t)v * 3 + 2], __int_as_float((int)v));
   }
-  if (tid == 0) { hdr[0] = ctr[3] & 1; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; hdr[4] = (ctr[3] & 1) || stop_level == 0 ? 0 : ctr[cur]; hdr[5] = cur; }
+  if (tid == 0) { hdr[0] = ctr[3] & 1; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; hdr[4] = (ctr[3] & 1) || stop_level == 0 ? 0 : ctr[cur]; hdr[5] = cur; hdr[6] = level; }
 }
 __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_par_kernel(int b, int n, const float* __restrict__ pts_all,
                                                                            char* __restrict__ ws_all, size_t stride, size_t recs_off, int stop_level,
@@ -677,13 +681,177 @@ __device__ __forceinline__ KtSplit ktb_split_node(float4* rec, unsigned short* s
   return r;
 }
 
+// A LARGE node split by the WHOLE workgroup (round 6).  One wave per node (above) walks a node of c points in c / 64 trips per pass
+// and ten passes: the root of an 8192-point cloud alone took ~80 us of the first phase's 153, while fifteen waves waited for the
+// level to end.  Here all KTB_WAVES waves work on the one node: min / max, the counts and the ranks of planeSplit's closed form
+// (header of the parallel build) per wave CHUNK of consecutive positions -- chunk counts through LDS, violators ranked ascending
+// from the chunks before, satisfiers descending from the chunks behind -- then the swaps and the children's tight bounds, all in
+// strides of the workgroup.  The permutation is the same, element for element: the i-th violator among the first cnt positions
+// (ascending) changes places with the i-th satisfier behind them (descending).  rec / sc: LDS or global memory (PosT: positions
+// inside the node, 16 bits where a node has < 65536 points); red: >= 6 * KTB_WAVES words of LDS.
+template <typename PosT>
+__device__ __forceinline__ KtSplit ktb_split_node_wg(float4* rec, PosT* sc, float* red, const KtWork& wk, const unsigned left,
+                                                     const unsigned right, const int tid) {
+  constexpr int T = KTB_WAVES * 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  const unsigned count = right - left;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int* redi = reinterpret_cast<int*>(red);
+  // ---- middleSplit_ (:966-1005); computeMinMax (:898-907) of all three dimensions in one pass
+  const float EPS = 0.00001f;
+  float max_span = wk.box[1] - wk.box[0];
+  for (int d = 1; d < 3; ++d) {
+    const float span = wk.box[2 * d + 1] - wk.box[2 * d];
+    if (span > max_span) max_span = span;
+  }
+  float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (unsigned p = tid; p < count; p += T) {
+    const float4 r = rec[left + p];
+    const float c[3] = {r.x, r.y, r.z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn3[d] = c[d] < mn3[d] ? c[d] : mn3[d];
+      mx3[d] = c[d] > mx3[d] ? c[d] : mx3[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { mn3[d] = wave_min_f32(mn3[d]); mx3[d] = wave_max_f32(mx3[d]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { red[wave * 6 + 2 * d] = mn3[d]; red[wave * 6 + 2 * d + 1] = mx3[d]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float l = red[2 * d], h = red[2 * d + 1];
+    for (int w = 1; w < KTB_WAVES; ++w) { l = fminf(l, red[w * 6 + 2 * d]); h = fmaxf(h, red[w * 6 + 2 * d + 1]); }
+    mn3[d] = l; mx3[d] = h;
+  }
+  __syncthreads();  // (red is used again below)
+  float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
+  int cutfeat = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float span = wk.box[2 * d + 1] - wk.box[2 * d];
+    if (span > (1 - EPS) * max_span) {
+      const float spread = mx3[d] - mn3[d];
+      if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn3[d]; mx_c = mx3[d]; }
+    }
+  }
+  const float blo = cutfeat == 0 ? wk.box[0] : (cutfeat == 1 ? wk.box[2] : wk.box[4]);
+  const float bhi = cutfeat == 0 ? wk.box[1] : (cutfeat == 1 ? wk.box[3] : wk.box[5]);
+  const float split_val = (blo + bhi) / 2;
+  float cutval;
+  if (split_val < mn_c) cutval = mn_c;
+  else if (split_val > mx_c) cutval = mx_c;
+  else cutval = split_val;
+  const float* cutc = reinterpret_cast<const float*>(rec) + cutfeat;  // cutc[4 i] = the cut coordinate of record i
+  // ---- planeSplit (:1016-1043)
+  unsigned lim[2];
+  unsigned lo_p = 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    auto pred = [&](float v) { return pass == 0 ? v < cutval : v <= cutval; };
+    // this wave's chunk of the positions [lo_p, count): a multiple of 64 positions, consecutive chunks for consecutive waves
+    const unsigned span = count - lo_p;
+    const unsigned chunk = ((span + T - 1) / T) * 64;
+    const unsigned cs = min(count, lo_p + (unsigned)wave * chunk), ce = min(count, cs + chunk);
+    unsigned c = 0;
+    for (unsigned p0 = cs; p0 < ce; p0 += 64) {
+      const unsigned p = p0 + lane;
+      c += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p < ce && pred(cutc[4 * (left + p)])));
+    }
+    if (lane == 0) redi[wave] = (int)c;
+    __syncthreads();
+    unsigned cnt = 0;
+    for (int w = 0; w < KTB_WAVES; ++w) cnt += (unsigned)redi[w];
+    const unsigned mid = lo_p + cnt;  // where the pointers meet
+    __syncthreads();
+    unsigned nv = 0, nr = 0;
+    for (unsigned p0 = cs; p0 < ce; p0 += 64) {
+      const unsigned p = p0 + lane;
+      const bool in = p < ce, sat = in && pred(cutc[4 * (left + p)]);
+      nv += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in && p < mid && !sat));
+      nr += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sat && p >= mid));
+    }
+    if (lane == 0) { redi[wave] = (int)nv; redi[KTB_WAVES + wave] = (int)nr; }
+    __syncthreads();
+    unsigned vbase = 0, rbase = 0, nl = 0;
+    for (int w = 0; w < KTB_WAVES; ++w) {
+      const unsigned v = (unsigned)redi[w], r = (unsigned)redi[KTB_WAVES + w];
+      nl += v;
+      if (w < wave) vbase += v;   // violators in the chunks before this one
+      if (w > wave) rbase += r;   // satisfiers in the chunks behind this one
+    }
+    __syncthreads();
+    unsigned runv = 0, runr = 0;
+    for (unsigned p0 = cs; p0 < ce; p0 += 64) {
+      const unsigned p = p0 + lane;
+      const bool in = p < ce, sat = in && pred(cutc[4 * (left + p)]);
+      const bool viol = in && p < mid && !sat, rs = sat && p >= mid;
+      const unsigned long long mv = __builtin_amdgcn_ballot_w64(viol), mr = __builtin_amdgcn_ballot_w64(rs);
+      if (viol) sc[left + lo_p + vbase + runv + (unsigned)__builtin_popcountll(mv & lt_mask)] = (PosT)p;
+      if (rs) {
+        const unsigned asc = runr + (unsigned)__builtin_popcountll(mr & lt_mask);  // rank inside the chunk, ascending
+        sc[right - 1 - (rbase + (nr - 1 - asc))] = (PosT)p;                        // descending over the whole node
+      }
+      runv += (unsigned)__builtin_popcountll(mv);
+      runr += (unsigned)__builtin_popcountll(mr);
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < nl; i += T) {
+      const unsigned a = left + (unsigned)sc[left + lo_p + i], b = left + (unsigned)sc[right - 1 - i];
+      const float4 ra = rec[a], rb = rec[b];
+      rec[a] = rb; rec[b] = ra;
+    }
+    __syncthreads();
+    lim[pass] = mid;
+    lo_p = mid;
+  }
+  unsigned index;
+  if (lim[0] > count / 2) index = lim[0];
+  else if (lim[1] < count / 2) index = lim[1];
+  else index = count / 2;
+  // ---- the children's tight boxes along cutfeat: divlow = max of the left part, divhigh = min of the right part (:956-957)
+  float dl = -INFINITY, dh = INFINITY;
+  for (unsigned p = tid; p < count; p += T) {
+    const float v = cutc[4 * (left + p)];
+    if (p < index) dl = v > dl ? v : dl;
+    else dh = v < dh ? v : dh;
+  }
+  dl = wave_max_f32(dl); dh = wave_min_f32(dh);
+  if (lane == 0) { red[wave * 2] = dl; red[wave * 2 + 1] = dh; }
+  __syncthreads();
+  dl = red[0]; dh = red[1];
+  for (int w = 1; w < KTB_WAVES; ++w) { dl = fmaxf(dl, red[w * 2]); dh = fminf(dh, red[w * 2 + 1]); }
+  __syncthreads();
+  KtSplit r;
+  r.cutfeat = cutfeat; r.cutval = cutval; r.index = index; r.dl = dl; r.dh = dh;
+  return r;
+}
+#ifndef KT_COOP_MIN_V
+#define KT_COOP_MIN_V 4096  // measured (16 x 8192 self-kNN, 4 flagged clouds): 1024: 576 us, 2048: 518, 4096: 484, never: 505
+#endif
+constexpr unsigned KT_COOP_MIN = KT_COOP_MIN_V;  // nodes above this many points are split by the whole workgroup, one after the other
+// ... as a real CALL in the kernels that also hold the one-wave forms (inlined there, the three forms together need more than the 128
+// registers a 1024-thread workgroup has: 140 bytes of scratch per lane, the deep kernel 132 -> 395 us); a large node is
+// hundreds of trips: the call and the generic addressing of LDS do not show
+__device__ __attribute__((noinline)) KtSplit ktb_split_node_wg_lds(float4* rec, unsigned short* sc, float* red, const float b0, const float b1,
+                                                                   const float b2, const float b3, const float b4, const float b5,
+                                                                   const unsigned left, const unsigned right, const int tid) {
+  KtWork wk;
+  wk.node = 0; wk.left = left; wk.right = right;
+  wk.box[0] = b0; wk.box[1] = b1; wk.box[2] = b2; wk.box[3] = b3; wk.box[4] = b4; wk.box[5] = b5;
+  return ktb_split_node_wg<unsigned short>(rec, sc, red, wk, left, right, tid);
+}
+
 __device__ void knn_tree_build_lds_body(int cloud, int n, const float* __restrict__ pts_all, char* __restrict__ ws_all, size_t stride,
                                         size_t recs_off, int stop_level) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* rec = reinterpret_cast<float4*>(smem);                             // [n] {x, y, z, index bits}: the points move with the index list
   unsigned short* sc = reinterpret_cast<unsigned short*>(rec + n);           // [n] positions of misplaced elements
   float* part = reinterpret_cast<float*>(sc + ((n + 1) & ~1));               // [KTB_WAVES][6] root-box partials
-  int* ctr = reinterpret_cast<int*>(part + KTB_WAVES * 6);                   // [0], [1]: queue lengths; [2]: nodes used; [3]: flag
+  int* ctr = reinterpret_cast<int*>(part + KTB_WAVES * 6);                   // [0], [1]: queue lengths; [2]: nodes used; [3]: flag; [4], [5]: large nodes in queue 0 / 1
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* pts = pts_all + (size_t)cloud * n * 3;
   char* ws = ws_all + (size_t)cloud * stride;
@@ -714,7 +882,7 @@ __device__ void knn_tree_build_lds_body(int cloud, int n, const float* __restric
 #pragma unroll
     for (int d = 0; d < 3; ++d) { part[wave * 6 + 2 * d] = lo[d]; part[wave * 6 + 2 * d + 1] = hi[d]; }
   }
-  if (tid < 4) ctr[tid] = 0;
+  if (tid < 6) ctr[tid] = 0;
   __syncthreads();
   float root[6];
 #pragma unroll
@@ -732,6 +900,7 @@ __device__ void knn_tree_build_lds_body(int cloud, int n, const float* __restric
       for (int i = 0; i < 6; ++i) w0.box[i] = root[i];
       queue[0][0] = w0;
       ctr[0] = 1;
+      ctr[4] = (unsigned)n > KT_COOP_MIN ? 1 : 0;
     }
     for (int i = 0; i < 6; ++i) fr[1].bbox[i] = root[i];  // root_bbox after divideTree = the tight box of all points (what the search reads)
   }
@@ -744,42 +913,54 @@ __device__ void knn_tree_build_lds_body(int cloud, int n, const float* __restric
     if (nq == 0) break;
     if (stop_level > 0 && level >= stop_level) break;  // the pending subtrees go to knn_tree_build_deep_kernel, one workgroup each
     if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }  // deeper than the search's stack: flagged, not built
+    // the children of a split node: ids, leaves, the next level's queue (one lane)
+    auto emit = [&](const KtWork& wk, const KtSplit& sp_) {
+      const unsigned left = wk.left, right = wk.right, index = sp_.index;
+      const int cutfeat = sp_.cutfeat;
+      const float cutval = sp_.cutval;
+      int child[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const unsigned cl = c == 0 ? left : left + index, cr = c == 0 ? left + index : right;
+        const int id = atomicAdd(&ctr[2], 1);
+        child[c] = id;
+        if (cr - cl <= (unsigned)KT_LEAF) {  // leaf (:921-936)
+          nodes[id].child1 = nodes[id].child2 = -1;
+          nodes[id].a = (int)cl;
+          nodes[id].divlow = __int_as_float((int)cr);
+          nodes[id].divhigh = 0.f;
+        } else {
+          KtWork w;
+          w.node = id; w.left = cl; w.right = cr;
+          // left child: high = cutval (:946-947); right child: low = cutval (:951-952)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) w.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : wk.box[i];
+          queue[cur ^ 1][atomicAdd(&ctr[cur ^ 1], 1)] = w;
+          if (cr - cl > KT_COOP_MIN) atomicAdd(&ctr[4 + (cur ^ 1)], 1);
+        }
+      }
+      KtNode nd;
+      nd.child1 = child[0]; nd.child2 = child[1]; nd.a = cutfeat; nd.divlow = sp_.dl; nd.divhigh = sp_.dh;
+      nodes[wk.node] = nd;
+    };
+    if (ctr[4 + cur] != 0) {  // (uniform) the level's large nodes first, one after the other, by the whole workgroup
+      for (int e = 0; e < nq; ++e) {
+        const KtWork wk = kt_load_work(queue[cur] + e, lane);
+        if (wk.right - wk.left <= KT_COOP_MIN) continue;
+        const KtSplit sp_ = ktb_split_node_wg_lds(rec, sc, part, wk.box[0], wk.box[1], wk.box[2], wk.box[3], wk.box[4], wk.box[5], wk.left, wk.right, tid);
+        if (tid == 0) emit(wk, sp_);
+      }
+    }
     for (int e = wave; e < nq; e += KTB_WAVES) {
       const KtWork wk = kt_load_work(queue[cur] + e, lane);
       const unsigned left = wk.left, right = wk.right;
+      if (right - left > KT_COOP_MIN) continue;
       const KtSplit sp_ = ktb_split_node(rec, sc, wk, left, right, lane, lt_mask);
-      const int cutfeat = sp_.cutfeat;
-      const float cutval = sp_.cutval, dl = sp_.dl, dh = sp_.dh;
-      const unsigned index = sp_.index;
-      if (lane == 0) {
-        int child[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const unsigned cl = c == 0 ? left : left + index, cr = c == 0 ? left + index : right;
-          const int id = atomicAdd(&ctr[2], 1);
-          child[c] = id;
-          if (cr - cl <= (unsigned)KT_LEAF) {  // leaf (:921-936)
-            nodes[id].child1 = nodes[id].child2 = -1;
-            nodes[id].a = (int)cl;
-            nodes[id].divlow = __int_as_float((int)cr);
-            nodes[id].divhigh = 0.f;
-          } else {
-            KtWork w;
-            w.node = id; w.left = cl; w.right = cr;
-            // left child: high = cutval (:946-947); right child: low = cutval (:951-952)
-#pragma unroll
-            for (int i = 0; i < 6; ++i) w.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : wk.box[i];
-            queue[cur ^ 1][atomicAdd(&ctr[cur ^ 1], 1)] = w;
-          }
-        }
-        KtNode nd;
-        nd.child1 = child[0]; nd.child2 = child[1]; nd.a = cutfeat; nd.divlow = dl; nd.divhigh = dh;
-        nodes[wk.node] = nd;
-      }
+      if (lane == 0) emit(wk, sp_);
     }
     __threadfence_block();
     __syncthreads();
-    if (tid == 0) ctr[cur] = 0;
+    if (tid == 0) { ctr[cur] = 0; ctr[4 + cur] = 0; }
     cur ^= 1;
     ++level;
     __syncthreads();
@@ -791,7 +972,7 @@ __device__ void knn_tree_build_lds_body(int cloud, int n, const float* __restric
     gvind[i] = (unsigned)__float_as_int(r.w);
     recs[i] = r;
   }
-  if (tid == 0) { hdr[0] = ctr[3]; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; hdr[4] = ctr[3] ? 0 : ctr[cur]; hdr[5] = cur; }
+  if (tid == 0) { hdr[0] = ctr[3]; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; hdr[4] = ctr[3] ? 0 : ctr[cur]; hdr[5] = cur; hdr[6] = level; }
 }
 __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int b, int n, const float* __restrict__ pts_all,
                                                                            char* __restrict__ ws_all, size_t stride, size_t recs_off, int stop_level,
@@ -803,12 +984,133 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_lds_kernel(int 
   }
 }
 
+// First phase for clouds that do not fit a workgroup's LDS (n > KTB_LDS_NMAX; round 6 -- before: a gathering build up to 10240
+// points, 325 us for 8 lidar clouds, and ONE LANE beyond, ~1 s at 81920 points): the records live in the workspace, every node
+// that is too large for the second phase (> KTD_LDSQ_MAX points) is split by the whole workgroup (ktb_split_node_wg on global
+// memory), level by level; the rest is carried along.  What is left pending goes to knn_tree_build_deep_kernel, one workgroup per
+// subtree with its records in LDS.  Scratch positions: 32 bits, in the index list's slot of the workspace (written last).
+__device__ void knn_tree_build_big_body(int cloud, int n, const float* __restrict__ pts_all, char* __restrict__ ws_all, size_t stride,
+                                        size_t recs_off) {
+  __shared__ float part[KTB_WAVES * 6];
+  __shared__ int ctr[8];  // [0], [1]: queue lengths; [2]: nodes used; [3]: flag; [4]: large nodes left
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* pts = pts_all + (size_t)cloud * n * 3;
+  char* ws = ws_all + (size_t)cloud * stride;
+  int* hdr = reinterpret_cast<int*>(ws);
+  unsigned* sc = reinterpret_cast<unsigned*>(ws + kt_align(KT_HDR));  // [n] (the index list's slot)
+  KtNode* nodes = reinterpret_cast<KtNode*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4));
+  KtFrame* fr = reinterpret_cast<KtFrame*>(ws + kt_align(KT_HDR) + kt_align((size_t)n * 4) + kt_align((size_t)KT_NNODES(n) * sizeof(KtNode)));
+  const int qcap = n / (KT_LEAF + 1) + 2;
+  KtWork* queue[2];
+  queue[0] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(fr) + kt_align((size_t)KT_DEPTH * sizeof(KtFrame)));
+  queue[1] = reinterpret_cast<KtWork*>(reinterpret_cast<char*>(queue[0]) + kt_align((size_t)qcap * sizeof(KtWork)));
+  float4* rec = reinterpret_cast<float4*>(ws + recs_off);
+  // init_vind (:1318), computeBoundingBox (:1321-1346)
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = tid; i < n; i += KTB_WAVES * 64) {
+    const float c[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
+    rec[i] = make_float4(c[0], c[1], c[2], __int_as_float(i));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = c[d] < lo[d] ? c[d] : lo[d];
+      hi[d] = c[d] > hi[d] ? c[d] : hi[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { lo[d] = wave_min_f32(lo[d]); hi[d] = wave_max_f32(hi[d]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { part[wave * 6 + 2 * d] = lo[d]; part[wave * 6 + 2 * d + 1] = hi[d]; }
+  }
+  if (tid < 8) ctr[tid] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    float root[6];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float l = part[2 * d], h = part[2 * d + 1];
+      for (int w = 1; w < KTB_WAVES; ++w) { l = fminf(l, part[w * 6 + 2 * d]); h = fmaxf(h, part[w * 6 + 2 * d + 1]); }
+      root[2 * d] = l; root[2 * d + 1] = h;
+    }
+    ctr[2] = 1;  // node 0 = the root
+    KtWork w0; w0.node = 0; w0.left = 0; w0.right = (unsigned)n;
+    for (int i = 0; i < 6; ++i) w0.box[i] = root[i];
+    queue[0][0] = w0;
+    ctr[0] = 1;
+    ctr[4] = 1;  // n > KTB_LDS_NMAX > KTD_LDSQ_MAX
+    for (int i = 0; i < 6; ++i) fr[1].bbox[i] = root[i];  // root_bbox after divideTree = the tight box of all points (what the search reads)
+  }
+  __threadfence_block();
+  __syncthreads();
+  int cur = 0, level = 0;
+  // until every pending node fits a workgroup's LDS -- and for KTD_TOP levels at least: the second phase works a subtree off with
+  // ONE workgroup, whose time is the thousands of small nodes at its deep levels (two subtrees of 5120 points: 309 us; sixteen of
+  // 640: 40)
+  while (ctr[4] != 0 || (level < KTD_TOP && ctr[cur] != 0)) {  // (uniform)
+    const int nq = ctr[cur];
+    if (level + 2 >= KT_DEPTH || ctr[2] + 2 * nq + 2 > KT_TOPIDS || 2 * nq > KTD_MAXWORK) { if (tid == 0) ctr[3] = 1; break; }  // flagged, not built
+    __syncthreads();
+    if (tid == 0) ctr[4] = 0;
+    __syncthreads();
+    for (int e = 0; e < nq; ++e) {
+      const KtWork wk = kt_load_work(queue[cur] + e, lane);
+      const unsigned left = wk.left, right = wk.right;
+      if (level >= KTD_TOP && right - left <= (unsigned)KTD_LDSQ_MAX) {  // fits the second phase: carried to the next level as it is
+        if (tid == 0) queue[cur ^ 1][atomicAdd(&ctr[cur ^ 1], 1)] = wk;
+        continue;
+      }
+      const KtSplit sp_ = ktb_split_node_wg<unsigned>(rec, sc, part, wk, left, right, tid);
+      if (tid == 0) {
+        int child[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const unsigned cl = c == 0 ? left : left + sp_.index, cr = c == 0 ? left + sp_.index : right;
+          const int id = atomicAdd(&ctr[2], 1);
+          child[c] = id;
+          if (cr - cl <= (unsigned)KT_LEAF) {  // leaf (:921-936)
+            nodes[id].child1 = nodes[id].child2 = -1;
+            nodes[id].a = (int)cl;
+            nodes[id].divlow = __int_as_float((int)cr);
+            nodes[id].divhigh = 0.f;
+          } else {
+            KtWork w;
+            w.node = id; w.left = cl; w.right = cr;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w.box[i] = (i == 2 * sp_.cutfeat + 1 - c) ? sp_.cutval : wk.box[i];
+            queue[cur ^ 1][atomicAdd(&ctr[cur ^ 1], 1)] = w;
+            if (cr - cl > (unsigned)KTD_LDSQ_MAX) atomicAdd(&ctr[4], 1);
+          }
+        }
+        KtNode nd;
+        nd.child1 = child[0]; nd.child2 = child[1]; nd.a = sp_.cutfeat; nd.divlow = sp_.dl; nd.divhigh = sp_.dh;
+        nodes[wk.node] = nd;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) ctr[cur] = 0;
+    cur ^= 1;
+    ++level;
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) { hdr[0] = ctr[3]; hdr[1] = 0; hdr[2] = ctr[2]; hdr[3] = level; hdr[4] = ctr[3] ? 0 : ctr[cur]; hdr[5] = cur; hdr[6] = level; }
+}
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_big_kernel(int b, int n, const float* __restrict__ pts_all,
+                                                                           char* __restrict__ ws_all, size_t stride, size_t recs_off,
+                                                                           const int* __restrict__ nflag) {
+  for (int cloud = blockIdx.x; cloud < b; cloud += gridDim.x) {
+    if (nflag && nflag[cloud] == 0) continue;
+    knn_tree_build_big_body(cloud, n, pts_all, ws_all, stride, recs_off);
+    __syncthreads();
+  }
+}
+
 // Second phase of the two-phase build: one workgroup per subtree the first phase left pending after KTD_TOP levels (<= 16 per
 // cloud).  The deep levels are thousands of small nodes with ~3.5 us of fixed cost each; one workgroup per cloud worked them off
 // 16 at a time on ONE CU -- here every subtree has its own workgroup (and CU), its records in LDS, its own node-id range
 // (32 + 2 left ..: a subtree of c points has < 2 c nodes) and its level queues in LDS (or, for a subtree too large for that --
 // then the only one of its size in the cloud -- in the workspace).
-constexpr int KTD_LDSQ_MAX = 6000;  // points of a subtree whose two level queues still fit in LDS behind its records
 __device__ void knn_tree_build_deep_body(int cloud, int item, int n, char* __restrict__ ws_all, size_t stride, size_t recs_off) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -832,64 +1134,77 @@ __device__ void knn_tree_build_deep_body(int cloud, int item, int n, char* __res
   float4* rec = reinterpret_cast<float4*>(smem);                                  // [count0]
   unsigned short* sc = reinterpret_cast<unsigned short*>(rec + count0);           // [count0]
   char* after = smem + (((size_t)count0 * 18 + 15) & ~(size_t)15);
-  int* ctr = reinterpret_cast<int*>(after);                                       // [0], [1]: queue lengths; [2]: nodes used; [3]: flag
+  int* ctr = reinterpret_cast<int*>(after);                                       // [0], [1]: queue lengths; [2]: nodes used; [3]: flag; [4], [5]: large nodes in queue a / b
+  float* red = reinterpret_cast<float*>(after + 32);                              // [KTB_WAVES][6] scratch of the workgroup-wide split
   const int lq = (int)(count0 / (KT_LEAF + 1)) + 2;
   const bool ldsq = count0 <= (unsigned)KTD_LDSQ_MAX;
-  KtWork* const qa = ldsq ? reinterpret_cast<KtWork*>(after + 16) : g2[0];  // (two named pointers: an indexed pair of pointers
+  KtWork* const qa = ldsq ? reinterpret_cast<KtWork*>(after + 32 + KTB_WAVES * 6 * 4) : g2[0];  // (two named pointers: an indexed pair of pointers
   KtWork* const qb = ldsq ? qa + lq : g2[1];                                //  into different address spaces would live in scratch)
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   for (unsigned i = tid; i < count0; i += KTB_WAVES * 64) rec[i] = grecs[left0 + i];
-  if (tid < 4) ctr[tid] = 0;
+  if (tid < 6) ctr[tid] = 0;
   __syncthreads();
   if (tid == 0) {
     KtWork w = w0;
     w.left = 0; w.right = count0;
     qa[0] = w;
     ctr[0] = 1;
+    ctr[4] = count0 > KT_COOP_MIN ? 1 : 0;
   }
   __threadfence_block();
   __syncthreads();
-  const int idbase = 32 + 2 * (int)left0;
-  int cur = 0, level = KTD_TOP;  // (hdr[4] > 0: the first phase stopped exactly there)
+  const int idbase = KT_TOPIDS + 2 * (int)left0;
+  int cur = 0, level = hdr[6];  // the level the first phase stopped at
   for (;;) {
     const int nq = ctr[cur];
     if (nq == 0) break;
     if (level + 2 >= KT_DEPTH) { if (tid == 0) ctr[3] = 1; break; }
+    auto emit = [&](const KtWork& wk, const KtSplit& sp_) {
+      const unsigned left = wk.left, right = wk.right, index = sp_.index;
+      const int cutfeat = sp_.cutfeat;
+      const float cutval = sp_.cutval;
+      int child[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const unsigned cl = c == 0 ? left : left + index, cr = c == 0 ? left + index : right;
+        const int id = idbase + atomicAdd(&ctr[2], 1);
+        child[c] = id;
+        if (cr - cl <= (unsigned)KT_LEAF) {  // leaf (:921-936): positions in the CLOUD's leaf order
+          nodes[id].child1 = nodes[id].child2 = -1;
+          nodes[id].a = (int)(left0 + cl);
+          nodes[id].divlow = __int_as_float((int)(left0 + cr));
+          nodes[id].divhigh = 0.f;
+        } else {
+          KtWork w;
+          w.node = id; w.left = cl; w.right = cr;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) w.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : wk.box[i];
+          (cur ? qa : qb)[atomicAdd(&ctr[cur ^ 1], 1)] = w;
+          if (cr - cl > KT_COOP_MIN) atomicAdd(&ctr[4 + (cur ^ 1)], 1);
+        }
+      }
+      KtNode nd;
+      nd.child1 = child[0]; nd.child2 = child[1]; nd.a = cutfeat; nd.divlow = sp_.dl; nd.divhigh = sp_.dh;
+      nodes[wk.node] = nd;
+    };
+    if (ctr[4 + cur] != 0) {  // (uniform) large nodes: the whole workgroup, one node after the other
+      for (int e = 0; e < nq; ++e) {
+        const KtWork wk = kt_load_work((cur ? qb : qa) + e, lane);
+        if (wk.right - wk.left <= KT_COOP_MIN) continue;
+        const KtSplit sp_ = ktb_split_node_wg_lds(rec, sc, red, wk.box[0], wk.box[1], wk.box[2], wk.box[3], wk.box[4], wk.box[5], wk.left, wk.right, tid);
+        if (tid == 0) emit(wk, sp_);
+      }
+    }
     for (int e = wave; e < nq; e += KTB_WAVES) {
       const KtWork wk = kt_load_work((cur ? qb : qa) + e, lane);
       const unsigned left = wk.left, right = wk.right;
+      if (right - left > KT_COOP_MIN) continue;
       const KtSplit sp_ = ktb_split_node(rec, sc, wk, left, right, lane, lt_mask);
-      const int cutfeat = sp_.cutfeat;
-      const float cutval = sp_.cutval;
-      const unsigned index = sp_.index;
-      if (lane == 0) {
-        int child[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const unsigned cl = c == 0 ? left : left + index, cr = c == 0 ? left + index : right;
-          const int id = idbase + atomicAdd(&ctr[2], 1);
-          child[c] = id;
-          if (cr - cl <= (unsigned)KT_LEAF) {  // leaf (:921-936): positions in the CLOUD's leaf order
-            nodes[id].child1 = nodes[id].child2 = -1;
-            nodes[id].a = (int)(left0 + cl);
-            nodes[id].divlow = __int_as_float((int)(left0 + cr));
-            nodes[id].divhigh = 0.f;
-          } else {
-            KtWork w;
-            w.node = id; w.left = cl; w.right = cr;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) w.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : wk.box[i];
-            (cur ? qa : qb)[atomicAdd(&ctr[cur ^ 1], 1)] = w;
-          }
-        }
-        KtNode nd;
-        nd.child1 = child[0]; nd.child2 = child[1]; nd.a = cutfeat; nd.divlow = sp_.dl; nd.divhigh = sp_.dh;
-        nodes[wk.node] = nd;
-      }
+      if (lane == 0) emit(wk, sp_);
     }
     __threadfence_block();
     __syncthreads();
-    if (tid == 0) ctr[cur] = 0;
+    if (tid == 0) { ctr[cur] = 0; ctr[4 + cur] = 0; }
     cur ^= 1;
     ++level;
     __syncthreads();
@@ -907,10 +1222,18 @@ __device__ void knn_tree_build_deep_body(int cloud, int item, int n, char* __res
 }
 __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_build_deep_kernel(int b, int n, char* __restrict__ ws_all, size_t stride,
                                                                             size_t recs_off, const int* __restrict__ nflag) {
-  // (cloud, pending subtree) pairs, walked by a capped grid (knn_tree_build_kernel's note)
-  for (int w = blockIdx.x; w < b * KTD_MAXWORK; w += gridDim.x) {
-    const int cloud = w / KTD_MAXWORK, item = w - cloud * KTD_MAXWORK;
-    if (nflag && nflag[cloud] == 0) continue;  // (the first phase did not run: the header is stale)
+  // The pending subtrees of all clouds, numbered cloud after cloud, dealt round-robin to the workgroups of a (capped) grid.  (A
+  // fixed (cloud, slot) -> workgroup map put subtree i of EVERY cloud on workgroup i: four flagged clouds worked their subtrees
+  // off four at a time on 16 of the 64 workgroups, 172 us where one round takes 40.)
+  for (int g = blockIdx.x;; g += gridDim.x) {
+    int cloud = -1, item = 0, base = 0;
+    for (int c = 0; c < b; ++c) {  // (b <= a few dozen header reads; uniform)
+      if (nflag && nflag[c] == 0) continue;  // (the first phase did not run: the header is stale)
+      const int cnt = reinterpret_cast<const int*>(ws_all + (size_t)c * stride)[4];
+      if (g < base + cnt) { cloud = c; item = g - base; break; }
+      base += cnt;
+    }
+    if (cloud < 0) return;
     knn_tree_build_deep_body(cloud, item, n, ws_all, stride, recs_off);
     __syncthreads();
   }
@@ -1303,6 +1626,7 @@ __global__ __launch_bounds__(KTW_WAVES * 64) void knn_tree_search_wave_kernel(in
 // costs ~40 us here where build + deep + lane search took 184.  The build is knn_tree_build_lds_kernel's (same split code).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int KTS_NMAX = 2048;
+#define KTS_NNODES(n) (2 * (n) + 32)  // (one id range: the whole tree is built by one workgroup)
 #ifdef PASNL_TUNING
 // phase probe of the FIRST flagged cloud a workgroup takes (tools/knn_small_probe.py): s_memtime at [0] entry, [1] records + box in
 // LDS, [2 + l] level l done (l < 20), [30] build done, [31] searches done
@@ -1313,7 +1637,7 @@ __device__ unsigned long long kts_probe[32];
 #endif
 __host__ __device__ inline size_t kts_lds_bytes(int n) {
   const size_t lq = (size_t)(n / (KT_LEAF + 1)) + 2;
-  return (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15) + (size_t)KT_NNODES(n) * sizeof(KtNode) + 2 * lq * sizeof(KtWork) + 64 +
+  return (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15) + (size_t)KTS_NNODES(n) * sizeof(KtNode) + 2 * lq * sizeof(KtWork) + 64 +
          KTB_WAVES * 6 * 4 + (size_t)KTB_WAVES * KT_DEPTH * 3 * 4;
 }
 template <typename IdxT>
@@ -1324,9 +1648,9 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* rec = reinterpret_cast<float4*>(smem);                                          // [n]
   unsigned short* sc = reinterpret_cast<unsigned short*>(rec + n);                        // [n]
-  KtNode* nodes = reinterpret_cast<KtNode*>(smem + (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15));  // [KT_NNODES(n)]
+  KtNode* nodes = reinterpret_cast<KtNode*>(smem + (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15));  // [KTS_NNODES(n)]
   const int lq = n / (KT_LEAF + 1) + 2;
-  KtWork* const qa = reinterpret_cast<KtWork*>(nodes + KT_NNODES(n));
+  KtWork* const qa = reinterpret_cast<KtWork*>(nodes + KTS_NNODES(n));
   KtWork* const qb = qa + lq;
   int* ctr = reinterpret_cast<int*>(qb + lq);                                             // [0], [1] queue lengths, [2] nodes used, [3] flag; then the root box
   float* rootbox = reinterpret_cast<float*>(ctr + 4);                                     // [6] (+ padding to 64 bytes)
@@ -1453,12 +1777,13 @@ using namespace pasnl;
 // points (the first phase keeps larger ones to itself), or those of KTD_LDSQ_MAX points plus their two level queues --
 // whichever is larger
 static int knn_tree_deep_launch(int b, int n, char* clouds, size_t stride, size_t recs_off, const int* nflag, hipStream_t st) {
-  const int grid = nflag ? std::min(b * pasnl::KTD_MAXWORK, 64) : b * pasnl::KTD_MAXWORK;  // (capped under _ref: knn_tree_build_kernel's note)
+  const int grid = nflag ? std::min(b * 16, 64) : b * 16;  // the pending subtrees are dealt to the grid; capped under _ref (knn_tree_build_kernel's note)
   using namespace pasnl;
   const size_t cmax = (size_t)(n < KTB_LDS_NMAX ? n : KTB_LDS_NMAX);
   const size_t c = cmax < (size_t)KTD_LDSQ_MAX ? cmax : (size_t)KTD_LDSQ_MAX;
-  const size_t with_q = ((c * 18 + 15) & ~(size_t)15) + 16 + 2 * (c / (KT_LEAF + 1) + 2) * sizeof(KtWork);
-  const size_t without = ((cmax * 18 + 15) & ~(size_t)15) + 16;
+  const size_t fixed = 32 + KTB_WAVES * 6 * 4;  // counters + the scratch of the workgroup-wide split
+  const size_t with_q = ((c * 18 + 15) & ~(size_t)15) + fixed + 2 * (c / (KT_LEAF + 1) + 2) * sizeof(KtWork);
+  const size_t without = ((cmax * 18 + 15) & ~(size_t)15) + fixed;
   const size_t lds2 = with_q > without ? with_q : without;
   if (lds2 > 160 * 1024) return PASNL_EUNSUPPORTED;
   if (lds2 > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_tree_build_deep_kernel),
@@ -1504,12 +1829,17 @@ int pasnl::knn_tree_launch(int b, int n, int m, int k, const float* support, con
   const int bgrid = nflag ? std::min(b, 32) : b;
   char* clouds = base + 256;
   const size_t stride = kt_cloud_bytes(n);
-  const bool serial = n > KTB_NMAX || tune_env("PASNL_KNN_TREE_SERIAL") != nullptr;  // (tuning build: the checker of the parallel build)
+  const bool serial = tune_env("PASNL_KNN_TREE_SERIAL") != nullptr;  // (tuning build: the one-lane transcription, the checker of the parallel builds)
   const size_t recs_off = kt_recs_offset(n);
-  if (serial) {
+  if (!serial && (n > KTB_LDS_NMAX || tune_env("PASNL_KNN_TREE_BIG")) && !(n <= KTB_NMAX && tune_env("PASNL_KNN_TREE_GATHER"))) {
+    // records in the workspace, large nodes by the whole workgroup, then one workgroup per LDS-sized subtree
+    hipLaunchKernelGGL(knn_tree_build_big_kernel, dim3(bgrid), dim3(KTB_WAVES * 64), 0, st, b, n, support, clouds, stride, recs_off, nflag);
+    const int rc = knn_tree_deep_launch(b, n, clouds, stride, recs_off, nflag, st);
+    if (rc != PASNL_OK) return rc;
+  } else if (serial) {
     hipLaunchKernelGGL(knn_tree_build_kernel, dim3(bgrid), dim3(64), 0, st, b, n, support, clouds, stride, recs_off, nflag);
   } else if (n <= KTB_LDS_NMAX && tune_env("PASNL_KNN_TREE_GATHER") == nullptr) {  // (tuning build: A/B against the gathering build)
-    const size_t lds = (size_t)n * 16 + (size_t)((n + 1) & ~1) * 2 + (KTB_WAVES * 6 + 4) * 4;
+    const size_t lds = (size_t)n * 16 + (size_t)((n + 1) & ~1) * 2 + (KTB_WAVES * 6 + 8) * 4;
     if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(knn_tree_build_lds_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return PASNL_ELAUNCH;

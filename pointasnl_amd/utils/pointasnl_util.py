@@ -19,6 +19,7 @@ from pointasnl_amd import tf_sampling, tf_grouping, nearest_neighbors
 from pointasnl_amd.tf_interpolate import three_nn, three_interpolate, three_weights, fp_interpolate_cat
 from pointasnl_amd.utils import tf_util
 
+NL_KEY_PARTS = True  # nl_attention: keys over workgroups where the query tiles alone leave CUs empty (pasnl_nl_attention_ws)
 NL_VARIANT = 0  # 0 auto / 1 vector-FMA / 2 MFMA  (pasnl_nl_attention); bench.py --ops sweeps it
 
 
@@ -399,8 +400,14 @@ def nl_attention(q, kv, variant=None):
     n = kv.shape[1]
     q, kv = q.contiguous(), kv.contiguous()
     out = torch.empty_like(q)
-    _hip.launch("pasnl_nl_attention", "nl_attention", b, p, n, cb, _hip.ptr(q), _hip.ptr(kv), _hip.ptr(out),
-                                             int(NL_VARIANT if variant is None else variant))
+    v = int(NL_VARIANT if variant is None else variant)
+    nbytes = int(_hip.lib().pasnl_nl_attention_workspace_bytes(b, p, n, cb)) if v == 0 and NL_KEY_PARTS else 0
+    if nbytes:  # few query tiles for the chip: the keys split over workgroups too, parts combined in a fixed order
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=q.device)
+        _hip.launch("pasnl_nl_attention_ws", "nl_attention", b, p, n, cb, _hip.ptr(q), _hip.ptr(kv), _hip.ptr(out), v, _hip.ptr(ws),
+                    ctypes.c_size_t(nbytes))
+        return out
+    _hip.launch("pasnl_nl_attention", "nl_attention", b, p, n, cb, _hip.ptr(q), _hip.ptr(kv), _hip.ptr(out), v)
     return out
 
 

@@ -70,6 +70,54 @@ def test_nl_attention_two_tiles_per_wave(b, p, n):
     np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("b,p,n", [
+    (8, 1280, 10240),  # SemanticKITTI layer 1_1: 160 workgroups for 256 CUs
+    (4, 1024, 8192),   # a ScanNet layer 1 at a small batch
+    (2, 1280, 10240),
+    (1, 100, 4096),    # a ragged pair of query tiles, one cloud: 2 workgroups -> the largest number of parts
+    (3, 70, 4160),     # 130 key blocks: parts of unequal length, the last one short
+])
+def test_nl_attention_keys_over_workgroups(b, p, n):
+    """cb = 32 with too few query tiles for the chip: pasnl_nl_attention_ws splits the KEYS over workgroups too and combines the
+    parts in ascending key order.  Same 1e-5 contract against fp64 (a late spike in the LAST part and one in the first: the
+    cross-part rescale in both directions), bit-identical from call to call (fixed merge order), and the plain form agrees."""
+    import ctypes
+
+    from pointasnl_amd import _hip
+    from pointasnl_amd.utils import pointasnl_util as U
+
+    cb = 32
+    rng = np.random.default_rng(p + n)
+    q = rng.standard_normal((b, p, cb)).astype(np.float32)
+    kv = rng.standard_normal((b, n, 2 * cb)).astype(np.float32)
+    kv[0, n - 3, :cb] = q[0, min(40, p - 1)] * 5.0
+    kv[b - 1, 2, :cb] = q[b - 1, 1] * 5.0
+    assert U.NL_KEY_PARTS
+    nbytes = int(_hip.lib().pasnl_nl_attention_workspace_bytes(b, p, n, cb))
+    assert nbytes > 0, "these shapes are the ones the partitioned form exists for"
+    got = U.nl_attention(dev(q), dev(kv))
+    again = U.nl_attention(dev(q), dev(kv))
+    assert torch.equal(got, again)
+    sel = sorted({0, b - 1})
+    want = cells.nl_attention_core(q[sel].astype(np.float64), kv[sel].astype(np.float64), cb)
+    np.testing.assert_allclose(got.cpu().numpy()[sel], want, rtol=1e-5, atol=1e-5)
+    plain = U.nl_attention(dev(q), dev(kv), variant=2)   # an explicit variant: the one-workgroup form
+    np.testing.assert_allclose(got.cpu().numpy(), plain.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    # the C ABI refuses a workspace that is too small before anything is launched
+    out = torch.empty((b, p, cb), dtype=torch.float32, device="cuda")
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device="cuda")
+    with pytest.raises(_hip.PasnlError):
+        _hip.launch("pasnl_nl_attention_ws", "nl", b, p, n, cb, _hip.ptr(dev(q)), _hip.ptr(dev(kv)), _hip.ptr(out), 0, _hip.ptr(ws),
+                    ctypes.c_size_t(nbytes - 1))
+
+
+def test_nl_attention_full_shapes_do_not_take_the_partitioned_form():
+    from pointasnl_amd import _hip
+
+    for b, p, n, cb in [(64, 512, 1024, 32), (16, 1024, 8192, 32), (8, 80, 320, 64), (8, 1280, 10250, 32), (8, 320, 1280, 32)]:
+        assert int(_hip.lib().pasnl_nl_attention_workspace_bytes(b, p, n, cb)) == 0
+
+
 @pytest.mark.parametrize("b,p,n,cb", [(2, 128, 512, 64), (2, 45, 77, 32)])
 def test_nl_attention_lds_staged_kernel_still_agrees(b, p, n, cb):
     """cb <= 64 runs the kernel that takes its operands straight from global memory; the LDS-staged one (the only one

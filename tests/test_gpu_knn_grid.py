@@ -170,10 +170,13 @@ def test_knn_nanoflann_matches_live_reference_when_built():
 
 
 @pytest.mark.parametrize("n,m,k,kind", [(8192, 300, 32, "lattice"), (10240, 200, 16, "dup"), (37, 20, 8, "lattice"), (11, 5, 3, "lattice"),
-                                        (10, 4, 3, "lattice"), (5000, 256, 32, "plane"), (12000, 64, 8, "lattice")])
+                                        (10, 4, 3, "lattice"), (5000, 256, 32, "plane"), (12000, 64, 8, "lattice"),
+                                        (3000, 100, 16, "lattice"), (6500, 100, 16, "clustered"), (20000, 128, 16, "lattice"),
+                                        (30000, 100, 8, "clustered"), (70000, 64, 16, "dup")])
 def test_knn_nanoflann_parallel_build_matches_live_reference(n, m, k, kind):
-    """The workgroup-per-cloud build (n <= 10240; csrc/knn_tree.hip knn_tree_build_par_kernel) and the one-lane build behind it
-    (n = 12000) against the reference library itself, on clouds made of ties: lattices, duplicated points, a flat cloud."""
+    """The parallel builds (csrc/knn_tree.hip: records in LDS up to 8192 points, in the workspace above; nodes above 2048 points split
+    by the whole workgroup, nodes up to 64 points in registers) against the reference library itself, on clouds made of ties:
+    lattices, duplicated points, a flat cloud, clouds with 90 % of their points in one corner (lopsided trees)."""
     from oracle import ref
     if not ref.available("libref_knn.so"):
         pytest.skip("oracle/_ref/libref_knn.so not built here")
@@ -187,6 +190,9 @@ def test_knn_nanoflann_parallel_build_matches_live_reference(n, m, k, kind):
     elif kind == "plane":
         sup[..., 2] = 0.5
         sup = np.round(sup * 40) / 40
+    elif kind == "clustered":  # lopsided trees: 90 % of the points in a corner of the box (the large-node splits several levels deep)
+        sup[:, : n * 9 // 10] *= 0.03
+        sup = np.round(sup * 512) / 512
     sup = sup.astype(np.float32)
     qry = np.concatenate([sup[:, : m // 2], rng.random((3, m - m // 2, 3)).astype(np.float32)], axis=1)
     want = ref.knn_batch(sup, qry, k)
