@@ -221,6 +221,8 @@ def kernel_table(records):
         row = {"kernel": sym, "dims": list(ints), "launches": cnt, "avg_us": round(avg_s * 1e6, 2), "bound": bound,
                "alg_bytes": by, "alg_flops": fl, "GB/s": round(by / avg_s / 1e9, 2),
                "TFLOP/s": round(fl / avg_s / 1e12, 3)}
+        if bound in ("valu", "latency"):  # the roof these are bound by: the vector issue ports (committed counter pass, or null)
+            row["valu_frac"] = measured_valu_frac(sym, ints)
         rows.append(row)
     rows.sort(key=lambda r: -r["avg_us"] * 1.0)
     return rows
@@ -318,6 +320,20 @@ def measured_traffic(symbol, dims):
     if changed:
         return None, f"stale: {', '.join(changed)} changed since profiles/traffic.json was collected at {src.get('commit', '?')}"
     return data[key], f"profiles/traffic.json@{src.get('commit', '?')} (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; {owner} unchanged since)"
+
+
+def measured_valu_frac(symbol, dims):
+    """Fraction of the vector-issue roof a launch of (symbol, dims) reached -- SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x kernel cycles),
+    from the same committed counter collection as the traffic (third pass of profiles/collect_traffic.sh), under the same
+    staleness rule -> fraction or None.  What the rows labelled "valu" / "latency" are bound by (VERDICT r05 missing 5)."""
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tfile):
+        return None
+    data = json.load(open(tfile))
+    v = (data.get("_valu_frac") or {}).get(symbol + ":" + ",".join(map(str, dims)))
+    if v is None or measured_traffic(symbol, dims)[0] is None:  # (absent, or the kernel's source changed since)
+        return None
+    return v
 
 
 
@@ -445,25 +461,30 @@ def supervise(argv):
 
 
 def protocol_only(args, rank, world):
-    """--model none: everything of a bench run except the model -- rendezvous, barriers, a per-step all-gather of (B,40)
-    stand-in logits, max-over-ranks timing, an all-reduce sanity value and the JSON line.  Runs on CPU with gloo."""
+    """--model none: everything of a bench run except the model -- rendezvous, NUMA binding, barriers, a per-step all-gather of
+    stand-in logits of the chosen model's width (--proto-shape cls: (B,40); sem_seg_res: (B, 10240 x 20)), max-over-ranks timing,
+    the per-rank times, the gathered-rows / shards-differ checks, an all-reduce sanity value and the JSON line with every key the
+    multi-rank line of a real run carries.  Runs on CPU with gloo: the first 8-GPU run then exercises nothing new but the wire."""
     import torch
     import torch.distributed as dist
 
     from pointasnl_amd import sharding
 
     dev = "cpu"
+    numa_node, cpus_bound = None, 0
     if args.backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dev = torch.device("cuda", torch.cuda.current_device())
+        numa_node, cpus_bound = sharding.bind_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")))
     multi = world > 1 or args.force_dist
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
     B = args.batch
-    logits = torch.full((B, 40), float(rank + 1), device=dev)
-    gather = sharding.LogitsGather(world, B, 40, dev, force=multi)
+    width = 40 if args.proto_shape == "cls" else 10240 * 20
+    logits = torch.full((B, width), float(rank + 1), device=dev)
+    gather = sharding.LogitsGather(world, B, width, dev, force=multi)
     beat("run", 0.25 * (args.warmup + args.steps))
     for _ in range(args.warmup):
         gather.all_gather(logits)
@@ -474,29 +495,43 @@ def protocol_only(args, rank, world):
         out = gather.all_gather(logits)
     if multi:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
+    mine = time.perf_counter() - t0
+    elapsed = mine
     beat("post")
-    check, ranks = float(rank + 1), 1
+    check, ranks, per_rank, gathered_ok, shards_differ = float(rank + 1), 1, [round(mine / args.steps * 1e3, 4)], None, None
     if multi:
         t = torch.tensor([elapsed, float(rank + 1)], dtype=torch.float64, device=dev)
         dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
         elapsed, check, ranks = float(t[0]), float(t[1]), dist.get_world_size()
-        assert torch.equal(out[:, 0].cpu(), torch.arange(1, world + 1, dtype=torch.float32).repeat_interleave(B))
+        every = torch.empty((world,), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, torch.tensor([mine], dtype=torch.float64, device=dev))
+        per_rank = [round(float(v) / args.steps * 1e3, 4) for v in every]
+        # the checks of a real multi-rank run: this rank's rows of the gathered tensor are its own logits, every rank's rows carry
+        # that rank's checksum, and the shards differ
+        gathered_ok = bool(torch.equal(out[rank * B:(rank + 1) * B], logits))
+        sums = torch.empty((world,), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(sums, logits.double().sum().reshape(1))
+        gathered_ok = gathered_ok and bool(torch.allclose(sums, out.view(world, -1).double().sum(1), rtol=1e-9, atol=0.0))
+        shards_differ = bool(len(set(sums.tolist())) == world)
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps({"metric": "protocol only (no model)", "value": round(world * B * args.steps / elapsed, 2),
                           "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "none", "backend": args.backend, "rccl_ranks": ranks,
-                                     "allreduce_check": check, "global_batch": world * B}}), flush=True)
+                          "config": {"workload": f"none ({args.proto_shape}-shaped logits)", "backend": args.backend, "rccl_ranks": ranks,
+                                     "allreduce_check": check, "global_batch": world * B, "per_rank_ms_per_step": per_rank,
+                                     "gathered_rows_match_local": gathered_ok, "shards_differ": shards_differ,
+                                     "numa_node": numa_node, "cpus_bound": cpus_bound,
+                                     "parallelism": f"batch-shard x{world}, all-gather of logits ({B} x {width} per rank)"}}), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------------------------
 # one configuration: inputs, capture, timed replays, agreement with the eager forward, per-kernel pass
 # ---------------------------------------------------------------------------------------------------------------
 _FORWARD_STREAM = None
+SETTLE_REPLAYS = 40  # untimed replays of the captured step between the capture and the W warm-up steps (config.settle_replays)
 SPLIT_PREFIX = os.environ.get('PASNL_BENCH_SPLIT_PREFIX', '1') != '0'  # tuning switch: sem_seg_res prefix as two plain branches
 FORK_AT_DEFAULT = os.environ.get("PASNL_BENCH_FORK_AT", "cell2")  # cls: where the next batch's prefix is forked (head / conv2 / cell2)
 SELF_KNN_PREFIX = os.environ.get('PASNL_BENCH_SELF_KNN', '0') != '0'    # tuning switch: cls / sem_seg prefix = sampler || self-kNN, then a row gather (measured: 1.335-1.349 vs 1.315 ms)
@@ -798,6 +833,13 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
             beat("run", 0.25 * (warmup + steps))
             if os.environ.get("PASNL_BENCH_FAKE_STALL") == "run":  # supervisor test hook: the worker hangs in the watched region
                 time.sleep(1e6)
+        if announce and graphs:
+            # settle (part of the set-up, not of the W warm-up steps): the first block of replays after the capture ran 1-2 % slower
+            # than the blocks behind it on every box (clocks / power state after the eager and capture phases) -- a fixed number of
+            # untimed replays before the contract's warm-up; an even count, so that buffer 0 is still next
+            for _ in range(SETTLE_REPLAYS):
+                step()
+            torch.cuda.synchronize()
         for _ in range(warmup + (warmup + len(graphs)) % max(1, len(graphs))):  # an even number of steps: buffer 0 is next
             step()
         # ---- timed region: barrier + sync on both sides, max over ranks
@@ -816,7 +858,11 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
         elapsed = time.perf_counter() - t0
         if announce:
             beat("post")
+        per_rank_ms = [elapsed / steps * 1e3]
         if multi:
+            every = torch.empty((world,), dtype=torch.float64, device=x.device)
+            dist.all_gather_into_tensor(every, torch.tensor([elapsed], dtype=torch.float64, device=x.device))
+            per_rank_ms = [float(v) / steps * 1e3 for v in every]
             t = torch.tensor([elapsed], dtype=torch.float64, device=x.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -875,7 +921,7 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
     from pointasnl_amd.utils.nearest_neighbors.lib.python import nearest_neighbors as NN
     torch.cuda.synchronize()
     NN.check_deferred_flags(clear=True)  # (the reference's tie order is the default: the sticky tree-depth flag of every search so far)
-    return {"B": B, "N": N, "elapsed": elapsed, "block_ms": block_ms, "ms_per_step": elapsed / steps * 1e3, "enqueue_ms_per_step": enqueued / steps * 1e3, "clouds_per_s": world * B * steps / elapsed,
+    return {"B": B, "N": N, "elapsed": elapsed, "block_ms": block_ms, "per_rank_ms": per_rank_ms, "ms_per_step": elapsed / steps * 1e3, "enqueue_ms_per_step": enqueued / steps * 1e3, "clouds_per_s": world * B * steps / elapsed,
             "graph": bool(graphs), "pipeline": pipeline if graphs else "eager", "outputs_agree": agree, "gathered_ok": gathered_ok,
             "shards_differ": shards_differ, "rows": rows, "launch_order": launch_order, "pc": pc, "store": store,
             "mode_dev": mode_dev}
@@ -909,10 +955,54 @@ def ball_query_sweep(batches=(64, 256, 1024, 4096), iters=20):
         traffic, src = measured_traffic("pasnl_query_ball_point", [b, 1024, 512, 32])
         out.append({"B": b, "dims": [b, 1024, 512, 32], "radius": 0.2, "median_us": round(med, 2), "min_us": round(min(us), 2),
                     "alg_MB": round(by / 1e6, 2), "GB/s": round(by / med / 1e3, 1), "hbm_frac": round(by / med / 1e3 / HBM_PEAK_GBS, 4),
-                    "traffic": traffic})
+                    "traffic": traffic, "valu_frac": measured_valu_frac("pasnl_query_ball_point", [b, 1024, 512, 32])})
         sources.add(src)
         del x, q
     return out, "; ".join(sorted(sources))
+
+
+def input_stage_row(iters=10):
+    """SURVEY 8(f) rank 4, the step BEFORE the path for configs[4]: voxel-grid subsampling of a raw scan at 0.06 m + the
+    kNN crop of 8 x (10240 + buffer) points around 8 centres (semantic_kitti_dataset_grid.py:265-286), on the device, no
+    host KD-tree.  Synthetic lidar-like scan (bench.synth_kitti's recipe before its crop), HIP-event medians."""
+    import torch
+
+    from pointasnl_amd.SemanticKITTI import semantic_kitti_dataset_grid as G
+    from pointasnl_amd.utils.cpp_wrappers.cpp_subsampling import grid_subsampling
+
+    rng = np.random.Generator(np.random.PCG64(4242))
+    m = 120000                                            # a 64-beam sweep
+    r = 2.0 + 38.0 * rng.random(m) ** 2
+    th = rng.random(m) * 2 * np.pi
+    raw = np.stack([r * np.cos(th), r * np.sin(th), rng.standard_normal(m) * 0.02], 1).astype(np.float32)
+    raw_d = torch.from_numpy(raw).cuda()
+
+    def ev(fn):
+        us = []
+        for _ in range(iters):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            us.append(e0.elapsed_time(e1) * 1e3)
+        return float(np.median(us))
+
+    sub = grid_subsampling.compute(raw, sampleDl=0.06)    # (host round trip: numpy in / out like the reference wrapper)
+    t_sub = ev(lambda: grid_subsampling.compute(raw_d, sampleDl=0.06))
+    scan = torch.from_numpy(sub).cuda()
+    n = int(scan.shape[0])
+    b, num_point, buf = 8, 10240, 2560
+    centres = scan[torch.from_numpy(rng.integers(0, n, b)).cuda()].contiguous()
+    ks = torch.from_numpy((num_point + buf + rng.integers(0, buf // 4, b)).astype(np.int32)).cuda()
+    kcap = min(n, num_point + buf + buf // 4)
+    G.select_batch(scan, centres, k=ks, kcap=kcap)
+    t_crop = ev(lambda: G.select_batch(scan, centres, k=ks, kcap=kcap))
+    by, _, _ = algorithmic("pasnl_knn_crop", (b, n, 0, kcap))
+    return {"workload": "SemanticKITTI input stage on the device (SURVEY 8(f) rank 4): grid_subsampling 0.06 m + crop_pc's kNN search",
+            "raw_points": m, "subsampled_points": n, "grid_subsample_us": round(t_sub, 1) if t_sub else None,
+            "crops": b, "k": f"{num_point} + {buf}..{buf + buf // 4 - 1}", "knn_crop_us": round(t_crop, 1),
+            "knn_crop_alg_MB": round(by / 1e6, 2), "knn_crop_GB/s": round(by / t_crop / 1e3, 1),
+            "knn_crop_hbm_frac": round(by / t_crop / 1e3 / HBM_PEAK_GBS, 4),
+            "note": "the crop is 8 launches of an exact radix selection over the scan (csrc/crop.hip): launch-bound at one scan; "
+                    "the reference: a pickled sklearn KDTree per scan and ~4 ms per query on the host"}
 
 
 def traffic_pass(args):
@@ -968,6 +1058,7 @@ def main():
     ap.add_argument("--worker", action="store_true", help="run the measurement in this process without a supervisor (the supervisor passes it; use it under profilers)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--proto-shape", choices=["cls", "sem_seg_res"], default="cls", help="--model none: the width of the stand-in logits")
     ap.add_argument("--blocks", type=int, default=5, help="timed blocks of --steps steps each: the first one is `value` (the contract's exactly-K-steps region), all of them go to ms_per_step_blocks")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="clouds per GPU (weak scaling); default: the BASELINE config's")
@@ -1091,7 +1182,7 @@ def main():
         cpu = cpu_baseline(res["pc"], res["store"].export_numpy(), spec["AS"])
         beat("post")
 
-    others, sweep, sweep_traffic_source, modes = None, None, None, None
+    others, sweep, sweep_traffic_source, modes, input_stage = None, None, None, None, None
     if world == 1 and not args.no_others and not args.force_dist:
         others = []
         for ci, ospec in WORKLOADS.items():
@@ -1111,6 +1202,11 @@ def main():
                                                                    max(1, min(args.other_steps, 20)), 1),
                            "kernels": sorted(r["rows"], key=lambda k: -k["avg_us"])[:8]})
         sweep, sweep_traffic_source = ball_query_sweep()
+        beat("post")
+        try:
+            input_stage = input_stage_row()
+        except Exception as e:  # (the input stage is not the path: its failure must not take the line down)
+            input_stage = {"error": repr(e)}
         beat("post")
         modes = []
         for md in MODES:
@@ -1156,12 +1252,13 @@ def main():
     config.update({"serial_outputs_agree": serial["outputs_agree"] if serial else None,
                    "serial_clouds_per_s": serial["clouds_per_s"] if serial else None,
                    "enqueue_ms_per_step": round(res["enqueue_ms_per_step"], 4), "hip_graph": res["graph"],
-                   "prefix_forked_at": FORK_AT_DEFAULT if args.model == "cls" else "head"})
+                   "prefix_forked_at": FORK_AT_DEFAULT if args.model == "cls" else "head", "settle_replays": SETTLE_REPLAYS})
     for mo in modes or []:
         config[f"mode_{mo['mode']}_ms"] = mo["ms_per_step"]
     if multi:  # multi-rank checks (constants / nulls in a plain N = 1 run; --force-dist rehearses them with one rank)
         config.update({"rccl_ranks": rccl_ranks, "allreduce_check": allreduce_check, "gathered_rows_match_local": res["gathered_ok"],
-                       "shards_differ": res["shards_differ"], "numa_node": numa_node, "cpus_bound": cpus_bound})
+                       "shards_differ": res["shards_differ"], "numa_node": numa_node, "cpus_bound": cpus_bound,
+                       "per_rank_ms_per_step": [round(v, 4) for v in res["per_rank_ms"]]})
     # every tuning switch that was active in this process: an empty list on the driver's command line
     config["switches"] = sorted(f"{k}={v}" for k, v in os.environ.items() if k.startswith("PASNL_BENCH_") and k not in SUPERVISOR_ENV) + \
         [f"--set {v}" for v in (args.set or [])]
@@ -1190,6 +1287,7 @@ def main():
         "other_configs": others,
         "modes": modes,
         "ball_traffic_source": sweep_traffic_source,
+        "input_stage": input_stage,
         "serial": serial,
         "other_configs_summary": summary,
         "ball_query_sweep": sweep,

@@ -11,4 +11,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $c -d gpurun_out/pmc_$c -o all -f csv -- \
     python bench.py --worker --traffic-pass > gpurun_out/pmc_$c.json 2> gpurun_out/pmc_$c.err || true
 done
+# third pass (round 6): vector-issue busy cycles and the kernel's cycles -> `valu_frac` of the issue-bound kernels
+rm -rf gpurun_out/pmc_VALU
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d gpurun_out/pmc_VALU -o all -f csv -- \
+  python bench.py --worker --traffic-pass > gpurun_out/pmc_VALU.json 2> gpurun_out/pmc_VALU.err || true
 find gpurun_out -name "*counter_collection.csv" | head

@@ -21,19 +21,19 @@ import sys
 from collections import defaultdict
 
 
-def dispatches(root, counter):
+def dispatches(root, counter, passdir=None):
     rows = {}
-    for f in glob.glob(os.path.join(root, f"pmc_{counter}", "**", "*counter_collection.csv"), recursive=True):
+    for f in glob.glob(os.path.join(root, f"pmc_{passdir or counter}", "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == counter:
                 rows[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]))
     return [rows[k] for k in sorted(rows)]
 
 
-def per_launch(root, counter, nlaunch):
+def per_launch(root, counter, nlaunch, passdir=None):
     """-> [(kernel names, summed counter value)] per marked launch"""
     out, cur = [], None
-    for name, val in dispatches(root, counter):
+    for name, val in dispatches(root, counter, passdir):
         if "spin_kernel" in name:
             cur = [[], 0.0]
             out.append(cur)
@@ -52,6 +52,20 @@ def main(root, out):
         raise SystemExit(f"no launch_sequence line found (run profiles/collect_traffic.sh): {e}")
     fetch = per_launch(root, "FETCH_SIZE", len(seq))
     write = per_launch(root, "WRITE_SIZE", len(seq))
+    # VALU-issue fraction (round 6): SQ_ACTIVE_INST_VALU counts the cycles the vector issue ports are busy in units of FOUR cycles,
+    # summed over the SIMDs; GRBM_GUI_ACTIVE the cycles the launch kept the GPU busy, summed over the 8 XCDs:
+    #   valu_frac = 4 ACTIVE / (1024 SIMDs x GUI / 8) = ACTIVE / (32 GUI)      (1.0 = every SIMD issues a vector instruction every cycle)
+    valu = {}
+    try:
+        act = per_launch(root, "SQ_ACTIVE_INST_VALU", len(seq), "VALU")
+        gui = per_launch(root, "GRBM_GUI_ACTIVE", len(seq), "VALU")
+        vagg = defaultdict(list)
+        for (sym, dims), (_, a), (_, g) in zip(seq, act, gui):
+            if not sym.startswith("_") and g > 0:
+                vagg[sym + ":" + ",".join(map(str, dims))].append(a / (32.0 * g))
+        valu = {k: round(sum(v) / len(v), 4) for k, v in vagg.items()}
+    except SystemExit as e:
+        print(f"(no VALU pass: {e})")
     agg, kern = defaultdict(list), {}
     for (sym, dims), (names, f), (_, w) in zip(seq, fetch, write):
         if sym.startswith("_"):  # "_unmeasured": first launches, which also create weights and workspaces
@@ -74,8 +88,10 @@ def main(root, out):
     import bench
     commit = subprocess.run(["git", "-C", here, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
     traffic["_source"] = {"commit": commit, "csrc_sha256": bench.csrc_digests()}
+    traffic["_valu_frac"] = valu
     json.dump(traffic, open(out, "w"), indent=1, sort_keys=True)
     del traffic["_source"]
+    del traffic["_valu_frac"]
     json.dump(detail, open(out.replace(".json", "_detail.json"), "w"), indent=1, sort_keys=True)
     for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]):
         print(f"{k:64s} {v/1e6:10.2f} MB   {kern[k][:60]}")

@@ -157,3 +157,40 @@ def test_two_ranks_over_rccl():
     assert one.returncode == 0, one.stderr[-2000:]
     v1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["value"]
     assert line["value"] > 1.2 * v1, (line["value"], v1)  # two shards in about the time of one
+
+
+@pytest.mark.parametrize("shape,width", [("cls", 40), ("sem_seg_res", 10240 * 20)])
+def test_eight_ranks_protocol_line_carries_every_multi_rank_key(shape, width):
+    """VERDICT r05 #8 (first-run insurance for the 8-GPU scaling bench): `python bench.py --gpus 8 --model none` starts eight
+    ranks (gloo here), every step all-gathers stand-in logits of the model's width, and rank 0's ONE line already carries what
+    the real 8-GPU line carries: n_gpus, the max-over-ranks step time, every rank's own step time, the gathered-rows and
+    shards-differ checks, the NUMA binding fields, the all-reduce over all ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--model", "none",
+                        "--proto-shape", shape, "--steps", "3", "--warmup", "1", "--batch", "2"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 8 and cfg["rccl_ranks"] == 8 and cfg["allreduce_check"] == 36.0 and cfg["global_batch"] == 16
+    assert len(cfg["per_rank_ms_per_step"]) == 8 and all(v > 0 for v in cfg["per_rank_ms_per_step"])
+    assert line["ms_per_step"] >= max(cfg["per_rank_ms_per_step"]) - 1e-3   # the line's figure is the slowest rank's
+    assert cfg["gathered_rows_match_local"] is True and cfg["shards_differ"] is True
+    assert "numa_node" in cfg and "cpus_bound" in cfg and str(width) in cfg["parallelism"]
+    assert line["scaling"] == "weak" and line["value"] > 0 and line["unit"] == "point-clouds/s"
+
+
+@pytest.mark.gpu
+def test_one_rank_through_the_multi_rank_path_agrees_with_the_plain_line():
+    """--gpus 1 --force-dist (RCCL init, per-step all-gather, barriers, max-over-ranks) against the plain N = 1 line of the same
+    process layout: within 2 %, so that the first SCALE record is comparable with BENCH by construction."""
+    a = _bench("--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-others", timeout=900)
+    b = _bench("--gpus", "1", "--force-dist", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-others", timeout=900)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-1500:], b.stderr[-1500:])
+    la = json.loads([l for l in a.stdout.splitlines() if l.startswith("{")][-1])
+    lb = json.loads([l for l in b.stdout.splitlines() if l.startswith("{")][-1])
+    ma, mb = la["ms_per_step_blocks"]["median"], lb["ms_per_step_blocks"]["median"]
+    assert abs(ma - mb) / ma < 0.02, (ma, mb)
+    assert len(lb["config"]["per_rank_ms_per_step"]) == 1

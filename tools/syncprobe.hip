@@ -64,6 +64,45 @@ template <int MODE> void run(const char* name, int* out, long long* t, int threa
   long long h; (void)hipMemcpy(&h, t, 8, hipMemcpyDeviceToHost);
   printf("%-58s waves %2d: %7.1f ns per round (%.1f clock64 ticks)\n", name, threads / 64, ms * 1e6 / iters, (double)h / iters);
 }
+// Cross-WORKGROUP exchange through L2 (two workgroups per cloud exchanging one 64-bit word per round): workgroups
+// 2 i and 2 i + 1 each post a 64-bit key with a device-scope atomic max and wait until both have posted (a generation counter
+// bumped with a device-scope atomic add, polled with s_sleep 1 between loads), then read the winner.  One slot pair per parity.
+__global__ void pair_probe(unsigned long long* slots, unsigned int* gens, long long* t, int* out, int iters) {
+  const int tid = threadIdx.x, pair = blockIdx.x >> 1;
+  unsigned long long* slot = slots + pair * 4;
+  unsigned int* gen = gens + pair * 4;
+  int v = tid * 7 + 3 + blockIdx.x;
+  __syncthreads();
+  long long c0 = clock64();
+  for (int j = 0; j < iters; ++j) {
+    if (tid == 0) {
+      __hip_atomic_fetch_max(&slot[j & 1], ((unsigned long long)(unsigned)v << 32) | (unsigned)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&gen[j & 1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = 2u * (unsigned)(j / 2 + 1);
+      while (__hip_atomic_load(&gen[j & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
+      v += (int)(__hip_atomic_load(&slot[j & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) & 3;
+    }
+    __syncthreads();  // the workgroup waits for its lane 0 (the round's local barrier)
+  }
+  long long c1 = clock64();
+  if (tid == 0) t[blockIdx.x] = c1 - c0;
+  out[blockIdx.x * blockDim.x + tid] = v;
+}
+static void run_pair(int* out, long long* t, int threads) {
+  unsigned long long* slots; unsigned int* gens;
+  (void)hipMalloc(&slots, 64 * 4 * 8); (void)hipMalloc(&gens, 64 * 4 * 4);
+  const int iters = 20000;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int rep = 0; rep < 2; ++rep) {
+    (void)hipMemset(slots, 0, 64 * 4 * 8); (void)hipMemset(gens, 0, 64 * 4 * 4);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    pair_probe<<<16, threads>>>(slots, gens, t, out, iters);  // 8 pairs: all sixteen workgroups are resident at once
+    (void)hipEventRecord(e1); (void)hipDeviceSynchronize();
+  }
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  printf("%-58s waves %2d: %7.1f ns per round\n", "cross-workgroup: atomic max + generation counter through L2", threads / 64, ms * 1e6 / iters);
+}
 int main() {
   int* out; long long* t;
   (void)hipMalloc(&out, 64 * 1024 * 4); (void)hipMalloc(&t, 64 * 8);
@@ -74,6 +113,7 @@ int main() {
     run<3>("ds_max_u64 + barrier + ds_read_b64", out, t, threads, 0);
     run<4>("two dependent ds_reads", out, t, threads, 0);
     run<5>("full fps_kernel exchange", out, t, threads, 0);
+    run_pair(out, t, threads);
   }
   return 0;
 }
