@@ -35,6 +35,14 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# HIP maps the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and the forks of a captured
+# forward that land on one queue serialise.  With four queues the mapping that RCCL's own streams leave for the forward is a bad one:
+# the SAME captured step took 1.75-1.80 ms instead of 1.32 once a process group existed -- no collective in the step --, which the
+# driver's N = 2 run would have shown as a 25 % scaling loss.  With three queues every workload runs as with four (cls 1.322 /
+# 1.322, sem_seg 4.39 / 4.37, sem_seg_res 2.376 / 2.376 ms) and RCCL's presence changes nothing (1.32; sem_seg_res 2.375):
+# profiles/r06_hw_queues.txt.  Read by the HIP runtime when it initialises, so it is set before torch is imported; a value the
+# caller exported wins.  Recorded in config.hip_hw_queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -813,14 +821,21 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
             graphs, outs = [g], [out]
         step_no = [0]
 
+        gather_mode = os.environ.get("PASNL_BENCH_GATHER", "async")  # tuning switch: async (default) / sync (round 5's blocking form) / none
+
         def step():
             if graphs:
                 i = step_no[0] % len(graphs)
                 step_no[0] += 1
                 with torch.cuda.stream(side):
+                    if gather is not None and gather_mode == "async":
+                        gather.before_reuse(i)  # the all-gather that read outs[i] len(graphs) steps ago
                     graphs[i].replay()
                     if gather is not None:
-                        gather.all_gather(outs[i])
+                        if gather_mode == "async":
+                            gather.all_gather_async(outs[i], i)
+                        elif gather_mode == "sync":
+                            gather.all_gather(outs[i])
                 return outs[i]
             o = forward()
             if gather is not None:
@@ -959,6 +974,21 @@ def ball_query_sweep(batches=(64, 256, 1024, 4096), iters=20):
         sources.add(src)
         del x, q
     return out, "; ".join(sorted(sources))
+
+
+def precreate_streams():
+    """The forward's streams, created in the order a plain N = 1 run creates them, BEFORE RCCL creates its own: HIP maps streams to
+    a few hardware queues in creation order, and the side streams of a forward that share a queue serialise.  With the
+    streams created after dist.init_process_group the one-rank RCCL path ran 1.75-1.79 ms per step against 1.32 of the plain
+    path -- with NO collective in the step -- which would have read as a 25 % 'scaling loss' from N = 1 to N = 2."""
+    import torch
+
+    from pointasnl_amd.utils import pointasnl_util
+    global _FORWARD_STREAM
+    for slot in (1, 0, 2, 3, 4):  # the order of first use in a cls forward + the prefetch slots
+        pointasnl_util._side_stream(slot)
+    if _FORWARD_STREAM is None:
+        _FORWARD_STREAM = torch.cuda.Stream(priority=-1)
 
 
 def input_stage_row(iters=10):
@@ -1142,7 +1172,10 @@ def main():
     if multi:
         from pointasnl_amd import sharding as _sh
 
-        numa_node, cpus_bound = _sh.bind_to_gpu_numa(local_rank)  # before RCCL starts its proxy thread (it inherits the mask)
+        if os.environ.get("PASNL_BENCH_NO_BIND") != "1":  # (tuning switch)
+            numa_node, cpus_bound = _sh.bind_to_gpu_numa(local_rank)  # before RCCL starts its proxy thread (it inherits the mask)
+        if os.environ.get("PASNL_BENCH_PRECREATE", "1") == "1":
+            precreate_streams()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -1252,7 +1285,8 @@ def main():
     config.update({"serial_outputs_agree": serial["outputs_agree"] if serial else None,
                    "serial_clouds_per_s": serial["clouds_per_s"] if serial else None,
                    "enqueue_ms_per_step": round(res["enqueue_ms_per_step"], 4), "hip_graph": res["graph"],
-                   "prefix_forked_at": FORK_AT_DEFAULT if args.model == "cls" else "head", "settle_replays": SETTLE_REPLAYS})
+                   "prefix_forked_at": FORK_AT_DEFAULT if args.model == "cls" else "head", "settle_replays": SETTLE_REPLAYS,
+                   "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")})
     for mo in modes or []:
         config[f"mode_{mo['mode']}_ms"] = mo["ms_per_step"]
     if multi:  # multi-rank checks (constants / nulls in a plain N = 1 run; --force-dist rehearses them with one rank)
