@@ -13,10 +13,11 @@
 //     eight k values of a column are 16 contiguous bytes);
 //   * the activations are split on the fly, once per element, while a 128 x 32 tile goes from global memory into LDS (three
 //     bf16 planes, 80-byte row pitch: conflict-free 16-byte reads): v_cvt_pk_bf16_f32 for the rounding, the remainder in fp32;
-//   * a workgroup of four waves owns a 128 x 128 tile of the output, a wave a 64 x 64 quarter (2 x 2 blocks of 32 x 32: four
-//     accumulators); per 32 contraction indices a wave issues 48 matrix instructions from 12 LDS reads (A) and 12 global
-//     reads (W: L2-resident, shared by the two waves of a column half); the next tile of A is requested before the products
-//     of the current one and split / stored behind them (double-buffered LDS).
+//   * a workgroup of EIGHT waves (__launch_bounds__(512, 4)) owns a 128 x 128 tile of the output, a wave a 64 x 32 slab (two
+//     blocks of 32 x 32: two accumulators); per 32 contraction indices a wave issues 24 matrix instructions (six products x two
+//     k-halves x two row blocks) from 12 LDS reads (A: three planes x two row blocks x two k-halves) and 6 global reads (W:
+//     L2-resident, requested one k-step ahead); the next tile of A is requested before the products of the current one and
+//     split / stored behind them (double-buffered LDS, two tiles in flight).  104 VGPRs, 61 KB of LDS: two workgroups per CU.
 #include "common.hpp"
 
 namespace pasnl {

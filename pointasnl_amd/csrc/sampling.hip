@@ -649,7 +649,7 @@ static int fps_pruned_launch(int b, int n, int m, const float* xyz, int* idx, hi
 }
 
 #ifdef PASNL_TUNING
-#include "experimental/fps_multi.inc"  // several picks per round: measured slower, tuning build only (EXPERIMENTS.md)
+#include "../../tools/experimental/fps_multi.inc"  // several picks per round: measured slower, tuning build only (EXPERIMENTS.md)
 #endif
 
 // ---------------------------------------------------------------------------------------------

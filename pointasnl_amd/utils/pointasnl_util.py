@@ -523,7 +523,20 @@ class Forked:
             self._fork_ev.record(main)
             self._main = main
             self._fn = fn
-            _hip.AFTER_LAUNCH.append(self._start_if_main)
+            # (a weak callback: a fork that is dropped before .get() -- an exception in the forward -- must not leave its start
+            # behind the next launch of a LATER forward)
+            import weakref
+            ref = weakref.ref(self)
+
+            def _cb():
+                me = ref()
+                if me is None or me._fn is None:
+                    if _cb in _hip.AFTER_LAUNCH:
+                        _hip.AFTER_LAUNCH.remove(_cb)
+                    return
+                me._start_if_main()
+            self._cb = _cb
+            _hip.AFTER_LAUNCH.append(_cb)
             return
         self._side.wait_stream(main)
         self._run(fn)
@@ -546,9 +559,15 @@ class Forked:
         fn, self._fn = self._fn, None
         if fn is None:
             return
-        if self._start_if_main in _hip.AFTER_LAUNCH:
-            _hip.AFTER_LAUNCH.remove(self._start_if_main)
+        if getattr(self, "_cb", None) in _hip.AFTER_LAUNCH:
+            _hip.AFTER_LAUNCH.remove(self._cb)
+        # allocator safety (class docstring): the side stream must not reuse a block before its last consumer on the caller's stream
+        # has run -- consumers enqueued between the fork point and this deferred start included, so the side work waits for the
+        # caller's stream AS IT IS NOW, not only for the fork event.  Eagerly that is the whole ordering; under capture
+        # it adds one edge from the caller's latest node, which is the node this start was deferred behind anyway.
         self._side.wait_event(self._fork_ev)
+        if torch.cuda.current_stream() == self._main:
+            self._side.wait_stream(self._main)
         self._run(fn)
 
     def get(self):

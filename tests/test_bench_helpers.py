@@ -130,3 +130,38 @@ def test_asm_scan_flags_inline_assembly_next_to_matrix_instructions():
 """.split("\n")
     assert asm_scan.asm_mfma_hazards(good, 0, len(good)) == []
     assert asm_scan.regs_of("v[4:7]") == {"v4", "v5", "v6", "v7"} and asm_scan.regs_of("a3") == {"a3"} and asm_scan.regs_of("s[0:1]") == set()
+
+
+def test_asm_scan_checks_wait_states_in_front_of_inline_dpp():
+    """tools/asm_scan.py `asm_dpp`: a DPP instruction in inline assembly needs two wait states behind the vector
+    instruction that wrote the register it reads from other lanes (ball_grid.hip's v_min_i32_dpp reductions carry s_nop 1)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("asm_scan", os.path.join(ROOT, "tools", "asm_scan.py"))
+    asm_scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(asm_scan)
+    bad = """_Zk:
+	v_xor_b32_e32 v4, v5, v6
+	;;#ASMSTART
+	v_min_i32_dpp v4, v4, v4 row_shr:1 row_mask:0xf bank_mask:0xf
+	s_nop 0
+	v_min_i32_dpp v4, v4, v4 row_shr:2 row_mask:0xf bank_mask:0xf
+	;;#ASMEND
+""".split("\n")
+    found = asm_scan.asm_mfma_hazards(bad, 0, len(bad))
+    assert len(found) == 2 and "0 wait" in found[0] and "1 wait" in found[1]
+    good = """_Zk:
+	v_xor_b32_e32 v4, v5, v6
+	;;#ASMSTART
+	s_nop 1
+	v_min_i32_dpp v4, v4, v4 row_shr:1 row_mask:0xf bank_mask:0xf
+	s_nop 1
+	v_min_i32_dpp v4, v4, v4 row_shr:2 row_mask:0xf bank_mask:0xf
+	;;#ASMEND
+	v_add_u32_e32 v7, v8, v9
+	v_add_u32_e32 v7, v8, v9
+	;;#ASMSTART
+	v_min_i32_dpp v4, v4, v4 row_shr:4 row_mask:0xf bank_mask:0xf
+	;;#ASMEND
+""".split("\n")
+    assert asm_scan.asm_mfma_hazards(good, 0, len(good)) == []

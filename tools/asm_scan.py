@@ -21,7 +21,10 @@ assembly is opaque to it.  Flagged, conservatively (straight-line distance, ever
 And `asm_sgpr` (round 5: the ball query's inline-assembly v_addc read a lane mask that a vector compare had written too
 recently -- duplicated hits): an inline-assembly vector instruction that reads a scalar register (or vcc) which a vector
 instruction (v_cmp*, v_*_co_*, v_readlane, v_readfirstlane, v_div_scale*) wrote at most SGPR_BEFORE wait states earlier.
-The script exits non-zero when one of either kind is found."""
+And `asm_dpp` (round 6): an inline-assembly DPP instruction less than DPP_BEFORE wait states behind the vector instruction that
+wrote a register it reads (ball_grid.hip's v_min_i32_dpp reductions carry their own s_nop: this checks them under whatever
+schedule the compiler chose around the block).
+The script exits non-zero when one of any kind is found."""
 import argparse
 import glob
 import os
@@ -43,6 +46,7 @@ def demangle(name):
 
 MFMA_BEFORE, MFMA_AFTER = 20, 6  # wait states: a 16-pass product's result -> vector read needs 19; vector write -> product read 2..4
 SGPR_BEFORE = 4                  # wait states between a vector instruction's scalar result and a vector instruction that reads it
+DPP_BEFORE = 2                   # wait states between a vector instruction's result and a DPP instruction that reads it
 
 
 def sregs_of(operand):
@@ -133,6 +137,18 @@ def asm_mfma_hazards(lines, start, end):
             if srd & sw2:
                 found.append(f"line {ln}: inline-asm `{mn}` reads {sorted(srd & sw2)[:3]} {dist} wait state(s) behind `{m2}` (line {l2})")
                 break
+        if "_dpp" in mn:  # asm_dpp: a DPP instruction reads another LANE's copy of a register a vector instruction
+            # wrote: two wait states in between, which the hazard recogniser inserts for the compiler's own code only
+            between = 0
+            for j in range(i - 1, -1, -1):
+                l2, m2, w2, _, _, wt, _, _ = instrs[j]
+                if m2.startswith("v_") and (w2 & (rd | wr)):
+                    if between < DPP_BEFORE:
+                        found.append(f"line {ln}: inline-asm `{mn}` reads {sorted(w2 & (rd | wr))[:3]} {between} wait state(s) behind `{m2}` (line {l2}); {DPP_BEFORE} needed")
+                    break
+                between += wt
+                if between >= DPP_BEFORE:
+                    break
         dist = 0
         for j in range(i - 1, -1, -1):
             l2, m2, w2, r2, _, wt, _, _ = instrs[j]
