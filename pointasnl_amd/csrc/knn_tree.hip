@@ -832,7 +832,8 @@ __device__ __forceinline__ KtSplit ktb_split_node_wg(float4* rec, PosT* sc, floa
 #ifndef KT_COOP_MIN_V
 #define KT_COOP_MIN_V 4096  // measured (16 x 8192 self-kNN, 4 flagged clouds): 1024: 576 us, 2048: 518, 4096: 484, never: 505
 #endif
-constexpr unsigned KT_COOP_MIN = KT_COOP_MIN_V;  // nodes above this many points are split by the whole workgroup, one after the other
+constexpr unsigned KT_COOP_MIN = KT_COOP_MIN_V;
+constexpr unsigned KT_COOP_FEW = 768;  // ... in a level of at most two nodes  // nodes above this many points are split by the whole workgroup, one after the other
 // ... as a real CALL in the kernels that also hold the one-wave forms (inlined there, the three forms together need more than the 128
 // registers a 1024-thread workgroup has: 140 bytes of scratch per lane, the deep kernel 132 -> 395 us); a large node is
 // hundreds of trips: the call and the generic addressing of LDS do not show
@@ -943,10 +944,13 @@ __device__ void knn_tree_build_lds_body(int cloud, int n, const float* __restric
       nd.child1 = child[0]; nd.child2 = child[1]; nd.a = cutfeat; nd.divlow = sp_.dl; nd.divhigh = sp_.dh;
       nodes[wk.node] = nd;
     };
-    if (ctr[4 + cur] != 0) {  // (uniform) the level's large nodes first, one after the other, by the whole workgroup
+    // a level of ONE or TWO nodes (the top of a tree, of a lopsided subtree) leaves fourteen waves idle while one walks a node in
+    // count / 64 trips per pass: there the whole workgroup takes every node above KT_COOP_FEW points
+    const unsigned coop_min = nq <= 2 ? KT_COOP_FEW : KT_COOP_MIN;
+    if (ctr[4 + cur] != 0 || nq <= 2) {  // (uniform) the level's large nodes first, one after the other, by the whole workgroup
       for (int e = 0; e < nq; ++e) {
         const KtWork wk = kt_load_work(queue[cur] + e, lane);
-        if (wk.right - wk.left <= KT_COOP_MIN) continue;
+        if (wk.right - wk.left <= coop_min) continue;
         const KtSplit sp_ = ktb_split_node_wg_lds(rec, sc, part, wk.box[0], wk.box[1], wk.box[2], wk.box[3], wk.box[4], wk.box[5], wk.left, wk.right, tid);
         if (tid == 0) emit(wk, sp_);
       }
@@ -954,7 +958,7 @@ __device__ void knn_tree_build_lds_body(int cloud, int n, const float* __restric
     for (int e = wave; e < nq; e += KTB_WAVES) {
       const KtWork wk = kt_load_work(queue[cur] + e, lane);
       const unsigned left = wk.left, right = wk.right;
-      if (right - left > KT_COOP_MIN) continue;
+      if (right - left > coop_min) continue;
       const KtSplit sp_ = ktb_split_node(rec, sc, wk, left, right, lane, lt_mask);
       if (lane == 0) emit(wk, sp_);
     }
@@ -1187,10 +1191,11 @@ __device__ void knn_tree_build_deep_body(int cloud, int item, int n, char* __res
       nd.child1 = child[0]; nd.child2 = child[1]; nd.a = cutfeat; nd.divlow = sp_.dl; nd.divhigh = sp_.dh;
       nodes[wk.node] = nd;
     };
-    if (ctr[4 + cur] != 0) {  // (uniform) large nodes: the whole workgroup, one node after the other
+    const unsigned coop_min = nq <= 2 ? KT_COOP_FEW : KT_COOP_MIN;  // (knn_tree_build_lds_body's note)
+    if (ctr[4 + cur] != 0 || nq <= 2) {  // (uniform) large nodes: the whole workgroup, one node after the other
       for (int e = 0; e < nq; ++e) {
         const KtWork wk = kt_load_work((cur ? qb : qa) + e, lane);
-        if (wk.right - wk.left <= KT_COOP_MIN) continue;
+        if (wk.right - wk.left <= coop_min) continue;
         const KtSplit sp_ = ktb_split_node_wg_lds(rec, sc, red, wk.box[0], wk.box[1], wk.box[2], wk.box[3], wk.box[4], wk.box[5], wk.left, wk.right, tid);
         if (tid == 0) emit(wk, sp_);
       }
@@ -1198,7 +1203,7 @@ __device__ void knn_tree_build_deep_body(int cloud, int item, int n, char* __res
     for (int e = wave; e < nq; e += KTB_WAVES) {
       const KtWork wk = kt_load_work((cur ? qb : qa) + e, lane);
       const unsigned left = wk.left, right = wk.right;
-      if (right - left > KT_COOP_MIN) continue;
+      if (right - left > coop_min) continue;
       const KtSplit sp_ = ktb_split_node(rec, sc, wk, left, right, lane, lt_mask);
       if (lane == 0) emit(wk, sp_);
     }
