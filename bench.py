@@ -40,9 +40,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 # the SAME captured step took 1.75-1.80 ms instead of 1.32 once a process group existed -- no collective in the step --, which the
 # driver's N = 2 run would have shown as a 25 % scaling loss.  With three queues every workload runs as with four (cls 1.322 /
 # 1.322, sem_seg 4.39 / 4.37, sem_seg_res 2.376 / 2.376 ms) and RCCL's presence changes nothing (1.32; sem_seg_res 2.375):
-# profiles/r06_hw_queues.txt.  Read by the HIP runtime when it initialises, so it is set before torch is imported; a value the
-# caller exported wins.  Recorded in config.hip_hw_queues.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
+# profiles/r06_hw_queues.txt.  Read by the HIP runtime when it initialises, so main() sets it before torch is imported -- in
+# MULTI-RANK runs only (a plain N = 1 run keeps the runtime's default, under which every number of rounds 1-5 was taken; a value the
+# caller exported wins).  Recorded in config.hip_hw_queues.
+MULTI_RANK_HW_QUEUES = "3"
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -1131,12 +1132,15 @@ def main():
 
         faulthandler.dump_traceback_later(float(os.environ["PASNL_BENCH_WATCHDOG"]), exit=True)
 
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if (world > 1 or args.force_dist) and args.model != "none":
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", MULTI_RANK_HW_QUEUES)  # (before torch loads the HIP runtime: the comment at the top of the file)
+
+    import torch
+    import torch.distributed as dist
+
     if world != args.gpus:  # never degrade silently: a line that says n_gpus=1 for a --gpus 8 request is a wrong measurement
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to run", file=sys.stderr)
         sys.exit(4)
@@ -1286,7 +1290,7 @@ def main():
                    "serial_clouds_per_s": serial["clouds_per_s"] if serial else None,
                    "enqueue_ms_per_step": round(res["enqueue_ms_per_step"], 4), "hip_graph": res["graph"],
                    "prefix_forked_at": FORK_AT_DEFAULT if args.model == "cls" else "head", "settle_replays": SETTLE_REPLAYS,
-                   "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")})
+                   "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")})
     for mo in modes or []:
         config[f"mode_{mo['mode']}_ms"] = mo["ms_per_step"]
     if multi:  # multi-rank checks (constants / nulls in a plain N = 1 run; --force-dist rehearses them with one rank)
