@@ -1774,6 +1774,610 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// A FEW listed queries in a cloud of thousands of points (pasnl_knn_batch_ref on the segmentation models' input levels: one
+// chance tie per ~1e5 queries): the search visits ~60 of the tree's ~2000 nodes, yet the whole tree was built for it -- 390 us
+// for an 8192-point cloud, 470 for a lidar-like 10240-point one, every step.  Here the tree is built ON DEMAND: one workgroup
+// per listed cloud holds the index list, the cut coordinate of the node being split and a table of the nodes created so far in
+// LDS; wave 0 runs nanoflann's search (knn_tree_search_wave's walk and result list) and stops at a node that has not been
+// split yet; the whole workgroup then splits exactly that node (middleSplit_ + planeSplit in the closed form of
+// ktb_split_node_wg, coordinates gathered from the cloud) and the walk resumes.  A node's split depends on its own slice of
+// the index list alone, and that slice is what its ancestors' splits left there -- all of them on the walk's path, all done
+// before: the nodes that exist are the reference tree's nodes, bit for bit; subtrees the search prunes are never touched.
+// A batch with more listed queries than KTL_MAXQ goes to the full builds (`nwork` tells the later kernels what is left).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int KTL_NMAX = 10240;     // index list + cut coordinates + scratch positions of a cloud in LDS: 10 bytes per point
+constexpr int KTL_MAXNODES = 768;   // nodes the searches of one cloud may create (a search creates ~2 per level it descends)
+constexpr int KTL_MAXQ = 32;        // listed queries per BATCH this form takes (a workgroup each, side by side)
+struct KtlNode {                    // child1: >= 0 first child (the second follows it), -1 leaf, -2 not split yet
+  unsigned left, right;
+  int child1, cutfeat;
+  float divlow, divhigh;
+  float box[6];                     // the box handed down to this node (what middleSplit_ reads)
+};
+__host__ __device__ inline size_t ktl_lds_bytes(int n) {
+  return (size_t)n * 4 + (size_t)n * 4 + (((size_t)n * 2 + 15) & ~(size_t)15) + (size_t)KTL_MAXNODES * sizeof(KtlNode) + KTB_WAVES * 6 * 4 + 64 +
+         (size_t)KT_DEPTH * 3 * 4;
+}
+
+// split node `nid` (count > KT_LEAF) by the whole workgroup; creates its two children.  false: the node table is full
+__device__ __forceinline__ bool ktl_expand(const float* __restrict__ pts, unsigned* vind, float* vals, unsigned short* sc, float* red,
+                                           KtlNode* nodes, int* ctl, const int nid, const int tid) {
+  constexpr int T = KTB_WAVES * 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int* redi = reinterpret_cast<int*>(red);
+  const unsigned left = nodes[nid].left, right = nodes[nid].right, count = right - left;
+  float box[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) box[i] = nodes[nid].box[i];
+  if (ctl[0] + 2 > KTL_MAXNODES) return false;  // (uniform)
+  // ---- middleSplit_ (:966-1005): computeMinMax of all three dimensions in one gathering pass
+  const float EPS = 0.00001f;
+  float max_span = box[1] - box[0];
+#pragma unroll
+  for (int d = 1; d < 3; ++d) {
+    const float span = box[2 * d + 1] - box[2 * d];
+    if (span > max_span) max_span = span;
+  }
+  float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (unsigned p = tid; p < count; p += T) {
+    const float* q = pts + (size_t)vind[left + p] * 3;
+    const float c[3] = {q[0], q[1], q[2]};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn3[d] = c[d] < mn3[d] ? c[d] : mn3[d];
+      mx3[d] = c[d] > mx3[d] ? c[d] : mx3[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { mn3[d] = wave_min_f32(mn3[d]); mx3[d] = wave_max_f32(mx3[d]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { red[wave * 6 + 2 * d] = mn3[d]; red[wave * 6 + 2 * d + 1] = mx3[d]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    float l = red[2 * d], h = red[2 * d + 1];
+    for (int w = 1; w < KTB_WAVES; ++w) { l = fminf(l, red[w * 6 + 2 * d]); h = fmaxf(h, red[w * 6 + 2 * d + 1]); }
+    mn3[d] = l; mx3[d] = h;
+  }
+  __syncthreads();
+  float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
+  int cutfeat = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float span = box[2 * d + 1] - box[2 * d];
+    if (span > (1 - EPS) * max_span) {
+      const float spread = mx3[d] - mn3[d];
+      if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn3[d]; mx_c = mx3[d]; }
+    }
+  }
+  const float blo = cutfeat == 0 ? box[0] : (cutfeat == 1 ? box[2] : box[4]);
+  const float bhi = cutfeat == 0 ? box[1] : (cutfeat == 1 ? box[3] : box[5]);
+  const float split_val = (blo + bhi) / 2;
+  float cutval;
+  if (split_val < mn_c) cutval = mn_c;
+  else if (split_val > mx_c) cutval = mx_c;
+  else cutval = split_val;
+  for (unsigned p = tid; p < count; p += T) vals[left + p] = pts[(size_t)vind[left + p] * 3 + cutfeat];
+  __syncthreads();
+  // ---- planeSplit (:1016-1043): the closed form, ranks per wave chunk (ktb_split_node_wg)
+  unsigned lim[2];
+  unsigned lo_p = 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    auto pred = [&](float v) { return pass == 0 ? v < cutval : v <= cutval; };
+    const unsigned span = count - lo_p;
+    const unsigned chunk = ((span + T - 1) / T) * 64;
+    const unsigned cs = min(count, lo_p + (unsigned)wave * chunk), ce = min(count, cs + chunk);
+    unsigned c = 0;
+    for (unsigned p0 = cs; p0 < ce; p0 += 64) {
+      const unsigned p = p0 + lane;
+      c += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p < ce && pred(vals[left + (p < ce ? p : cs)])));
+    }
+    if (lane == 0) redi[wave] = (int)c;
+    __syncthreads();
+    unsigned cnt = 0;
+    for (int w = 0; w < KTB_WAVES; ++w) cnt += (unsigned)redi[w];
+    const unsigned mid = lo_p + cnt;
+    __syncthreads();
+    unsigned nv = 0, nr = 0;
+    for (unsigned p0 = cs; p0 < ce; p0 += 64) {
+      const unsigned p = p0 + lane;
+      const bool in = p < ce, sat = in && pred(vals[left + (in ? p : cs)]);
+      nv += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in && p < mid && !sat));
+      nr += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sat && p >= mid));
+    }
+    if (lane == 0) { redi[wave] = (int)nv; redi[KTB_WAVES + wave] = (int)nr; }
+    __syncthreads();
+    unsigned vbase = 0, rbase = 0, nl = 0;
+    for (int w = 0; w < KTB_WAVES; ++w) {
+      const unsigned v = (unsigned)redi[w], r = (unsigned)redi[KTB_WAVES + w];
+      nl += v;
+      if (w < wave) vbase += v;
+      if (w > wave) rbase += r;
+    }
+    __syncthreads();
+    unsigned runv = 0, runr = 0;
+    for (unsigned p0 = cs; p0 < ce; p0 += 64) {
+      const unsigned p = p0 + lane;
+      const bool in = p < ce, sat = in && pred(vals[left + (in ? p : cs)]);
+      const bool viol = in && p < mid && !sat, rs = sat && p >= mid;
+      const unsigned long long mv = __builtin_amdgcn_ballot_w64(viol), mr = __builtin_amdgcn_ballot_w64(rs);
+      if (viol) sc[left + lo_p + vbase + runv + (unsigned)__builtin_popcountll(mv & lt_mask)] = (unsigned short)p;
+      if (rs) {
+        const unsigned asc = runr + (unsigned)__builtin_popcountll(mr & lt_mask);
+        sc[right - 1 - (rbase + (nr - 1 - asc))] = (unsigned short)p;
+      }
+      runv += (unsigned)__builtin_popcountll(mv);
+      runr += (unsigned)__builtin_popcountll(mr);
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < nl; i += T) {
+      const unsigned a = left + (unsigned)sc[left + lo_p + i], b = left + (unsigned)sc[right - 1 - i];
+      const unsigned ta = vind[a], tb = vind[b];
+      const float va = vals[a], vb = vals[b];
+      vind[a] = tb; vind[b] = ta;
+      vals[a] = vb; vals[b] = va;
+    }
+    __syncthreads();
+    lim[pass] = mid;
+    lo_p = mid;
+  }
+  unsigned index;
+  if (lim[0] > count / 2) index = lim[0];
+  else if (lim[1] < count / 2) index = lim[1];
+  else index = count / 2;
+  float dl = -INFINITY, dh = INFINITY;  // divlow = max of the left part, divhigh = min of the right part (:956-957)
+  for (unsigned p = tid; p < count; p += T) {
+    const float v = vals[left + p];
+    if (p < index) dl = v > dl ? v : dl;
+    else dh = v < dh ? v : dh;
+  }
+  dl = wave_max_f32(dl); dh = wave_min_f32(dh);
+  if (lane == 0) { red[wave * 2] = dl; red[wave * 2 + 1] = dh; }
+  __syncthreads();
+  if (tid == 0) {
+    float l = red[0], h = red[1];
+    for (int w = 1; w < KTB_WAVES; ++w) { l = fmaxf(l, red[w * 2]); h = fminf(h, red[w * 2 + 1]); }
+    const int c1 = ctl[0];
+    ctl[0] = c1 + 2;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      KtlNode ch;
+      ch.left = c == 0 ? left : left + index;
+      ch.right = c == 0 ? left + index : right;
+      ch.child1 = ch.right - ch.left <= (unsigned)KT_LEAF ? -1 : -2;
+      ch.cutfeat = 0; ch.divlow = 0.f; ch.divhigh = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ch.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : box[i];  // left: high = cutval; right: low = cutval
+      nodes[c1 + c] = ch;
+    }
+    nodes[nid].child1 = c1;
+    nodes[nid].cutfeat = cutfeat;
+    nodes[nid].divlow = l;
+    nodes[nid].divhigh = h;
+  }
+  __syncthreads();
+  return true;
+}
+
+// ... and for nodes of at most 64 points (most of what a search reaches): one point per lane, both partition passes in registers
+// (ktb_split_node_small on the index list: the coordinates gathered once, the partner's lane through scratch, ds_bpermute)
+__device__ __forceinline__ bool ktl_expand_small(const float* __restrict__ pts, unsigned* vind, unsigned short* sc, KtlNode* nodes,
+                                                 int* ctl, const int nid, const int lane) {
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const unsigned left = nodes[nid].left, right = nodes[nid].right, count = right - left;
+  float box[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) box[i] = nodes[nid].box[i];
+  if (ctl[0] + 2 > KTL_MAXNODES) return false;
+  const bool in = (unsigned)lane < count;
+  unsigned vi = vind[left + (in ? lane : 0)];
+  float rx, ry, rz;
+  { const float* q = pts + (size_t)vi * 3; rx = q[0]; ry = q[1]; rz = q[2]; }
+  const float EPS = 0.00001f;
+  float max_span = box[1] - box[0];
+#pragma unroll
+  for (int d = 1; d < 3; ++d) {
+    const float span = box[2 * d + 1] - box[2 * d];
+    if (span > max_span) max_span = span;
+  }
+  float mn3[3], mx3[3];
+  {
+    const float c[3] = {rx, ry, rz};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { mn3[d] = wave_min_f32(in ? c[d] : INFINITY); mx3[d] = wave_max_f32(in ? c[d] : -INFINITY); }
+  }
+  float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
+  int cutfeat = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float span = box[2 * d + 1] - box[2 * d];
+    if (span > (1 - EPS) * max_span) {
+      const float spread = mx3[d] - mn3[d];
+      if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn3[d]; mx_c = mx3[d]; }
+    }
+  }
+  const float blo = cutfeat == 0 ? box[0] : (cutfeat == 1 ? box[2] : box[4]);
+  const float bhi = cutfeat == 0 ? box[1] : (cutfeat == 1 ? box[3] : box[5]);
+  const float split_val = (blo + bhi) / 2;
+  float cutval;
+  if (split_val < mn_c) cutval = mn_c;
+  else if (split_val > mx_c) cutval = mx_c;
+  else cutval = split_val;
+  float v = cutfeat == 0 ? rx : (cutfeat == 1 ? ry : rz);  // the cut coordinate travels with the index
+  unsigned lim[2];
+  unsigned lo_p = 0;
+  unsigned short* scr = sc + left;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool inr = in && (unsigned)lane >= lo_p;
+    const bool sat = inr && (pass == 0 ? v < cutval : v <= cutval);
+    const unsigned cnt = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(sat));
+    const unsigned mid = lo_p + cnt;
+    const bool viol = inr && (unsigned)lane < mid && !sat;
+    const bool rsat = sat && (unsigned)lane >= mid;
+    const unsigned long long mv = __builtin_amdgcn_ballot_w64(viol), mr = __builtin_amdgcn_ballot_w64(rsat);
+    if (mv != 0ull) {
+      const unsigned vrank = (unsigned)__builtin_popcountll(mv & lt_mask);
+      const unsigned rrank = (unsigned)__builtin_popcountll(mr & ~lt_mask & ~(1ull << lane));
+      if (viol) scr[vrank] = (unsigned short)lane;
+      if (rsat) scr[count - 1 - rrank] = (unsigned short)lane;
+      ktb_wave_sync();
+      int partner = lane;
+      if (viol) partner = scr[count - 1 - vrank];
+      if (rsat) partner = scr[rrank];
+      ktb_wave_sync();
+      vi = (unsigned)__shfl((int)vi, partner);
+      v = __shfl(v, partner);
+    }
+    lim[pass] = mid;
+    lo_p = mid;
+  }
+  unsigned index;
+  if (lim[0] > count / 2) index = lim[0];
+  else if (lim[1] < count / 2) index = lim[1];
+  else index = count / 2;
+  const float dl = wave_max_f32(in && (unsigned)lane < index ? v : -INFINITY);
+  const float dh = wave_min_f32(in && (unsigned)lane >= index ? v : INFINITY);
+  if (in) vind[left + lane] = vi;
+  if (lane == 0) {
+    const int c1 = ctl[0];
+    ctl[0] = c1 + 2;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      KtlNode ch;
+      ch.left = c == 0 ? left : left + index;
+      ch.right = c == 0 ? left + index : right;
+      ch.child1 = ch.right - ch.left <= (unsigned)KT_LEAF ? -1 : -2;
+      ch.cutfeat = 0; ch.divlow = 0.f; ch.divhigh = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ch.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : box[i];
+      nodes[c1 + c] = ch;
+    }
+    nodes[nid].child1 = c1;
+    nodes[nid].cutfeat = cutfeat;
+    nodes[nid].divlow = dl;
+    nodes[nid].divhigh = dh;
+  }
+  ktb_wave_sync();
+  return true;
+}
+
+// the same split by ONE wave (the searching one) for nodes of at most KTL_WAVE_MAX points: the ~50 small nodes a search reaches cost
+// ~12 us each through the workgroup form (a dozen barriers of sixteen waves); the trips of one wave over <= 512 points are cheaper.
+// The code of knn_tree_build_par_body's wave-per-node split on the (index list, cut coordinate) pair.
+constexpr unsigned KTL_WAVE_MAX = 512;
+__device__ __forceinline__ bool ktl_expand_wave(const float* __restrict__ pts, unsigned* vind, float* vals, unsigned short* sc,
+                                                KtlNode* nodes, int* ctl, const int nid, const int lane) {
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const unsigned left = nodes[nid].left, right = nodes[nid].right, count = right - left;
+  float box[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) box[i] = nodes[nid].box[i];
+  if (ctl[0] + 2 > KTL_MAXNODES) return false;
+  const float EPS = 0.00001f;
+  float max_span = box[1] - box[0];
+#pragma unroll
+  for (int d = 1; d < 3; ++d) {
+    const float span = box[2 * d + 1] - box[2 * d];
+    if (span > max_span) max_span = span;
+  }
+  float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (unsigned p = lane; p < count; p += 64) {
+    const float* q = pts + (size_t)vind[left + p] * 3;
+    const float c[3] = {q[0], q[1], q[2]};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      mn3[d] = c[d] < mn3[d] ? c[d] : mn3[d];
+      mx3[d] = c[d] > mx3[d] ? c[d] : mx3[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { mn3[d] = wave_min_f32(mn3[d]); mx3[d] = wave_max_f32(mx3[d]); }
+  float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
+  int cutfeat = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float span = box[2 * d + 1] - box[2 * d];
+    if (span > (1 - EPS) * max_span) {
+      const float spread = mx3[d] - mn3[d];
+      if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn3[d]; mx_c = mx3[d]; }
+    }
+  }
+  const float blo = cutfeat == 0 ? box[0] : (cutfeat == 1 ? box[2] : box[4]);
+  const float bhi = cutfeat == 0 ? box[1] : (cutfeat == 1 ? box[3] : box[5]);
+  const float split_val = (blo + bhi) / 2;
+  float cutval;
+  if (split_val < mn_c) cutval = mn_c;
+  else if (split_val > mx_c) cutval = mx_c;
+  else cutval = split_val;
+  for (unsigned p = lane; p < count; p += 64) vals[left + p] = pts[(size_t)vind[left + p] * 3 + cutfeat];
+  ktb_wave_sync();
+  unsigned lim[2];
+  unsigned lo_p = 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+    auto pred = [&](float v) { return pass == 0 ? v < cutval : v <= cutval; };
+    unsigned cnt = 0;
+    for (unsigned p0 = lo_p; p0 < count; p0 += 64) {
+      const unsigned p = p0 + lane;
+      cnt += (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(p < count && pred(vals[left + (p < count ? p : lo_p)])));
+    }
+    const unsigned mid = lo_p + cnt;
+    unsigned nl = 0, nr = 0;
+    for (unsigned p0 = lo_p; p0 < mid; p0 += 64) {  // violators among the first cnt positions, ascending
+      const unsigned p = p0 + lane;
+      const bool mis = p < mid && !pred(vals[left + (p < mid ? p : lo_p)]);
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(mis);
+      if (mis) sc[left + lo_p + nl + (unsigned)__builtin_popcountll(mk & lt_mask)] = (unsigned short)p;
+      nl += (unsigned)__builtin_popcountll(mk);
+    }
+    for (unsigned q0 = 0; mid + q0 < count; q0 += 64) {  // satisfiers among the rest, descending
+      const unsigned q = q0 + lane;
+      const bool in = mid + q < count;
+      const unsigned p = count - 1 - (in ? q : 0);
+      const bool mis = in && pred(vals[left + p]);
+      const unsigned long long mk = __builtin_amdgcn_ballot_w64(mis);
+      if (mis) sc[right - 1 - (nr + (unsigned)__builtin_popcountll(mk & lt_mask))] = (unsigned short)p;
+      nr += (unsigned)__builtin_popcountll(mk);
+    }
+    ktb_wave_sync();
+    for (unsigned i = lane; i < nl; i += 64) {
+      const unsigned a = left + sc[left + lo_p + i], b = left + sc[right - 1 - i];
+      const unsigned ta = vind[a], tb = vind[b];
+      const float va = vals[a], vb = vals[b];
+      vind[a] = tb; vind[b] = ta;
+      vals[a] = vb; vals[b] = va;
+    }
+    ktb_wave_sync();
+    lim[pass] = mid;
+    lo_p = mid;
+  }
+  unsigned index;
+  if (lim[0] > count / 2) index = lim[0];
+  else if (lim[1] < count / 2) index = lim[1];
+  else index = count / 2;
+  float dl = -INFINITY, dh = INFINITY;
+  for (unsigned p = lane; p < count; p += 64) {
+    const float v = vals[left + p];
+    if (p < index) dl = v > dl ? v : dl;
+    else dh = v < dh ? v : dh;
+  }
+  dl = wave_max_f32(dl); dh = wave_min_f32(dh);
+  if (lane == 0) {
+    const int c1 = ctl[0];
+    ctl[0] = c1 + 2;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      KtlNode ch;
+      ch.left = c == 0 ? left : left + index;
+      ch.right = c == 0 ? left + index : right;
+      ch.child1 = ch.right - ch.left <= (unsigned)KT_LEAF ? -1 : -2;
+      ch.cutfeat = 0; ch.divlow = 0.f; ch.divhigh = 0.f;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ch.box[i] = (i == 2 * cutfeat + 1 - c) ? cutval : box[i];
+      nodes[c1 + c] = ch;
+    }
+    nodes[nid].child1 = c1;
+    nodes[nid].cutfeat = cutfeat;
+    nodes[nid].divlow = dl;
+    nodes[nid].divhigh = dh;
+  }
+  ktb_wave_sync();
+  return true;
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_lazy_kernel(int b, int n, int m, int k, const float* __restrict__ pts_all,
+                                                                      const float* __restrict__ queries, IdxT* __restrict__ out,
+                                                                      int* __restrict__ flag, const int* __restrict__ nflag,
+                                                                      const int* __restrict__ flist, int* __restrict__ nwork) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned* vind = reinterpret_cast<unsigned*>(smem);                                   // [n]
+  float* vals = reinterpret_cast<float*>(vind + n);                                      // [n] cut coordinate of the node being split
+  unsigned short* sc = reinterpret_cast<unsigned short*>(vals + n);                      // [n]
+  KtlNode* nodes = reinterpret_cast<KtlNode*>(smem + (size_t)n * 8 + (((size_t)n * 2 + 15) & ~(size_t)15));
+  float* red = reinterpret_cast<float*>(nodes + KTL_MAXNODES);                           // [KTB_WAVES * 6]
+  int* ctl = reinterpret_cast<int*>(red + KTB_WAVES * 6);                                // [0] nodes used, [1] command, [2] node to split, [3] failed
+  uint32_t* stk = reinterpret_cast<uint32_t*>(ctl + 16);                                 // [KT_DEPTH * 3]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ONE listed query per workgroup, each with its own on-demand tree (two queries of a cloud do not wait for each other; a shared
+  // tree would make them take turns: measured 170 us per query on uniform 8192-point clouds against 225 for the full build of the
+  // cloud) -- if the batch lists at most KTL_MAXQ queries in all; otherwise the full builds take everything (`nwork` = the counts).
+  int total = 0;
+  for (int c = 0; c < b; ++c) total += nflag[c];  // (b <= a few dozen; uniform)
+  if (total > KTL_MAXQ) {
+    for (int c = blockIdx.x * (KTB_WAVES * 64) + tid; c < b; c += gridDim.x * KTB_WAVES * 64) nwork[c] = nflag[c];
+    return;
+  }
+  for (int g = blockIdx.x; g < total; g += gridDim.x) {
+    int cloud = 0, first = 0;
+    for (int c = 0, base = 0; c < b; ++c) {
+      const int cnt = nflag[c];
+      if (g < base + cnt) { cloud = c; first = g - base; break; }
+      base += cnt;
+    }
+    const int nq = first + 1;  // (this workgroup: entry `first` of the cloud's list only)
+    const float* pts = pts_all + (size_t)cloud * n * 3;
+    // init_vind (:1318), computeBoundingBox (:1321-1346)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < n; i += KTB_WAVES * 64) {
+      vind[i] = (unsigned)i;
+      const float c[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = c[d] < lo[d] ? c[d] : lo[d];
+        hi[d] = c[d] > hi[d] ? c[d] : hi[d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = wave_min_f32(lo[d]); hi[d] = wave_max_f32(hi[d]); }
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { red[wave * 6 + 2 * d] = lo[d]; red[wave * 6 + 2 * d + 1] = hi[d]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      KtlNode root;
+      root.left = 0; root.right = (unsigned)n; root.child1 = n <= KT_LEAF ? -1 : -2; root.cutfeat = 0; root.divlow = root.divhigh = 0.f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float l = red[2 * d], h = red[2 * d + 1];
+        for (int w = 1; w < KTB_WAVES; ++w) { l = fminf(l, red[w * 6 + 2 * d]); h = fmaxf(h, red[w * 6 + 2 * d + 1]); }
+        root.box[2 * d] = l; root.box[2 * d + 1] = h;
+      }
+      nodes[0] = root;
+      ctl[0] = 1; ctl[3] = 0;
+    }
+    __syncthreads();
+    float rootbox[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rootbox[i] = nodes[0].box[i];  // root_bbox = the tight box of all points (what the search reads)
+    for (int e = first; e < nq; ++e) {
+      const int j = flist[(size_t)cloud * m + e];
+      const float* qp = queries + ((size_t)cloud * m + j) * 3;
+      const float vec[3] = {qp[0], qp[1], qp[2]};
+      // ---- wave 0: nanoflann's search (knn_tree_search_wave), resumable: it stops at a node that has not been split yet
+      float dists[3] = {0.f, 0.f, 0.f};
+      float distsq = 0.f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (vec[d] < rootbox[2 * d]) { dists[d] = (vec[d] - rootbox[2 * d]) * (vec[d] - rootbox[2 * d]); distsq += dists[d]; }
+        if (vec[d] > rootbox[2 * d + 1]) { dists[d] = (vec[d] - rootbox[2 * d + 1]) * (vec[d] - rootbox[2 * d + 1]); distsq += dists[d]; }
+      }
+      float ld = KT_FLT_MAX, worst = KT_FLT_MAX, mindistsq = distsq;
+      int li = 0, node = 0, sp = 0;
+      bool descending = true, finished = false, failed = false;
+      for (;;) {
+        if (wave == 0 && !finished) {
+          int want = -1;
+          for (;;) {
+            if (descending) {
+              KtlNode nd = nodes[node];
+              if (nd.child1 == -2) {  // not split yet
+                if (nd.right - nd.left > KTL_WAVE_MAX) { want = node; break; }  // a large node: the workgroup does it, then this step runs again
+                const bool ok = nd.right - nd.left <= 64u ? ktl_expand_small(pts, vind, sc, nodes, ctl, node, lane)
+                                                          : ktl_expand_wave(pts, vind, vals, sc, nodes, ctl, node, lane);
+                if (!ok) { want = -2; break; }  // (node table full)
+                nd = nodes[node];
+              }
+              if (nd.child1 == -1) {                        // leaf (:1355-1369)
+                const int left = (int)nd.left, right = (int)nd.right;
+                const bool in = left + lane < right;
+                const unsigned pi = vind[in ? left + lane : left];
+                const float* c = pts + (size_t)pi * 3;
+                float dist = 0.f;
+                { const float diff = vec[0] - c[0]; dist += diff * diff; }
+                { const float diff = vec[1] - c[1]; dist += diff * diff; }
+                { const float diff = vec[2] - c[2]; dist += diff * diff; }
+                unsigned long long mask = __builtin_amdgcn_ballot_w64(in && dist < worst);
+                while (mask != 0ull) {
+                  const int src = (int)__builtin_ctzll(mask);
+                  mask &= mask - 1ull;
+                  const float cd = readlane_f(dist, src);
+                  const int ci = __builtin_amdgcn_readlane((int)pi, src);
+                  const int pos = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < k && ld <= cd));
+                  if (pos < k) {
+                    const float sd = wave_shr1_f(ld);
+                    const int si = wave_shr1_i(li);
+                    if (lane > pos) { ld = sd; li = si; }
+                    if (lane == pos) { ld = cd; li = ci; }
+                  }
+                }
+                worst = readlane_f(ld, k - 1);
+                descending = false;
+              } else {
+                const int idx = nd.cutfeat;
+                const float val = idx == 0 ? vec[0] : (idx == 1 ? vec[1] : vec[2]);
+                const float diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
+                int best, other;
+                float cut;
+                if ((diff1 + diff2) < 0) { best = nd.child1; other = nd.child1 + 1; cut = (val - nd.divhigh) * (val - nd.divhigh); }
+                else { best = nd.child1 + 1; other = nd.child1; cut = (val - nd.divlow) * (val - nd.divlow); }
+                if (sp + 1 >= KT_DEPTH) { failed = true; finished = true; break; }
+                stk[sp * 3] = (uint32_t)other | ((uint32_t)idx << 28) | (1u << 30);
+                stk[sp * 3 + 1] = __float_as_uint(mindistsq);
+                stk[sp * 3 + 2] = __float_as_uint(cut);
+                ++sp;
+                node = best;
+              }
+            } else {
+              if (sp == 0) { finished = true; break; }
+              const uint32_t w0 = stk[(sp - 1) * 3];
+              const int feat = (int)((w0 >> 28) & 3u);
+              if ((w0 >> 30) == 1u) {
+                const float fmind = __uint_as_float(stk[(sp - 1) * 3 + 1]), cut = __uint_as_float(stk[(sp - 1) * 3 + 2]);
+                const float dst = feat == 0 ? dists[0] : (feat == 1 ? dists[1] : dists[2]);
+                const float mind = fmind + cut - dst;
+                if (mind * 1.f <= worst) {
+                  if (feat == 0) dists[0] = cut; else if (feat == 1) dists[1] = cut; else dists[2] = cut;
+                  stk[(sp - 1) * 3] = (w0 & 0x3FFFFFFFu) | (2u << 30);
+                  stk[(sp - 1) * 3 + 2] = __float_as_uint(dst);
+                  node = (int)(w0 & 0x0FFFFFFFu);
+                  mindistsq = mind;
+                  descending = true;
+                } else {
+                  --sp;
+                }
+              } else {
+                const float dst = __uint_as_float(stk[(sp - 1) * 3 + 2]);
+                if (feat == 0) dists[0] = dst; else if (feat == 1) dists[1] = dst; else dists[2] = dst;
+                --sp;
+              }
+            }
+          }
+          if (lane == 0) { ctl[1] = finished ? 0 : 1; ctl[2] = want; if (failed) ctl[3] = 1; if (want == -2) { ctl[3] = 2; ctl[1] = 0; } }
+        }
+        __syncthreads();
+        const int cmd = ctl[1], want = ctl[2];
+        if (cmd == 0) break;  // (uniform) the search is over (or the node table is full)
+        const bool ok = ktl_expand(pts, vind, vals, sc, red, nodes, ctl, want, tid);  // (ends with a workgroup barrier)
+        if (!ok) {  // the node table is full: this cloud goes to the full build after all
+          if (tid == 0) { ctl[3] = 2; ctl[1] = 0; }
+          __syncthreads();
+          break;
+        }
+      }
+      __syncthreads();
+      const int bad = ctl[3];
+      if (bad == 2) {  // (uniform) hand the cloud over: every listed query of it, the done ones too (their rows are simply written again)
+        if (tid == 0) atomicExch(&nwork[cloud], nflag[cloud]);
+        __syncthreads();
+        break;
+      }
+      if (bad == 1) { if (tid == 0) { atomicExch(flag, 1); ctl[3] = 0; } }  // deeper than the stack: the row keeps the canonical order
+      else if (wave == 0 && lane < k) out[((size_t)cloud * m + j) * k + lane] = (IdxT)li;
+      __syncthreads();
+    }
+    __syncthreads();  // the next cloud re-uses the LDS
+  }
+}
+
 }  // namespace pasnl
 
 using namespace pasnl;
@@ -1913,18 +2517,19 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
 // and (4) searched for exactly those queries, whose rows are overwritten.  A query that is not listed has a single possible
 // answer under both orders, so the output is cpp_knn_batch's bit for bit (knn_.cxx:72-135, nanoflann.hpp:119-123).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void knn_ref_clear_kernel(int b, int* __restrict__ nflag) {
+__global__ void knn_ref_clear_kernel(int b, int* __restrict__ nflag, int* __restrict__ nwork) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < b) nflag[i] = 0;
+  if (i < b) { nflag[i] = 0; nwork[i] = 0; }
 }
 
 namespace {
-struct RefLayout { size_t nflag, flist, grid, tree, total; };
+struct RefLayout { size_t nflag, nwork, flist, grid, tree, total; };
 RefLayout ref_layout(int b, int n, int m, int k) {
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   RefLayout L;
   L.nflag = 0;
-  L.flist = al((size_t)b * 4);
+  L.nwork = al((size_t)b * 4);
+  L.flist = L.nwork + al((size_t)b * 4);
   L.grid = L.flist + al((size_t)b * m * 4);
   L.tree = L.grid + al(k <= 64 ? pasnl::knn_grid_ws_bytes(b, n) : 0);
   L.total = L.tree + al(pasnl::knn_tree_ws_bytes(b, n, m, k));
@@ -1951,7 +2556,7 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
   hipStream_t st = pasnl_hip_stream(stream);
   char* base = static_cast<char*>(workspace);
   pasnl::KnnTieFlags flags{reinterpret_cast<int*>(base + L.nflag), reinterpret_cast<int*>(base + L.flist)};
-  hipLaunchKernelGGL(knn_ref_clear_kernel, dim3((b + 255) / 256), dim3(256), 0, st, b, flags.nflag);
+  hipLaunchKernelGGL(knn_ref_clear_kernel, dim3((b + 255) / 256), dim3(256), 0, st, b, flags.nflag, reinterpret_cast<int*>(base + L.nwork));
   int rc = pasnl::knn_grid_launch(b, n, m, k, support, queries, idx, idx_is_i64, nullptr, base + L.grid, L.tree - L.grid,
                                   max_workgroups, flags, st);
   if (rc != PASNL_OK) return rc;
@@ -1970,6 +2575,27 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
     if (idx_is_i64) PASNL_KTS(long long) else PASNL_KTS(int)
 #undef PASNL_KTS
     return pasnl_launch_status();
+  }
+  if (n > pasnl::KTB_LDS_NMAX && n <= pasnl::KTL_NMAX && k <= 64) {
+    // a FEW listed queries (the chance ties of the input levels) in clouds whose full build is the slow one (records in the
+    // workspace: 455 us for a lidar-like 10240-point cloud): the tree on demand, along each search's path (177 us); `nwork` (b ints
+    // behind the lists' counters) = what it leaves to the full builds below.  (Clouds up to 8192 points keep the full build: 225 us
+    // with the records in LDS, against 170-300 per on-demand search on uniform clouds, whose searches reach ~100 nodes.)
+    int* nwork = reinterpret_cast<int*>(base + L.nwork);
+    const size_t lds = pasnl::ktl_lds_bytes(n);
+    const int grid = pasnl::KTL_MAXQ;  // one workgroup per listed query
+#define PASNL_KTL(T)                                                                                                             \
+    {                                                                                                                             \
+      auto kern = pasnl::knn_tree_lazy_kernel<T>;                                                                                 \
+      if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                 (int)lds) != hipSuccess)                                                         \
+        return PASNL_ELAUNCH;                                                                                                     \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(pasnl::KTB_WAVES * 64), lds, st, b, n, m, k, support, queries, static_cast<T*>(idx), \
+                         depth_flag, flags.nflag, flags.flist, nwork);                                                            \
+    }
+    if (idx_is_i64) PASNL_KTL(long long) else PASNL_KTL(int)
+#undef PASNL_KTL
+    flags.nflag = nwork;
   }
   return pasnl::knn_tree_launch(b, n, m, k, support, queries, idx, idx_is_i64, base + L.tree, L.total - L.tree, flags, depth_flag, st);
 }

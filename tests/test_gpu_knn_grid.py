@@ -327,3 +327,47 @@ def test_the_references_own_shape_81920_points():
     got2 = P.nearest_neighbors.knn_batch(torch.from_numpy(sup2).cuda(), torch.from_numpy(q2).cuda(), 16)
     if ref.available("libref_knn.so"):
         np.testing.assert_array_equal(got2.cpu().numpy(), ref.knn_batch(sup2, q2, 16))
+
+
+@pytest.mark.parametrize("many", [False, True])
+@pytest.mark.parametrize("n,k,kind", [(10240, 32, "kitti"), (9000, 16, "ball"), (10240, 64, "ball"), (10240, 8, "plane"), (8193, 32, "ball"),
+                                      (8192, 32, "ball")])
+def test_few_listed_queries_take_the_on_demand_tree(n, k, kind, many):
+    """Clouds of thousands of points with a HANDFUL of tied queries (what the segmentation models' input levels meet: chance ties):
+    knn_tree_lazy_kernel builds the reference's KD-tree only along each search's path, a workgroup per listed query.  Ties are
+    planted -- a few duplicated points -- so that a handful of queries in two clouds of four are listed; `many`: a dozen more in a
+    third cloud, past the form's limit (the batch then takes the full builds).  Equal to the reference library, to
+    every-query-through-the-tree, and deterministic; `stats[1]` says which form ran."""
+    from oracle import ref
+    b = 4
+    if kind == "kitti":
+        sup = B.synth_kitti(n, b, n)
+    else:
+        sup = B.synth_clouds(n, b, n)
+        if kind == "plane":
+            sup[..., 2] = 0.0
+    sup = sup.copy()
+    sup[0, 2000] = sup[0, 7]                  # one duplicated support point next to a query: its neighbours see a tie
+    sup[1, 2000] = sup[1, 47]
+    sup[1, 2001] = sup[1, 130]
+    if many:
+        for t in range(40):
+            sup[2, 2100 + t] = sup[2, 5 + 7 * t]
+    qry = np.ascontiguousarray(sup[:, :300])
+    s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    stats = []
+    got = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, stats=stats)
+    counts, left = stats[0].cpu().numpy(), stats[1].cpu().numpy()
+    assert counts[0] >= 1 and counts[1] >= 2 and counts[3] <= 1, counts
+    if n <= 8192:
+        pass                                             # (records fit the LDS: the full build is the faster form there)
+    elif counts.sum() > 32:
+        assert many and (left == counts).all(), (counts, left)                  # past the limit: the full builds took the batch
+    else:
+        assert not many and counts.sum() >= 3 and (left == 0).all(), (counts, left)   # every listed query got its own on-demand tree
+    again = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32)
+    assert torch.equal(got, again)
+    full = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="nanoflann")
+    assert torch.equal(got, full)
+    if ref.available("libref_knn.so"):
+        np.testing.assert_array_equal(got.cpu().numpy(), ref.knn_batch(sup, qry, k))
