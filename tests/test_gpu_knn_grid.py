@@ -371,3 +371,40 @@ def test_few_listed_queries_take_the_on_demand_tree(n, k, kind, many):
     assert torch.equal(got, full)
     if ref.available("libref_knn.so"):
         np.testing.assert_array_equal(got.cpu().numpy(), ref.knn_batch(sup, qry, k))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_on_demand_tree_random_sweep(seed):
+    """The on-demand tree (clouds of 8193..10240 points, at most 32 listed queries in the batch) on varied geometry: clustered
+    (lopsided trees), flat, anisotropic and lattice-with-jitter clouds, queries outside the cloud's box, K from 1 to 64, batches
+    of 1-6 clouds; ties planted by duplicating a few points / snapping a few coordinates.  Against the reference library and
+    against every-query-through-the-tree."""
+    from oracle import ref
+    rng = np.random.default_rng(1000 + seed)
+    b = int(rng.integers(1, 7))
+    n = int(rng.choice([8193, 8500, 9000, 9999, 10240]))
+    k = int(rng.choice([1, 2, 8, 16, 32, 33, 64]))
+    m = int(rng.integers(50, 400))
+    sup = rng.random((b, n, 3))
+    kind = seed % 5
+    if kind == 0:
+        sup[:, : n * 9 // 10] *= 0.05                      # clustered: very lopsided trees
+    elif kind == 1:
+        sup[..., 2] *= 1e-3                                # nearly flat
+    elif kind == 2:
+        sup *= np.array([50.0, 1.0, 0.02])                 # anisotropic
+    elif kind == 3:
+        sup = np.round(sup * 40) / 40 + rng.random((b, n, 3)) * 1e-4   # lattice with jitter: near-ties everywhere, few exact ones
+    sup = sup.astype(np.float32)
+    qry = np.concatenate([sup[:, : m // 2], (rng.random((b, m - m // 2, 3)) * 1.5 - 0.25).astype(np.float32) * sup.max((0, 1))], axis=1)
+    for t in range(int(rng.integers(1, 4))):               # a few exact ties next to queries
+        c = int(rng.integers(0, b))
+        sup[c, n - 1 - t] = sup[c, int(rng.integers(0, m // 2))]
+    qry = np.ascontiguousarray(qry)
+    s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    stats = []
+    got = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, stats=stats)
+    full = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="nanoflann")
+    assert torch.equal(got, full), (b, n, k, kind, stats[0].tolist(), stats[1].tolist())
+    if ref.available("libref_knn.so"):
+        np.testing.assert_array_equal(got.cpu().numpy(), ref.knn_batch(sup, qry, k))
