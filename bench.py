@@ -156,7 +156,7 @@ def algorithmic(symbol, ints):
     if symbol == "pasnl_three_weights":
         (rows,) = ints
         return 24 * rows, 8 * rows, "hbm"
-    if symbol == "pasnl_nl_attention":
+    if symbol in ("pasnl_nl_attention", "pasnl_nl_attention_ws"):
         b, p, n, cb = ints[:4]
         return 4 * b * cb * (2 * p + 2 * n), 4 * b * p * n * cb + 5 * b * p * n, "mfma"
     if symbol == "pasnl_as_attention":
