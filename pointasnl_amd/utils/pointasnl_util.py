@@ -87,6 +87,9 @@ def sa_group(xyz, feature, idx, new_xyz):
     return new_point, skip
 
 
+SELF_KNN_RATIO = 2       # sa_search: the self-kNN of the level (then a row gather) beside the sampler when at least 1 / RATIO of the points are
+#                          sampled.  (4 -- layer 2 of the classifier, whose search sits on the critical path of the --AS model -- puts a
+#                          fork inside a forked search: the captured graph then crashed inside hipGraphLaunch, round 6.  Leave it at 2.)
 SA_TAIL_MIN_ROWS = 2048
 FP_HEAD_FUSED = True     # PointASNLDecodingLayer (inference, no autograd): three_weights + three_interpolate as one kernel
 SA_CELL_PACKED = True    # the wide cells (one workgroup per group, weights from L2) get their matrices packed in operand order too
@@ -645,7 +648,7 @@ def sa_search(xyz, feature, npoint, nsample, use_knn=True, radius=None, knn_all=
         else:
             idx, _ = tf_grouping.query_ball_point(radius, nsample, xyz, xyz)
         return xyz, None, idx
-    if use_knn and knn_all is None and OVERLAP and 2 * npoint >= num_points:
+    if use_knn and knn_all is None and OVERLAP and SELF_KNN_RATIO * npoint >= num_points:
         knn_all = Forked(lambda: knn_query(nsample, xyz, xyz), slot=1)
     fps_idx, new_xyz = tf_sampling.farthest_point_sample_gather(npoint, xyz)  # the sampler writes the sampled rows itself
     if use_knn and knn_all is not None:
