@@ -2560,9 +2560,11 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
   int rc = pasnl::knn_grid_launch(b, n, m, k, support, queries, idx, idx_is_i64, nullptr, base + L.grid, L.tree - L.grid,
                                   max_workgroups, flags, st);
   if (rc != PASNL_OK) return rc;
+  if (pasnl::tune_env("PASNL_KNN_REF_NO_TREE")) return pasnl_launch_status();  // (tuning build: the canonical search + flags alone, A/B)
   if (n <= pasnl::KTS_NMAX && k <= 64) {  // tree + searches of a flagged cloud in one workgroup, all in LDS
     const size_t lds = pasnl::kts_lds_bytes(n);
-    const int grid = std::min(b, 64);
+    const int grid = pasnl::tune_env("PASNL_KNN_REF_EMPTY_TREE") ? 0 : std::min(b, 64);
+    if (grid == 0) return pasnl_launch_status();
 #define PASNL_KTS(T)                                                                                                             \
     {                                                                                                                             \
       auto kern = pasnl::knn_tree_small_kernel<T>;                                                                                \

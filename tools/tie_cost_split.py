@@ -1,0 +1,19 @@
+"""Where the default neighbour order's cost on the cls step comes from (tuning build): canonical / flags only / full default."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pointasnl_amd import _hip
+_hip.LIB_PATH = os.path.join(ROOT, "pointasnl_amd", "csrc", "libpasnl_hip_tuning.so")
+import numpy as np
+import bench
+from pointasnl_amd.utils import pointasnl_util as U
+res = {}
+for rnd in range(3):
+    for tag, order, env in (("canonical", "index", None), ("flags, no tree kernels", "reference", "PASNL_KNN_REF_NO_TREE"), ("default", "reference", None)):
+        for e in ("PASNL_KNN_REF_NO_TREE",): os.environ.pop(e, None)
+        if env: os.environ[env] = "1"
+        U.KNN_TIE_ORDER = order
+        r = bench.run_config(1, dict(bench.WORKLOADS[1]), 20, 5, graph=True, kernel_pass=False, announce=False, pipeline="prefetch", extra_blocks=2)
+        res.setdefault(tag, []).append(float(np.median(r["block_ms"])))
+        print(rnd, tag, [round(v, 4) for v in r["block_ms"]], flush=True)
+for k, v in res.items(): print(k, round(float(np.median(v)), 4))
