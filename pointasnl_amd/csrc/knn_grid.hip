@@ -558,12 +558,24 @@ size_t pasnl::knn_grid_ws_bytes(int b, int n) {
 }
 extern "C" size_t pasnl_knn_workspace_bytes(int b, int n) { return pasnl::knn_grid_ws_bytes(b, n); }
 
+#ifdef PASNL_TUNING
+extern "C" void pasnl_tuning_stamp(int slot, hipStream_t st);
+#endif
 int pasnl::knn_grid_launch(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
                            float* dist2, void* workspace, size_t workspace_bytes, int max_workgroups, pasnl::KnnTieFlags flags,
                            hipStream_t st) {
   const size_t need = knn_grid_ws_bytes(b, n);
-  if (need == 0 || k > 64 || k > n || m <= 0)  // small clouds / wide lists: the brute-force kernels (same results)
+  if (need == 0 || k > 64 || k > n || m <= 0) {  // small clouds / wide lists: the brute-force kernels (same results)
+#ifdef PASNL_TUNING
+    const bool stamp = tune_env("PASNL_STAMP_N") && atoi(tune_env("PASNL_STAMP_N")) == n;  // (tools/step_stamps.py)
+    if (stamp) pasnl_tuning_stamp(6, st);
+    const int rc = knn_brute_launch(b, n, m, k, support, queries, idx, idx_is_i64, dist2, flags, st);
+    if (stamp) pasnl_tuning_stamp(7, st);
+    return rc;
+#else
     return knn_brute_launch(b, n, m, k, support, queries, idx, idx_is_i64, dist2, flags, st);
+#endif
+  }
   PASNL_REQUIRE(b >= 0 && n > 0 && m >= 0 && k > 0, PASNL_EINVAL);
   PASNL_REQUIRE(support && queries && idx, PASNL_ENULL);
   PASNL_REQUIRE(workspace != nullptr, PASNL_ENULL);

@@ -1640,10 +1640,455 @@ __device__ unsigned long long kts_probe[32];
 #else
 #define KTS_MARK(i) do { } while (0)
 #endif
+// ---------------------------------------------------------------------------------------------------------------------
+// Tie paths (round 6): what the tree search DOES to a listed query's row, without the search.
+//
+// nanoflann's result set is a stable insertion sort cut at K (KNNResultSet::addPoint :115-134: a candidate goes behind every
+// entry at the same distance; what falls off the end is gone), fed with the points in the order the walk reaches them; a
+// subtree the walk prunes holds only points farther than the worst entry of that moment, which could not enter anyway.  So the
+// row the reference returns is: all points sorted by (distance, ARRIVAL), first K -- the arrival order being the depth-first
+// order of the whole tree with the query's near child first at every node, positions left to right inside a leaf.  The
+// canonical row (distance, index) already has every entry whose distance is unique in its final place; only the entries of a
+// run of EQUAL distances (and, for a run that reaches the K-th distance, the points outside the row at that distance) have
+// to be put in arrival order.  Two points arrive in the order the tree decides at the node that separates them: the one in
+// the query's near child first; never separated, the one at the lower position of their leaf first.
+// Hence: one workgroup per listed query holds the cloud's records in LDS (the LDS build's layout), finds the tied points by
+// one pass over the cloud (the same canonical fp32 distance, bit for bit), and splits ONLY the nodes that still hold two
+// points of one run -- middleSplit_ + planeSplit by the whole workgroup (ktb_split_node_wg) or by one wave (<= 64 points),
+// the same code as the builds, so these nodes are the reference tree's nodes.  Each tied point collects one bit per level
+// (0: it went to the query's near child); (bits, final position) sorts a run into arrival order.  A chance tie between two
+// unrelated points separates after ~2 splits: ~10 us for a 1024-point cloud where tree + search took 85, ~40 for an
+// 8192-point one (225 + the search).  More than KTP_MAXQ listed queries in the batch, more than KTP_TMAX tied points for a
+// query (lattices, padded clouds), more than KTP_MAXW splits: the cloud goes to the full build and search below (`nwork`).
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef PASNL_TUNING
+// phase probe of workgroup 0 (tools/tie_path_probe.py): s_memtime at [0] entry, [1] the listed queries counted, [2] records + box in
+// LDS, [3] the tied points listed, [4 + i] split i done (i < 24), [30] the row written
+#define KTP_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == ktp_probe_wg) kts_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ int ktp_probe_wg = 0;  // (knn_tree_small_kernel: the workgroup of the first listed cloud)
+#else
+#define KTP_MARK(i) do { } while (0)
+#endif
+constexpr int KTP_MAXQ = 32;    // listed queries per batch this form takes (a workgroup each)
+constexpr int KTP_TMAX = 64;    // tied points of one query (a lane each)
+constexpr int KTP_MAXW = 64;    // nodes split for one query
+constexpr int KTP_DEPTH = 126;  // levels whose near / far bit fits the 128-bit key
+constexpr int KTP_RED_WORDS = 256;  // [0, 96) min / max partials, [96, 160) the passes' masks (2 x 16 x 64 bits), [160, 192) divlow / divhigh partials
+struct KtpWork { unsigned left, right; float box[6]; int depth; };
+struct KtpShared {
+  float dk[PASNL_KNN_MAX_K];    // the canonical row's distances (ascending)
+  int mem_idx[KTP_TMAX], mem_pos[KTP_TMAX], mem_grp[KTP_TMAX], mem_node[KTP_TMAX];  // a tied point per lane of wave 0: index, position,
+  unsigned long long mem_khi[KTP_TMAX], mem_klo[KTP_TMAX];                           // run (its first slot in the row), node, key
+  int cur_idx[KTP_TMAX], cur_m[KTP_TMAX];  // the tied points inside the node being split: index, lane
+  KtpWork work[KTP_MAXW];
+  KtSplit split;
+  int nmem, nw, ncur, bad;
+  int cloud, entry;
+  int wsum[KTB_WAVES];
+};
+__host__ __device__ inline size_t ktp_lds_bytes(int n) {
+  return (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15) + KTP_RED_WORDS * 4 + ((sizeof(KtpShared) + 15) & ~(size_t)15);
+}
+__device__ __forceinline__ unsigned long long ktp_readlane_u64(unsigned long long v, int src) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+// A node of 65 .. 1024 points by the whole workgroup, ONE POINT PER THREAD, held in registers through both partition passes
+// (ktb_split_node_small's scheme one level up; ktb_split_node_wg's general strides cost ~10 us a node in barriers and LDS round
+// trips, most of a chance tie's whole resolution).  planeSplit's closed form (header of the parallel build): with cnt satisfiers
+// in [lo, count), the i-th violator among positions [lo, lo + cnt) (ascending) and the i-th satisfier at or behind lo + cnt
+// (descending) change places.  Every wave publishes the ballot of its satisfiers; from the 16 masks every thread derives cnt and
+// the ranks (popcounts of masks), the partners meet through `sc`, the records change places in LDS and in the registers.
+// red: KTP_RED_WORDS words.  Nine barriers.  Ends with a barrier.
+__device__ __forceinline__ unsigned long long ktp_lanes_below(const int th) {  // lanes l of a wave with l < th
+  return th <= 0 ? 0ull : (th >= 64 ? ~0ull : ((1ull << th) - 1ull));
+}
+__device__ __forceinline__ KtSplit ktp_split_node_1k(float4* rec, unsigned short* sc, float* red, const float* box, const unsigned left,
+                                                     const unsigned count, const int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const unsigned right = left + count;
+  const bool in = (unsigned)tid < count;
+  float4 r = rec[left + (in ? (unsigned)tid : 0u)];
+  // ---- middleSplit_ (:966-1005); computeMinMax (:898-907) of all three dimensions
+  const float EPS = 0.00001f;
+  float max_span = box[1] - box[0];
+  for (int d = 1; d < 3; ++d) {
+    const float span = box[2 * d + 1] - box[2 * d];
+    if (span > max_span) max_span = span;
+  }
+  float mn3[3], mx3[3];
+  {
+    const float c[3] = {r.x, r.y, r.z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { mn3[d] = wave_min_f32(in ? c[d] : INFINITY); mx3[d] = wave_max_f32(in ? c[d] : -INFINITY); }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { red[wave * 6 + 2 * d] = mn3[d]; red[wave * 6 + 2 * d + 1] = mx3[d]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {  // (lane l takes wave l & 15's partial: every partial is in, some four times)
+    mn3[d] = wave_min_f32(red[(lane & (KTB_WAVES - 1)) * 6 + 2 * d]);
+    mx3[d] = wave_max_f32(red[(lane & (KTB_WAVES - 1)) * 6 + 2 * d + 1]);
+  }
+  float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
+  int cutfeat = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float span = box[2 * d + 1] - box[2 * d];
+    if (span > (1 - EPS) * max_span) {
+      const float spread = mx3[d] - mn3[d];
+      if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn3[d]; mx_c = mx3[d]; }
+    }
+  }
+  const float blo = cutfeat == 0 ? box[0] : (cutfeat == 1 ? box[2] : box[4]);
+  const float bhi = cutfeat == 0 ? box[1] : (cutfeat == 1 ? box[3] : box[5]);
+  const float split_val = (blo + bhi) / 2;
+  float cutval;
+  if (split_val < mn_c) cutval = mn_c;
+  else if (split_val > mx_c) cutval = mx_c;
+  else cutval = split_val;
+  // ---- planeSplit (:1016-1043)
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(red + 96);
+  unsigned lim[2];
+  unsigned lo_p = 0;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const float v = cutfeat == 0 ? r.x : (cutfeat == 1 ? r.y : r.z);
+    const bool sat = in && (unsigned)tid >= lo_p && (pass == 0 ? v < cutval : v <= cutval);
+    const unsigned long long mine = __builtin_amdgcn_ballot_w64(sat);
+    if (lane == 0) masks[pass * KTB_WAVES + wave] = mine;
+    __syncthreads();
+    // lanes 0 .. 15 take one wave's mask each: counts, then prefix sums over the lanes
+    const unsigned long long mw = lane < KTB_WAVES ? masks[pass * KTB_WAVES + lane] : 0ull;
+    const int cincl = wave_inclusive_sum_i32((int)__builtin_popcountll(mw));
+    const unsigned cnt = (unsigned)__builtin_amdgcn_readlane(cincl, 63);
+    const unsigned mid = lo_p + cnt;  // where the pointers meet
+    const unsigned long long below_l = ktp_lanes_below((int)mid - 64 * lane);
+    const unsigned long long in_l = ktp_lanes_below((int)count - 64 * lane) & ~ktp_lanes_below((int)lo_p - 64 * lane);
+    const int vc = lane < KTB_WAVES ? (int)__builtin_popcountll(in_l & below_l & ~mw) : 0;  // violators in front of mid
+    const int rc = lane < KTB_WAVES ? (int)__builtin_popcountll(mw & ~below_l) : 0;         // satisfiers at or behind it
+    const int vincl = wave_inclusive_sum_i32(vc), rincl = wave_inclusive_sum_i32(rc);
+    const unsigned vbase = (unsigned)__builtin_amdgcn_readlane(vincl - vc, wave);            // violators before this wave's positions
+    const unsigned rbase = (unsigned)(__builtin_amdgcn_readlane(rincl, 63) - __builtin_amdgcn_readlane(rincl, wave));  // satisfiers behind them
+    const unsigned long long below = ktp_lanes_below((int)mid - 64 * wave);
+    const unsigned long long inw = ktp_lanes_below((int)count - 64 * wave) & ~ktp_lanes_below((int)lo_p - 64 * wave);
+    const unsigned long long myviol = inw & below & ~mine, myrs = mine & ~below;
+    const bool is_v = ((myviol >> lane) & 1ull) != 0ull, is_r = ((myrs >> lane) & 1ull) != 0ull;
+    unsigned rank = 0;  // of a violator: ascending; of a satisfier: descending
+    if (is_v) {
+      rank = vbase + (unsigned)__builtin_popcountll(myviol & lt_mask);
+      sc[left + lo_p + rank] = (unsigned short)tid;
+    }
+    if (is_r) {
+      rank = rbase + ((unsigned)__builtin_popcountll(myrs) - 1u - (unsigned)__builtin_popcountll(myrs & lt_mask));
+      sc[right - 1 - rank] = (unsigned short)tid;
+    }
+    __syncthreads();
+    unsigned partner = 0;
+    float4 other = r;
+    if (is_v) partner = left + (unsigned)sc[right - 1 - rank];
+    if (is_r) partner = left + (unsigned)sc[left + lo_p + rank];
+    if (is_v || is_r) other = rec[partner];
+    __syncthreads();
+    if (is_v || is_r) { rec[partner] = r; r = other; }
+    lim[pass] = mid;
+    lo_p = mid;
+  }
+  unsigned index;
+  if (lim[0] > count / 2) index = lim[0];
+  else if (lim[1] < count / 2) index = lim[1];
+  else index = count / 2;
+  // ---- divlow = max of the left part, divhigh = min of the right part along cutfeat (:956-957)
+  {
+    const float v = cutfeat == 0 ? r.x : (cutfeat == 1 ? r.y : r.z);
+    const float dl0 = wave_max_f32(in && (unsigned)tid < index ? v : -INFINITY), dh0 = wave_min_f32(in && (unsigned)tid >= index ? v : INFINITY);
+    if (lane == 0) { red[160 + wave * 2] = dl0; red[160 + wave * 2 + 1] = dh0; }
+  }
+  __syncthreads();
+  KtSplit o;
+  o.cutfeat = cutfeat; o.cutval = cutval; o.index = index;
+  o.dl = wave_max_f32(red[160 + (lane & (KTB_WAVES - 1)) * 2]);
+  o.dh = wave_min_f32(red[160 + (lane & (KTB_WAVES - 1)) * 2 + 1]);
+  __syncthreads();
+  return o;
+}
+// One listed query, by the whole workgroup.  rec: the cloud's records in INDEX order (position == index); rootbox: the tight box
+// of the cloud (computeBoundingBox :1321-1346); orow: the query's canonical row, rewritten in place.  -> 0, or 1: not
+// resolved here (the row is untouched or partly in arrival order -- the caller hands the cloud to the full build).  Uniform.
+template <typename IdxT>
+__device__ __forceinline__ int ktp_resolve(float4* rec, unsigned short* sc, float* red, KtpShared* S, const float* rootbox, const int n, const int k,
+                           const float qx, const float qy, const float qz, IdxT* __restrict__ orow, const int tid) {
+  constexpr int T = KTB_WAVES * 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int i = tid; i < k; i += T) {
+    const float4 r = rec[(int)orow[i]];
+    S->dk[i] = dist2(qx, qy, qz, r.x, r.y, r.z);
+  }
+  if (tid == 0) { S->nmem = 0; S->bad = 0; S->nw = 0; }
+  __syncthreads();
+  const float rk = S->dk[k - 1];
+  // the tied points: every point at a distance the row holds twice, or at the K-th distance (the run that may reach outside the row)
+  for (int p = tid; p < n; p += T) {
+    const float4 r = rec[p];
+    const float d = dist2(qx, qy, qz, r.x, r.y, r.z);
+    if (d <= rk) {
+      int lo = 0, hi = k - 1;  // the first slot whose distance is >= d (slot k - 1 holds rk >= d)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (S->dk[mid] < d) lo = mid + 1; else hi = mid;
+      }
+      if (S->dk[lo] != d) S->bad = 1;  // (a point inside the K-th distance that the row does not hold: not a canonical row)
+      else if (d == rk || S->dk[lo + 1] == d) {
+        const int slot = atomicAdd(&S->nmem, 1);
+        if (slot < KTP_TMAX) { S->mem_idx[slot] = p; S->mem_grp[slot] = lo; }
+      }
+    }
+  }
+  __syncthreads();
+  const int t = S->nmem;
+  KTP_MARK(3);
+  if (S->bad != 0 || t > KTP_TMAX) return 1;
+  // wave 0: one tied point per lane -- index, position, run (= its first slot in the row), the node it is in, its key; kept in LDS
+  // between the steps (values held in registers across the splits cost more registers than a 1024-thread workgroup has)
+  if (wave == 0) {
+    int m_grp = -1 - lane;
+    if (lane < t) {
+      const int m_idx = S->mem_idx[lane];
+      m_grp = S->mem_grp[lane];
+      S->mem_pos[lane] = m_idx; S->mem_node[lane] = 0; S->mem_khi[lane] = 0ull; S->mem_klo[lane] = 0ull;
+    }
+    bool peer = false;
+    for (int o = 0; o < t; ++o) peer |= (o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp);
+    if (n > KT_LEAF && __builtin_amdgcn_ballot_w64(lane < t && peer) != 0ull && lane == 0) {
+      KtpWork w0;
+      w0.left = 0u; w0.right = (unsigned)n; w0.depth = 0;
+      for (int i = 0; i < 6; ++i) w0.box[i] = rootbox[i];
+      S->work[0] = w0;
+      S->nw = 1;
+    }
+  }
+  __syncthreads();
+  for (int cur = 0;; ++cur) {
+    if (cur >= S->nw) break;  // (uniform: written before the last barrier)
+    const unsigned xleft = S->work[cur].left, xright = S->work[cur].right, count = xright - xleft;
+    if (wave == 0) {
+      const bool mine = lane < t && S->mem_node[lane < t ? lane : 0] == cur;
+      const unsigned long long mm = __builtin_amdgcn_ballot_w64(mine);
+      if (mine) {
+        const int s0 = (int)__builtin_popcountll(mm & lt_mask);
+        S->cur_idx[s0] = S->mem_idx[lane];
+        S->cur_m[s0] = lane;
+      }
+      if (lane == 0) S->ncur = (int)__builtin_popcountll(mm);
+    }
+    KtSplit sp;
+    if (count > (unsigned)T) {  // (the top of a large cloud: a real call, see ktb_split_node_wg_lds)
+      const float* bx = S->work[cur].box;
+      sp = ktb_split_node_wg_lds(rec, sc, red, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], xleft, xright, tid);
+    } else if (count > 64u) {
+      sp = ktp_split_node_1k(rec, sc, red, S->work[cur].box, xleft, count, tid);
+    } else {
+      if (wave == 0) {
+        KtWork wk;
+        wk.node = 0; wk.left = xleft; wk.right = xright;
+        for (int i = 0; i < 6; ++i) wk.box[i] = S->work[cur].box[i];
+        const KtSplit s1 = ktb_split_node_small(rec, sc, wk, xleft, count, lane, lt_mask);
+        if (lane == 0) S->split = s1;
+      }
+      __syncthreads();
+      sp = S->split;
+    }
+    // where the node's tied points are now
+    const int ncur = S->ncur;
+    for (unsigned p = xleft + tid; p < xright; p += T) {
+      const int w = __float_as_int(rec[p].w);
+      for (int s0 = 0; s0 < ncur; ++s0)
+        if (S->cur_idx[s0] == w) S->mem_pos[S->cur_m[s0]] = (int)p;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int ml = lane < t ? lane : 0;
+      const bool mine = lane < t && S->mem_node[ml] == cur;
+      const int m_grp = lane < t ? S->mem_grp[ml] : -1 - lane, m_pos = S->mem_pos[ml];
+      const int depth = S->work[cur].depth;
+      int nw_reg = S->nw;
+      // searchLevel (:1380-1393): the child on the query's side of the gap first
+      const float val = sp.cutfeat == 0 ? qx : (sp.cutfeat == 1 ? qy : qz);
+      const float diff1 = val - sp.dl, diff2 = val - sp.dh;
+      const int nearside = (diff1 + diff2) < 0 ? 0 : 1;
+      const int side = (unsigned)m_pos >= xleft + sp.index ? 1 : 0;
+      if (mine && side != nearside) {
+        if (depth < 64) S->mem_khi[ml] |= 1ull << (63 - depth); else S->mem_klo[ml] |= 1ull << (127 - depth);
+      }
+      bool fail = false;
+      int node_next = -1;
+#pragma unroll 1
+      for (int c = 0; c < 2; ++c) {
+        const unsigned cl = c == 0 ? xleft : xleft + sp.index, cr = c == 0 ? xleft + sp.index : xright;
+        const bool in_c = mine && side == c;
+        const unsigned long long cm = __builtin_amdgcn_ballot_w64(in_c);
+        bool peer = false;
+        for (int o = 0; o < t; ++o) peer |= (((cm >> o) & 1ull) != 0ull && o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp);
+        int e = -1;
+        if (cr - cl > (unsigned)KT_LEAF && __builtin_amdgcn_ballot_w64(in_c && peer) != 0ull) {  // two of a run in an inner node: split it too
+          if (nw_reg >= KTP_MAXW || depth + 1 >= KTP_DEPTH) fail = true;
+          else {
+            e = nw_reg++;
+            if (lane == 0) {
+              KtpWork w1;
+              w1.left = cl; w1.right = cr; w1.depth = depth + 1;
+              for (int i = 0; i < 6; ++i) w1.box[i] = (i == 2 * sp.cutfeat + 1 - c) ? sp.cutval : S->work[cur].box[i];
+              S->work[e] = w1;
+            }
+          }
+        }
+        if (in_c) node_next = e;
+      }
+      if (mine) S->mem_node[ml] = node_next;
+      if (lane == 0) { S->nw = nw_reg; if (fail) S->bad = 1; }
+    }
+    __syncthreads();
+    if (cur < 24) KTP_MARK(4 + cur);
+    if (S->bad != 0) return 1;
+  }
+  // a run in arrival order: (key, position) ascending, from the run's first slot on; what does not fit the row is dropped
+  if (wave == 0) {
+    const int ml = lane < t ? lane : 0;
+    const int m_grp = lane < t ? S->mem_grp[ml] : -1 - lane, m_pos = S->mem_pos[ml];
+    const unsigned long long khi = S->mem_khi[ml], klo = S->mem_klo[ml];
+    int rank = 0;
+    for (int o = 0; o < t; ++o) {
+      const int og = __builtin_amdgcn_readlane(m_grp, o), op = __builtin_amdgcn_readlane(m_pos, o);
+      const unsigned long long oh = ktp_readlane_u64(khi, o), ol = ktp_readlane_u64(klo, o);
+      const bool before = oh < khi || (oh == khi && (ol < klo || (ol == klo && op < m_pos)));
+      rank += (o != lane && og == m_grp && before) ? 1 : 0;
+    }
+    if (lane < t && m_grp + rank < k) orow[m_grp + rank] = (IdxT)S->mem_idx[ml];
+  }
+  __syncthreads();
+  KTP_MARK(30);
+  return 0;
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tie_path_kernel(int b, int n, int m, int k, const float* __restrict__ pts_all,
+                                                                     const float* __restrict__ queries, IdxT* __restrict__ out,
+                                                                     const int* __restrict__ nflag, const int* __restrict__ flist,
+                                                                     int* __restrict__ nwork) {
+  constexpr int T = KTB_WAVES * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* rec = reinterpret_cast<float4*>(smem);                                          // [n]
+  unsigned short* sc = reinterpret_cast<unsigned short*>(rec + n);                        // [n]
+  float* red = reinterpret_cast<float*>(smem + (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15));  // [KTP_RED_WORDS]
+  KtpShared* S = reinterpret_cast<KtpShared*>(red + KTP_RED_WORDS);
+  __shared__ float rootbox[6];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  KTP_MARK(0);
+  // the batch's listed queries, numbered thread-major (every workgroup computes the same numbering)
+  int cnt = 0;
+  for (int c = tid; c < b; c += T) cnt += nflag[c];
+  const int incl = wave_inclusive_sum_i32(cnt);
+  if (lane == 63) S->wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < KTB_WAVES; ++w) {
+    const int v = S->wsum[w];
+    if (w < wave) base += v;
+    total += v;
+  }
+  if (total > KTP_MAXQ) {  // (uniform) too many for a workgroup each: everything to the full builds
+    for (int c = blockIdx.x * T + tid; c < b; c += gridDim.x * T) nwork[c] = nflag[c];
+    return;
+  }
+  const int excl = base + incl - cnt;
+  KTP_MARK(1);
+  for (int g = blockIdx.x; g < total; g += gridDim.x) {
+    __syncthreads();
+    if (g >= excl && g < excl + cnt) {  // (one thread)
+      int rem = g - excl;
+      for (int c = tid; c < b; c += T) {
+        const int v = nflag[c];
+        if (rem < v) { S->cloud = c; S->entry = rem; break; }
+        rem -= v;
+      }
+    }
+    __syncthreads();
+    const int cloud = S->cloud, entry = S->entry;
+    const float* pts = pts_all + (size_t)cloud * n * 3;
+    // init_vind (:1318), computeBoundingBox (:1321-1346)
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < n; i += T) {
+      const float c[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
+      rec[i] = make_float4(c[0], c[1], c[2], __int_as_float(i));
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        lo[d] = c[d] < lo[d] ? c[d] : lo[d];
+        hi[d] = c[d] > hi[d] ? c[d] : hi[d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { lo[d] = wave_min_f32(lo[d]); hi[d] = wave_max_f32(hi[d]); }
+    if (lane == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { red[wave * 6 + 2 * d] = lo[d]; red[wave * 6 + 2 * d + 1] = hi[d]; }
+    }
+    __syncthreads();
+    if (tid < 6) {
+      float v = red[tid];
+      for (int w = 1; w < KTB_WAVES; ++w) v = (tid & 1) ? fmaxf(v, red[w * 6 + tid]) : fminf(v, red[w * 6 + tid]);
+      rootbox[tid] = v;
+    }
+    __syncthreads();
+    KTP_MARK(2);
+    const int j = flist[(size_t)cloud * m + entry];
+    const float* qp = queries + ((size_t)cloud * m + j) * 3;
+    const int rc = ktp_resolve<IdxT>(rec, sc, red, S, rootbox, n, k, qp[0], qp[1], qp[2], out + ((size_t)cloud * m + j) * k, tid);
+    if (rc != 0 && tid == 0) atomicExch(&nwork[cloud], nflag[cloud]);  // every listed query of the cloud, the done ones too (rows are simply written again)
+  }
+}
+
 __host__ __device__ inline size_t kts_lds_bytes(int n) {
   const size_t lq = (size_t)(n / (KT_LEAF + 1)) + 2;
   return (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15) + (size_t)KTS_NNODES(n) * sizeof(KtNode) + 2 * lq * sizeof(KtWork) + 64 +
-         KTB_WAVES * 6 * 4 + (size_t)KTB_WAVES * KT_DEPTH * 3 * 4;
+         KTB_WAVES * 6 * 4 + (size_t)KTB_WAVES * KT_DEPTH * 3 * 4 + KTP_RED_WORDS * 4 + ((sizeof(KtpShared) + 15) & ~(size_t)15);
+}
+constexpr int KTS_FEW = 2;  // listed queries of a cloud that take the tie paths, one after the other (a third would cost as much as tree + searches)
+// init_vind (:1318), computeBoundingBox (:1321-1346): the cloud's records {x, y, z, index} in index order and its tight box in
+// LDS (part: 6 words per wave).  Barriers at both ends (the LDS may still be in use / is ready on return).
+__device__ __forceinline__ void kts_load_records(const float* __restrict__ pts, const int n, float4* rec, float* part, float* rootbox,
+                                                 const int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  __syncthreads();
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = tid; i < n; i += KTB_WAVES * 64) {
+    const float c[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
+    rec[i] = make_float4(c[0], c[1], c[2], __int_as_float(i));
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = c[d] < lo[d] ? c[d] : lo[d];
+      hi[d] = c[d] > hi[d] ? c[d] : hi[d];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { lo[d] = wave_min_f32(lo[d]); hi[d] = wave_max_f32(hi[d]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { part[wave * 6 + 2 * d] = lo[d]; part[wave * 6 + 2 * d + 1] = hi[d]; }
+  }
+  __syncthreads();
+  if (wave == 0) {  // (lane l takes wave l & 15's partial)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const float l = wave_min_f32(part[(lane & (KTB_WAVES - 1)) * 6 + 2 * d]), h = wave_max_f32(part[(lane & (KTB_WAVES - 1)) * 6 + 2 * d + 1]);
+      if (lane == 0) { rootbox[2 * d] = l; rootbox[2 * d + 1] = h; }
+    }
+  }
+  __syncthreads();
 }
 template <typename IdxT>
 __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, int n, int m, int k, const float* __restrict__ pts_all,
@@ -1661,51 +2106,45 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
   float* rootbox = reinterpret_cast<float*>(ctr + 4);                                     // [6] (+ padding to 64 bytes)
   float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ctr) + 64);              // [KTB_WAVES][6]
   uint32_t* stacks = reinterpret_cast<uint32_t*>(part + KTB_WAVES * 6);                   // [KTB_WAVES][KT_DEPTH * 3]
+  float* red = reinterpret_cast<float*>(stacks + KTB_WAVES * KT_DEPTH * 3);               // [KTP_RED_WORDS] the tie paths' scratch
+  KtpShared* S = reinterpret_cast<KtpShared*>(red + KTP_RED_WORDS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #ifdef PASNL_TUNING
   int kts_first = -1;
   for (int c = 0; c < b && kts_first < 0; ++c) if (nflag[c] != 0) kts_first = c % gridDim.x;
 #endif
+#ifdef PASNL_TUNING
+  if (tid == 0 && blockIdx.x == 0) ktp_probe_wg = kts_first;
+#endif
   for (int cloud = blockIdx.x; cloud < b; cloud += gridDim.x) {
     const int nq = nflag[cloud];
     if (nq == 0) continue;  // (uniform)
     KTS_MARK(0);
     const float* pts = pts_all + (size_t)cloud * n * 3;
-    // init_vind (:1318), computeBoundingBox (:1321-1346)
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < n; i += KTB_WAVES * 64) {
-      const float c[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
-      rec[i] = make_float4(c[0], c[1], c[2], __int_as_float(i));
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        lo[d] = c[d] < lo[d] ? c[d] : lo[d];
-        hi[d] = c[d] > hi[d] ? c[d] : hi[d];
+    // A FEW listed queries (chance ties): their runs of equal distances put in arrival order along the tree paths that separate them
+    // (ktp_resolve: ~12 us a query where tree + search take 85); anything it does not take: the tree and the searches below
+    bool resolved = false;
+    if (nq <= KTS_FEW) {
+      resolved = true;
+      for (int e = 0; e < nq && resolved; ++e) {
+        kts_load_records(pts, n, rec, part, rootbox, tid);
+        const int j = flist[(size_t)cloud * m + e];
+        const float* qp = queries + ((size_t)cloud * m + j) * 3;
+        resolved = ktp_resolve<IdxT>(rec, sc, red, S, rootbox, n, k, qp[0], qp[1], qp[2], out + ((size_t)cloud * m + j) * k, tid) == 0;
       }
     }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { lo[d] = wave_min_f32(lo[d]); hi[d] = wave_max_f32(hi[d]); }
-    if (lane == 0) {
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { part[wave * 6 + 2 * d] = lo[d]; part[wave * 6 + 2 * d + 1] = hi[d]; }
-    }
+    if (resolved) { KTS_MARK(31); continue; }  // (uniform)
+    kts_load_records(pts, n, rec, part, rootbox, tid);
     if (tid < 4) ctr[tid] = 0;
     __syncthreads();
     if (tid == 0) {
-      float root[6];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        float l = part[2 * d], h = part[2 * d + 1];
-        for (int w = 1; w < KTB_WAVES; ++w) { l = fminf(l, part[w * 6 + 2 * d]); h = fmaxf(h, part[w * 6 + 2 * d + 1]); }
-        root[2 * d] = l; root[2 * d + 1] = h;
-      }
-      for (int i = 0; i < 6; ++i) rootbox[i] = root[i];  // root_bbox after divideTree = the tight box of all points (what the search reads)
       ctr[2] = 1;  // node 0 = the root
       if (n <= KT_LEAF) {
         nodes[0].child1 = nodes[0].child2 = -1; nodes[0].a = 0; nodes[0].divlow = __int_as_float(n); nodes[0].divhigh = 0.f;
       } else {
         KtWork w0; w0.node = 0; w0.left = 0; w0.right = (unsigned)n;
-        for (int i = 0; i < 6; ++i) w0.box[i] = root[i];
+        for (int i = 0; i < 6; ++i) w0.box[i] = rootbox[i];  // root_bbox after divideTree = the tight box of all points (what the search reads)
         qa[0] = w0;
         ctr[0] = 1;
       }
@@ -2381,6 +2820,18 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_lazy_kernel(int b, in
 }  // namespace pasnl
 
 using namespace pasnl;
+#ifdef PASNL_TUNING
+extern "C" void pasnl_tuning_stamp(int slot, hipStream_t st);
+template <int VG>
+__global__ __launch_bounds__(1024) void pasnl_dummy_kernel(const int* nflag) {
+  extern __shared__ char dsm[];
+  if (nflag[0] == 123456789) {
+    if (VG == 128) asm volatile("v_mov_b32 v125, 0" ::: "v125");
+    if (VG == 64) asm volatile("v_mov_b32 v62, 0" ::: "v62");
+    dsm[threadIdx.x] = 1;
+  }
+}
+#endif
 
 // LDS of a subtree's workgroup: records + scratch positions (18 bytes per point) for a subtree of up to min(n, KTB_LDS_NMAX)
 // points (the first phase keeps larger ones to itself), or those of KTD_LDSQ_MAX points plus their two level queues --
@@ -2556,14 +3007,56 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
   hipStream_t st = pasnl_hip_stream(stream);
   char* base = static_cast<char*>(workspace);
   pasnl::KnnTieFlags flags{reinterpret_cast<int*>(base + L.nflag), reinterpret_cast<int*>(base + L.flist)};
+#ifdef PASNL_TUNING
+  const bool stamp = pasnl::tune_env("PASNL_STAMP_N") && atoi(pasnl::tune_env("PASNL_STAMP_N")) == n;
+  if (stamp) pasnl_tuning_stamp(0, st);
+#define PASNL_STAMP(i) do { if (stamp) pasnl_tuning_stamp(i, st); } while (0)
+#else
+#define PASNL_STAMP(i) do { } while (0)
+#endif
   hipLaunchKernelGGL(knn_ref_clear_kernel, dim3((b + 255) / 256), dim3(256), 0, st, b, flags.nflag, reinterpret_cast<int*>(base + L.nwork));
   int rc = pasnl::knn_grid_launch(b, n, m, k, support, queries, idx, idx_is_i64, nullptr, base + L.grid, L.tree - L.grid,
                                   max_workgroups, flags, st);
   if (rc != PASNL_OK) return rc;
+  PASNL_STAMP(1);
   if (pasnl::tune_env("PASNL_KNN_REF_NO_TREE")) return pasnl_launch_status();  // (tuning build: the canonical search + flags alone, A/B)
-  if (n <= pasnl::KTS_NMAX && k <= 64) {  // tree + searches of a flagged cloud in one workgroup, all in LDS
+#ifdef PASNL_TUNING
+  if (const char* dm = pasnl::tune_env("PASNL_KNN_REF_DUMMY")) {  // (tuning build: what does an EMPTY kernel of a given footprint cost the step)
+    int th = 256, vg = 128, ldsb = 0, gr = 64;
+    sscanf(dm, "%d,%d,%d,%d", &th, &vg, &ldsb, &gr);
+    auto kern = vg > 64 ? pasnl_dummy_kernel<128> : (vg > 32 ? pasnl_dummy_kernel<64> : pasnl_dummy_kernel<32>);
+    if (ldsb > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+    hipLaunchKernelGGL(kern, dim3(gr), dim3(th), ldsb, st, flags.nflag);
+    return pasnl_launch_status();
+  }
+#endif
+  if (pasnl::tune_env("PASNL_KNN_REF_TINY_ONLY")) {  // (tuning build: what does ANY kernel behind the search cost the step)
+    hipLaunchKernelGGL(knn_tree_clear_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<int*>(base + L.nwork));
+    return pasnl_launch_status();
+  }
+  const bool small = n <= pasnl::KTS_NMAX && k <= 64;  // one kernel: the tie paths of a cloud's few listed queries, else its tree + searches
+  if (n <= pasnl::KTB_LDS_NMAX && !small && pasnl::tune_env("PASNL_KNN_REF_NO_TIE_PATH") == nullptr) {
+    // a FEW listed queries (chance ties): the runs of equal distances put in the tree's arrival order along the tree paths that
+    // separate them, a workgroup per query; `nwork` (b ints behind the lists' counters) = what is left to the builds below
+    int* nwork = reinterpret_cast<int*>(base + L.nwork);
+    const size_t lds = pasnl::ktp_lds_bytes(n) + (pasnl::tune_env("PASNL_KTP_LDS_EXTRA") ? (size_t)atoi(pasnl::tune_env("PASNL_KTP_LDS_EXTRA")) : 0);
+#define PASNL_KTP(T)                                                                                                             \
+    {                                                                                                                             \
+      auto kern = pasnl::knn_tie_path_kernel<T>;                                                                                  \
+      if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                 (int)lds) != hipSuccess)                                                         \
+        return PASNL_ELAUNCH;                                                                                                     \
+      hipLaunchKernelGGL(kern, dim3(pasnl::KTP_MAXQ), dim3(pasnl::KTB_WAVES * 64), lds, st, b, n, m, k, support, queries,          \
+                         static_cast<T*>(idx), flags.nflag, flags.flist, nwork);                                                  \
+    }
+    if (idx_is_i64) PASNL_KTP(long long) else PASNL_KTP(int)
+#undef PASNL_KTP
+    flags.nflag = nwork;
+    if (pasnl::tune_env("PASNL_KNN_REF_TIE_PATH_ONLY")) return pasnl_launch_status();  // (tuning build: timing without the builds' launches)
+  }
+  if (small) {  // (tree + searches of a listed cloud in one workgroup, all in LDS)
     const size_t lds = pasnl::kts_lds_bytes(n);
-    const int grid = pasnl::tune_env("PASNL_KNN_REF_EMPTY_TREE") ? 0 : std::min(b, 64);
+    const int grid = pasnl::tune_env("PASNL_KNN_REF_EMPTY_TREE") ? 0 : std::min(b, pasnl::tune_env("PASNL_KNN_SMALL_GRID") ? atoi(pasnl::tune_env("PASNL_KNN_SMALL_GRID")) : 64);
     if (grid == 0) return pasnl_launch_status();
 #define PASNL_KTS(T)                                                                                                             \
     {                                                                                                                             \
@@ -2576,6 +3069,7 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
     }
     if (idx_is_i64) PASNL_KTS(long long) else PASNL_KTS(int)
 #undef PASNL_KTS
+    PASNL_STAMP(2);
     return pasnl_launch_status();
   }
   if (n > pasnl::KTB_LDS_NMAX && n <= pasnl::KTL_NMAX && k <= 64) {
@@ -2603,6 +3097,13 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
 }
 
 #ifdef PASNL_TUNING
+// time stamps inside a captured step (tools/step_stamps.py): a one-thread kernel per stamp, wall_clock64() = the 100 MHz constant clock
+__device__ unsigned long long pasnl_stamps[16];
+__global__ void pasnl_stamp_kernel(int slot) { pasnl_stamps[slot] = wall_clock64(); }
+extern "C" void pasnl_tuning_stamp(int slot, hipStream_t st) { hipLaunchKernelGGL(pasnl_stamp_kernel, dim3(1), dim3(1), 0, st, slot); }
+extern "C" int pasnl_tuning_stamps_read(unsigned long long* host16) {
+  return hipMemcpyFromSymbol(host16, HIP_SYMBOL(pasnl_stamps), sizeof(pasnl_stamps)) == hipSuccess ? 0 : -1;
+}
 extern "C" int pasnl_knn_small_probe_read(unsigned long long* host32) {
   return hipMemcpyFromSymbol(host32, HIP_SYMBOL(pasnl::kts_probe), sizeof(pasnl::kts_probe)) == hipSuccess ? 0 : -1;
 }

@@ -846,10 +846,21 @@ extern "C" int pasnl_farthest_point_sample(int b, int n, int m, const float* xyz
   return fps_dispatch(b, n, m, xyz, idx, nullptr, stream);
 }
 
+#ifdef PASNL_TUNING
+extern "C" void pasnl_tuning_stamp(int slot, hipStream_t st);
+#endif
 extern "C" int pasnl_farthest_point_sample_gather(int b, int n, int m, const float* xyz, int* idx, float* new_xyz,
                                                   pasnl_stream_t stream) {
   PASNL_REQUIRE(b == 0 || new_xyz, PASNL_ENULL);
+#ifdef PASNL_TUNING
+  const bool stamp = pasnl::tune_env("PASNL_STAMP_N") && atoi(pasnl::tune_env("PASNL_STAMP_N")) == n;  // (tools/step_stamps.py)
+  if (stamp) pasnl_tuning_stamp(4, pasnl_hip_stream(stream));
+  const int rc = fps_dispatch(b, n, m, xyz, idx, new_xyz, stream);
+  if (stamp) pasnl_tuning_stamp(5, pasnl_hip_stream(stream));
+  return rc;
+#else
   return fps_dispatch(b, n, m, xyz, idx, new_xyz, stream);
+#endif
 }
 
 static int grid_for(long total) {
