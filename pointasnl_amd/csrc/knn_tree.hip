@@ -1664,10 +1664,12 @@ __device__ unsigned long long kts_probe[32];
 #ifdef PASNL_TUNING
 // phase probe of workgroup 0 (tools/tie_path_probe.py): s_memtime at [0] entry, [1] the listed queries counted, [2] records + box in
 // LDS, [3] the tied points listed, [4 + i] split i done (i < 24), [30] the row written
-#define KTP_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == ktp_probe_wg) kts_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)
-__device__ int ktp_probe_wg = 0;  // (knn_tree_small_kernel: the workgroup of the first listed cloud)
+#define KTP_MARK(i) do { if (threadIdx.x == 0 && S->probe != 0) kts_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)  // (S->probe: LDS; a flag in global memory costs a mark ~1 us)
+__device__ int ktp_paths[8];       // clouds by the form that took them: [0] sets only, [1] records moved, [2] tree + search, [3] return code 1 of the set form, [4] code 2
+#define KTP_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&ktp_paths[i], 1); } while (0)
 #else
 #define KTP_MARK(i) do { } while (0)
+#define KTP_COUNT(i) do { } while (0)
 #endif
 constexpr int KTP_MAXQ = 32;    // listed queries per batch this form takes (a workgroup each)
 constexpr int KTP_TMAX = 64;    // tied points of one query (a lane each)
@@ -1675,15 +1677,23 @@ constexpr int KTP_MAXW = 64;    // nodes split for one query
 constexpr int KTP_DEPTH = 126;  // levels whose near / far bit fits the 128-bit key
 constexpr int KTP_RED_WORDS = 256;  // [0, 96) min / max partials, [96, 160) the passes' masks (2 x 16 x 64 bits), [160, 192) divlow / divhigh partials
 struct KtpWork { unsigned left, right; float box[6]; int depth; };
+constexpr int KTP_FEWQ = 4;     // listed queries of one cloud resolved together
+// a node of the descent WITHOUT records moved (ktp_resolve_cloud): the node's points are the cloud's points inside lo .. hi (bit d of
+// inc: lo[d] belongs to the node, bit 3 + d: hi[d] does); box: the box handed down to it (what middleSplit_ reads)
+struct KtiWork { float lo[3], hi[3], box[6]; int inc, depth; };
 struct KtpShared {
-  float dk[PASNL_KNN_MAX_K];    // the canonical row's distances (ascending)
+  float dkq[KTP_FEWQ][PASNL_KNN_MAX_K];  // the canonical rows' distances (ascending); the one-query form uses dkq[0]
+  float qxyz[KTP_FEWQ][4];
+  int qj[KTP_FEWQ];
   int mem_idx[KTP_TMAX], mem_pos[KTP_TMAX], mem_grp[KTP_TMAX], mem_node[KTP_TMAX];  // a tied point per lane of wave 0: index, position,
-  unsigned long long mem_khi[KTP_TMAX], mem_klo[KTP_TMAX];                           // run (its first slot in the row), node, key
+  unsigned long long mem_khi[KTP_TMAX], mem_klo[KTP_TMAX];                           // run (query << 8 | its first slot in the row), node, key
   int cur_idx[KTP_TMAX], cur_m[KTP_TMAX];  // the tied points inside the node being split: index, lane
-  KtpWork work[KTP_MAXW];
+  union { KtpWork work[KTP_MAXW]; KtiWork iwork[KTP_MAXW]; };
   KtSplit split;
   int nmem, nw, ncur, bad;
-  int cloud, entry;
+  int cloud, entry, probe;
+  int stage, cutfeat, adv;  // the set form's pass over the current node: -1 fresh, 0 min / max of all dimensions, 1 the cut at the box's middle, 2 at the points' edge
+  float cutval;
   int wsum[KTB_WAVES];
 };
 __host__ __device__ inline size_t ktp_lds_bytes(int n) {
@@ -1827,11 +1837,12 @@ __device__ __forceinline__ int ktp_resolve(float4* rec, unsigned short* sc, floa
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   for (int i = tid; i < k; i += T) {
     const float4 r = rec[(int)orow[i]];
-    S->dk[i] = dist2(qx, qy, qz, r.x, r.y, r.z);
+    S->dkq[0][i] = dist2(qx, qy, qz, r.x, r.y, r.z);
   }
   if (tid == 0) { S->nmem = 0; S->bad = 0; S->nw = 0; }
   __syncthreads();
-  const float rk = S->dk[k - 1];
+  const float* dk = S->dkq[0];
+  const float rk = dk[k - 1];
   // the tied points: every point at a distance the row holds twice, or at the K-th distance (the run that may reach outside the row)
   for (int p = tid; p < n; p += T) {
     const float4 r = rec[p];
@@ -1840,10 +1851,10 @@ __device__ __forceinline__ int ktp_resolve(float4* rec, unsigned short* sc, floa
       int lo = 0, hi = k - 1;  // the first slot whose distance is >= d (slot k - 1 holds rk >= d)
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (S->dk[mid] < d) lo = mid + 1; else hi = mid;
+        if (dk[mid] < d) lo = mid + 1; else hi = mid;
       }
-      if (S->dk[lo] != d) S->bad = 1;  // (a point inside the K-th distance that the row does not hold: not a canonical row)
-      else if (d == rk || S->dk[lo + 1] == d) {
+      if (dk[lo] != d) S->bad = 1;  // (a point inside the K-th distance that the row does not hold: not a canonical row)
+      else if (d == rk || dk[lo + 1] == d) {
         const int slot = atomicAdd(&S->nmem, 1);
         if (slot < KTP_TMAX) { S->mem_idx[slot] = p; S->mem_grp[slot] = lo; }
       }
@@ -1975,89 +1986,6 @@ __device__ __forceinline__ int ktp_resolve(float4* rec, unsigned short* sc, floa
   return 0;
 }
 
-template <typename IdxT>
-__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tie_path_kernel(int b, int n, int m, int k, const float* __restrict__ pts_all,
-                                                                     const float* __restrict__ queries, IdxT* __restrict__ out,
-                                                                     const int* __restrict__ nflag, const int* __restrict__ flist,
-                                                                     int* __restrict__ nwork) {
-  constexpr int T = KTB_WAVES * 64;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float4* rec = reinterpret_cast<float4*>(smem);                                          // [n]
-  unsigned short* sc = reinterpret_cast<unsigned short*>(rec + n);                        // [n]
-  float* red = reinterpret_cast<float*>(smem + (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15));  // [KTP_RED_WORDS]
-  KtpShared* S = reinterpret_cast<KtpShared*>(red + KTP_RED_WORDS);
-  __shared__ float rootbox[6];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  KTP_MARK(0);
-  // the batch's listed queries, numbered thread-major (every workgroup computes the same numbering)
-  int cnt = 0;
-  for (int c = tid; c < b; c += T) cnt += nflag[c];
-  const int incl = wave_inclusive_sum_i32(cnt);
-  if (lane == 63) S->wsum[wave] = incl;
-  __syncthreads();
-  int base = 0, total = 0;
-  for (int w = 0; w < KTB_WAVES; ++w) {
-    const int v = S->wsum[w];
-    if (w < wave) base += v;
-    total += v;
-  }
-  if (total > KTP_MAXQ) {  // (uniform) too many for a workgroup each: everything to the full builds
-    for (int c = blockIdx.x * T + tid; c < b; c += gridDim.x * T) nwork[c] = nflag[c];
-    return;
-  }
-  const int excl = base + incl - cnt;
-  KTP_MARK(1);
-  for (int g = blockIdx.x; g < total; g += gridDim.x) {
-    __syncthreads();
-    if (g >= excl && g < excl + cnt) {  // (one thread)
-      int rem = g - excl;
-      for (int c = tid; c < b; c += T) {
-        const int v = nflag[c];
-        if (rem < v) { S->cloud = c; S->entry = rem; break; }
-        rem -= v;
-      }
-    }
-    __syncthreads();
-    const int cloud = S->cloud, entry = S->entry;
-    const float* pts = pts_all + (size_t)cloud * n * 3;
-    // init_vind (:1318), computeBoundingBox (:1321-1346)
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = tid; i < n; i += T) {
-      const float c[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
-      rec[i] = make_float4(c[0], c[1], c[2], __int_as_float(i));
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        lo[d] = c[d] < lo[d] ? c[d] : lo[d];
-        hi[d] = c[d] > hi[d] ? c[d] : hi[d];
-      }
-    }
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { lo[d] = wave_min_f32(lo[d]); hi[d] = wave_max_f32(hi[d]); }
-    if (lane == 0) {
-#pragma unroll
-      for (int d = 0; d < 3; ++d) { red[wave * 6 + 2 * d] = lo[d]; red[wave * 6 + 2 * d + 1] = hi[d]; }
-    }
-    __syncthreads();
-    if (tid < 6) {
-      float v = red[tid];
-      for (int w = 1; w < KTB_WAVES; ++w) v = (tid & 1) ? fmaxf(v, red[w * 6 + tid]) : fminf(v, red[w * 6 + tid]);
-      rootbox[tid] = v;
-    }
-    __syncthreads();
-    KTP_MARK(2);
-    const int j = flist[(size_t)cloud * m + entry];
-    const float* qp = queries + ((size_t)cloud * m + j) * 3;
-    const int rc = ktp_resolve<IdxT>(rec, sc, red, S, rootbox, n, k, qp[0], qp[1], qp[2], out + ((size_t)cloud * m + j) * k, tid);
-    if (rc != 0 && tid == 0) atomicExch(&nwork[cloud], nflag[cloud]);  // every listed query of the cloud, the done ones too (rows are simply written again)
-  }
-}
-
-__host__ __device__ inline size_t kts_lds_bytes(int n) {
-  const size_t lq = (size_t)(n / (KT_LEAF + 1)) + 2;
-  return (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15) + (size_t)KTS_NNODES(n) * sizeof(KtNode) + 2 * lq * sizeof(KtWork) + 64 +
-         KTB_WAVES * 6 * 4 + (size_t)KTB_WAVES * KT_DEPTH * 3 * 4 + KTP_RED_WORDS * 4 + ((sizeof(KtpShared) + 15) & ~(size_t)15);
-}
-constexpr int KTS_FEW = 2;  // listed queries of a cloud that take the tie paths, one after the other (a third would cost as much as tree + searches)
 // init_vind (:1318), computeBoundingBox (:1321-1346): the cloud's records {x, y, z, index} in index order and its tight box in
 // LDS (part: 6 words per wave).  Barriers at both ends (the LDS may still be in use / is ready on return).
 __device__ __forceinline__ void kts_load_records(const float* __restrict__ pts, const int n, float4* rec, float* part, float* rootbox,
@@ -2090,6 +2018,334 @@ __device__ __forceinline__ void kts_load_records(const float* __restrict__ pts, 
   }
   __syncthreads();
 }
+// The listed queries of ONE cloud together (nq <= KTP_FEWQ), WITHOUT moving a record: a node of the reference tree is a SET of points,
+// and which child a point goes to is a comparison with the cut value -- positions decide only where points lie exactly on the cut
+// and the split falls among them (index = count / 2 strictly between lim1 and lim2, :1037-1042), and in which order a leaf is
+// read.  So a node is kept as the half-open box its ancestors' cuts left (KtiWork); a level is two passes of reductions over the
+// cloud (middleSplit_'s min / max and count; planeSplit's lim1, lim2 and the children's divlow / divhigh as the extremes of
+// the two sets) -- ~2 us where moving the records of a 1024-point node takes 7.  Two tied points that reach a leaf together, or a
+// split that falls among equal coordinates: 2 = take the forms that move the records (ktp_resolve, a query at a time).
+// rec: the records in index order, untouched.  -> 0 done, 1 not taken (the full build), 2 see above.  Uniform.
+template <typename IdxT>
+__device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, float* red, KtpShared* S, const float* rootbox, const int n, const int k,
+                                                 const int nq, const int* __restrict__ flist_c, const float* __restrict__ queries_c,
+                                                 IdxT* __restrict__ out_c, const int tid) {
+  constexpr int T = KTB_WAVES * 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  if (tid < nq) {
+    const int j = flist_c[tid];
+    S->qj[tid] = j;
+    S->qxyz[tid][0] = queries_c[(size_t)j * 3]; S->qxyz[tid][1] = queries_c[(size_t)j * 3 + 1]; S->qxyz[tid][2] = queries_c[(size_t)j * 3 + 2];
+  }
+  if (tid == 0) { S->nmem = 0; S->bad = 0; S->nw = 0; }
+  __syncthreads();
+  for (int i = tid; i < nq * k; i += T) {
+    const int q = i / k, s0 = i - q * k;
+    const float4 r = rec[(int)out_c[(size_t)S->qj[q] * k + s0]];
+    S->dkq[q][s0] = dist2(S->qxyz[q][0], S->qxyz[q][1], S->qxyz[q][2], r.x, r.y, r.z);
+  }
+  __syncthreads();
+  // the tied points of every query: at a distance its row holds twice, or at its K-th distance
+  for (int p = tid; p < n; p += T) {
+    const float4 r = rec[p];
+    for (int q = 0; q < nq; ++q) {
+      const float* dk = S->dkq[q];
+      const float d = dist2(S->qxyz[q][0], S->qxyz[q][1], S->qxyz[q][2], r.x, r.y, r.z), rk = dk[k - 1];
+      if (d <= rk) {
+        int lo = 0, hi = k - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (dk[mid] < d) lo = mid + 1; else hi = mid;
+        }
+        if (dk[lo] != d) S->bad = 1;
+        else if (d == rk || dk[lo + 1] == d) {
+          const int slot = atomicAdd(&S->nmem, 1);
+          if (slot < KTP_TMAX) { S->mem_idx[slot] = p; S->mem_grp[slot] = (q << 8) | lo; }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int t = S->nmem;
+  KTP_MARK(3);
+  if (S->bad != 0 || t > KTP_TMAX) return 1;
+  // The descent.  A level = ONE pass of the workgroup over the cloud (the node's count, lim1, lim2 by ballots; its extremes along the cut
+  // dimension by wave reductions), the waves' partials through LDS, and wave 0's turn: the split, the tied points' sides, the children
+  // that still hold two of a run.  Two barriers a level.  (Measured: a level of a 1024-point cloud 4.4 us; by wave 0 alone, no
+  // barriers: 9.5 -- the pass is ~60 dependent instructions per 64 points.)
+  // wave 0: one tied point per lane, in registers -- index, run (query << 8 | first slot), node, its coordinates, its query's, its key
+  int m_idx = 0, m_grp = -1 - lane, m_node = -1, nw_reg = 0;
+  float px = 0.f, py = 0.f, pz = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
+  unsigned long long khi = 0ull, klo = 0ull;
+  if (wave == 0) {
+    if (lane < t) {
+      m_idx = S->mem_idx[lane]; m_grp = S->mem_grp[lane]; m_node = 0;
+      const float4 r = rec[m_idx];
+      px = r.x; py = r.y; pz = r.z;
+      ux = S->qxyz[m_grp >> 8][0]; uy = S->qxyz[m_grp >> 8][1]; uz = S->qxyz[m_grp >> 8][2];
+    }
+    bool peer = false;
+    for (int o = 0; o < t; ++o) peer |= (o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp);
+    if (n > KT_LEAF && __builtin_amdgcn_ballot_w64(lane < t && peer) != 0ull) {
+      nw_reg = 1;
+      if (lane == 0) {
+        KtiWork* w0 = &S->iwork[0];
+        for (int d = 0; d < 3; ++d) { w0->lo[d] = -INFINITY; w0->hi[d] = INFINITY; }
+        for (int i = 0; i < 6; ++i) w0->box[i] = rootbox[i];
+        w0->inc = 63; w0->depth = 0;
+        S->nw = 1;
+      }
+    }
+    if (lane == 0) S->stage = -1;
+  }
+  __syncthreads();
+  int cur = 0, npass = 0;
+  for (;;) {
+    if (cur >= S->nw) break;  // (uniform: written before the last barrier)
+    // (the node stays in LDS: an index that is not a constant -- box[2 * cutfeat] -- would send a copy in registers to scratch memory)
+    const KtiWork* X = &S->iwork[cur];
+    const int inc = X->inc;
+    const float xlo[3] = {X->lo[0], X->lo[1], X->lo[2]}, xhi[3] = {X->hi[0], X->hi[1], X->hi[2]};
+    // ---- middleSplit_ (:966-1005): the dimensions whose box side is (nearly) the longest may be cut
+    const float EPS = 0.00001f;
+    const float span[3] = {X->box[1] - X->box[0], X->box[3] - X->box[2], X->box[5] - X->box[4]};
+    float max_span = span[0];
+    for (int d = 1; d < 3; ++d) if (span[d] > max_span) max_span = span[d];
+    int qual = 0;
+    for (int d = 0; d < 3; ++d) qual |= span[d] > (1 - EPS) * max_span ? 1 << d : 0;
+    int stage = S->stage, cutfeat = S->cutfeat;
+    float cutval = S->cutval;
+    if (stage < 0) {  // a fresh node
+      if ((qual & (qual - 1)) == 0) {  // one candidate (a box has a longest side; ties between sides are the exception): no look at the spreads
+        stage = 1;
+        cutfeat = qual == 1 ? 0 : (qual == 2 ? 1 : 2);
+        cutval = (X->box[2 * cutfeat] + X->box[2 * cutfeat + 1]) / 2;
+      } else stage = 0;
+    }
+    // ---- one pass over the cloud: the node's points are the points inside lo .. hi.  stage 0: f = min x, y, z, max x, y, z
+    // (computeMinMax :898-907); stages 1 (the cut at the box's middle), 2 (at the points' edge): ci = count, lim1 = points below the
+    // cut, lim2 = at or below it; f[0] min, f[3] max along cutfeat, f[1] the least coordinate above the cut, f[4] the greatest below
+    int ci[3] = {0, 0, 0};
+    float f[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int p0 = wave * 64; p0 < n; p0 += T) {
+      const int p = p0 + lane;
+      const float4 r = rec[p < n ? p : 0];
+      const float c[3] = {r.x, r.y, r.z};
+      bool in = p < n;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        in = in && (((inc >> d) & 1) ? c[d] >= xlo[d] : c[d] > xlo[d]);
+        in = in && (((inc >> (3 + d)) & 1) ? c[d] <= xhi[d] : c[d] < xhi[d]);
+      }
+      if (stage == 0) {
+        if (in) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) { f[d] = c[d] < f[d] ? c[d] : f[d]; f[3 + d] = c[d] > f[3 + d] ? c[d] : f[3 + d]; }
+        }
+      } else {
+        const float v = cutfeat == 0 ? c[0] : (cutfeat == 1 ? c[1] : c[2]);
+        ci[0] += (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+        ci[1] += (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in && v < cutval));
+        ci[2] += (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in && v <= cutval));
+        if (in) {
+          f[0] = v < f[0] ? v : f[0];
+          f[3] = v > f[3] ? v : f[3];
+          if (v > cutval) f[1] = v < f[1] ? v : f[1];
+          if (v < cutval) f[4] = v > f[4] ? v : f[4];
+        }
+      }
+    }
+    if (stage == 0) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { f[d] = wave_min_f32(f[d]); f[3 + d] = wave_max_f32(f[3 + d]); }
+    } else {
+      f[0] = wave_min_f32(f[0]); f[1] = wave_min_f32(f[1]); f[3] = wave_max_f32(f[3]); f[4] = wave_max_f32(f[4]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) red[wave * 12 + i] = f[i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) red[wave * 12 + 6 + i] = __int_as_float(ci[i]);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int wl = lane & (KTB_WAVES - 1);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { f[i] = wave_min_f32(red[wl * 12 + i]); f[3 + i] = wave_max_f32(red[wl * 12 + 3 + i]); }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        ci[i] = __builtin_amdgcn_readlane(wave_inclusive_sum_i32(lane < KTB_WAVES ? __float_as_int(red[lane * 12 + 6 + i]) : 0), 63);
+      int adv = 0, fail = 0;
+      if (stage == 0) {
+        float max_spread = -1.f;
+        int cf = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          if ((qual >> d) & 1) {
+            const float spread = f[3 + d] - f[d];
+            if (spread > max_spread) { cf = d; max_spread = spread; }
+          }
+        }
+        if (lane == 0) { S->stage = 1; S->cutfeat = cf; S->cutval = (X->box[2 * cf] + X->box[2 * cf + 1]) / 2; }
+      } else if (stage == 1 && (cutval < f[0] || cutval > f[3])) {  // the box's middle misses the points: the cut goes to their edge (:996-1001)
+        if (lane == 0) { S->stage = 2; S->cutfeat = cutfeat; S->cutval = cutval < f[0] ? f[0] : f[3]; }
+      } else {
+        // ---- planeSplit (:1016-1043) on the SET
+        const unsigned count = (unsigned)ci[0], lim1 = (unsigned)ci[1], lim2 = (unsigned)ci[2], half = count / 2;
+        unsigned index;
+        int mode;  // 0: the left child is {v < cut}, 1: {v <= cut}, -1: the split falls among the points ON the cut
+        if (lim1 > half) { index = lim1; mode = 0; }
+        else if (lim2 < half) { index = lim2; mode = 1; }
+        else { index = half; mode = half == lim1 ? 0 : (half == lim2 ? 1 : -1); }
+        if (mode < 0) fail = 2;
+        else {
+          // divlow = the greatest coordinate of the left child, divhigh = the least of the right one (:956-957); points ON the cut, if any,
+          // are the left child's greatest (mode 1) or the right child's least (mode 0)
+          const bool on_cut = lim2 > lim1;
+          const float dl = mode == 1 && on_cut ? cutval : f[4], dh = mode == 0 && on_cut ? cutval : f[1];
+          const bool mine = m_node == cur;
+          const int depth = X->depth;
+          const float v = cutfeat == 0 ? px : (cutfeat == 1 ? py : pz);
+          const int side = (mode == 0 ? v < cutval : v <= cutval) ? 0 : 1;
+          // searchLevel (:1380-1393): the child on the query's side of the gap first
+          const float val = cutfeat == 0 ? ux : (cutfeat == 1 ? uy : uz);
+          const float diff1 = val - dl, diff2 = val - dh;
+          const int nearside = (diff1 + diff2) < 0 ? 0 : 1;
+          if (mine && side != nearside) {
+            if (depth < 64) khi |= 1ull << (63 - depth); else klo |= 1ull << (127 - depth);
+          }
+          int node_next = -1;
+#pragma unroll 1
+          for (int c = 0; c < 2; ++c) {
+            const unsigned cc = c == 0 ? index : count - index;
+            const bool in_c = mine && side == c;
+            const unsigned long long cm = __builtin_amdgcn_ballot_w64(in_c);
+            bool peer = false;
+            for (int o = 0; o < t; ++o) peer |= (((cm >> o) & 1ull) != 0ull && o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp);
+            int e = -1;
+            if (__builtin_amdgcn_ballot_w64(in_c && peer) != 0ull) {  // two of a run in this child
+              if (cc <= (unsigned)KT_LEAF) fail = 2;  // ... a leaf: its reading order is a matter of positions
+              else if (nw_reg >= KTP_MAXW || depth + 1 >= KTP_DEPTH) fail = 1;
+              else {
+                e = nw_reg++;
+                if (lane < 14) reinterpret_cast<float*>(&S->iwork[e])[lane] = reinterpret_cast<const float*>(X)[lane];  // (a copy of the node ...
+                ktb_wave_sync();
+                if (lane == 0) {                                                                                        // ... with one face moved)
+                  KtiWork* w1 = &S->iwork[e];
+                  w1->depth = depth + 1;
+                  w1->box[2 * cutfeat + 1 - c] = cutval;
+                  if (c == 0) { w1->hi[cutfeat] = cutval; w1->inc = (inc & ~(8 << cutfeat)) | (mode == 1 ? (8 << cutfeat) : 0); }
+                  else { w1->lo[cutfeat] = cutval; w1->inc = (inc & ~(1 << cutfeat)) | (mode == 0 ? (1 << cutfeat) : 0); }
+                }
+              }
+            }
+            if (in_c) node_next = e;
+          }
+          if (mine) m_node = node_next;
+          adv = 1;
+        }
+        if (lane == 0) { S->stage = -1; S->nw = nw_reg; }
+      }
+      if (lane == 0) { S->adv = adv; if (fail != 0) S->bad = fail; }
+    }
+    __syncthreads();
+    if (npass < 24) KTP_MARK(4 + npass);
+    ++npass;
+    if (S->bad != 0) return S->bad;
+    cur += S->adv;
+  }
+  // every run in arrival order (no two of a run share a leaf below the root: the keys differ; a cloud that IS one leaf is read in index order)
+  if (wave == 0) {
+    int rank = 0;
+    for (int o = 0; o < t; ++o) {
+      const int og = __builtin_amdgcn_readlane(m_grp, o), op = __builtin_amdgcn_readlane(m_idx, o);
+      const unsigned long long oh = ktp_readlane_u64(khi, o), ol = ktp_readlane_u64(klo, o);
+      const bool before = oh < khi || (oh == khi && (ol < klo || (ol == klo && op < m_idx)));
+      rank += (o != lane && og == m_grp && before) ? 1 : 0;
+    }
+    const int slot = (m_grp & 255) + rank;
+    if (lane < t && slot < k) out_c[(size_t)S->qj[m_grp >> 8] * k + slot] = (IdxT)m_idx;
+  }
+  __syncthreads();
+  KTP_MARK(30);
+  return 0;
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(KTB_WAVES * 64) void knn_tie_path_kernel(int b, int n, int m, int k, const float* __restrict__ pts_all,
+                                                                     const float* __restrict__ queries, IdxT* __restrict__ out,
+                                                                     const int* __restrict__ nflag, const int* __restrict__ flist,
+                                                                     int* __restrict__ nwork) {
+  constexpr int T = KTB_WAVES * 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* rec = reinterpret_cast<float4*>(smem);                                          // [n]
+  unsigned short* sc = reinterpret_cast<unsigned short*>(rec + n);                        // [n]
+  float* red = reinterpret_cast<float*>(smem + (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15));  // [KTP_RED_WORDS]
+  KtpShared* S = reinterpret_cast<KtpShared*>(red + KTP_RED_WORDS);
+  __shared__ float rootbox[6];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef PASNL_TUNING
+  if (tid == 0) S->probe = blockIdx.x == 0 ? 1 : 0;
+  __syncthreads();
+#endif
+  KTP_MARK(0);
+  // the batch's listed CLOUDS, numbered thread-major (every workgroup computes the same numbering)
+  int cnt = 0;
+  for (int c = tid; c < b; c += T) cnt += nflag[c] != 0 ? 1 : 0;
+  const int incl = wave_inclusive_sum_i32(cnt);
+  if (lane == 63) S->wsum[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < KTB_WAVES; ++w) {
+    const int v = S->wsum[w];
+    if (w < wave) base += v;
+    total += v;
+  }
+  if (total > KTP_MAXQ) {  // (uniform) too many for a workgroup each: everything to the full builds
+    for (int c = blockIdx.x * T + tid; c < b; c += gridDim.x * T) nwork[c] = nflag[c];
+    return;
+  }
+  const int excl = base + incl - cnt;
+  KTP_MARK(1);
+  for (int g = blockIdx.x; g < total; g += gridDim.x) {
+    __syncthreads();
+    if (g >= excl && g < excl + cnt) {  // (one thread)
+      int rem = g - excl;
+      for (int c = tid; c < b; c += T) {
+        if (nflag[c] == 0) continue;
+        if (rem == 0) { S->cloud = c; break; }
+        --rem;
+      }
+    }
+    __syncthreads();
+    const int cloud = S->cloud, nq = nflag[cloud];
+    if (nq > KTP_FEWQ) {  // (uniform) a cloud of many ties: the full build
+      if (tid == 0) atomicExch(&nwork[cloud], nq);
+      continue;
+    }
+    const float* pts = pts_all + (size_t)cloud * n * 3;
+    kts_load_records(pts, n, rec, red, rootbox, tid);
+    KTP_MARK(2);
+    int rc = ktp_resolve_cloud<IdxT>(rec, red, S, rootbox, n, k, nq, flist + (size_t)cloud * m, queries + (size_t)cloud * m * 3,
+                                     out + (size_t)cloud * m * k, tid);
+    if (rc == 2) {  // two tied points in one leaf, or a split among equal coordinates: the form that moves the records, a query at a time
+      rc = 0;
+      for (int e = 0; e < nq && rc == 0; ++e) {
+        if (e > 0) kts_load_records(pts, n, rec, red, rootbox, tid);
+        const int j = flist[(size_t)cloud * m + e];
+        const float* qp = queries + ((size_t)cloud * m + j) * 3;
+        rc = ktp_resolve<IdxT>(rec, sc, red, S, rootbox, n, k, qp[0], qp[1], qp[2], out + ((size_t)cloud * m + j) * k, tid);
+      }
+    }
+    if (rc != 0 && tid == 0) atomicExch(&nwork[cloud], nq);  // every listed query of the cloud, the done ones too (rows are simply written again)
+  }
+}
+
+__host__ __device__ inline size_t kts_lds_bytes(int n) {
+  const size_t lq = (size_t)(n / (KT_LEAF + 1)) + 2;
+  return (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15) + (size_t)KTS_NNODES(n) * sizeof(KtNode) + 2 * lq * sizeof(KtWork) + 64 +
+         KTB_WAVES * 6 * 4 + (size_t)KTB_WAVES * KT_DEPTH * 3 * 4 + KTP_RED_WORDS * 4 + ((sizeof(KtpShared) + 15) & ~(size_t)15);
+}
 template <typename IdxT>
 __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, int n, int m, int k, const float* __restrict__ pts_all,
                                                                        const float* __restrict__ queries, IdxT* __restrict__ out,
@@ -2115,7 +2371,8 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
   for (int c = 0; c < b && kts_first < 0; ++c) if (nflag[c] != 0) kts_first = c % gridDim.x;
 #endif
 #ifdef PASNL_TUNING
-  if (tid == 0 && blockIdx.x == 0) ktp_probe_wg = kts_first;
+  if (tid == 0) S->probe = blockIdx.x == kts_first ? 1 : 0;
+  __syncthreads();
 #endif
   for (int cloud = blockIdx.x; cloud < b; cloud += gridDim.x) {
     const int nq = nflag[cloud];
@@ -2123,18 +2380,28 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
     KTS_MARK(0);
     const float* pts = pts_all + (size_t)cloud * n * 3;
     // A FEW listed queries (chance ties): their runs of equal distances put in arrival order along the tree paths that separate them
-    // (ktp_resolve: ~12 us a query where tree + search take 85); anything it does not take: the tree and the searches below
+    // (ktp_resolve_cloud: ~10 us where tree + search take 85); anything it does not take: the tree and the searches below
     bool resolved = false;
-    if (nq <= KTS_FEW) {
-      resolved = true;
-      for (int e = 0; e < nq && resolved; ++e) {
-        kts_load_records(pts, n, rec, part, rootbox, tid);
-        const int j = flist[(size_t)cloud * m + e];
-        const float* qp = queries + ((size_t)cloud * m + j) * 3;
-        resolved = ktp_resolve<IdxT>(rec, sc, red, S, rootbox, n, k, qp[0], qp[1], qp[2], out + ((size_t)cloud * m + j) * k, tid) == 0;
+    if (nq <= KTP_FEWQ) {
+      kts_load_records(pts, n, rec, part, rootbox, tid);
+      const int rc = ktp_resolve_cloud<IdxT>(rec, red, S, rootbox, n, k, nq, flist + (size_t)cloud * m, queries + (size_t)cloud * m * 3,
+                                            out + (size_t)cloud * m * k, tid);
+      resolved = rc == 0;
+      if (rc == 0) KTP_COUNT(0);
+      if (rc == 1) KTP_COUNT(3);
+      if (rc == 2) KTP_COUNT(4);
+      if (rc == 2) {  // two tied points in one leaf, or a split among equal coordinates: the form that moves the records, a query at a time
+        resolved = true;
+        for (int e = 0; e < nq && resolved; ++e) {
+          if (e > 0) kts_load_records(pts, n, rec, part, rootbox, tid);
+          const int j = flist[(size_t)cloud * m + e];
+          const float* qp = queries + ((size_t)cloud * m + j) * 3;
+          resolved = ktp_resolve<IdxT>(rec, sc, red, S, rootbox, n, k, qp[0], qp[1], qp[2], out + ((size_t)cloud * m + j) * k, tid) == 0;
+        }
       }
     }
     if (resolved) { KTS_MARK(31); continue; }  // (uniform)
+    KTP_COUNT(2);
     kts_load_records(pts, n, rec, part, rootbox, tid);
     if (tid < 4) ctr[tid] = 0;
     __syncthreads();
@@ -3103,6 +3370,11 @@ __global__ void pasnl_stamp_kernel(int slot) { pasnl_stamps[slot] = wall_clock64
 extern "C" void pasnl_tuning_stamp(int slot, hipStream_t st) { hipLaunchKernelGGL(pasnl_stamp_kernel, dim3(1), dim3(1), 0, st, slot); }
 extern "C" int pasnl_tuning_stamps_read(unsigned long long* host16) {
   return hipMemcpyFromSymbol(host16, HIP_SYMBOL(pasnl_stamps), sizeof(pasnl_stamps)) == hipSuccess ? 0 : -1;
+}
+extern "C" int pasnl_tie_paths_read(int* host8, int clear) {
+  if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(pasnl::ktp_paths), sizeof(pasnl::ktp_paths)) != hipSuccess) return -1;
+  if (clear) { int z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pasnl::ktp_paths), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
 }
 extern "C" int pasnl_knn_small_probe_read(unsigned long long* host32) {
   return hipMemcpyFromSymbol(host32, HIP_SYMBOL(pasnl::kts_probe), sizeof(pasnl::kts_probe)) == hipSuccess ? 0 : -1;

@@ -1,0 +1,81 @@
+"""GPU: the tie paths of the default kNN order (csrc/knn_tree.hip: ktp_resolve_cloud, ktp_resolve, knn_tie_path_kernel and the
+first stage of knn_tree_small_kernel).  A batch with at most 32 listed clouds of at most 4 listed queries each never builds a tree:
+the runs of equal distances of a listed query's canonical row are put in the order the reference tree's search would have reached
+them.  Checked here against (a) every query through the real tree + search (tie_order="nanoflann": nothing shared with the tie
+paths but the split code) and (b) the reference library itself where it was built (oracle/_ref/libref_knn.so, knn_.cxx:72-135).
+Clouds are quantised to 2^-q: runs inside the row, runs across its end, duplicates of the query, several queries of one cloud,
+tied points that share a leaf (the record-moving form), splits among equal coordinates."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(rng, b, n, q, dup):
+    sup = rng.normal(size=(b, n, 3)).astype(np.float32)
+    sup /= np.maximum(1.0, np.abs(sup).max())
+    sup = (np.round(sup * 2 ** q) / 2 ** q).astype(np.float32)
+    if dup and n > 8:
+        sup[:, 5] = sup[:, 3]  # an exact duplicate: two tied points that no split separates
+    return sup
+
+
+def _run(sup, qry, k):
+    import pointasnl_amd as P
+    from oracle import ref
+
+    s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    stats = []
+    got = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, stats=stats)
+    full = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="nanoflann")
+    assert torch.equal(got, full)
+    if ref.available("libref_knn.so"):
+        np.testing.assert_array_equal(got.cpu().numpy(), ref.knn_batch(sup, qry, k))
+    return stats[0].cpu().numpy(), stats[1].cpu().numpy()
+
+
+@pytest.mark.parametrize("n,k,m", [(7, 3, 7), (40, 8, 20), (300, 16, 32), (1024, 32, 32), (1024, 1, 32), (2048, 64, 16),
+                                   (2048, 100, 8), (4096, 32, 16), (8192, 32, 8), (8192, 200, 4)])
+def test_tie_paths_equal_the_tree_search_and_the_reference(n, k, m):
+    rng = np.random.default_rng(n * 131 + k)
+    listed = left = 0
+    for q in (5, 7, 9, 11, 13):
+        for b in (1, 3):
+            sup = _cloud(rng, b, n, q, dup=q >= 11)
+            mm = max(1, m // b)
+            if q % 4 == 1:  # queries that are not support points
+                qry = ((np.round(rng.normal(size=(b, mm, 3)) * 2 ** q) / 2 ** q) * 0.3).astype(np.float32)
+            else:
+                qry = np.ascontiguousarray(sup[:, :mm])
+            nflag, nwork = _run(sup, qry, k)
+            listed += int(nflag.sum())
+            left += int(nwork.sum())
+    assert listed > 0 or n < 300
+    # (clouds of up to 2048 points with k <= 64 resolve inside knn_tree_small_kernel and report nothing; the others report what the
+    # tie paths left to the full builds: clouds whose listed queries have more than 64 tied points in all -- the coarse lattices at k >= 100)
+    assert left < listed or listed == 0, (listed, left)
+
+
+def test_many_listed_queries_of_one_cloud_and_many_listed_clouds():
+    """More than KTP_FEWQ listed queries in a cloud / more than KTP_MAXQ listed clouds: the full builds take them, same result."""
+    rng = np.random.default_rng(3)
+    for b, n, m, q in [(2, 1024, 200, 6), (40, 600, 6, 6), (40, 3000, 3, 5), (2, 5000, 300, 6)]:
+        sup = _cloud(rng, b, n, q, dup=True)
+        nflag, nwork = _run(sup, np.ascontiguousarray(sup[:, :m]), 24)
+        assert nflag.sum() > 0
+
+
+def test_chance_ties_on_the_benchmark_shapes_are_resolved_without_a_tree():
+    """The classifier's and the segmentation models' own search shapes (synthetic benchmark clouds + one planted tie each)."""
+    import bench as B
+
+    for sup, m in [(B.synth_clouds(1, 8, 1024), 512), (np.ascontiguousarray(B.synth_scannet(3, 4, 8192)[..., :3]), 1024)]:
+        sup = sup.copy()
+        # a planted exact tie for query 0 of cloud 1: two points mirrored about it on a dyadic grid
+        q0 = (np.round(sup[1, 0] * 256) / 256).astype(np.float32)
+        sup[1, 0] = q0
+        sup[1, 1] = q0 + np.float32(1 / 512)
+        sup[1, 2] = q0 - np.float32(1 / 512)
+        nflag, nwork = _run(sup, np.ascontiguousarray(sup[:, :m]), 32)
+        assert nflag[1] >= 1 and nwork.sum() == 0, (nflag, nwork)
