@@ -1696,7 +1696,7 @@ struct KtpShared {
   float cutval;
   int wsum[KTB_WAVES];
 };
-__host__ __device__ inline size_t ktp_lds_bytes(int n) {
+__host__ __device__ inline size_t ktp_lds_bytes(int n) {  // (n = 0: the form that reads the cloud in global memory)
   return (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15) + KTP_RED_WORDS * 4 + ((sizeof(KtpShared) + 15) & ~(size_t)15);
 }
 __device__ __forceinline__ unsigned long long ktp_readlane_u64(unsigned long long v, int src) {
@@ -1988,6 +1988,7 @@ __device__ __forceinline__ int ktp_resolve(float4* rec, unsigned short* sc, floa
 
 // init_vind (:1318), computeBoundingBox (:1321-1346): the cloud's records {x, y, z, index} in index order and its tight box in
 // LDS (part: 6 words per wave).  Barriers at both ends (the LDS may still be in use / is ready on return).
+template <bool STORE = true>
 __device__ __forceinline__ void kts_load_records(const float* __restrict__ pts, const int n, float4* rec, float* part, float* rootbox,
                                                  const int tid) {
   const int lane = tid & 63, wave = tid >> 6;
@@ -1995,7 +1996,7 @@ __device__ __forceinline__ void kts_load_records(const float* __restrict__ pts, 
   float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = tid; i < n; i += KTB_WAVES * 64) {
     const float c[3] = {pts[(size_t)i * 3], pts[(size_t)i * 3 + 1], pts[(size_t)i * 3 + 2]};
-    rec[i] = make_float4(c[0], c[1], c[2], __int_as_float(i));
+    if (STORE) rec[i] = make_float4(c[0], c[1], c[2], __int_as_float(i));  // (false: the box only, the points stay in global memory)
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       lo[d] = c[d] < lo[d] ? c[d] : lo[d];
@@ -2026,12 +2027,17 @@ __device__ __forceinline__ void kts_load_records(const float* __restrict__ pts, 
 // the two sets) -- ~2 us where moving the records of a 1024-point node takes 7.  Two tied points that reach a leaf together, or a
 // split that falls among equal coordinates: 2 = take the forms that move the records (ktp_resolve, a query at a time).
 // rec: the records in index order, untouched.  -> 0 done, 1 not taken (the full build), 2 see above.  Uniform.
-template <typename IdxT>
-__device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, float* red, KtpShared* S, const float* rootbox, const int n, const int k,
-                                                 const int nq, const int* __restrict__ flist_c, const float* __restrict__ queries_c,
-                                                 IdxT* __restrict__ out_c, const int tid) {
+// GLOBAL: the points are read from the cloud in global memory (pts; rec unused) -- clouds of any size, no LDS but the bookkeeping's.
+template <typename IdxT, bool GLOBAL = false>
+__device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, const float* __restrict__ pts, float* red, KtpShared* S, const float* rootbox,
+                                                 const int n, const int k, const int nq, const int* __restrict__ flist_c,
+                                                 const float* __restrict__ queries_c, IdxT* __restrict__ out_c, const int tid) {
   constexpr int T = KTB_WAVES * 64;
   const int lane = tid & 63, wave = tid >> 6;
+  auto point = [&](const int p) -> float4 {
+    if (GLOBAL) return make_float4(pts[(size_t)p * 3], pts[(size_t)p * 3 + 1], pts[(size_t)p * 3 + 2], 0.f);
+    return rec[p];
+  };
   if (tid < nq) {
     const int j = flist_c[tid];
     S->qj[tid] = j;
@@ -2041,13 +2047,13 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, float* red, 
   __syncthreads();
   for (int i = tid; i < nq * k; i += T) {
     const int q = i / k, s0 = i - q * k;
-    const float4 r = rec[(int)out_c[(size_t)S->qj[q] * k + s0]];
+    const float4 r = point((int)out_c[(size_t)S->qj[q] * k + s0]);
     S->dkq[q][s0] = dist2(S->qxyz[q][0], S->qxyz[q][1], S->qxyz[q][2], r.x, r.y, r.z);
   }
   __syncthreads();
   // the tied points of every query: at a distance its row holds twice, or at its K-th distance
   for (int p = tid; p < n; p += T) {
-    const float4 r = rec[p];
+    const float4 r = point(p);
     for (int q = 0; q < nq; ++q) {
       const float* dk = S->dkq[q];
       const float d = dist2(S->qxyz[q][0], S->qxyz[q][1], S->qxyz[q][2], r.x, r.y, r.z), rk = dk[k - 1];
@@ -2080,7 +2086,7 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, float* red, 
   if (wave == 0) {
     if (lane < t) {
       m_idx = S->mem_idx[lane]; m_grp = S->mem_grp[lane]; m_node = 0;
-      const float4 r = rec[m_idx];
+      const float4 r = point(m_idx);
       px = r.x; py = r.y; pz = r.z;
       ux = S->qxyz[m_grp >> 8][0]; uy = S->qxyz[m_grp >> 8][1]; uz = S->qxyz[m_grp >> 8][2];
     }
@@ -2127,9 +2133,11 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, float* red, 
     // cut, lim2 = at or below it; f[0] min, f[3] max along cutfeat, f[1] the least coordinate above the cut, f[4] the greatest below
     int ci[3] = {0, 0, 0};
     float f[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float4 nxt = point(wave * 64 + lane < n ? wave * 64 + lane : 0);  // (one trip ahead: a trip's ballots keep the loop from being pipelined)
     for (int p0 = wave * 64; p0 < n; p0 += T) {
       const int p = p0 + lane;
-      const float4 r = rec[p < n ? p : 0];
+      const float4 r = nxt;
+      if (p0 + T < n) nxt = point(p + T < n ? p + T : 0);
       const float c[3] = {r.x, r.y, r.z};
       bool in = p < n;
 #pragma unroll
@@ -2271,16 +2279,18 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, float* red, 
   return 0;
 }
 
-template <typename IdxT>
+template <typename IdxT, bool GLOBAL>
 __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tie_path_kernel(int b, int n, int m, int k, const float* __restrict__ pts_all,
                                                                      const float* __restrict__ queries, IdxT* __restrict__ out,
                                                                      const int* __restrict__ nflag, const int* __restrict__ flist,
                                                                      int* __restrict__ nwork) {
   constexpr int T = KTB_WAVES * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // GLOBAL (clouds of more than KTB_LDS_NMAX points): no records in LDS, the set form reads the cloud; what it does not take goes on
+  const size_t rec_bytes = GLOBAL ? 0 : (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15);
   float4* rec = reinterpret_cast<float4*>(smem);                                          // [n]
   unsigned short* sc = reinterpret_cast<unsigned short*>(rec + n);                        // [n]
-  float* red = reinterpret_cast<float*>(smem + (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15));  // [KTP_RED_WORDS]
+  float* red = reinterpret_cast<float*>(smem + rec_bytes);                                // [KTP_RED_WORDS]
   KtpShared* S = reinterpret_cast<KtpShared*>(red + KTP_RED_WORDS);
   __shared__ float rootbox[6];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2324,12 +2334,15 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tie_path_kernel(int b, int
       continue;
     }
     const float* pts = pts_all + (size_t)cloud * n * 3;
-    kts_load_records(pts, n, rec, red, rootbox, tid);
+    kts_load_records<!GLOBAL>(pts, n, rec, red, rootbox, tid);
     KTP_MARK(2);
-    int rc = ktp_resolve_cloud<IdxT>(rec, red, S, rootbox, n, k, nq, flist + (size_t)cloud * m, queries + (size_t)cloud * m * 3,
-                                     out + (size_t)cloud * m * k, tid);
-    if (rc == 2) {  // two tied points in one leaf, or a split among equal coordinates: the form that moves the records, a query at a time
-      rc = 0;
+    int rc = ktp_resolve_cloud<IdxT, GLOBAL>(rec, pts, red, S, rootbox, n, k, nq, flist + (size_t)cloud * m, queries + (size_t)cloud * m * 3,
+                                             out + (size_t)cloud * m * k, tid);
+    if (rc == 0) KTP_COUNT(0);
+    if (rc == 1) KTP_COUNT(3);
+    if (rc == 2) KTP_COUNT(4);
+    if (rc == 2 && !GLOBAL) {  // two tied points in one leaf, or a split among equal coordinates: the form that moves the records, a query at a time
+      rc = 0;       // (clouds of thousands of points: their full build costs more than a few queries here)
       for (int e = 0; e < nq && rc == 0; ++e) {
         if (e > 0) kts_load_records(pts, n, rec, red, rootbox, tid);
         const int j = flist[(size_t)cloud * m + e];
@@ -2367,8 +2380,14 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #ifdef PASNL_TUNING
-  int kts_first = -1;
-  for (int c = 0; c < b && kts_first < 0; ++c) if (nflag[c] != 0) kts_first = c % gridDim.x;
+  // (the first listed cloud, found by the whole workgroup: one thread reading the counters one after the other cost every launch of
+  // the tuning build ~30 us and misled a round of experiments)
+  __shared__ int kts_first_s;
+  if (tid == 0) kts_first_s = 0x7fffffff;
+  __syncthreads();
+  for (int c = tid; c < b; c += KTB_WAVES * 64) if (nflag[c] != 0) atomicMin(&kts_first_s, c);
+  __syncthreads();
+  const int kts_first = kts_first_s == 0x7fffffff ? -1 : kts_first_s % (int)gridDim.x;
 #endif
 #ifdef PASNL_TUNING
   if (tid == 0) S->probe = blockIdx.x == kts_first ? 1 : 0;
@@ -2384,20 +2403,18 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
     bool resolved = false;
     if (nq <= KTP_FEWQ) {
       kts_load_records(pts, n, rec, part, rootbox, tid);
-      const int rc = ktp_resolve_cloud<IdxT>(rec, red, S, rootbox, n, k, nq, flist + (size_t)cloud * m, queries + (size_t)cloud * m * 3,
+      const int rc = ktp_resolve_cloud<IdxT>(rec, pts, red, S, rootbox, n, k, nq, flist + (size_t)cloud * m, queries + (size_t)cloud * m * 3,
                                             out + (size_t)cloud * m * k, tid);
       resolved = rc == 0;
       if (rc == 0) KTP_COUNT(0);
       if (rc == 1) KTP_COUNT(3);
       if (rc == 2) KTP_COUNT(4);
-      if (rc == 2) {  // two tied points in one leaf, or a split among equal coordinates: the form that moves the records, a query at a time
-        resolved = true;
-        for (int e = 0; e < nq && resolved; ++e) {
-          if (e > 0) kts_load_records(pts, n, rec, part, rootbox, tid);
-          const int j = flist[(size_t)cloud * m + e];
-          const float* qp = queries + ((size_t)cloud * m + j) * 3;
-          resolved = ktp_resolve<IdxT>(rec, sc, red, S, rootbox, n, k, qp[0], qp[1], qp[2], out + ((size_t)cloud * m + j) * k, tid) == 0;
-        }
+      if (rc == 2 && nq == 1) {  // two tied points in one leaf, or a split among equal coordinates: the form that moves the records (one query:
+        //                          ~20 us; more of them, one after the other, would cost more than the tree + parallel searches below)
+        const int j = flist[(size_t)cloud * m];
+        const float* qp = queries + ((size_t)cloud * m + j) * 3;
+        resolved = ktp_resolve<IdxT>(rec, sc, red, S, rootbox, n, k, qp[0], qp[1], qp[2], out + ((size_t)cloud * m + j) * k, tid) == 0;
+        if (resolved) KTP_COUNT(1);
       }
     }
     if (resolved) { KTS_MARK(31); continue; }  // (uniform)
@@ -3235,19 +3252,20 @@ extern "C" int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* sup
 // and (4) searched for exactly those queries, whose rows are overwritten.  A query that is not listed has a single possible
 // answer under both orders, so the output is cpp_knn_batch's bit for bit (knn_.cxx:72-135, nanoflann.hpp:119-123).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void knn_ref_clear_kernel(int b, int* __restrict__ nflag, int* __restrict__ nwork) {
+__global__ void knn_ref_clear_kernel(int b, int* __restrict__ nflag, int* __restrict__ nwork) {  // nwork: 2 b ints (both hand-over counters)
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < b) { nflag[i] = 0; nwork[i] = 0; }
+  if (i < b) { nflag[i] = 0; nwork[i] = 0; nwork[b + i] = 0; }
 }
 
 namespace {
-struct RefLayout { size_t nflag, nwork, flist, grid, tree, total; };
+struct RefLayout { size_t nflag, nwork, nwork2, flist, grid, tree, total; };
 RefLayout ref_layout(int b, int n, int m, int k) {
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   RefLayout L;
   L.nflag = 0;
   L.nwork = al((size_t)b * 4);
-  L.flist = L.nwork + al((size_t)b * 4);
+  L.nwork2 = L.nwork + (size_t)b * 4;  // (right behind: one clearing pass, one aligned block)
+  L.flist = L.nwork + al((size_t)b * 8);
   L.grid = L.flist + al((size_t)b * m * 4);
   L.tree = L.grid + al(k <= 64 ? pasnl::knn_grid_ws_bytes(b, n) : 0);
   L.total = L.tree + al(pasnl::knn_tree_ws_bytes(b, n, m, k));
@@ -3302,21 +3320,24 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
     return pasnl_launch_status();
   }
   const bool small = n <= pasnl::KTS_NMAX && k <= 64;  // one kernel: the tie paths of a cloud's few listed queries, else its tree + searches
-  if (n <= pasnl::KTB_LDS_NMAX && !small && pasnl::tune_env("PASNL_KNN_REF_NO_TIE_PATH") == nullptr) {
+  if (!small && pasnl::tune_env("PASNL_KNN_REF_NO_TIE_PATH") == nullptr) {
     // a FEW listed queries (chance ties): the runs of equal distances put in the tree's arrival order along the tree paths that
-    // separate them, a workgroup per query; `nwork` (b ints behind the lists' counters) = what is left to the builds below
+    // separate them, a workgroup per listed cloud; `nwork` (b ints behind the lists' counters) = what is left to the builds below.
+    // Clouds of more than KTB_LDS_NMAX points: the form that reads the cloud in global memory (no records in LDS).
     int* nwork = reinterpret_cast<int*>(base + L.nwork);
-    const size_t lds = pasnl::ktp_lds_bytes(n) + (pasnl::tune_env("PASNL_KTP_LDS_EXTRA") ? (size_t)atoi(pasnl::tune_env("PASNL_KTP_LDS_EXTRA")) : 0);
-#define PASNL_KTP(T)                                                                                                             \
+    const bool global = n > pasnl::KTB_LDS_NMAX;
+    const size_t lds = pasnl::ktp_lds_bytes(global ? 0 : n) + (pasnl::tune_env("PASNL_KTP_LDS_EXTRA") ? (size_t)atoi(pasnl::tune_env("PASNL_KTP_LDS_EXTRA")) : 0);
+#define PASNL_KTP(T, G)                                                                                                          \
     {                                                                                                                             \
-      auto kern = pasnl::knn_tie_path_kernel<T>;                                                                                  \
+      auto kern = pasnl::knn_tie_path_kernel<T, G>;                                                                               \
       if (lds > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                                  (int)lds) != hipSuccess)                                                         \
         return PASNL_ELAUNCH;                                                                                                     \
       hipLaunchKernelGGL(kern, dim3(pasnl::KTP_MAXQ), dim3(pasnl::KTB_WAVES * 64), lds, st, b, n, m, k, support, queries,          \
                          static_cast<T*>(idx), flags.nflag, flags.flist, nwork);                                                  \
     }
-    if (idx_is_i64) PASNL_KTP(long long) else PASNL_KTP(int)
+    if (global) { if (idx_is_i64) PASNL_KTP(long long, true) else PASNL_KTP(int, true) }
+    else { if (idx_is_i64) PASNL_KTP(long long, false) else PASNL_KTP(int, false) }
 #undef PASNL_KTP
     flags.nflag = nwork;
     if (pasnl::tune_env("PASNL_KNN_REF_TIE_PATH_ONLY")) return pasnl_launch_status();  // (tuning build: timing without the builds' launches)
@@ -3344,7 +3365,7 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
     // workspace: 455 us for a lidar-like 10240-point cloud): the tree on demand, along each search's path (177 us); `nwork` (b ints
     // behind the lists' counters) = what it leaves to the full builds below.  (Clouds up to 8192 points keep the full build: 225 us
     // with the records in LDS, against 170-300 per on-demand search on uniform clouds, whose searches reach ~100 nodes.)
-    int* nwork = reinterpret_cast<int*>(base + L.nwork);
+    int* nwork = reinterpret_cast<int*>(base + L.nwork2);  // (its input: what the tie paths left)
     const size_t lds = pasnl::ktl_lds_bytes(n);
     const int grid = pasnl::KTL_MAXQ;  // one workgroup per listed query
 #define PASNL_KTL(T)                                                                                                             \

@@ -84,11 +84,13 @@ def _knn_ref_dev(pts, queries, K, i64, out=None, max_workgroups=None, stats=None
     ws = torch.empty((max(nbytes, 256),), dtype=torch.uint8, device=pts.device)
     _hip.launch("pasnl_knn_batch_ref", "knn_batch", b, n, m, int(K), _hip.ptr(pts), _hip.ptr(queries), _hip.ptr(out), int(i64),
                 _hip.ptr(_depth_flag(pts.device)), _hip.ptr(ws), ctypes.c_size_t(nbytes), int(max_workgroups or 0))
-    if stats is not None:  # (tests, bench) the per-cloud numbers of queries that went through the tree: the workspace's first b ints;
-        # and, 256-byte aligned behind them, what the on-demand tree (few listed queries, clouds of 2049..10240 points) left to the full builds
+    if stats is not None:  # (tests, bench) per cloud: the listed queries (the workspace's first b ints); 256-byte aligned behind them what
+        # the tie paths left to the builds (clouds of up to 2048 points with K <= 64 resolve inside one kernel and report 0), and what the
+        # on-demand tree (clouds of 8193..10240 points) left to the full builds
         stats.append(ws[:4 * b].view(torch.int32))
         off = (4 * b + 255) // 256 * 256
         stats.append(ws[off:off + 4 * b].view(torch.int32))
+        stats.append(ws[off + 4 * b:off + 8 * b].view(torch.int32))
     return out
 
 

@@ -337,7 +337,7 @@ def test_few_listed_queries_take_the_on_demand_tree(n, k, kind, many):
     knn_tree_lazy_kernel builds the reference's KD-tree only along each search's path, a workgroup per listed query.  Ties are
     planted -- a few duplicated points -- so that a handful of queries in two clouds of four are listed; `many`: a dozen more in a
     third cloud, past the form's limit (the batch then takes the full builds).  Equal to the reference library, to
-    every-query-through-the-tree, and deterministic; `stats[1]` says which form ran."""
+    every-query-through-the-tree, and deterministic; `stats[1]`, `stats[2]` say which form ran."""
     from oracle import ref
     b = 4
     if kind == "kitti":
@@ -357,14 +357,17 @@ def test_few_listed_queries_take_the_on_demand_tree(n, k, kind, many):
     s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
     stats = []
     got = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, stats=stats)
-    counts, left = stats[0].cpu().numpy(), stats[1].cpu().numpy()
+    # stats: listed queries per cloud; what the tie paths left (duplicates share a leaf: its reading order needs positions -- clouds of
+    # more than 8192 points hand those on); what the on-demand tree left to the full builds
+    counts, left, left2 = stats[0].cpu().numpy(), stats[1].cpu().numpy(), stats[2].cpu().numpy()
     assert counts[0] >= 1 and counts[1] >= 2 and counts[3] <= 1, counts
+    assert ((left == 0) | (left == counts)).all(), (counts, left)
     if n <= 8192:
         pass                                             # (records fit the LDS: the full build is the faster form there)
-    elif counts.sum() > 32:
-        assert many and (left == counts).all(), (counts, left)                  # past the limit: the full builds took the batch
+    elif left.sum() > 32:
+        assert many and (left2 == left).all(), (counts, left, left2)            # past the limit: the full builds took what was left
     else:
-        assert not many and counts.sum() >= 3 and (left == 0).all(), (counts, left)   # every listed query got its own on-demand tree
+        assert not many and left.sum() >= 3 and (left2 == 0).all(), (counts, left, left2)   # every query left got its own on-demand tree
     again = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32)
     assert torch.equal(got, again)
     full = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="nanoflann")

@@ -36,7 +36,7 @@ def _run(sup, qry, k):
 
 
 @pytest.mark.parametrize("n,k,m", [(7, 3, 7), (40, 8, 20), (300, 16, 32), (1024, 32, 32), (1024, 1, 32), (2048, 64, 16),
-                                   (2048, 100, 8), (4096, 32, 16), (8192, 32, 8), (8192, 200, 4)])
+                                   (2048, 100, 8), (4096, 32, 16), (8192, 32, 8), (8192, 200, 4), (10240, 32, 8), (20000, 16, 4)])
 def test_tie_paths_equal_the_tree_search_and_the_reference(n, k, m):
     rng = np.random.default_rng(n * 131 + k)
     listed = left = 0
@@ -54,7 +54,7 @@ def test_tie_paths_equal_the_tree_search_and_the_reference(n, k, m):
     assert listed > 0 or n < 300
     # (clouds of up to 2048 points with k <= 64 resolve inside knn_tree_small_kernel and report nothing; the others report what the
     # tie paths left to the full builds: clouds whose listed queries have more than 64 tied points in all -- the coarse lattices at k >= 100)
-    assert left < listed or listed == 0, (listed, left)
+    assert left < listed or listed == 0 or n > 8192, (listed, left)  # (above 8192 points two tied points in one leaf are handed on)
 
 
 def test_many_listed_queries_of_one_cloud_and_many_listed_clouds():
@@ -70,7 +70,8 @@ def test_chance_ties_on_the_benchmark_shapes_are_resolved_without_a_tree():
     """The classifier's and the segmentation models' own search shapes (synthetic benchmark clouds + one planted tie each)."""
     import bench as B
 
-    for sup, m in [(B.synth_clouds(1, 8, 1024), 512), (np.ascontiguousarray(B.synth_scannet(3, 4, 8192)[..., :3]), 1024)]:
+    for sup, m in [(B.synth_clouds(1, 8, 1024), 512), (np.ascontiguousarray(B.synth_scannet(3, 4, 8192)[..., :3]), 1024),
+                   (np.ascontiguousarray(B.synth_kitti(4, 2, 10240)[..., :3]), 1280)]:
         sup = sup.copy()
         # a planted exact tie for query 0 of cloud 1: two points mirrored about it on a dyadic grid
         q0 = (np.round(sup[1, 0] * 256) / 256).astype(np.float32)
@@ -78,4 +79,6 @@ def test_chance_ties_on_the_benchmark_shapes_are_resolved_without_a_tree():
         sup[1, 1] = q0 + np.float32(1 / 512)
         sup[1, 2] = q0 - np.float32(1 / 512)
         nflag, nwork = _run(sup, np.ascontiguousarray(sup[:, :m]), 32)
-        assert nflag[1] >= 1 and nwork.sum() == 0, (nflag, nwork)
+        # (the two planted points are neighbours: they share a leaf.  Up to 8192 points the record-moving form reads its order; above, the
+        # on-demand tree takes the query -- stats[1] counts it)
+        assert nflag[1] >= 1 and (nwork.sum() == 0 or sup.shape[1] > 8192), (nflag, nwork)

@@ -8,12 +8,13 @@ import numpy as np
 import bench
 from pointasnl_amd.utils import pointasnl_util as U
 res = {}
+CFG = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 for rnd in range(3):
-    for tag, order, env in (("flags, no tree kernels", "reference", "PASNL_KNN_REF_NO_TREE"), ("dummy 1024 thr 128 vgpr 74 KB x64", "reference", "PASNL_KNN_REF_DUMMY=1024,128,75000,64"), ("dummy 1024 thr 64 vgpr 74 KB x64", "reference", "PASNL_KNN_REF_DUMMY=1024,64,75000,64"), ("dummy 1024 thr 32 vgpr 0 KB x64", "reference", "PASNL_KNN_REF_DUMMY=1024,32,0,64"), ("dummy 256 thr 128 vgpr 25 KB x64", "reference", "PASNL_KNN_REF_DUMMY=256,128,25000,64"), ("dummy 256 thr 128 vgpr 25 KB x8", "reference", "PASNL_KNN_REF_DUMMY=256,128,25000,8"), ("dummy 64 thr 128 vgpr 25 KB x64", "reference", "PASNL_KNN_REF_DUMMY=64,128,25000,64"), ("dummy 64 thr 32 vgpr 0 KB x64", "reference", "PASNL_KNN_REF_DUMMY=64,32,0,64"), ("default", "reference", None)):
+    for tag, order, env in (("canonical", "index", None), ("flags, no tree kernels", "reference", "PASNL_KNN_REF_NO_TREE"), ("default", "reference", None)):
         for e in ("PASNL_KNN_REF_NO_TREE", "PASNL_KNN_REF_NO_TIE_PATH", "PASNL_KNN_REF_TINY_ONLY", "PASNL_KNN_REF_TIE_PATH_ONLY", "PASNL_KNN_SMALL_GRID", "PASNL_KTP_LDS_EXTRA", "PASNL_KNN_REF_DUMMY"): os.environ.pop(e, None)
         for ev in ([env] if env and "DUMMY" in env else env.split(",") if env else ()): os.environ[ev.split("=", 1)[0]] = ev.split("=", 1)[1] if "=" in ev else "1"
         U.KNN_TIE_ORDER = order
-        r = bench.run_config(1, dict(bench.WORKLOADS[1]), 20, 5, graph=True, kernel_pass=False, announce=False, pipeline="prefetch", extra_blocks=2)
+        r = bench.run_config(CFG, dict(bench.WORKLOADS[CFG]), 20, 5, graph=True, kernel_pass=False, announce=False, pipeline="prefetch", extra_blocks=2)
         res.setdefault(tag, []).append(float(np.median(r["block_ms"])))
         print(rnd, tag, [round(v, 4) for v in r["block_ms"]], flush=True)
-for k, v in res.items(): print(k, round(float(np.median(v)), 4))
+for k, v in res.items(): print("cfg", CFG, k, round(float(np.median(v)), 4))
