@@ -1677,12 +1677,14 @@ constexpr int KTP_MAXW = 64;    // nodes split for one query
 constexpr int KTP_DEPTH = 126;  // levels whose near / far bit fits the 128-bit key
 constexpr int KTP_RED_WORDS = 256;  // [0, 96) min / max partials, [96, 160) the passes' masks (2 x 16 x 64 bits), [160, 192) divlow / divhigh partials
 struct KtpWork { unsigned left, right; float box[6]; int depth; };
-constexpr int KTP_FEWQ = 4;     // listed queries of one cloud resolved together
+constexpr int KTP_FEWQ = 16;    // listed queries of one cloud resolved together, at most (duplicated points list a dozen queries around them) ...
+constexpr int KTP_DK_WORDS = 1024;  // ... and as many as their rows' distances fit here
+__host__ __device__ inline int ktp_max_queries(int k) { return KTP_DK_WORDS / k < KTP_FEWQ ? KTP_DK_WORDS / k : KTP_FEWQ; }
 // a node of the descent WITHOUT records moved (ktp_resolve_cloud): the node's points are the cloud's points inside lo .. hi (bit d of
 // inc: lo[d] belongs to the node, bit 3 + d: hi[d] does); box: the box handed down to it (what middleSplit_ reads)
 struct KtiWork { float lo[3], hi[3], box[6]; int inc, depth; };
 struct KtpShared {
-  float dkq[KTP_FEWQ][PASNL_KNN_MAX_K];  // the canonical rows' distances (ascending); the one-query form uses dkq[0]
+  float dk[KTP_DK_WORDS];  // the canonical rows' distances (ascending), k per listed query
   float qxyz[KTP_FEWQ][4];
   int qj[KTP_FEWQ];
   int mem_idx[KTP_TMAX], mem_pos[KTP_TMAX], mem_grp[KTP_TMAX], mem_node[KTP_TMAX];  // a tied point per lane of wave 0: index, position,
@@ -1826,44 +1828,22 @@ __device__ __forceinline__ KtSplit ktp_split_node_1k(float4* rec, unsigned short
   __syncthreads();
   return o;
 }
-// One listed query, by the whole workgroup.  rec: the cloud's records in INDEX order (position == index); rootbox: the tight box
-// of the cloud (computeBoundingBox :1321-1346); orow: the query's canonical row, rewritten in place.  -> 0, or 1: not
-// resolved here (the row is untouched or partly in arrival order -- the caller hands the cloud to the full build).  Uniform.
+// The listed queries of one cloud with the records MOVED (ktp_list_tied has listed their tied points in S): the splits of the builds
+// on the cloud's records, so that positions are known -- what the set form (ktp_descend_sets below) cannot tell: the reading order of a
+// leaf that holds two points of a run (duplicated points: never separated), a split that falls among points exactly on the cut.
+// All queries share the one descent: a run's arrival order differs between queries only in the near / far bits.
+// rec: the cloud's records in INDEX order (position == index); rootbox: the tight box of the cloud (computeBoundingBox :1321-1346);
+// out_c: the cloud's rows, the listed ones rewritten in place.  -> 0, or 1: not resolved here (rows untouched or partly in arrival
+// order -- the caller hands the cloud to the full build).  Uniform.
 template <typename IdxT>
-__device__ __forceinline__ int ktp_resolve(float4* rec, unsigned short* sc, float* red, KtpShared* S, const float* rootbox, const int n, const int k,
-                           const float qx, const float qy, const float qz, IdxT* __restrict__ orow, const int tid) {
+__device__ __forceinline__ int ktp_descend_records(float4* rec, unsigned short* sc, float* red, KtpShared* S, const float* rootbox, const int n,
+                                                   const int k, IdxT* __restrict__ out_c, const int tid) {
   constexpr int T = KTB_WAVES * 64;
   const int lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  for (int i = tid; i < k; i += T) {
-    const float4 r = rec[(int)orow[i]];
-    S->dkq[0][i] = dist2(qx, qy, qz, r.x, r.y, r.z);
-  }
-  if (tid == 0) { S->nmem = 0; S->bad = 0; S->nw = 0; }
-  __syncthreads();
-  const float* dk = S->dkq[0];
-  const float rk = dk[k - 1];
-  // the tied points: every point at a distance the row holds twice, or at the K-th distance (the run that may reach outside the row)
-  for (int p = tid; p < n; p += T) {
-    const float4 r = rec[p];
-    const float d = dist2(qx, qy, qz, r.x, r.y, r.z);
-    if (d <= rk) {
-      int lo = 0, hi = k - 1;  // the first slot whose distance is >= d (slot k - 1 holds rk >= d)
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (dk[mid] < d) lo = mid + 1; else hi = mid;
-      }
-      if (dk[lo] != d) S->bad = 1;  // (a point inside the K-th distance that the row does not hold: not a canonical row)
-      else if (d == rk || dk[lo + 1] == d) {
-        const int slot = atomicAdd(&S->nmem, 1);
-        if (slot < KTP_TMAX) { S->mem_idx[slot] = p; S->mem_grp[slot] = lo; }
-      }
-    }
-  }
+  if (tid == 0) { S->bad = 0; S->nw = 0; }
   __syncthreads();
   const int t = S->nmem;
-  KTP_MARK(3);
-  if (S->bad != 0 || t > KTP_TMAX) return 1;
   // wave 0: one tied point per lane -- index, position, run (= its first slot in the row), the node it is in, its key; kept in LDS
   // between the steps (values held in registers across the splits cost more registers than a 1024-thread workgroup has)
   if (wave == 0) {
@@ -1929,7 +1909,7 @@ __device__ __forceinline__ int ktp_resolve(float4* rec, unsigned short* sc, floa
       const int depth = S->work[cur].depth;
       int nw_reg = S->nw;
       // searchLevel (:1380-1393): the child on the query's side of the gap first
-      const float val = sp.cutfeat == 0 ? qx : (sp.cutfeat == 1 ? qy : qz);
+      const float val = S->qxyz[lane < t ? (m_grp >> 8) : 0][sp.cutfeat];
       const float diff1 = val - sp.dl, diff2 = val - sp.dh;
       const int nearside = (diff1 + diff2) < 0 ? 0 : 1;
       const int side = (unsigned)m_pos >= xleft + sp.index ? 1 : 0;
@@ -1979,7 +1959,8 @@ __device__ __forceinline__ int ktp_resolve(float4* rec, unsigned short* sc, floa
       const bool before = oh < khi || (oh == khi && (ol < klo || (ol == klo && op < m_pos)));
       rank += (o != lane && og == m_grp && before) ? 1 : 0;
     }
-    if (lane < t && m_grp + rank < k) orow[m_grp + rank] = (IdxT)S->mem_idx[ml];
+    const int slot = (m_grp & 255) + rank;
+    if (lane < t && slot < k) out_c[(size_t)S->qj[m_grp >> 8] * k + slot] = (IdxT)S->mem_idx[ml];
   }
   __syncthreads();
   KTP_MARK(30);
@@ -2019,7 +2000,7 @@ __device__ __forceinline__ void kts_load_records(const float* __restrict__ pts, 
   }
   __syncthreads();
 }
-// The listed queries of ONE cloud together (nq <= KTP_FEWQ), WITHOUT moving a record: a node of the reference tree is a SET of points,
+// The listed queries of ONE cloud together (nq <= ktp_max_queries(k)), WITHOUT moving a record: a node of the reference tree is a SET of points,
 // and which child a point goes to is a comparison with the cut value -- positions decide only where points lie exactly on the cut
 // and the split falls among them (index = count / 2 strictly between lim1 and lim2, :1037-1042), and in which order a leaf is
 // read.  So a node is kept as the half-open box its ancestors' cuts left (KtiWork); a level is two passes of reductions over the
@@ -2048,14 +2029,14 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, const float*
   for (int i = tid; i < nq * k; i += T) {
     const int q = i / k, s0 = i - q * k;
     const float4 r = point((int)out_c[(size_t)S->qj[q] * k + s0]);
-    S->dkq[q][s0] = dist2(S->qxyz[q][0], S->qxyz[q][1], S->qxyz[q][2], r.x, r.y, r.z);
+    S->dk[q * k + s0] = dist2(S->qxyz[q][0], S->qxyz[q][1], S->qxyz[q][2], r.x, r.y, r.z);
   }
   __syncthreads();
   // the tied points of every query: at a distance its row holds twice, or at its K-th distance
   for (int p = tid; p < n; p += T) {
     const float4 r = point(p);
     for (int q = 0; q < nq; ++q) {
-      const float* dk = S->dkq[q];
+      const float* dk = S->dk + q * k;
       const float d = dist2(S->qxyz[q][0], S->qxyz[q][1], S->qxyz[q][2], r.x, r.y, r.z), rk = dk[k - 1];
       if (d <= rk) {
         int lo = 0, hi = k - 1;
@@ -2090,9 +2071,15 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, const float*
       px = r.x; py = r.y; pz = r.z;
       ux = S->qxyz[m_grp >> 8][0]; uy = S->qxyz[m_grp >> 8][1]; uz = S->qxyz[m_grp >> 8][2];
     }
-    bool peer = false;
-    for (int o = 0; o < t; ++o) peer |= (o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp);
-    if (n > KT_LEAF && __builtin_amdgcn_ballot_w64(lane < t && peer) != 0ull) {
+    bool peer = false, twin = false;
+    for (int o = 0; o < t; ++o) {
+      const bool same = o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp;
+      peer |= same;
+      twin |= same && readlane_f(px, o) == px && readlane_f(py, o) == py && readlane_f(pz, o) == pz;
+    }
+    if (n > KT_LEAF && __builtin_amdgcn_ballot_w64(lane < t && twin) != 0ull) {  // duplicated points: no cut separates them
+      if (lane == 0) S->bad = 2;
+    } else if (n > KT_LEAF && __builtin_amdgcn_ballot_w64(lane < t && peer) != 0ull) {
       nw_reg = 1;
       if (lane == 0) {
         KtiWork* w0 = &S->iwork[0];
@@ -2105,6 +2092,7 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, const float*
     if (lane == 0) S->stage = -1;
   }
   __syncthreads();
+  if (S->bad != 0) return S->bad;  // (uniform)
   int cur = 0, npass = 0;
   for (;;) {
     if (cur >= S->nw) break;  // (uniform: written before the last barrier)
@@ -2329,7 +2317,7 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tie_path_kernel(int b, int
     }
     __syncthreads();
     const int cloud = S->cloud, nq = nflag[cloud];
-    if (nq > KTP_FEWQ) {  // (uniform) a cloud of many ties: the full build
+    if (nq > ktp_max_queries(k)) {  // (uniform) a cloud of many ties: the full build
       if (tid == 0) atomicExch(&nwork[cloud], nq);
       continue;
     }
@@ -2341,14 +2329,9 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tie_path_kernel(int b, int
     if (rc == 0) KTP_COUNT(0);
     if (rc == 1) KTP_COUNT(3);
     if (rc == 2) KTP_COUNT(4);
-    if (rc == 2 && !GLOBAL) {  // two tied points in one leaf, or a split among equal coordinates: the form that moves the records, a query at a time
-      rc = 0;       // (clouds of thousands of points: their full build costs more than a few queries here)
-      for (int e = 0; e < nq && rc == 0; ++e) {
-        if (e > 0) kts_load_records(pts, n, rec, red, rootbox, tid);
-        const int j = flist[(size_t)cloud * m + e];
-        const float* qp = queries + ((size_t)cloud * m + j) * 3;
-        rc = ktp_resolve<IdxT>(rec, sc, red, S, rootbox, n, k, qp[0], qp[1], qp[2], out + ((size_t)cloud * m + j) * k, tid);
-      }
+    if (rc == 2 && !GLOBAL) {  // two tied points in one leaf (duplicated points), or a split among equal coordinates: the form that moves the records
+      rc = ktp_descend_records<IdxT>(rec, sc, red, S, rootbox, n, k, out + (size_t)cloud * m * k, tid);
+      if (rc == 0) KTP_COUNT(1);
     }
     if (rc != 0 && tid == 0) atomicExch(&nwork[cloud], nq);  // every listed query of the cloud, the done ones too (rows are simply written again)
   }
@@ -2401,7 +2384,7 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
     // A FEW listed queries (chance ties): their runs of equal distances put in arrival order along the tree paths that separate them
     // (ktp_resolve_cloud: ~10 us where tree + search take 85); anything it does not take: the tree and the searches below
     bool resolved = false;
-    if (nq <= KTP_FEWQ) {
+    if (nq <= ktp_max_queries(k)) {
       kts_load_records(pts, n, rec, part, rootbox, tid);
       const int rc = ktp_resolve_cloud<IdxT>(rec, pts, red, S, rootbox, n, k, nq, flist + (size_t)cloud * m, queries + (size_t)cloud * m * 3,
                                             out + (size_t)cloud * m * k, tid);
@@ -2409,13 +2392,9 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
       if (rc == 0) KTP_COUNT(0);
       if (rc == 1) KTP_COUNT(3);
       if (rc == 2) KTP_COUNT(4);
-      if (rc == 2 && nq == 1) {  // two tied points in one leaf, or a split among equal coordinates: the form that moves the records (one query:
-        //                          ~20 us; more of them, one after the other, would cost more than the tree + parallel searches below)
-        const int j = flist[(size_t)cloud * m];
-        const float* qp = queries + ((size_t)cloud * m + j) * 3;
-        resolved = ktp_resolve<IdxT>(rec, sc, red, S, rootbox, n, k, qp[0], qp[1], qp[2], out + ((size_t)cloud * m + j) * k, tid) == 0;
-        if (resolved) KTP_COUNT(1);
-      }
+      // (2: two tied points in one leaf -- duplicated points --, or a split among equal coordinates.  The form that moves the records,
+      // ktp_descend_records, walks one chain of ~8 splits per leaf involved, 60-180 us on the clouds met here: the tree + parallel
+      // searches below take 85.  It pays above 2048 points: knn_tie_path_kernel)
     }
     if (resolved) { KTS_MARK(31); continue; }  // (uniform)
     KTP_COUNT(2);
