@@ -165,16 +165,23 @@ int pasnl_knn_batch_tree(int b, int n, int m, int k, const float* support, const
  * replaces cpp_knn_batch / cpp_knn_batch_omp  knn_.cxx:72-135 (result-set order: nanoflann.hpp:115-134).
  * nanoflann's list can differ from the (distance, index) list only where distances are EQUAL -- two of them inside a query's
  * K-list, or a candidate beyond the list at exactly the K-th distance.  So: the canonical search (pasnl_knn_batch_ws's choice
- * of kernel) writes every row and, from the sorted keys it already holds, lists the queries with such a tie; then the KD-tree
- * of every cloud that has a listed query is built and searched for THOSE queries (pasnl_knn_batch_tree's kernels), whose rows
- * are overwritten.  All counts stay on the device: every kernel is launched and returns at once where nothing is listed -- no
- * host synchronisation, capturable.  Tie-free clouds pay four empty launches; output == pasnl_knn_batch_tree's bit for bit.
+ * of kernel) writes every row and, from the sorted keys it already holds, lists the queries with such a tie.  A listed row
+ * differs from nanoflann's only INSIDE its runs of equal distances, and two points of a run are reached by nanoflann's search in
+ * the order decided at the tree node that separates them (the query's near child first, :1380-1393; positions left to right in a
+ * leaf): for a FEW listed queries (<= 32 listed clouds, <= 16 queries and <= 64 tied points a cloud) only those nodes of the
+ * reference tree are computed -- as point sets, one pass of reductions over the cloud per level, no tree built, no search run;
+ * two tied points in one leaf (duplicated points): the records of a cloud of more than 2048 points are moved along that one
+ * path.  Everything else: the KD-tree of the cloud is built and searched for its listed queries (pasnl_knn_batch_tree's
+ * kernels).  All counts stay on the device: every kernel is launched and returns at once where nothing is listed -- no host
+ * synchronisation, capturable.  Tie-free clouds pay two to five empty launches; output == pasnl_knn_batch_tree's bit for bit.
  * depth_flag (device int, required): set to 1 -- never cleared by the library -- if a listed query's tree or search was deeper
  * than 96 levels; such rows KEEP the canonical order (valid neighbours, canonical order among equals).
  * max_workgroups > 0: the grid-pruned canonical search as a background job (pasnl_knn_batch_ws_bg); 0: the usual grid.
- * k <= n, k <= PASNL_KNN_MAX_K.  Clouds of up to 2048 points (k <= 64): tree and searches of a listed cloud in ONE workgroup, all
- * in LDS; larger ones: the builds of pasnl_knn_batch_tree + one wave per listed query.
- * workspace: pasnl_knn_batch_ref_workspace_bytes(b, n, m, k). */
+ * k <= n, k <= PASNL_KNN_MAX_K.  Clouds of up to 2048 points (k <= 64): ONE kernel after the search -- the tie paths of a cloud's
+ * <= 4 listed queries, else its tree and searches in one workgroup, all in LDS; larger ones: a tie-path kernel, then the builds
+ * of pasnl_knn_batch_tree + one wave per listed query.
+ * workspace: pasnl_knn_batch_ref_workspace_bytes(b, n, m, k); afterwards its first b int32 = the listed queries per cloud, and,
+ * 256-byte aligned behind them, 2 b int32: what the tie paths / the on-demand tree left to the next stage (diagnostics). */
 size_t pasnl_knn_batch_ref_workspace_bytes(int b, int n, int m, int k);
 int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* support, const float* queries, void* idx, int idx_is_i64,
                         int* depth_flag, void* workspace, size_t workspace_bytes, int max_workgroups, pasnl_stream_t stream);

@@ -1679,6 +1679,7 @@ constexpr int KTP_RED_WORDS = 256;  // [0, 96) min / max partials, [96, 160) the
 struct KtpWork { unsigned left, right; float box[6]; int depth; };
 constexpr int KTP_FEWQ = 16;    // listed queries of one cloud resolved together, at most (duplicated points list a dozen queries around them) ...
 constexpr int KTP_DK_WORDS = 1024;  // ... and as many as their rows' distances fit here
+constexpr int KTS_FEWQ = 4;         // ... in knn_tree_small_kernel (K <= 64: their rows always fit)
 __host__ __device__ inline int ktp_max_queries(int k) { return KTP_DK_WORDS / k < KTP_FEWQ ? KTP_DK_WORDS / k : KTP_FEWQ; }
 // a node of the descent WITHOUT records moved (ktp_resolve_cloud): the node's points are the cloud's points inside lo .. hi (bit d of
 // inc: lo[d] belongs to the node, bit 3 + d: hi[d] does); box: the box handed down to it (what middleSplit_ reads)
@@ -2384,7 +2385,7 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
     // A FEW listed queries (chance ties): their runs of equal distances put in arrival order along the tree paths that separate them
     // (ktp_resolve_cloud: ~10 us where tree + search take 85); anything it does not take: the tree and the searches below
     bool resolved = false;
-    if (nq <= ktp_max_queries(k)) {
+    if (nq <= KTS_FEWQ) {  // (more listed queries in a small cloud: duplicated points, as a rule -- the tree)
       kts_load_records(pts, n, rec, part, rootbox, tid);
       const int rc = ktp_resolve_cloud<IdxT>(rec, pts, red, S, rootbox, n, k, nq, flist + (size_t)cloud * m, queries + (size_t)cloud * m * 3,
                                             out + (size_t)cloud * m * k, tid);
@@ -3085,15 +3086,6 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_lazy_kernel(int b, in
 using namespace pasnl;
 #ifdef PASNL_TUNING
 extern "C" void pasnl_tuning_stamp(int slot, hipStream_t st);
-template <int VG>
-__global__ __launch_bounds__(1024) void pasnl_dummy_kernel(const int* nflag) {
-  extern __shared__ char dsm[];
-  if (nflag[0] == 123456789) {
-    if (VG == 128) asm volatile("v_mov_b32 v125, 0" ::: "v125");
-    if (VG == 64) asm volatile("v_mov_b32 v62, 0" ::: "v62");
-    dsm[threadIdx.x] = 1;
-  }
-}
 #endif
 
 // LDS of a subtree's workgroup: records + scratch positions (18 bytes per point) for a subtree of up to min(n, KTB_LDS_NMAX)
@@ -3284,20 +3276,6 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
   if (rc != PASNL_OK) return rc;
   PASNL_STAMP(1);
   if (pasnl::tune_env("PASNL_KNN_REF_NO_TREE")) return pasnl_launch_status();  // (tuning build: the canonical search + flags alone, A/B)
-#ifdef PASNL_TUNING
-  if (const char* dm = pasnl::tune_env("PASNL_KNN_REF_DUMMY")) {  // (tuning build: what does an EMPTY kernel of a given footprint cost the step)
-    int th = 256, vg = 128, ldsb = 0, gr = 64;
-    sscanf(dm, "%d,%d,%d,%d", &th, &vg, &ldsb, &gr);
-    auto kern = vg > 64 ? pasnl_dummy_kernel<128> : (vg > 32 ? pasnl_dummy_kernel<64> : pasnl_dummy_kernel<32>);
-    if (ldsb > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
-    hipLaunchKernelGGL(kern, dim3(gr), dim3(th), ldsb, st, flags.nflag);
-    return pasnl_launch_status();
-  }
-#endif
-  if (pasnl::tune_env("PASNL_KNN_REF_TINY_ONLY")) {  // (tuning build: what does ANY kernel behind the search cost the step)
-    hipLaunchKernelGGL(knn_tree_clear_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<int*>(base + L.nwork));
-    return pasnl_launch_status();
-  }
   const bool small = n <= pasnl::KTS_NMAX && k <= 64;  // one kernel: the tie paths of a cloud's few listed queries, else its tree + searches
   if (!small && pasnl::tune_env("PASNL_KNN_REF_NO_TIE_PATH") == nullptr) {
     // a FEW listed queries (chance ties): the runs of equal distances put in the tree's arrival order along the tree paths that
@@ -3305,7 +3283,7 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
     // Clouds of more than KTB_LDS_NMAX points: the form that reads the cloud in global memory (no records in LDS).
     int* nwork = reinterpret_cast<int*>(base + L.nwork);
     const bool global = n > pasnl::KTB_LDS_NMAX;
-    const size_t lds = pasnl::ktp_lds_bytes(global ? 0 : n) + (pasnl::tune_env("PASNL_KTP_LDS_EXTRA") ? (size_t)atoi(pasnl::tune_env("PASNL_KTP_LDS_EXTRA")) : 0);
+    const size_t lds = pasnl::ktp_lds_bytes(global ? 0 : n);
 #define PASNL_KTP(T, G)                                                                                                          \
     {                                                                                                                             \
       auto kern = pasnl::knn_tie_path_kernel<T, G>;                                                                               \
@@ -3323,7 +3301,7 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
   }
   if (small) {  // (tree + searches of a listed cloud in one workgroup, all in LDS)
     const size_t lds = pasnl::kts_lds_bytes(n);
-    const int grid = pasnl::tune_env("PASNL_KNN_REF_EMPTY_TREE") ? 0 : std::min(b, pasnl::tune_env("PASNL_KNN_SMALL_GRID") ? atoi(pasnl::tune_env("PASNL_KNN_SMALL_GRID")) : 64);
+    const int grid = pasnl::tune_env("PASNL_KNN_REF_EMPTY_TREE") ? 0 : std::min(b, 64);
     if (grid == 0) return pasnl_launch_status();
 #define PASNL_KTS(T)                                                                                                             \
     {                                                                                                                             \

@@ -4,7 +4,6 @@ import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["PASNL_STAMP_N"] = "1024"
-os.environ["PASNL_BENCH_STAMPS"] = "1"
 from pointasnl_amd import _hip
 _hip.LIB_PATH = os.path.join(ROOT, "pointasnl_amd", "csrc", "libpasnl_hip_tuning.so")
 import numpy as np
@@ -21,6 +20,5 @@ for order, env in (("index", None), ("reference", "PASNL_KNN_REF_NO_TREE"), ("re
         assert _hip.lib().pasnl_tuning_stamps_read(buf) == 0
         t = np.array(list(buf), dtype=np.float64) / 100.0  # us
         rows.append((r["ms_per_step"], t[4] - t[6], t[5] - t[4], t[7] - t[6], t[2] - t[7] if not env and order == "reference" else 0.0, t[5] - t[7]))
-        print("   step start -> head start %.1f | head (forward ends) %.1f | joins %.1f | head start -> sampler start %.1f, -> kNN start %.1f | sampler end -> step end %.1f" % (t[9] - t[8], t[10] - t[9], t[11] - t[10], t[4] - t[9], t[6] - t[9], t[11] - t[5]))
     for row in rows:
         print(order, env or "", "ms/step %.4f | sampler starts %+.1f us after the kNN kernel, runs %.1f | kNN %.1f | tree kernel %.1f | sampler ends %+.1f us after the kNN kernel" % row, flush=True)

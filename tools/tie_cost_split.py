@@ -1,4 +1,6 @@
-"""Where the default neighbour order's cost on the cls step comes from (tuning build): canonical / flags only / full default."""
+"""Where the default neighbour order's cost on a step comes from (tuning build): canonical / flags only / full default.
+python tools/tie_cost_split.py [cfg]  (the tuning build's probes make its kernels a little slower than the product library's:
+tools/tie_order_ab.py is the A/B on the product library)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,8 +13,8 @@ res = {}
 CFG = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 for rnd in range(3):
     for tag, order, env in (("canonical", "index", None), ("flags, no tree kernels", "reference", "PASNL_KNN_REF_NO_TREE"), ("default", "reference", None)):
-        for e in ("PASNL_KNN_REF_NO_TREE", "PASNL_KNN_REF_NO_TIE_PATH", "PASNL_KNN_REF_TINY_ONLY", "PASNL_KNN_REF_TIE_PATH_ONLY", "PASNL_KNN_SMALL_GRID", "PASNL_KTP_LDS_EXTRA", "PASNL_KNN_REF_DUMMY"): os.environ.pop(e, None)
-        for ev in ([env] if env and "DUMMY" in env else env.split(",") if env else ()): os.environ[ev.split("=", 1)[0]] = ev.split("=", 1)[1] if "=" in ev else "1"
+        for e in ("PASNL_KNN_REF_NO_TREE", "PASNL_KNN_REF_NO_TIE_PATH", "PASNL_KNN_REF_TIE_PATH_ONLY"): os.environ.pop(e, None)
+        if env: os.environ[env] = "1"
         U.KNN_TIE_ORDER = order
         r = bench.run_config(CFG, dict(bench.WORKLOADS[CFG]), 20, 5, graph=True, kernel_pass=False, announce=False, pipeline="prefetch", extra_blocks=2)
         res.setdefault(tag, []).append(float(np.median(r["block_ms"])))
