@@ -579,12 +579,18 @@ MODES = [
               "accumulation: fp32-grade (1e-5 of scale against fp64), not the fp32 chain's bits", dtype="f32 (bf16x3 products)"),
     dict(tag="canonical_tie_order", cfg=1, switches={"pointasnl_util.KNN_TIE_ORDER": "index"},
          what="neighbour lists in canonical (distance, index) order: the default (the reference's order among equal distances) minus "
-              "its tie flags and the four tree kernels that return at once on tie-free clouds -- the price of the default", dtype="f32"),
+              "its tie flags, the tie paths of the few listed queries (chance ties) and the tree kernels that return at once -- the "
+              "price of the default", dtype="f32"),
+    dict(tag="canonical_tie_order_cfg2", cfg=2, switches={"pointasnl_util.KNN_TIE_ORDER": "index"},
+         what="configs[2] with canonical neighbour order: random-weight adaptive sampling collapses neighbouring points into duplicates, "
+              "whose order in the reference is their leaf's reading order -- the default builds those clouds' trees", dtype="f32"),
     dict(tag="canonical_tie_order_cfg3", cfg=3, switches={"pointasnl_util.KNN_TIE_ORDER": "index"},
-         what="configs[3] with canonical neighbour order: what the default's tie handling costs on 8192-point clouds", dtype="f32"),
+         what="configs[3] with canonical neighbour order: what the default's tie handling costs on 8192-point clouds (set-form tie paths, "
+              "one record-moving descent where two tied points share a leaf)", dtype="f32"),
     dict(tag="canonical_tie_order_cfg4", cfg=4, switches={"pointasnl_util.KNN_TIE_ORDER": "index"},
-         what="configs[4] with canonical neighbour order: voxel-thinned lidar clouds have equal distances in ~0.15 % of the lists, so "
-              "the default builds the KD-tree of every cloud at the input level", dtype="f32"),
+         what="configs[4] with canonical neighbour order: the crops are padded by resampling (duplicated points: the tree of that cloud at "
+              "the second level), the 10240-point input level meets a chance tie per step (tie paths on the cloud in global memory)",
+         dtype="f32"),
     dict(tag="lattice_default_tie_order", cfg=1, switches={}, lattice=8,
          what="the DEFAULT on clouds made of ties: coordinates snapped to multiples of 1/8 (SURVEY 8(d) lattice stress set) -- nearly "
               "every query is flagged and goes through the rebuilt KD-tree (build + leaf-order search inside the graph)", dtype="f32"),

@@ -141,12 +141,15 @@ def knn_batch(pts, queries, K, omp=False, dtype=None, tie_order="reference", out
     """(B,N,3), (B,M,3) -> (B,M,K) neighbour indices (int64 like the reference; ``dtype=torch.int32`` skips
     the cast the models do at pointasnl_util.py:30).  ``omp`` is accepted and ignored.
     tie_order: "reference" (default, what the models use) = cpp_knn_batch's result bit for bit, its order among EXACTLY equal
-    distances (nanoflann's KD-tree visit order) included: the canonical search, then the rebuilt tree for the queries whose list
-    contains or ends on a tie (none on clouds with distinct distances: the plain search's price); K <= 256.  "index" = ascending (distance, index), the canonical order: the same list
+    distances (nanoflann's KD-tree visit order) included: the canonical search; for the queries whose list contains or ends on a
+    tie (none on clouds with distinct distances: the plain search's price) the runs of equal distances are put in that order -- for
+    a few such queries from the tree nodes that separate their tied points alone, else through the rebuilt tree; K <= 256.
+    "index" = ascending (distance, index), the canonical order: the same list
     wherever distances are distinct.  "nanoflann" = every query through the rebuilt tree (same result as "reference", slower:
     the checker).  A tree deeper than 96 levels raises a sticky flag: check_deferred_flags().
     out: optional device buffer (B,M,K) of the result's dtype to write into.  stats: a list that receives, per "reference"
-    search, the (B,) int32 device tensor of how many queries of each cloud went through the tree.
+    search, three (B,) int32 device tensors: the listed queries of each cloud, what the tie paths left to the builds, what the
+    on-demand tree left to the full builds.
     max_workgroups: run the search of a large cloud as a background job on at most that many workgroups (a side stream's
     search beside other work; the same results, see pasnl_knn_batch_ws_bg)."""
     host = not isinstance(pts, torch.Tensor)

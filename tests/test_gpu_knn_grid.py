@@ -207,7 +207,7 @@ def test_knn_nanoflann_parallel_build_matches_live_reference(n, m, k, kind):
 # ---- the default path (pasnl_knn_batch_ref): which queries it sends through the tree
 @pytest.mark.parametrize("name", ["ball_8192_self", "scannet_8192", "kitti_10240", "k64", "queries_outside", "translated_1e4"])
 def test_default_order_on_tie_free_clouds_flags_nothing_and_is_the_canonical_list(name):
-    """Clouds whose distances are distinct: no query is flagged (the four tree kernels return at once), the result is the
+    """Clouds whose distances are distinct: no query is flagged (the kernels behind the search return at once), the result is the
     canonical list bit for bit -- and the reference library's where it is here."""
     from oracle import ref
     sup, qry, k = CASES[name]
