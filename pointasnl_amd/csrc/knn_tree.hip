@@ -1679,6 +1679,7 @@ constexpr int KTP_RED_WORDS = 256;  // [0, 96) min / max partials, [96, 160) the
 struct KtpWork { unsigned left, right; float box[6]; int depth; };
 constexpr int KTP_FEWQ = 16;    // listed queries of one cloud resolved together, at most (duplicated points list a dozen queries around them) ...
 constexpr int KTP_DK_WORDS = 1024;  // ... and as many as their rows' distances fit here
+constexpr unsigned KTP_GUARD_ULPS = 8;  // see ktp_resolve_cloud: candidates this close above the K-th distance send the cloud to the real search
 constexpr int KTS_FEWQ = 4;         // ... in knn_tree_small_kernel (K <= 64: their rows always fit)
 __host__ __device__ inline int ktp_max_queries(int k) { return KTP_DK_WORDS / k < KTP_FEWQ ? KTP_DK_WORDS / k : KTP_FEWQ; }
 // a node of the descent WITHOUT records moved (ktp_resolve_cloud): the node's points are the cloud's points inside lo .. hi (bit d of
@@ -1687,7 +1688,7 @@ struct KtiWork { float lo[3], hi[3], box[6]; int inc, depth; };
 struct KtpShared {
   float dk[KTP_DK_WORDS];  // the canonical rows' distances (ascending), k per listed query
   float qxyz[KTP_FEWQ][4];
-  int qj[KTP_FEWQ];
+  int qj[KTP_FEWQ], qcnt[KTP_FEWQ];  // the query's number; points at or within KTP_GUARD_ULPS above its K-th distance
   int mem_idx[KTP_TMAX], mem_pos[KTP_TMAX], mem_grp[KTP_TMAX], mem_node[KTP_TMAX];  // a tied point per lane of wave 0: index, position,
   unsigned long long mem_khi[KTP_TMAX], mem_klo[KTP_TMAX];                           // run (query << 8 | its first slot in the row), node, key
   int cur_idx[KTP_TMAX], cur_m[KTP_TMAX];  // the tied points inside the node being split: index, lane
@@ -2026,6 +2027,7 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, const float*
     S->qxyz[tid][0] = queries_c[(size_t)j * 3]; S->qxyz[tid][1] = queries_c[(size_t)j * 3 + 1]; S->qxyz[tid][2] = queries_c[(size_t)j * 3 + 2];
   }
   if (tid == 0) { S->nmem = 0; S->bad = 0; S->nw = 0; }
+  if (tid < KTP_FEWQ) S->qcnt[tid] = 0;
   __syncthreads();
   for (int i = tid; i < nq * k; i += T) {
     const int q = i / k, s0 = i - q * k;
@@ -2039,6 +2041,7 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, const float*
     for (int q = 0; q < nq; ++q) {
       const float* dk = S->dk + q * k;
       const float d = dist2(S->qxyz[q][0], S->qxyz[q][1], S->qxyz[q][2], r.x, r.y, r.z), rk = dk[k - 1];
+      if (d <= __uint_as_float(__float_as_uint(rk) + KTP_GUARD_ULPS)) atomicAdd(&S->qcnt[q], 1);  // (about K of them)
       if (d <= rk) {
         int lo = 0, hi = k - 1;
         while (lo < hi) {
@@ -2057,6 +2060,11 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, const float*
   const int t = S->nmem;
   KTP_MARK(3);
   if (S->bad != 0 || t > KTP_TMAX) return 1;
+  // More than K candidates at or within a few ulps above the K-th distance (a run that reaches beyond the row's end, a (K+1)-th
+  // point next to the K-th): WHICH of them the reference keeps can hinge on the rounding of its pruning bound (mindistsq + cut_dist -
+  // dists[idx], nanoflann.hpp:1396-1404, may exceed the distance of a point IN that subtree by an ulp: the subtree is skipped) -- not
+  // a property of the tree's shape.  Only the real search reproduces that (found by tools/tie_path_fuzz.py: 1 listed query in 3.8 M)
+  for (int q = 0; q < nq; ++q) if (S->qcnt[q] > k) return 1;  // (uniform)
   // The descent.  A level = ONE pass of the workgroup over the cloud (the node's count, lim1, lim2 by ballots; its extremes along the cut
   // dimension by wave reductions), the waves' partials through LDS, and wave 0's turn: the split, the tied points' sides, the children
   // that still hold two of a run.  Two barriers a level.  (Measured: a level of a 1024-point cloud 4.4 us; by wave 0 alone, no

@@ -82,3 +82,23 @@ def test_chance_ties_on_the_benchmark_shapes_are_resolved_without_a_tree():
         # (the two planted points are neighbours: they share a leaf.  Up to 8192 points the record-moving form reads its order; above, the
         # on-demand tree takes the query -- stats[1] counts it)
         assert nflag[1] >= 1 and (nwork.sum() == 0 or sup.shape[1] > 8192), (nflag, nwork)
+
+
+def test_a_row_that_hinges_on_the_rounding_of_nanoflanns_pruning_bound():
+    """tests/golden/knn_prune_rounding_case.npz (make_knn_prune_case.py; found by tools/tie_path_fuzz.py): the reference's own list
+    misses a point CLOSER than its last three entries -- the bound of the subtree that holds it rounds one ulp above its distance and the
+    subtree is skipped.  More than K candidates crowd the K-th distance there: the tie paths hand such a cloud to the real search,
+    which reproduces the reference's row, skipped subtree included; the canonical order returns the exact neighbours instead."""
+    import os
+    import pointasnl_amd as P
+
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "knn_prune_rounding_case.npz"))
+    sup, qry, k, want = d["sup"], d["qry"], int(d["k"]), d["reference"]
+    s, q = torch.from_numpy(sup).cuda(), torch.from_numpy(qry).cuda()
+    stats = []
+    got = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, stats=stats).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert int(stats[0].sum()) == 1 and int(stats[1].sum()) == 1          # listed, and left to the tree + search
+    np.testing.assert_array_equal(P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="nanoflann").cpu().numpy(), want)
+    canon = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="index").cpu().numpy()
+    assert 6152 in canon[0, 0] and 6152 not in want[0, 0]

@@ -143,3 +143,15 @@ def test_three_weights_sum_to_one():
     d = np.abs(clouds(1, 3, 100, "cube"))
     w = O.three_weights(d)
     np.testing.assert_allclose(w.sum(-1), 1.0, rtol=1e-6)
+
+
+def test_the_prune_rounding_fixture_is_what_it_says():
+    """tests/golden/knn_prune_rounding_case.npz: the reference library's row misses point 6152, which the exact (distance, index) list
+    holds -- nanoflann skips its subtree on a pruning bound rounded one ulp above its distance (tests/test_gpu_tie_paths.py)."""
+    d = np.load(os.path.join(HERE, "knn_prune_rounding_case.npz"))
+    sup, qry, k, want = d["sup"], d["qry"], int(d["k"]), d["reference"]
+    idx, dist = O.knn_batch(sup, qry, k, return_dist=True)
+    assert 6152 in idx[0, 0] and 6152 not in want[0, 0]
+    dref = np.array([((np.float32(sup[0, i, 0] - qry[0, 0, 0]) ** 2 + np.float32(sup[0, i, 1] - qry[0, 0, 1]) ** 2) + np.float32(sup[0, i, 2] - qry[0, 0, 2]) ** 2)
+                     for i in want[0, 0]], np.float32)
+    assert (np.diff(dref) >= 0).all() and dref[-1] > dist[0, 0][list(idx[0, 0]).index(6152)]
