@@ -1675,10 +1675,11 @@ constexpr int KTP_MAXQ = 32;    // listed queries per batch this form takes (a w
 constexpr int KTP_TMAX = 64;    // tied points of one query (a lane each)
 constexpr int KTP_MAXW = 64;    // nodes split for one query
 constexpr int KTP_DEPTH = 126;  // levels whose near / far bit fits the 128-bit key
-constexpr int KTP_RED_WORDS = 256;  // [0, 96) min / max partials, [96, 160) the passes' masks (2 x 16 x 64 bits), [160, 192) divlow / divhigh partials
+constexpr int KTP_RED_WORDS = 384;  // [0, 96) min / max partials, [96, 352) the waves' ballots (ktp_split_node_1k: 2 x 16 x 64 bits, _8k: 128 x 64 bits), then 32 divlow / divhigh partials
 struct KtpWork { unsigned left, right; float box[6]; int depth; };
 constexpr int KTP_FEWQ = 16;    // listed queries of one cloud resolved together, at most (duplicated points list a dozen queries around them) ...
 constexpr int KTP_DK_WORDS = 1024;  // ... and as many as their rows' distances fit here
+constexpr int KTS_RED_WORDS = 192;  // the set form alone (knn_tree_small_kernel): 16 waves x 12 partials
 constexpr unsigned KTP_GUARD_ULPS = 8;  // see ktp_resolve_cloud: candidates this close above the K-th distance send the cloud to the real search
 constexpr int KTS_FEWQ = 4;         // ... in knn_tree_small_kernel (K <= 64: their rows always fit)
 __host__ __device__ inline int ktp_max_queries(int k) { return KTP_DK_WORDS / k < KTP_FEWQ ? KTP_DK_WORDS / k : KTP_FEWQ; }
@@ -1700,7 +1701,7 @@ struct KtpShared {
   float cutval;
   int wsum[KTB_WAVES];
 };
-__host__ __device__ inline size_t ktp_lds_bytes(int n) {  // (n = 0: the form that reads the cloud in global memory)
+__host__ __device__ constexpr size_t ktp_lds_bytes(int n) {  // (n = 0: the form that reads the cloud in global memory)
   return (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15) + KTP_RED_WORDS * 4 + ((sizeof(KtpShared) + 15) & ~(size_t)15);
 }
 __device__ __forceinline__ unsigned long long ktp_readlane_u64(unsigned long long v, int src) {
@@ -1830,6 +1831,148 @@ __device__ __forceinline__ KtSplit ktp_split_node_1k(float4* rec, unsigned short
   __syncthreads();
   return o;
 }
+// The same for a node of 1025 .. 8192 points: position p = e * 1024 + tid, e < 8 -- a thread holds nothing but its violators' ranks; the
+// cut coordinates are read from the records in LDS where needed.  The 64-position chunks c = e * 16 + wave are in position order:
+// lanes l and 64 + l of every wave take the ballots of chunks l and 64 + l, prefix sums over the lanes give every chunk the
+// violators before it and the satisfiers behind it.  A violator exchanges the two records itself (the pairs are disjoint).
+// (ktb_split_node_wg's general strides: 31 / 23 / 20 us for 8192 / 4096 / 2048 points as a call; this form: see EXPERIMENTS.)
+__device__ __forceinline__ KtSplit ktp_split_node_8k(float4* rec, unsigned short* sc, float* red, const float* box, const unsigned left,
+                                                     const unsigned count, const int tid) {
+  constexpr int T = KTB_WAVES * 64;
+  const int lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const unsigned right = left + count;
+  // ---- middleSplit_ (:966-1005); computeMinMax (:898-907) of all three dimensions
+  const float EPS = 0.00001f;
+  float max_span = box[1] - box[0];
+  for (int d = 1; d < 3; ++d) {
+    const float span = box[2 * d + 1] - box[2 * d];
+    if (span > max_span) max_span = span;
+  }
+  float mn3[3] = {INFINITY, INFINITY, INFINITY}, mx3[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (unsigned p = tid; p < count; p += T) {
+    const float4 r = rec[left + p];
+    const float c[3] = {r.x, r.y, r.z};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { mn3[d] = c[d] < mn3[d] ? c[d] : mn3[d]; mx3[d] = c[d] > mx3[d] ? c[d] : mx3[d]; }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { mn3[d] = wave_min_f32(mn3[d]); mx3[d] = wave_max_f32(mx3[d]); }
+  if (lane == 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { red[wave * 6 + 2 * d] = mn3[d]; red[wave * 6 + 2 * d + 1] = mx3[d]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    mn3[d] = wave_min_f32(red[(lane & (KTB_WAVES - 1)) * 6 + 2 * d]);
+    mx3[d] = wave_max_f32(red[(lane & (KTB_WAVES - 1)) * 6 + 2 * d + 1]);
+  }
+  float max_spread = -1.f, mn_c = 0.f, mx_c = 0.f;
+  int cutfeat = 0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float span = box[2 * d + 1] - box[2 * d];
+    if (span > (1 - EPS) * max_span) {
+      const float spread = mx3[d] - mn3[d];
+      if (spread > max_spread) { cutfeat = d; max_spread = spread; mn_c = mn3[d]; mx_c = mx3[d]; }
+    }
+  }
+  const float split_val = (box[2 * cutfeat] + box[2 * cutfeat + 1]) / 2;
+  float cutval;
+  if (split_val < mn_c) cutval = mn_c;
+  else if (split_val > mx_c) cutval = mx_c;
+  else cutval = split_val;
+  const float* cutc = reinterpret_cast<const float*>(rec) + cutfeat;  // cutc[4 i] = the cut coordinate of record i
+  // ---- planeSplit (:1016-1043)
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(red + 96);  // [128]: chunk c = e * 16 + wave
+  unsigned lim[2];
+  unsigned lo_p = 0;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if ((unsigned)((e + 1) * T) <= lo_p || (unsigned)(e * T) >= count) {  // (uniform) no position of this stride takes part
+        if (lane == 0) masks[e * KTB_WAVES + wave] = 0ull;
+        continue;
+      }
+      const unsigned p = (unsigned)(e * T + tid);
+      const bool in = p >= lo_p && p < count;
+      const float v = cutc[4 * (left + (in ? p : 0u))];
+      const unsigned long long mine = __builtin_amdgcn_ballot_w64(in && (pass == 0 ? v < cutval : v <= cutval));
+      if (lane == 0) masks[e * KTB_WAVES + wave] = mine;
+    }
+    __syncthreads();
+    const unsigned long long mA = masks[lane], mB = masks[64 + lane];
+    const int cA = (int)__builtin_popcountll(mA), cB = (int)__builtin_popcountll(mB);
+    const unsigned cnt = (unsigned)(__builtin_amdgcn_readlane(wave_inclusive_sum_i32(cA), 63) + __builtin_amdgcn_readlane(wave_inclusive_sum_i32(cB), 63));
+    const unsigned mid = lo_p + cnt;  // where the pointers meet
+    const unsigned long long belA = ktp_lanes_below((int)mid - 64 * lane), belB = ktp_lanes_below((int)mid - 64 * (64 + lane));
+    const unsigned long long inA = ktp_lanes_below((int)count - 64 * lane) & ~ktp_lanes_below((int)lo_p - 64 * lane);
+    const unsigned long long inB = ktp_lanes_below((int)count - 64 * (64 + lane)) & ~ktp_lanes_below((int)lo_p - 64 * (64 + lane));
+    const int vA = (int)__builtin_popcountll(inA & belA & ~mA), vB = (int)__builtin_popcountll(inB & belB & ~mB);  // violators in front of mid
+    const int rA = (int)__builtin_popcountll(mA & ~belA), rB = (int)__builtin_popcountll(mB & ~belB);              // satisfiers at or behind it
+    const int viA = wave_inclusive_sum_i32(vA), viB = wave_inclusive_sum_i32(vB), riA = wave_inclusive_sum_i32(rA), riB = wave_inclusive_sum_i32(rB);
+    const int vtotA = __builtin_amdgcn_readlane(viA, 63), rtotA = __builtin_amdgcn_readlane(riA, 63), rtot = rtotA + __builtin_amdgcn_readlane(riB, 63);
+    unsigned vrank[8];
+    unsigned isv = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      vrank[e] = 0;
+      if ((unsigned)((e + 1) * T) <= lo_p || (unsigned)(e * T) >= count) continue;  // (uniform)
+      const int c = e * KTB_WAVES + wave;  // (uniform)
+      const unsigned p = (unsigned)(e * T + tid);
+      const unsigned long long m = masks[c];
+      const unsigned long long below = ktp_lanes_below((int)mid - 64 * c);
+      const unsigned long long inw = ktp_lanes_below((int)count - 64 * c) & ~ktp_lanes_below((int)lo_p - 64 * c);
+      const unsigned long long myviol = inw & below & ~m, myrs = m & ~below;
+      const unsigned vbase = (unsigned)(e < 4 ? __builtin_amdgcn_readlane(viA - vA, c & 63) : vtotA + __builtin_amdgcn_readlane(viB - vB, c & 63));
+      const unsigned rincl = (unsigned)(e < 4 ? __builtin_amdgcn_readlane(riA, c & 63) : rtotA + __builtin_amdgcn_readlane(riB, c & 63));
+      const unsigned rbase = (unsigned)rtot - rincl;  // satisfiers behind this chunk
+      if ((myviol >> lane) & 1ull) {
+        vrank[e] = vbase + (unsigned)__builtin_popcountll(myviol & lt_mask);
+        isv |= 1u << e;
+        sc[left + lo_p + vrank[e]] = (unsigned short)p;
+      }
+      if ((myrs >> lane) & 1ull) {
+        const unsigned rank = rbase + ((unsigned)__builtin_popcountll(myrs) - 1u - (unsigned)__builtin_popcountll(myrs & lt_mask));
+        sc[right - 1 - rank] = (unsigned short)p;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if ((isv >> e) & 1u) {
+        const unsigned a = left + (unsigned)(e * T + tid), b = left + (unsigned)sc[right - 1 - vrank[e]];
+        const float4 ra = rec[a], rb = rec[b];
+        rec[a] = rb; rec[b] = ra;
+      }
+    }
+    __syncthreads();
+    lim[pass] = mid;
+    lo_p = mid;
+  }
+  unsigned index;
+  if (lim[0] > count / 2) index = lim[0];
+  else if (lim[1] < count / 2) index = lim[1];
+  else index = count / 2;
+  // ---- divlow = max of the left part, divhigh = min of the right part along cutfeat (:956-957)
+  float dl = -INFINITY, dh = INFINITY;
+  for (unsigned p = tid; p < count; p += T) {
+    const float v = cutc[4 * (left + p)];
+    if (p < index) dl = v > dl ? v : dl;
+    else dh = v < dh ? v : dh;
+  }
+  dl = wave_max_f32(dl); dh = wave_min_f32(dh);
+  if (lane == 0) { red[352 + wave * 2] = dl; red[352 + wave * 2 + 1] = dh; }
+  __syncthreads();
+  KtSplit o;
+  o.cutfeat = cutfeat; o.cutval = cutval; o.index = index;
+  o.dl = wave_max_f32(red[352 + (lane & (KTB_WAVES - 1)) * 2]);
+  o.dh = wave_min_f32(red[352 + (lane & (KTB_WAVES - 1)) * 2 + 1]);
+  __syncthreads();
+  return o;
+}
 // The listed queries of one cloud with the records MOVED (ktp_list_tied has listed their tied points in S): the splits of the builds
 // on the cloud's records, so that positions are known -- what the set form (ktp_descend_sets below) cannot tell: the reading order of a
 // leaf that holds two points of a run (duplicated points: never separated), a split that falls among points exactly on the cut.
@@ -1880,9 +2023,8 @@ __device__ __forceinline__ int ktp_descend_records(float4* rec, unsigned short* 
       if (lane == 0) S->ncur = (int)__builtin_popcountll(mm);
     }
     KtSplit sp;
-    if (count > (unsigned)T) {  // (the top of a large cloud: a real call, see ktb_split_node_wg_lds)
-      const float* bx = S->work[cur].box;
-      sp = ktb_split_node_wg_lds(rec, sc, red, bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], xleft, xright, tid);
+    if (count > (unsigned)T) {  // (the top of a large cloud)
+      sp = ktp_split_node_8k(rec, sc, red, S->work[cur].box, xleft, count, tid);
     } else if (count > 64u) {
       sp = ktp_split_node_1k(rec, sc, red, S->work[cur].box, xleft, count, tid);
     } else {
@@ -2346,11 +2488,12 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tie_path_kernel(int b, int
   }
 }
 
-__host__ __device__ inline size_t kts_lds_bytes(int n) {
+__host__ __device__ constexpr size_t kts_lds_bytes(int n) {
   const size_t lq = (size_t)(n / (KT_LEAF + 1)) + 2;
   return (size_t)n * 16 + (((size_t)n * 2 + 15) & ~(size_t)15) + (size_t)KTS_NNODES(n) * sizeof(KtNode) + 2 * lq * sizeof(KtWork) + 64 +
-         KTB_WAVES * 6 * 4 + (size_t)KTB_WAVES * KT_DEPTH * 3 * 4 + KTP_RED_WORDS * 4 + ((sizeof(KtpShared) + 15) & ~(size_t)15);
+         KTB_WAVES * 6 * 4 + (size_t)KTB_WAVES * KT_DEPTH * 3 * 4 + KTS_RED_WORDS * 4 + ((sizeof(KtpShared) + 15) & ~(size_t)15);
 }
+static_assert(kts_lds_bytes(KTS_NMAX) <= 160 * 1024 && ktp_lds_bytes(KTB_LDS_NMAX) <= 160 * 1024, "a workgroup's LDS");
 template <typename IdxT>
 __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, int n, int m, int k, const float* __restrict__ pts_all,
                                                                        const float* __restrict__ queries, IdxT* __restrict__ out,
@@ -2367,8 +2510,8 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
   float* rootbox = reinterpret_cast<float*>(ctr + 4);                                     // [6] (+ padding to 64 bytes)
   float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ctr) + 64);              // [KTB_WAVES][6]
   uint32_t* stacks = reinterpret_cast<uint32_t*>(part + KTB_WAVES * 6);                   // [KTB_WAVES][KT_DEPTH * 3]
-  float* red = reinterpret_cast<float*>(stacks + KTB_WAVES * KT_DEPTH * 3);               // [KTP_RED_WORDS] the tie paths' scratch
-  KtpShared* S = reinterpret_cast<KtpShared*>(red + KTP_RED_WORDS);
+  float* red = reinterpret_cast<float*>(stacks + KTB_WAVES * KT_DEPTH * 3);               // [KTS_RED_WORDS] the set form's partials
+  KtpShared* S = reinterpret_cast<KtpShared*>(red + KTS_RED_WORDS);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
 #ifdef PASNL_TUNING
