@@ -1,5 +1,7 @@
 """Randomised sweep of the default kNN order against the live reference library on tie-rich clouds (few listed queries per batch, so
-that the tie paths take them): python tools/tie_path_fuzz.py [seconds] [seed]"""
+that the tie paths take them): python tools/tie_path_fuzz.py [seconds] [seed] [plain]
+plain: float clouds as they come (no quantisation), every point a query -- queries with DISTINCT distances, which keep the canonical
+row: does the reference ever return something else there (its pruning bound's rounding)?"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +11,9 @@ from oracle import ref
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+plain = len(sys.argv) > 3 and sys.argv[3] == "plain"
 t0 = time.time()
+queries = 0
 cases = listed = left = bad = 0
 shapes = {}
 while time.time() - t0 < budget:
@@ -20,6 +24,8 @@ while time.time() - t0 < budget:
     m = int(rng.integers(1, 1 + min(n, 24)))
     q = int(rng.integers(2, 14))
     kind = rng.integers(0, 4)
+    if plain:
+        n = int(rng.integers(64, 4000)); k = int(min(n, rng.choice([8, 16, 32, 64]))); m = n; q = 30; kind = int(rng.integers(0, 3))
     sup = rng.normal(size=(b, n, 3)).astype(np.float32)
     if kind == 1: sup[..., 2] = 0            # a plane
     if kind == 2: sup[..., 1:] *= 0.01       # a needle
@@ -29,7 +35,7 @@ while time.time() - t0 < budget:
         for _ in range(int(rng.integers(1, 4))):
             i, j = rng.integers(0, n, 2)
             sup[:, i] = sup[:, j]
-    if rng.random() < 0.5:
+    if plain or rng.random() < 0.5:
         qry = np.ascontiguousarray(sup[:, rng.permutation(n)[:m]])
     else:
         qry = ((np.round(rng.normal(size=(b, m, 3)) * 2 ** q) / 2 ** q) * 0.4).astype(np.float32)
@@ -39,6 +45,7 @@ while time.time() - t0 < budget:
                                         dtype=torch.int64 if i64 else torch.int32, stats=stats).cpu().numpy()
     want = ref.knn_batch(sup, qry, k)
     cases += 1
+    queries += b * m
     listed += int(stats[0].sum()); left += int(stats[1].sum())
     key = "n<=2048,k<=64" if n <= 2048 and k <= 64 else ("n<=8192" if n <= 8192 else "n>8192")
     shapes[key] = shapes.get(key, 0) + int(stats[0].sum())
@@ -46,4 +53,4 @@ while time.time() - t0 < budget:
         bad += 1
         print("MISMATCH n", n, "k", k, "b", b, "m", m, "q", q, "kind", kind, "i64", i64, "listed", stats[0].tolist(), "left", stats[1].tolist(), flush=True)
         np.savez(os.path.join(ROOT, "gpurun_out", f"fuzz_fail_{cases}.npz"), sup=sup, qry=qry, k=k)
-print(f"{cases} batches, {listed} listed queries ({shapes}), {left} left to the builds by the standalone tie-path kernel, mismatches: {bad}")
+print(f"{cases} batches, {queries} queries, {listed} listed queries ({shapes}), {left} left to the builds by the standalone tie-path kernel, mismatches: {bad}")
