@@ -1673,15 +1673,14 @@ __device__ int ktp_paths[8];       // clouds by the form that took them: [0] set
 #endif
 constexpr int KTP_MAXQ = 32;    // listed queries per batch this form takes (a workgroup each)
 constexpr int KTP_TMAX = 64;    // tied points of one query (a lane each)
-constexpr int KTP_MAXW = 64;    // nodes split for one query
+constexpr int KTP_MAXW = 32;    // nodes split for one cloud's listed queries
 constexpr int KTP_DEPTH = 126;  // levels whose near / far bit fits the 128-bit key
 constexpr int KTP_RED_WORDS = 384;  // [0, 96) min / max partials, [96, 352) the waves' ballots (ktp_split_node_1k: 2 x 16 x 64 bits, _8k: 128 x 64 bits), then 32 divlow / divhigh partials
 struct KtpWork { unsigned left, right; float box[6]; int depth; };
 constexpr int KTP_FEWQ = 16;    // listed queries of one cloud resolved together, at most (duplicated points list a dozen queries around them) ...
 constexpr int KTP_DK_WORDS = 1024;  // ... and as many as their rows' distances fit here
-constexpr int KTS_RED_WORDS = 192;  // the set form alone (knn_tree_small_kernel): 16 waves x 12 partials
+constexpr int KTS_RED_WORDS = 384;  // (knn_tree_small_kernel: the same; kept apart to keep its LDS budget in view)
 constexpr unsigned KTP_GUARD_ULPS = 8;  // see ktp_resolve_cloud: candidates this close above the K-th distance send the cloud to the real search
-constexpr int KTS_FEWQ = 4;         // ... in knn_tree_small_kernel (K <= 64: their rows always fit)
 __host__ __device__ inline int ktp_max_queries(int k) { return KTP_DK_WORDS / k < KTP_FEWQ ? KTP_DK_WORDS / k : KTP_FEWQ; }
 // a node of the descent WITHOUT records moved (ktp_resolve_cloud): the node's points are the cloud's points inside lo .. hi (bit d of
 // inc: lo[d] belongs to the node, bit 3 + d: hi[d] does); box: the box handed down to it (what middleSplit_ reads)
@@ -1690,13 +1689,17 @@ struct KtpShared {
   float dk[KTP_DK_WORDS];  // the canonical rows' distances (ascending), k per listed query
   float qxyz[KTP_FEWQ][4];
   int qj[KTP_FEWQ], qcnt[KTP_FEWQ];  // the query's number; points at or within KTP_GUARD_ULPS above its K-th distance
-  int mem_idx[KTP_TMAX], mem_pos[KTP_TMAX], mem_grp[KTP_TMAX], mem_node[KTP_TMAX];  // a tied point per lane of wave 0: index, position,
-  unsigned long long mem_khi[KTP_TMAX], mem_klo[KTP_TMAX];                           // run (query << 8 | its first slot in the row), node, key
-  int cur_idx[KTP_TMAX], cur_m[KTP_TMAX];  // the tied points inside the node being split: index, lane
+  int mem_idx[KTP_TMAX], mem_grp[KTP_TMAX], mem_pt[KTP_TMAX];  // a tied (query, point) per lane of wave 0: the point's index, its run
+  unsigned long long mem_khi[KTP_TMAX], mem_klo[KTP_TMAX];      // (query << 8 | the run's first slot in the row), its point's slot below, its key
+  // ktp_descend_records: the DISTINCT tied points (a duplicated pair is listed by a dozen queries): index, position, node, side at the
+  // last split, and the points it shares a run with (bit per point slot)
+  int pt_idx[KTP_TMAX], pt_pos[KTP_TMAX], pt_node[KTP_TMAX], pt_side[KTP_TMAX];
+  unsigned long long pt_peer[KTP_TMAX];
+  int cur_idx[KTP_TMAX], cur_m[KTP_TMAX];  // the tied points inside the node being split: index, point slot
   union { KtpWork work[KTP_MAXW]; KtiWork iwork[KTP_MAXW]; };
   KtSplit split;
   int nmem, nw, ncur, bad;
-  int cloud, entry, probe;
+  int cloud, entry, probe, npts;
   int stage, cutfeat, adv;  // the set form's pass over the current node: -1 fresh, 0 min / max of all dimensions, 1 the cut at the box's middle, 2 at the points' edge
   float cutval;
   int wsum[KTB_WAVES];
@@ -1989,35 +1992,48 @@ __device__ __forceinline__ int ktp_descend_records(float4* rec, unsigned short* 
   if (tid == 0) { S->bad = 0; S->nw = 0; }
   __syncthreads();
   const int t = S->nmem;
-  // wave 0: one tied point per lane -- index, position, run (= its first slot in the row), the node it is in, its key; kept in LDS
-  // between the steps (values held in registers across the splits cost more registers than a 1024-thread workgroup has)
+  // wave 0, two views: lane = a tied (query, point) -- its key; lane = a distinct tied POINT -- position, node (state in LDS between
+  // the steps: values held in registers across the splits cost more registers than a 1024-thread workgroup has)
   if (wave == 0) {
-    int m_grp = -1 - lane;
+    const int m_idx = lane < t ? S->mem_idx[lane] : -1 - lane, m_grp = lane < t ? S->mem_grp[lane] : -1 - lane;
+    int rep = lane;  // the first lane that lists the same point
+    for (int o = t - 1; o >= 0; --o) if (__builtin_amdgcn_readlane(m_idx, o) == m_idx) rep = o;
+    const unsigned long long firsts = __builtin_amdgcn_ballot_w64(lane < t && rep == lane);
+    const int npts = (int)__builtin_popcountll(firsts);
+    const int pslot = (int)__builtin_popcountll(firsts & ktp_lanes_below(rep));
     if (lane < t) {
-      const int m_idx = S->mem_idx[lane];
-      m_grp = S->mem_grp[lane];
-      S->mem_pos[lane] = m_idx; S->mem_node[lane] = 0; S->mem_khi[lane] = 0ull; S->mem_klo[lane] = 0ull;
+      S->mem_pt[lane] = pslot; S->mem_khi[lane] = 0ull; S->mem_klo[lane] = 0ull;
+      if (rep == lane) { S->pt_idx[pslot] = m_idx; S->pt_pos[pslot] = m_idx; S->pt_node[pslot] = 0; S->pt_peer[pslot] = 0ull; }
     }
-    bool peer = false;
-    for (int o = 0; o < t; ++o) peer |= (o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp);
-    if (n > KT_LEAF && __builtin_amdgcn_ballot_w64(lane < t && peer) != 0ull && lane == 0) {
+    ktb_wave_sync();
+    unsigned long long peers = 0ull;
+    for (int o = 0; o < t; ++o) {
+      const int ps = __builtin_amdgcn_readlane(pslot, o);
+      if (o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp) peers |= 1ull << ps;
+    }
+    if (lane < t && peers != 0ull) atomicOr(&S->pt_peer[pslot], peers);
+    ktb_wave_sync();
+    const unsigned long long pk = lane < npts ? S->pt_peer[lane] & ~(1ull << lane) : 0ull;
+    if (n > KT_LEAF && __builtin_amdgcn_ballot_w64(pk != 0ull) != 0ull && lane == 0) {
       KtpWork w0;
       w0.left = 0u; w0.right = (unsigned)n; w0.depth = 0;
       for (int i = 0; i < 6; ++i) w0.box[i] = rootbox[i];
       S->work[0] = w0;
       S->nw = 1;
     }
+    if (lane == 0) S->npts = npts;
   }
   __syncthreads();
+  const int npts = S->npts;
   for (int cur = 0;; ++cur) {
     if (cur >= S->nw) break;  // (uniform: written before the last barrier)
     const unsigned xleft = S->work[cur].left, xright = S->work[cur].right, count = xright - xleft;
     if (wave == 0) {
-      const bool mine = lane < t && S->mem_node[lane < t ? lane : 0] == cur;
+      const bool mine = lane < npts && S->pt_node[lane < npts ? lane : 0] == cur;
       const unsigned long long mm = __builtin_amdgcn_ballot_w64(mine);
       if (mine) {
         const int s0 = (int)__builtin_popcountll(mm & lt_mask);
-        S->cur_idx[s0] = S->mem_idx[lane];
+        S->cur_idx[s0] = S->pt_idx[lane];
         S->cur_m[s0] = lane;
       }
       if (lane == 0) S->ncur = (int)__builtin_popcountll(mm);
@@ -2025,14 +2041,14 @@ __device__ __forceinline__ int ktp_descend_records(float4* rec, unsigned short* 
     KtSplit sp;
     if (count > (unsigned)T) {  // (the top of a large cloud)
       sp = ktp_split_node_8k(rec, sc, red, S->work[cur].box, xleft, count, tid);
-    } else if (count > 64u) {
+    } else if (count > 256u) {
       sp = ktp_split_node_1k(rec, sc, red, S->work[cur].box, xleft, count, tid);
-    } else {
+    } else {  // one wave: 4-5 us for 65 .. 256 points (passes over LDS), ~1.5 for <= 64 (in registers); the workgroup's form: 7.5 whatever the size
       if (wave == 0) {
         KtWork wk;
         wk.node = 0; wk.left = xleft; wk.right = xright;
         for (int i = 0; i < 6; ++i) wk.box[i] = S->work[cur].box[i];
-        const KtSplit s1 = ktb_split_node_small(rec, sc, wk, xleft, count, lane, lt_mask);
+        const KtSplit s1 = ktb_split_node(rec, sc, wk, xleft, xright, lane, lt_mask);
         if (lane == 0) S->split = s1;
       }
       __syncthreads();
@@ -2043,49 +2059,58 @@ __device__ __forceinline__ int ktp_descend_records(float4* rec, unsigned short* 
     for (unsigned p = xleft + tid; p < xright; p += T) {
       const int w = __float_as_int(rec[p].w);
       for (int s0 = 0; s0 < ncur; ++s0)
-        if (S->cur_idx[s0] == w) S->mem_pos[S->cur_m[s0]] = (int)p;
+        if (S->cur_idx[s0] == w) S->pt_pos[S->cur_m[s0]] = (int)p;
     }
     __syncthreads();
     if (wave == 0) {
-      const int ml = lane < t ? lane : 0;
-      const bool mine = lane < t && S->mem_node[ml] == cur;
-      const int m_grp = lane < t ? S->mem_grp[ml] : -1 - lane, m_pos = S->mem_pos[ml];
       const int depth = S->work[cur].depth;
-      int nw_reg = S->nw;
-      // searchLevel (:1380-1393): the child on the query's side of the gap first
-      const float val = S->qxyz[lane < t ? (m_grp >> 8) : 0][sp.cutfeat];
-      const float diff1 = val - sp.dl, diff2 = val - sp.dh;
-      const int nearside = (diff1 + diff2) < 0 ? 0 : 1;
-      const int side = (unsigned)m_pos >= xleft + sp.index ? 1 : 0;
-      if (mine && side != nearside) {
-        if (depth < 64) S->mem_khi[ml] |= 1ull << (63 - depth); else S->mem_klo[ml] |= 1ull << (127 - depth);
-      }
-      bool fail = false;
-      int node_next = -1;
+      // the (query, point) view, first half: is its point in this node
+      const int mpt = lane < t ? S->mem_pt[lane] : 0;
+      const bool m_mine = lane < t && S->pt_node[mpt] == cur;
+      ktb_wave_sync();
+      // the point view: sides, and the children that still hold two points of a run
+      {
+        const int pl = lane < npts ? lane : 0;
+        const bool mine = lane < npts && S->pt_node[pl] == cur;
+        const unsigned long long pk = lane < npts ? S->pt_peer[pl] & ~(1ull << lane) : 0ull;
+        const int side = (unsigned)S->pt_pos[pl] >= xleft + sp.index ? 1 : 0;
+        if (mine) S->pt_side[pl] = side;
+        int nw_reg = S->nw;
+        bool fail = false;
+        int node_next = -1;
 #pragma unroll 1
-      for (int c = 0; c < 2; ++c) {
-        const unsigned cl = c == 0 ? xleft : xleft + sp.index, cr = c == 0 ? xleft + sp.index : xright;
-        const bool in_c = mine && side == c;
-        const unsigned long long cm = __builtin_amdgcn_ballot_w64(in_c);
-        bool peer = false;
-        for (int o = 0; o < t; ++o) peer |= (((cm >> o) & 1ull) != 0ull && o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp);
-        int e = -1;
-        if (cr - cl > (unsigned)KT_LEAF && __builtin_amdgcn_ballot_w64(in_c && peer) != 0ull) {  // two of a run in an inner node: split it too
-          if (nw_reg >= KTP_MAXW || depth + 1 >= KTP_DEPTH) fail = true;
-          else {
-            e = nw_reg++;
-            if (lane == 0) {
-              KtpWork w1;
-              w1.left = cl; w1.right = cr; w1.depth = depth + 1;
-              for (int i = 0; i < 6; ++i) w1.box[i] = (i == 2 * sp.cutfeat + 1 - c) ? sp.cutval : S->work[cur].box[i];
-              S->work[e] = w1;
+        for (int c = 0; c < 2; ++c) {
+          const unsigned cl = c == 0 ? xleft : xleft + sp.index, cr = c == 0 ? xleft + sp.index : xright;
+          const bool in_c = mine && side == c;
+          const unsigned long long cm = __builtin_amdgcn_ballot_w64(in_c);
+          int e = -1;
+          if (cr - cl > (unsigned)KT_LEAF && __builtin_amdgcn_ballot_w64(in_c && (pk & cm) != 0ull) != 0ull) {  // two of a run in an inner node: split it too
+            if (nw_reg >= KTP_MAXW || depth + 1 >= KTP_DEPTH) fail = true;
+            else {
+              e = nw_reg++;
+              if (lane == 0) {
+                KtpWork w1;
+                w1.left = cl; w1.right = cr; w1.depth = depth + 1;
+                for (int i = 0; i < 6; ++i) w1.box[i] = (i == 2 * sp.cutfeat + 1 - c) ? sp.cutval : S->work[cur].box[i];
+                S->work[e] = w1;
+              }
             }
           }
+          if (in_c) node_next = e;
         }
-        if (in_c) node_next = e;
+        if (mine) S->pt_node[pl] = node_next;
+        if (lane == 0) { S->nw = nw_reg; if (fail) S->bad = 1; }
       }
-      if (mine) S->mem_node[ml] = node_next;
-      if (lane == 0) { S->nw = nw_reg; if (fail) S->bad = 1; }
+      ktb_wave_sync();
+      // the (query, point) view, second half.  searchLevel (:1380-1393): the child on the query's side of the gap first
+      if (m_mine) {
+        const float val = S->qxyz[S->mem_grp[lane] >> 8][sp.cutfeat];
+        const float diff1 = val - sp.dl, diff2 = val - sp.dh;
+        const int nearside = (diff1 + diff2) < 0 ? 0 : 1;
+        if (S->pt_side[mpt] != nearside) {
+          if (depth < 64) S->mem_khi[lane] |= 1ull << (63 - depth); else S->mem_klo[lane] |= 1ull << (127 - depth);
+        }
+      }
     }
     __syncthreads();
     if (cur < 24) KTP_MARK(4 + cur);
@@ -2094,7 +2119,7 @@ __device__ __forceinline__ int ktp_descend_records(float4* rec, unsigned short* 
   // a run in arrival order: (key, position) ascending, from the run's first slot on; what does not fit the row is dropped
   if (wave == 0) {
     const int ml = lane < t ? lane : 0;
-    const int m_grp = lane < t ? S->mem_grp[ml] : -1 - lane, m_pos = S->mem_pos[ml];
+    const int m_grp = lane < t ? S->mem_grp[ml] : -1 - lane, m_pos = S->pt_pos[S->mem_pt[ml]];
     const unsigned long long khi = S->mem_khi[ml], klo = S->mem_klo[ml];
     int rank = 0;
     for (int o = 0; o < t; ++o) {
@@ -2222,12 +2247,14 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, const float*
       px = r.x; py = r.y; pz = r.z;
       ux = S->qxyz[m_grp >> 8][0]; uy = S->qxyz[m_grp >> 8][1]; uz = S->qxyz[m_grp >> 8][2];
     }
-    bool peer = false, twin = false;
+    bool peer = false, twin = false, first = lane < t;
     for (int o = 0; o < t; ++o) {
       const bool same = o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp;
       peer |= same;
       twin |= same && readlane_f(px, o) == px && readlane_f(py, o) == py && readlane_f(pz, o) == pz;
+      first = first && !(o < lane && __builtin_amdgcn_readlane(m_idx, o) == m_idx);
     }
+    if (lane == 0) S->npts = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(first));  // distinct tied points (several queries list the same)
     if (n > KT_LEAF && __builtin_amdgcn_ballot_w64(lane < t && twin) != 0ull) {  // duplicated points: no cut separates them
       if (lane == 0) S->bad = 2;
     } else if (n > KT_LEAF && __builtin_amdgcn_ballot_w64(lane < t && peer) != 0ull) {
@@ -2536,7 +2563,7 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
     // A FEW listed queries (chance ties): their runs of equal distances put in arrival order along the tree paths that separate them
     // (ktp_resolve_cloud: ~10 us where tree + search take 85); anything it does not take: the tree and the searches below
     bool resolved = false;
-    if (nq <= KTS_FEWQ) {  // (more listed queries in a small cloud: duplicated points, as a rule -- the tree)
+    if (nq <= ktp_max_queries(k)) {
       kts_load_records(pts, n, rec, part, rootbox, tid);
       const int rc = ktp_resolve_cloud<IdxT>(rec, pts, red, S, rootbox, n, k, nq, flist + (size_t)cloud * m, queries + (size_t)cloud * m * 3,
                                             out + (size_t)cloud * m * k, tid);
@@ -2544,9 +2571,13 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tree_small_kernel(int b, i
       if (rc == 0) KTP_COUNT(0);
       if (rc == 1) KTP_COUNT(3);
       if (rc == 2) KTP_COUNT(4);
-      // (2: two tied points in one leaf -- duplicated points --, or a split among equal coordinates.  The form that moves the records,
-      // ktp_descend_records, walks one chain of ~8 splits per leaf involved, 60-180 us on the clouds met here: the tree + parallel
-      // searches below take 85.  It pays above 2048 points: knn_tie_path_kernel)
+      // 2: two tied points in one leaf -- duplicated points --, or a split among equal coordinates.  The form that moves the records walks
+      // one chain of ~8 splits per leaf involved (~50 us), the tree + parallel searches below take 85-120: it pays for one or two
+      // leaves -- at most four distinct tied points, however many queries list them (a duplicated pair lists a dozen)
+      if (rc == 2 && S->npts <= 4) {
+        resolved = ktp_descend_records<IdxT>(rec, sc, red, S, rootbox, n, k, out + (size_t)cloud * m * k, tid) == 0;
+        if (resolved) KTP_COUNT(1);
+      }
     }
     if (resolved) { KTS_MARK(31); continue; }  // (uniform)
     KTP_COUNT(2);
