@@ -102,3 +102,19 @@ def test_a_row_that_hinges_on_the_rounding_of_nanoflanns_pruning_bound():
     np.testing.assert_array_equal(P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="nanoflann").cpu().numpy(), want)
     canon = P.nearest_neighbors.knn_batch(s, q, k, dtype=torch.int32, tie_order="index").cpu().numpy()
     assert 6152 in canon[0, 0] and 6152 not in want[0, 0]
+
+
+def test_randomised_sweep_against_the_reference_library():
+    """tools/tie_path_fuzz.py for 1500 batches of a fixed seed (n 1..12 000, K 1..256, planes / needles / duplicated points quantised to
+    2^-2..2^-13, queries on and off the cloud, int32 and int64 rows): every row equal to the library's.  (Minutes of it with other seeds:
+    10 M listed queries, one row that hinged on the rounding of nanoflann's pruning bound -- the fixture above.)"""
+    import os, sys
+    from oracle import ref
+
+    if not ref.available("libref_knn.so"):
+        pytest.skip("oracle/_ref/libref_knn.so not built here")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import tie_path_fuzz
+
+    batches, queries, listed, bad = tie_path_fuzz.run(budget=120.0, seed=11, max_cases=1500, save_failures=False)
+    assert batches == 1500 and listed > 1000 and bad == 0, (batches, queries, listed, bad)
