@@ -1627,8 +1627,10 @@ __global__ __launch_bounds__(KTW_WAVES * 64) void knn_tree_search_wave_kernel(in
 // ---------------------------------------------------------------------------------------------------------------------
 // Small clouds (n <= KTS_NMAX: the classifier's, the deep levels of the segmentation models): tree AND searches of a flagged
 // cloud in ONE workgroup, everything in LDS -- records, nodes, level queues, the searching waves' stacks.  One launch instead of
-// three, no global round trip inside the build's level loop or the walk: a single chance tie in a batch of 64 x 1024 points
-// costs ~40 us here where build + deep + lane search took 184.  The build is knn_tree_build_lds_kernel's (same split code).
+// three, no global round trip inside the build's level loop or the walk: a listed cloud costs 85 us here where build + deep +
+// lane search took 184.  The build is knn_tree_build_lds_kernel's (same split code).  Its first stage (the kernel is further
+// down, behind the tie paths): a cloud with a FEW listed queries never gets here -- ktp_resolve_cloud / ktp_descend_records put their
+// runs of equal distances in arrival order from the tree nodes that separate the tied points alone (~12 us for a chance tie).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int KTS_NMAX = 2048;
 #define KTS_NNODES(n) (2 * (n) + 32)  // (one id range: the whole tree is built by one workgroup)
