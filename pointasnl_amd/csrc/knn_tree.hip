@@ -1667,6 +1667,7 @@ __device__ unsigned long long kts_probe[32];
 // phase probe of workgroup 0 (tools/tie_path_probe.py): s_memtime at [0] entry, [1] the listed queries counted, [2] records + box in
 // LDS, [3] the tied points listed, [4 + i] split i done (i < 24), [30] the row written
 #define KTP_MARK(i) do { if (threadIdx.x == 0 && S->probe != 0) kts_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)  // (S->probe: LDS; a flag in global memory costs a mark ~1 us)
+__device__ unsigned long long ktp_wg_cycles[64];  // (knn_tie_path_kernel: cycles and final code of each listed cloud's workgroup, tools/tie_path_l2.py)
 __device__ int ktp_paths[8];       // clouds by the form that took them: [0] sets only, [1] records moved, [2] tree + search, [3] return code 1 of the set form, [4] code 2
 #define KTP_COUNT(i) do { if (threadIdx.x == 0) atomicAdd(&ktp_paths[i], 1); } while (0)
 #else
@@ -2249,11 +2250,17 @@ __device__ __forceinline__ int ktp_resolve_cloud(const float4* rec, const float*
       px = r.x; py = r.y; pz = r.z;
       ux = S->qxyz[m_grp >> 8][0]; uy = S->qxyz[m_grp >> 8][1]; uz = S->qxyz[m_grp >> 8][2];
     }
+    // twin: two points of a run at the same place (no cut separates them) -- or, in a cloud of thousands of points whose records are in
+    // LDS, so close together that they most likely share a leaf of ten (closer than half a leaf's radius, estimated from the query's
+    // own K-th distance: K points within r_K, so ten within ~r_K sqrt(10 / K)): the set form would walk ~10 levels at ~8 us to find
+    // that out, the record-moving form is as fast there and needs no second start.  A guess that only chooses the form, not the result.
+    const float near2 = !GLOBAL && n > KTS_NMAX && lane < t ? 2.5f * S->dk[(m_grp >> 8) * k + k - 1] / (float)k : 0.f;
     bool peer = false, twin = false, first = lane < t;
     for (int o = 0; o < t; ++o) {
       const bool same = o != lane && __builtin_amdgcn_readlane(m_grp, o) == m_grp;
       peer |= same;
-      twin |= same && readlane_f(px, o) == px && readlane_f(py, o) == py && readlane_f(pz, o) == pz;
+      const float ex = readlane_f(px, o) - px, ey = readlane_f(py, o) - py, ez = readlane_f(pz, o) - pz;
+      twin |= same && ((ex == 0.f && ey == 0.f && ez == 0.f) || (ex * ex + ey * ey) + ez * ez < near2);
       first = first && !(o < lane && __builtin_amdgcn_readlane(m_idx, o) == m_idx);
     }
     if (lane == 0) S->npts = (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(first));  // distinct tied points (several queries list the same)
@@ -2497,6 +2504,9 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tie_path_kernel(int b, int
     }
     __syncthreads();
     const int cloud = S->cloud, nq = nflag[cloud];
+#ifdef PASNL_TUNING
+    const unsigned long long ktp_t0 = __builtin_amdgcn_s_memtime();
+#endif
     if (nq > ktp_max_queries(k)) {  // (uniform) a cloud of many ties: the full build
       if (tid == 0) atomicExch(&nwork[cloud], nq);
       continue;
@@ -2514,6 +2524,9 @@ __global__ __launch_bounds__(KTB_WAVES * 64) void knn_tie_path_kernel(int b, int
       if (rc == 0) KTP_COUNT(1);
     }
     if (rc != 0 && tid == 0) atomicExch(&nwork[cloud], nq);  // every listed query of the cloud, the done ones too (rows are simply written again)
+#ifdef PASNL_TUNING
+    if (tid == 0 && g < 32) { ktp_wg_cycles[g] = __builtin_amdgcn_s_memtime() - ktp_t0; ktp_wg_cycles[32 + g] = (unsigned long long)(rc + 10 * S->npts + 1000 * S->nmem); }
+#endif
   }
 }
 
@@ -3460,6 +3473,8 @@ extern "C" int pasnl_knn_batch_ref(int b, int n, int m, int k, const float* supp
   if (rc != PASNL_OK) return rc;
   PASNL_STAMP(1);
   if (pasnl::tune_env("PASNL_KNN_REF_NO_TREE")) return pasnl_launch_status();  // (tuning build: the canonical search + flags alone, A/B)
+  if (const char* e = pasnl::tune_env("PASNL_KNN_REF_NO_TREE_ABOVE")) { if (n > atoi(e)) return pasnl_launch_status(); }  // (... for the large / the small
+  if (const char* e = pasnl::tune_env("PASNL_KNN_REF_NO_TREE_BELOW")) { if (n < atoi(e)) return pasnl_launch_status(); }  //      searches of a model only)
   const bool small = n <= pasnl::KTS_NMAX && k <= 64;  // one kernel: the tie paths of a cloud's few listed queries, else its tree + searches
   if (!small && pasnl::tune_env("PASNL_KNN_REF_NO_TIE_PATH") == nullptr) {
     // a FEW listed queries (chance ties): the runs of equal distances put in the tree's arrival order along the tree paths that
@@ -3532,6 +3547,9 @@ __global__ void pasnl_stamp_kernel(int slot) { pasnl_stamps[slot] = wall_clock64
 extern "C" void pasnl_tuning_stamp(int slot, hipStream_t st) { hipLaunchKernelGGL(pasnl_stamp_kernel, dim3(1), dim3(1), 0, st, slot); }
 extern "C" int pasnl_tuning_stamps_read(unsigned long long* host16) {
   return hipMemcpyFromSymbol(host16, HIP_SYMBOL(pasnl_stamps), sizeof(pasnl_stamps)) == hipSuccess ? 0 : -1;
+}
+extern "C" int pasnl_tie_path_wg_read(unsigned long long* host64) {
+  return hipMemcpyFromSymbol(host64, HIP_SYMBOL(pasnl::ktp_wg_cycles), sizeof(pasnl::ktp_wg_cycles)) == hipSuccess ? 0 : -1;
 }
 extern "C" int pasnl_tie_paths_read(int* host8, int clear) {
   if (hipMemcpyFromSymbol(host8, HIP_SYMBOL(pasnl::ktp_paths), sizeof(pasnl::ktp_paths)) != hipSuccess) return -1;

@@ -45,6 +45,11 @@ for p, q, K in cases:
     t = np.array(list(buf), dtype=np.float64)
     u = lambda a, b: (t[b] - t[a]) / 100.0
     print("   first listed cloud: entry -> tied points listed %.1f" % u(0, 3), "| levels", [round(u(3 + i, 4 + i), 1) for i in range(12) if t[4 + i] > t[3 + i]], "| total %.1f (x100 cycles)" % u(0, 31), "| node 0: load %.1f, last pass %.1f, reductions %.1f, bookkeeping %.1f" % (u(3, 16), u(16, 17), u(17, 18), u(18, 4)))
+    wg = (ctypes.c_ulonglong * 64)()
+    if _hip.lib().pasnl_tie_path_wg_read(wg) == 0 and (p.shape[1] > 2048 or K > 64):
+        nl = int((nf > 0).sum())
+        print("   standalone tie-path kernel, per listed cloud: x100 cycles", [round(wg[i] / 100) for i in range(min(nl, 32))],
+              "| 1000 tied + 10 distinct points + code", [int(wg[32 + i]) for i in range(min(nl, 32))])
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(50): P.nearest_neighbors.knn_batch(p, q, K, dtype=torch.int32)
