@@ -542,6 +542,9 @@ def protocol_only(args, rank, world):
 _FORWARD_STREAM = None
 SETTLE_REPLAYS = 40  # untimed replays of the captured step between the capture and the W warm-up steps (config.settle_replays)
 SPLIT_PREFIX = os.environ.get('PASNL_BENCH_SPLIT_PREFIX', '1') != '0'  # tuning switch: sem_seg_res prefix as two plain branches
+PREFIX_L2 = os.environ.get('PASNL_BENCH_PREFIX_L2', '1') != '0'   # the classifier's prefix (no adaptive sampling) carries BOTH levels' searches and is
+#   forked at the START of the step, not lazily: 1.320 -> 1.275 ms (prefix of layer 1 alone, forked behind layer 2's cell: 1.320; both
+#   levels forked there: 1.355 -- it then ends after the head; at the start but lazily: 1.307)
 FORK_AT_DEFAULT = os.environ.get("PASNL_BENCH_FORK_AT", "cell2")  # cls: where the next batch's prefix is forked (head / conv2 / cell2)
 SELF_KNN_PREFIX = os.environ.get('PASNL_BENCH_SELF_KNN', '0') != '0'    # tuning switch: cls / sem_seg prefix = sampler || self-kNN, then a row gather (measured: 1.335-1.349 vs 1.315 ms)
 # the next batch's self-kNN (large clouds: the grid-pruned search) as a background job on at most this many workgroups (0 = one wave
@@ -655,7 +658,10 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
     prefix results step k-1 left in a buffer) and, on a side stream of the same graph, the prefix of forward k+1 on the OTHER
     input buffer.  Every step still does one full forward's worth of work, every output is the output of a complete forward
     on its own input (checked bit for bit against the eager forward of both buffers), and only hand-written kernels run on
-    the side stream (two concurrent vendor Stream-K GEMMs can dead-lock)."""
+    the side stream (two concurrent vendor Stream-K GEMMs can dead-lock).
+    The classifier without adaptive sampling: layer 2's points are layer 1's sampled INPUT points, so its search reads the input
+    cloud alone as well -- the prefix carries both levels' searches (FPS 1024 -> 512, kNN, FPS 512 -> 128, kNN) and is forked at the
+    start of the step: no search is left on the forward's chain (PREFIX_L2)."""
     import importlib
 
     import torch
@@ -669,7 +675,8 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
     # cls only.  Measured: 1.315 -> 1.288 ms without adaptive sampling; the segmentation models lose (their samplers are ~1 ms
     # chains that have to start at once): 4.12 -> 5.0 and 2.27 -> 3.16 ms)
     lz = os.environ.get("PASNL_BENCH_LAZY_FORK")
-    lazy_model, lazy_prefix = (tuple(v == "1" for v in lz.split(",")) if lz else (None, spec["model"] == "cls" and not spec.get("AS")))
+    prefix_l2 = PREFIX_L2 and spec["model"] == "cls" and not spec.get("AS")  # both levels' searches in the prefix, forked at the start
+    lazy_model, lazy_prefix = (tuple(v == "1" for v in lz.split(",")) if lz else (None, spec["model"] == "cls" and not spec.get("AS") and not prefix_l2))
     if os.environ.get("PASNL_BENCH_GROUP_ALL") is not None:  # (tuning switch: which group_all modules take the fused kernel)
         from pointasnl_amd.utils import pointnet_util
         pointnet_util.GROUP_ALL_FUSED = tuple(int(v) for v in os.environ["PASNL_BENCH_GROUP_ALL"].split(",") if v)
@@ -745,7 +752,13 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
                 mw = PREFETCH_KNN_WGS if into is not None else None  # inside a step's graph the search is a background job
                 if not res:
                     _, new_xyz = tf_sampling.farthest_point_sample_gather(npnt, xyz, out=(None, o[0]))
-                    return [new_xyz, pointasnl_util.knn_query(nsamp, xyz, new_xyz, out=o[1], max_workgroups=mw)]
+                    r = [new_xyz, pointasnl_util.knn_query(nsamp, xyz, new_xyz, out=o[1], max_workgroups=mw)]
+                    if prefix_l2:
+                        # layer 2's search as well: its points are layer 1's sampled input points (no adaptive sampling)
+                        o2 = into[2:4] if into is not None else [None, None]
+                        _, xyz2 = tf_sampling.farthest_point_sample_gather(128, new_xyz, out=(None, o2[0]))
+                        r += [xyz2, pointasnl_util.knn_query(64, new_xyz, xyz2, out=o2[1])]
+                    return r
                 fps_idx, new_xyz = tf_sampling.farthest_point_sample_gather(N // 8, xyz, out=(None, o[1]))
                 if kf is not None:
                     k_all = kf.get()
@@ -758,6 +771,8 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
 
             def as_search(t, bufs):
                 if not res:
+                    if len(bufs) == 4:
+                        return {1: (bufs[0], None, bufs[1]), 2: (bufs[2], None, bufs[3])}
                     return (bufs[0], None, bufs[1])
                 return {0: (xyz_of(t), None, bufs[0]), 1: (bufs[1], None, bufs[2])}
 
@@ -799,7 +814,7 @@ def _run_config(cfg_index, spec, steps, warmup, rank=0, world=1, multi=False, gr
                     fk.append(pointasnl_util.Forked(run_prefix, slot=PREFETCH_SLOTS[0], lazy=lazy_prefix))
                     if kf is not None:
                         fk.append(kf)
-                if os.environ.get("PASNL_BENCH_PREFETCH_AT", spec.get("prefetch_at", "head")) == "start":  # (tuning switch)
+                if os.environ.get("PASNL_BENCH_PREFETCH_AT", "start" if prefix_l2 else spec.get("prefetch_at", "head")) == "start":
                     fork()
                 o = forward(xs[cur], search=as_search(xs[cur], S[cur]), before_head=None if fk else fork)
                 for f in fk:
@@ -1304,7 +1319,8 @@ def main():
     config.update({"serial_outputs_agree": serial["outputs_agree"] if serial else None,
                    "serial_clouds_per_s": serial["clouds_per_s"] if serial else None,
                    "enqueue_ms_per_step": round(res["enqueue_ms_per_step"], 4), "hip_graph": res["graph"],
-                   "prefix_forked_at": FORK_AT_DEFAULT if args.model == "cls" else "head", "settle_replays": SETTLE_REPLAYS,
+                   "prefix_forked_at": os.environ.get("PASNL_BENCH_PREFETCH_AT", "start") if (args.model == "cls" and not args.AS and PREFIX_L2) else (FORK_AT_DEFAULT if args.model == "cls" else "head"),
+                   "prefix_levels": 2 if (args.model == "cls" and not args.AS and PREFIX_L2) else 1, "settle_replays": SETTLE_REPLAYS,
                    "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")})
     for mo in modes or []:
         config[f"mode_{mo['mode']}_ms"] = mo["ms_per_step"]

@@ -40,10 +40,13 @@ def get_model(point_cloud, is_training=False, use_normal=False, bn_decay=None, w
     # Set abstraction layers.  Layer 2's search (FPS + kNN) reads layer 1's sampled coordinates only, so it is forked onto
     # a side stream the moment those are final and runs beside layer 1's MFMA / GEMM work (pointasnl_util.Forked)
     search2 = []
+    if isinstance(search, dict):  # {1: layer1's search, 2: layer2's}: without adaptive sampling layer 2's coordinates are layer 1's sampled
+        search2.append(search[2])  # input points -- its search, too, reads the input cloud alone and can be computed ahead
+        search = search[1]
     l1_xyz, l1_points = PointASNLSetAbstraction(l0_xyz, l0_points, npoint=512, nsample=32, mlp=[64, 64, 128],
                                                 is_training=is_training, bn_decay=bn_decay, weight_decay=weight_decay,
                                                 scope='layer1', as_neighbor=as_neighbor[0], search=search, xyz_concat=True,
-                                                after_sampling=lambda xyz1: search2.append(
+                                                after_sampling=None if search2 else lambda xyz1: search2.append(
                                                     Forked(lambda: sa_search(xyz1, None, 128, 64), lazy=lazy_fork)))
     end_points['l1_xyz'] = l1_xyz
     l2_xyz, l2_points = PointASNLSetAbstraction(l1_xyz, l1_points, npoint=128, nsample=64, mlp=[128, 128, 256],
