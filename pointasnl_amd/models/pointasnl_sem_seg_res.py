@@ -9,7 +9,8 @@ from pointasnl_amd.utils.pointasnl_util import (PointASNLSetAbstraction, get_rep
 from pointasnl_amd.tf_interpolate import three_nn
 
 
-LEVEL1_SELF_KNN = True  # level 1's search as self-kNN beside the sampler (A/B switch, see level1 below): 2.303 -> 2.278 ms per step
+LEVEL1_SELF_KNN = False  # level 1's search as self-kNN beside the sampler (A/B switch, see level1 below): default order 2.303 -> 2.278-2.294 ms
+#                          per step, but canonical order 2.11 -> 2.205 and the serial pipeline 2.87 -> 2.95: off
 
 def _Late(box):
     """the self-kNN that is forked AFTER the sampler (box[0], by the time anything asks)"""
